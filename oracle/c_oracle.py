@@ -1,0 +1,176 @@
+"""
+c_oracle.py -- ctypes loader for oracle/libforge_ec_oracle.so (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+All arrays are numpy uint64, little-endian limbs (see forge_ec_oracle.h).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libforge_ec_oracle.so")
+
+SECP256K1, P256, ED25519 = 0, 1, 2
+POINT_LIMBS = {SECP256K1: 12, P256: 12, ED25519: 16}
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "forge_ec_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libforge_ec_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        p = ctypes.c_void_p
+        L.fo_field_op.argtypes = [ctypes.c_int, ctypes.c_char_p, p, p, p]
+        L.fo_field_op.restype = ctypes.c_int
+        for name in ("fo_identity", "fo_generator"):
+            getattr(L, name).argtypes = [ctypes.c_int, p]
+            getattr(L, name).restype = None
+        L.fo_is_identity.argtypes = [ctypes.c_int, p]
+        L.fo_is_identity.restype = ctypes.c_int
+        L.fo_point_add.argtypes = [ctypes.c_int, p, p, p]
+        L.fo_point_add.restype = None
+        L.fo_point_double.argtypes = [ctypes.c_int, p, p]
+        L.fo_point_double.restype = None
+        L.fo_secp256k1_point_double_trait.argtypes = [p, p]
+        L.fo_secp256k1_point_double_trait.restype = None
+        L.fo_point_negate.argtypes = [ctypes.c_int, p, p]
+        L.fo_point_negate.restype = None
+        L.fo_to_affine.argtypes = [ctypes.c_int, p, p]
+        L.fo_to_affine.restype = ctypes.c_int
+        L.fo_multiply.argtypes = [ctypes.c_int, p, p, p]
+        L.fo_multiply.restype = None
+        L.fo_batch_mul.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_mul.restype = None
+        L.fo_batch_mul_fixed.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_mul_fixed.restype = None
+        L.fo_batch_double_mul.argtypes = [ctypes.c_int, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_double_mul.restype = None
+        L.fo_batch_to_affine.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_to_affine.restype = None
+        _lib = L
+    return _lib
+
+
+def _u64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def field_op(curve, op, a, b=None):
+    a = _u64(a)
+    b = _u64(b if b is not None else [0, 0, 0, 0])
+    r = np.zeros(4, dtype=np.uint64)
+    rc = lib().fo_field_op(curve, op.encode(), _ptr(a), _ptr(b), _ptr(r))
+    if rc != 0:
+        raise ValueError("fo_field_op rc=%d" % rc)
+    return r
+
+
+def identity(curve):
+    r = np.zeros(POINT_LIMBS[curve], dtype=np.uint64)
+    lib().fo_identity(curve, _ptr(r))
+    return r
+
+
+def generator(curve):
+    r = np.zeros(POINT_LIMBS[curve], dtype=np.uint64)
+    lib().fo_generator(curve, _ptr(r))
+    return r
+
+
+def is_identity(curve, p):
+    p = _u64(p)
+    return bool(lib().fo_is_identity(curve, _ptr(p)))
+
+
+def point_add(curve, p, q):
+    p, q = _u64(p), _u64(q)
+    r = np.zeros(POINT_LIMBS[curve], dtype=np.uint64)
+    lib().fo_point_add(curve, _ptr(p), _ptr(q), _ptr(r))
+    return r
+
+
+def point_double(curve, p):
+    p = _u64(p)
+    r = np.zeros(POINT_LIMBS[curve], dtype=np.uint64)
+    lib().fo_point_double(curve, _ptr(p), _ptr(r))
+    return r
+
+
+def secp256k1_point_double_trait(p):
+    p = _u64(p)
+    r = np.zeros(12, dtype=np.uint64)
+    lib().fo_secp256k1_point_double_trait(_ptr(p), _ptr(r))
+    return r
+
+
+def point_negate(curve, p):
+    p = _u64(p)
+    r = np.zeros(POINT_LIMBS[curve], dtype=np.uint64)
+    lib().fo_point_negate(curve, _ptr(p), _ptr(r))
+    return r
+
+
+def to_affine(curve, p):
+    p = _u64(p)
+    xy = np.zeros(8, dtype=np.uint64)
+    inf = lib().fo_to_affine(curve, _ptr(p), _ptr(xy))
+    return xy, bool(inf)
+
+
+def multiply(curve, point, scalar):
+    point, scalar = _u64(point), _u64(scalar)
+    r = np.zeros(POINT_LIMBS[curve], dtype=np.uint64)
+    lib().fo_multiply(curve, _ptr(point), _ptr(scalar), _ptr(r))
+    return r
+
+
+def batch_mul(curve, scalars, points, nthreads=1):
+    scalars, points = _u64(scalars), _u64(points)
+    n = scalars.size // 4
+    out = np.zeros((n, POINT_LIMBS[curve]), dtype=np.uint64)
+    lib().fo_batch_mul(curve, _ptr(scalars), _ptr(points), _ptr(out), n, nthreads)
+    return out
+
+
+def batch_mul_fixed(curve, scalars, base, nthreads=1):
+    scalars, base = _u64(scalars), _u64(base)
+    n = scalars.size // 4
+    out = np.zeros((n, POINT_LIMBS[curve]), dtype=np.uint64)
+    lib().fo_batch_mul_fixed(curve, _ptr(scalars), _ptr(base), _ptr(out), n, nthreads)
+    return out
+
+
+def batch_double_mul(curve, u1, u2, q, nthreads=1):
+    u1, u2, q = _u64(u1), _u64(u2), _u64(q)
+    n = u1.size // 4
+    out = np.zeros((n, POINT_LIMBS[curve]), dtype=np.uint64)
+    lib().fo_batch_double_mul(curve, _ptr(u1), _ptr(u2), _ptr(q), _ptr(out), n, nthreads)
+    return out
+
+
+def batch_to_affine(curve, points, nthreads=1):
+    points = _u64(points)
+    n = points.size // POINT_LIMBS[curve]
+    xy = np.zeros((n, 8), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    lib().fo_batch_to_affine(curve, _ptr(points), _ptr(xy), _ptr(inf), n, nthreads)
+    return xy, inf

@@ -1,0 +1,1037 @@
+/*
+ * forge_ec_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT A PRODUCT PATH)
+ *
+ * See forge_ec_oracle.h for scope, provenance and the parity-pinning statement.
+ * Citations are relative to /root/reference/forge-ec-curves/src/.
+ *
+ * Style: each function restates the reference's integer operation sequence in
+ * C with `unsigned __int128` standing for Rust's u128, `u64` wrap-around for
+ * wrapping_* / overflowing_* and explicit carries.  Nothing is algebraically
+ * simplified: the quirks ARE the specification.
+ */
+#include "forge_ec_oracle.h"
+
+#include <pthread.h>
+#include <string.h>
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+
+typedef struct { u64 v[4]; } fe;                 /* field element, LE limbs   */
+typedef struct { fe x, y, z; } jpt;              /* Jacobian X,Y,Z            */
+typedef struct { fe x, y, z, t; } ept;           /* Ed25519 extended X,Y,Z,T  */
+
+static int fe_eq(const fe* a, const fe* b) {
+  return a->v[0] == b->v[0] && a->v[1] == b->v[1] && a->v[2] == b->v[2] && a->v[3] == b->v[3];
+}
+static int fe_is_zero(const fe* a) { return (a->v[0] | a->v[1] | a->v[2] | a->v[3]) == 0; }
+static fe fe_small(u64 w) { fe r = {{w, 0, 0, 0}}; return r; }
+static fe fe_select(const fe* a, const fe* b, int choice) { return choice ? *b : *a; } /* subtle: c ? b : a */
+
+/* =====================================================================================
+ * secp256k1  (secp256k1.rs)
+ * ===================================================================================== */
+static const u64 K_P[4] = {0xFFFFFFFEFFFFFC2FULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL,
+                           0xFFFFFFFFFFFFFFFFULL};                       /* secp256k1.rs:22-23 */
+
+/* secp256k1.rs:47-75  compare_with_p: -1 / 0 / +1, most significant limb first */
+static int k_cmp_p(const u64 l[4]) {
+  int result = 0;
+  for (int i = 3; i >= 0; --i) {
+    int decided = result != 0;
+    int nr = (l[i] < K_P[i]) ? -1 : ((l[i] > K_P[i]) ? 1 : 0);
+    result = decided ? result : nr;
+  }
+  return result;
+}
+
+/* secp256k1.rs:78-102  reduce: one conditional subtraction of p */
+static void k_reduce(fe* s) {
+  fe red = *s;
+  u64 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 d1 = red.v[i] - K_P[i];
+    u64 b1 = red.v[i] < K_P[i];
+    u64 d2 = d1 - borrow;
+    u64 b2 = d1 < borrow;
+    red.v[i] = d2;
+    borrow = b1 | b2;
+  }
+  if (k_cmp_p(s->v) >= 0) *s = red;
+}
+
+/* secp256k1.rs:353-393  Add */
+static fe k_add(fe a, fe b) {
+  fe r = a;
+  u64 carry = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 sum1 = r.v[i] + b.v[i];
+    u64 sum2 = sum1 + carry;
+    u64 c1 = r.v[i] > ~b.v[i];
+    u64 c2 = sum1 > (~(u64)0 - carry);
+    r.v[i] = sum2;
+    carry = c1 | c2;
+  }
+  fe red = r;
+  u64 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 d1 = red.v[i] - K_P[i];
+    u64 b1 = red.v[i] < K_P[i];
+    u64 d2 = d1 - borrow;
+    u64 b2 = d1 < borrow;
+    red.v[i] = d2;
+    borrow = b1 | b2;
+  }
+  int should = (carry > 0) || (k_cmp_p(r.v) >= 0);
+  return fe_select(&r, &red, should);
+}
+
+/* secp256k1.rs:395-440  Sub */
+static fe k_sub(fe a, fe b) {
+  fe r = a;
+  u64 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 d1 = r.v[i] - b.v[i];
+    u64 d2 = d1 - borrow;
+    u64 b1 = r.v[i] < b.v[i];
+    u64 b2 = d1 < borrow;
+    r.v[i] = d2;
+    borrow = b1 | b2;
+  }
+  fe wp = r;
+  u64 carry = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 sum1 = wp.v[i] + K_P[i];
+    u64 sum2 = sum1 + carry;
+    u64 c1 = wp.v[i] > ~K_P[i];
+    u64 c2 = sum1 > (~(u64)0 - carry);
+    wp.v[i] = sum2;
+    carry = c1 | c2;
+  }
+  return fe_select(&r, &wp, borrow > 0);
+}
+
+/* secp256k1.rs:442-507  Mul: schoolbook + 4-round Montgomery reduction, `carry` declared
+ * OUTSIDE the round loop (470) and a carry leaving t[7] is lost. */
+static fe k_mul(fe a, fe b) {
+  u64 t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u64 carry = 0;
+    for (int j = 0; j < 4; ++j) {
+      u128 prod = (u128)a.v[i] * (u128)b.v[j] + (u128)t[i + j] + (u128)carry;
+      t[i + j] = (u64)prod;
+      carry = (u64)(prod >> 64);
+    }
+    t[i + 4] = carry;
+  }
+  const u64 N0 = 0xD838091DD2253531ULL;                                  /* :468 */
+  u64 carry = 0;                                                        /* :470 */
+  for (int i = 0; i < 4; ++i) {
+    u64 m = t[i] * N0;
+    u128 sum = (u128)t[i] + (u128)m * (u128)K_P[0] + (u128)carry;
+    carry = (u64)(sum >> 64);
+    for (int j = 1; j < 4; ++j) {
+      sum = (u128)t[i + j] + (u128)m * (u128)K_P[j] + (u128)carry;
+      t[i + j] = (u64)sum;
+      carry = (u64)(sum >> 64);
+    }
+    int j = i + 4;
+    while (j < 8 && carry > 0) {
+      u128 s2 = (u128)t[j] + (u128)carry;
+      t[j] = (u64)s2;
+      carry = (u64)(s2 >> 64);
+      ++j;
+    }
+  }
+  fe r = {{t[4], t[5], t[6], t[7]}};
+  if (k_cmp_p(r.v) >= 0) k_reduce(&r);
+  return r;
+}
+
+/* secp256k1.rs:509-539  Neg */
+static fe k_neg(fe a) {
+  fe r;
+  u64 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 d1 = K_P[i] - a.v[i];
+    u64 d2 = d1 - borrow;
+    u64 b1 = K_P[i] < a.v[i];
+    u64 b2 = d1 < borrow;
+    r.v[i] = d2;
+    borrow = b1 | b2;
+  }
+  return fe_select(&r, &a, fe_is_zero(&a));
+}
+
+/* secp256k1.rs:634-713  square: NOT Montgomery, NOT mul(x,x) */
+static fe k_sqr(fe a) {
+  u64 product[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {                                        /* :643-649 */
+    u128 sq = (u128)a.v[i] * (u128)a.v[i];
+    product[i * 2] = (u64)sq;
+    product[i * 2 + 1] = (u64)(sq >> 64);
+  }
+  for (int i = 0; i < 4; ++i) {                                        /* :652-679 */
+    for (int j = i + 1; j < 4; ++j) {
+      u128 cross = (u128)a.v[i] * (u128)a.v[j];
+      cross = cross * 2;                       /* u128 wrapping_mul(2): bit 127 lost */
+      u64 lo = (u64)cross;
+      u64 hi = (u64)(cross >> 64);
+      u64 sum = product[i + j] + lo;
+      int carry = sum < lo;
+      product[i + j] = sum;
+      u64 sumh = product[i + j + 1] + hi;      /* `carry` is NOT added here */
+      int carry2 = sumh < hi;
+      product[i + j + 1] = sumh;
+      if (carry || carry2) {                   /* a single +1, two positions up */
+        int k = i + j + 2;
+        while (k < 8) {
+          product[k] = product[k] + 1;
+          if (product[k] != 0) break;
+          ++k;
+        }
+      }
+    }
+  }
+  u64 result[4] = {product[0], product[1], product[2], product[3]};
+  u64 carry = 0;                                                        /* :692 */
+  for (int i = 4; i < 8; ++i) {
+    u64 m = product[i] * 0x1000003D1ULL;       /* low 64 bits only */
+    u64 t = result[0] + m;                     /* always into result[0] */
+    t = t + carry;
+    result[0] = t;
+    carry = (u64)(t < m) | ((u64)(t < carry) & (u64)(m != 0));          /* :698-699 */
+    for (int j = 1; j < 4; ++j) {
+      u64 t2 = result[j] + carry;
+      result[j] = t2;
+      carry = (u64)(t2 < carry);
+    }
+  }
+  fe r = {{result[0], result[1], result[2], result[3]}};
+  k_reduce(&r);
+  return r;
+}
+
+/* secp256k1.rs:599-632  invert: square-and-multiply over p-2, limbs visited LS->MS, bits MS->LS */
+static fe k_inv(fe a) {
+  if (fe_is_zero(&a)) return fe_small(0);      /* CtOption none; value is zero */
+  static const u64 e[4] = {0xFFFFFFFEFFFFFC2DULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL,
+                           0xFFFFFFFFFFFFFFFFULL};
+  fe result = fe_small(1);                     /* one() = raw 1, :585-593 */
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 63; j >= 0; --j) {
+      result = k_sqr(result);
+      if ((e[i] >> j) & 1) result = k_mul(result, a);
+    }
+  }
+  return result;
+}
+
+static jpt k_identity(void) {                  /* :1322-1324 */
+  jpt p = {fe_small(0), fe_small(1), fe_small(0)};
+  return p;
+}
+static int k_is_identity(const jpt* p) {       /* :1326-1340 */
+  if (fe_is_zero(&p->x) && fe_is_zero(&p->y) && fe_is_zero(&p->z)) return 1;
+  return fe_is_zero(&p->z);
+}
+
+/* secp256k1.rs:1502-1540  inherent ProjectivePoint::double -- the one the ladder reaches */
+static jpt k_double(const jpt* p) {
+  if (k_is_identity(p)) return k_identity();
+  fe a = k_sqr(p->x);
+  fe b = k_sqr(p->y);
+  fe c = k_sqr(b);
+  fe xpb = k_add(p->x, b);
+  fe xpb2 = k_sqr(xpb);
+  fe dd = k_sub(k_sub(xpb2, a), c);
+  fe d = k_add(dd, dd);                        /* field double(): s + s, :105-109 */
+  fe e = k_mul(a, fe_small(3));                /* raw 3 through the Montgomery Mul */
+  fe f = k_sqr(e);
+  fe x3 = k_sub(f, k_add(d, d));
+  fe y3 = k_sub(k_mul(e, k_sub(d, x3)), k_mul(c, fe_small(8)));
+  fe yz = k_mul(p->y, p->z);
+  fe z3 = k_add(yz, yz);
+  jpt r = {x3, y3, z3};
+  return r;
+}
+
+/* secp256k1.rs:1375-1418  trait PointProjective::double (not on the ladder path) */
+static jpt k_double_trait(const jpt* p) {
+  if (k_is_identity(p)) return k_identity();
+  fe xx = k_sqr(p->x);
+  fe yy = k_sqr(p->y);
+  fe yyyy = k_sqr(yy);
+  fe xy2 = k_sqr(k_add(p->x, yy));
+  fe w = k_sub(k_sub(xy2, xx), yyyy);
+  fe d = k_add(w, w);
+  fe e = k_mul(fe_small(3), xx);
+  fe ee = k_sqr(e);
+  fe x3 = k_sub(k_sub(ee, d), d);
+  fe eight_yyyy = k_mul(fe_small(8), yyyy);
+  fe y3 = k_sub(k_mul(e, k_sub(d, x3)), eight_yyyy);
+  fe z3 = k_add(p->y, p->y);
+  fe one = fe_small(1);
+  if (!fe_eq(&p->z, &one)) z3 = k_mul(z3, p->z);
+  jpt r = {x3, y3, z3};
+  return r;
+}
+
+/* secp256k1.rs:1444-1498  Add for ProjectivePoint */
+static jpt k_padd(const jpt* p, const jpt* q) {
+  if (k_is_identity(p)) return *q;
+  if (k_is_identity(q)) return *p;
+  fe z1s = k_sqr(p->z);
+  fe z2s = k_sqr(q->z);
+  fe u1 = k_mul(p->x, z2s);
+  fe u2 = k_mul(q->x, z1s);
+  fe z1c = k_mul(z1s, p->z);
+  fe z2c = k_mul(z2s, q->z);
+  fe s1 = k_mul(p->y, z2c);
+  fe s2 = k_mul(q->y, z1c);
+  if (fe_eq(&u1, &u2)) {
+    if (fe_eq(&s1, &s2)) return k_double(p);   /* resolves to the inherent double */
+    return k_identity();
+  }
+  fe h = k_sub(u2, u1);
+  fe r = k_sub(s2, s1);
+  fe h2 = k_sqr(h);
+  fe h3 = k_mul(h2, h);
+  fe u1h2 = k_mul(u1, h2);
+  fe x3 = k_sub(k_sub(k_sub(k_sqr(r), h3), u1h2), u1h2);
+  fe y3 = k_sub(k_mul(r, k_sub(u1h2, x3)), k_mul(s1, h3));
+  fe z3 = k_mul(k_mul(h, p->z), q->z);
+  jpt o = {x3, y3, z3};
+  return o;
+}
+
+/* secp256k1.rs:219-235 to_montgomery with the reference's R_SQUARED; 2608-2625 generator */
+static jpt k_generator(void) {
+  fe r2 = {{0x000E9F61ULL, 0x07A20000ULL, 0x00000100ULL, 0}};
+  fe gx = {{0x59F2815B16F81798ULL, 0x029BFCDB2DCE28D9ULL, 0x55A06295CE870B07ULL, 0x79BE667EF9DCBBACULL}};
+  fe gy = {{0x9C47D08FFB10D4B8ULL, 0xFD17B448A6855419ULL, 0x5DA4FBFC0E1108A8ULL, 0x483ADA7726A3C465ULL}};
+  jpt g = {k_mul(gx, r2), k_mul(gy, r2), fe_small(1)};
+  return g;
+}
+
+/* secp256k1.rs:1342-1363 to_affine */
+static int k_to_affine(const jpt* p, fe* x, fe* y) {
+  if (k_is_identity(p)) { *x = fe_small(0); *y = fe_small(0); return 1; }
+  fe zi = k_inv(p->z);
+  fe zi2 = k_sqr(zi);
+  fe zi3 = k_mul(zi2, zi);
+  *x = k_mul(p->x, zi2);
+  *y = k_mul(p->y, zi3);
+  return 0;
+}
+
+/* secp256k1.rs:2635-2692  Curve::multiply: Montgomery ladder over the inherent (little-endian)
+ * Scalar::to_bytes (1924-1933), bits MSB-first inside each byte => scalar consumed byte-reversed. */
+static jpt k_multiply(const jpt* point, const u64 k[4]) {
+  if (k_is_identity(point) || (k[0] | k[1] | k[2] | k[3]) == 0) return k_identity();
+  unsigned char bytes[32];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) bytes[i * 8 + j] = (unsigned char)(k[i] >> (j * 8));
+  jpt r0 = k_identity();
+  jpt r1 = *point;
+  for (int i = 0; i < 256; ++i) {
+    int bit = (bytes[i / 8] >> (7 - (i % 8))) & 1;
+    jpt s = k_padd(&r0, &r1);
+    jpt d0 = k_double(&r0);
+    jpt d1 = k_double(&r1);
+    r0 = bit ? s : d0;
+    r1 = bit ? d1 : s;
+  }
+  return r0;
+}
+
+/* =====================================================================================
+ * P-256  (p256.rs)
+ * ===================================================================================== */
+static const u64 N_P[4] = {0xFFFFFFFFFFFFFFFFULL, 0x00000000FFFFFFFFULL, 0x0000000000000000ULL,
+                           0xFFFFFFFF00000001ULL};                       /* p256.rs:18-19 */
+
+/* p256.rs:70-80 compare */
+static int n_cmp(const u64 a[4], const u64 b[4]) {
+  for (int i = 3; i >= 0; --i) {
+    if (a[i] < b[i]) return -1;
+    if (a[i] > b[i]) return 1;
+  }
+  return 0;
+}
+
+/* p256.rs:88-99 reduce: while >= p subtract p */
+static void n_reduce(fe* s) {
+  while (n_cmp(s->v, N_P) >= 0) {
+    u64 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+      u64 d1 = s->v[i] - N_P[i];
+      u64 b1 = s->v[i] < N_P[i];
+      u64 d2 = d1 - borrow;
+      u64 b2 = d1 < borrow;
+      s->v[i] = d2;
+      borrow = b1 + b2;
+    }
+  }
+}
+
+/* p256.rs:416-468 Add */
+static fe n_add(fe a, fe b) {
+  u64 r[4] = {a.v[0], a.v[1], a.v[2], a.v[3]};
+  u64 carry = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 s1 = r[i] + b.v[i];
+    u64 o1 = s1 < b.v[i];
+    u64 s2 = s1 + carry;
+    u64 o2 = s2 < carry;
+    r[i] = s2;
+    carry = o1 + o2;
+  }
+  while (carry > 0) {                                                   /* :436-452 */
+    static const u64 red[4] = {0x0000000000000001ULL, 0xFFFFFFFF00000000ULL, 0xFFFFFFFFFFFFFFFFULL,
+                               0x00000000FFFFFFFEULL};
+    u64 ac = 0;
+    for (int i = 0; i < 4; ++i) {
+      u64 s1 = r[i] + red[i];
+      u64 o1 = s1 < red[i];
+      u64 s2 = s1 + ac;
+      u64 o2 = s2 < ac;
+      r[i] = s2;
+      ac = o1 + o2;
+    }
+    carry = carry - 1 + ac;
+  }
+  fe out = {{r[0], r[1], r[2], r[3]}};
+  while (n_cmp(out.v, N_P) >= 0) {                                      /* :456-464 */
+    u64 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+      u64 d1 = out.v[i] - N_P[i];
+      u64 b1 = out.v[i] < N_P[i];
+      u64 d2 = d1 - borrow;
+      u64 b2 = d1 < borrow;
+      out.v[i] = d2;
+      borrow = b1 + b2;
+    }
+  }
+  return out;
+}
+
+/* p256.rs:470-496 Sub: `result += P` is undone by Add's own reduction; then a wrapping
+ * 256-bit subtraction => (a-b) mod 2^256 when a < b (possibly >= p). */
+static fe n_sub(fe a, fe b) {
+  fe r = a;
+  if (n_cmp(a.v, b.v) < 0) {
+    fe pp = {{N_P[0], N_P[1], N_P[2], N_P[3]}};
+    r = n_add(r, pp);
+  }
+  u64 borrow = 0;
+  fe d;
+  for (int i = 0; i < 4; ++i) {
+    u64 d1 = r.v[i] - b.v[i];
+    u64 b1 = r.v[i] < b.v[i];
+    u64 d2 = d1 - borrow;
+    u64 b2 = d1 < borrow;
+    d.v[i] = d2;
+    borrow = b1 + b2;
+  }
+  return d;
+}
+
+/* p256.rs:544-704 reduce_wide_p256 */
+static fe n_reduce_wide(const u64 wide[8]) {
+  u64 c[16];
+  for (int i = 0; i < 8; ++i) {
+    c[2 * i] = wide[i] & 0xFFFFFFFFULL;
+    c[2 * i + 1] = wide[i] >> 32;
+  }
+  i128 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  /* s1 */
+  for (int i = 0; i < 8; ++i) acc[i] += (i128)c[i];
+  /* 2*s2 */
+  acc[3] += 2 * (i128)c[11]; acc[4] += 2 * (i128)c[12]; acc[5] += 2 * (i128)c[13];
+  acc[6] += 2 * (i128)c[14]; acc[7] += 2 * (i128)c[15];
+  /* 2*s3 */
+  acc[3] += 2 * (i128)c[12]; acc[4] += 2 * (i128)c[13]; acc[5] += 2 * (i128)c[14];
+  acc[6] += 2 * (i128)c[15];
+  /* s4 */
+  acc[0] += (i128)c[8]; acc[1] += (i128)c[9]; acc[2] += (i128)c[10];
+  acc[6] += (i128)c[14]; acc[7] += (i128)c[15];
+  /* s5 */
+  acc[0] += (i128)c[9]; acc[1] += (i128)c[10]; acc[2] += (i128)c[11]; acc[3] += (i128)c[13];
+  acc[4] += (i128)c[14]; acc[5] += (i128)c[15]; acc[6] += (i128)c[13]; acc[7] += (i128)c[8];
+  /* -s6 */
+  acc[0] -= (i128)c[11]; acc[1] -= (i128)c[12]; acc[2] -= (i128)c[13];
+  acc[6] -= (i128)c[8]; acc[7] -= (i128)c[10];
+  /* -s7 */
+  acc[0] -= (i128)c[12]; acc[1] -= (i128)c[13]; acc[2] -= (i128)c[14]; acc[3] -= (i128)c[15];
+  acc[6] -= (i128)c[9]; acc[7] -= (i128)c[11];
+  /* -s8 */
+  acc[0] -= (i128)c[13]; acc[1] -= (i128)c[14]; acc[2] -= (i128)c[15]; acc[3] -= (i128)c[8];
+  acc[4] -= (i128)c[9]; acc[5] -= (i128)c[10]; acc[7] -= (i128)c[12];
+  /* -s9 */
+  acc[0] -= (i128)c[14]; acc[1] -= (i128)c[15]; acc[3] -= (i128)c[9]; acc[4] -= (i128)c[10];
+  acc[5] -= (i128)c[11]; acc[7] -= (i128)c[13];
+
+  for (int i = 0; i < 7; ++i) {                 /* :657-661, arithmetic >> on i128 */
+    i128 carry = acc[i] >> 32;
+    acc[i] &= (i128)0xFFFFFFFFULL;
+    acc[i + 1] += carry;
+  }
+  i128 carry = acc[7] >> 32;
+  acc[7] &= (i128)0xFFFFFFFFULL;
+
+  fe r;
+  r.v[0] = (u64)acc[0] | ((u64)acc[1] << 32);
+  r.v[1] = (u64)acc[2] | ((u64)acc[3] << 32);
+  r.v[2] = (u64)acc[4] | ((u64)acc[5] << 32);
+  r.v[3] = (u64)acc[6] | ((u64)acc[7] << 32);
+
+  while (carry > 0) {                           /* :677-686 wrapping subtract p */
+    u64 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+      u64 d1 = r.v[i] - N_P[i];
+      u64 b1 = r.v[i] < N_P[i];
+      u64 d2 = d1 - borrow;
+      u64 b2 = d1 < borrow;
+      r.v[i] = d2;
+      borrow = b1 + b2;
+    }
+    carry -= 1;
+  }
+  while (carry < 0) {                           /* :689-698 wrapping add p */
+    u64 cc = 0;
+    for (int i = 0; i < 4; ++i) {
+      u64 s1 = r.v[i] + N_P[i];
+      u64 o1 = s1 < N_P[i];
+      u64 s2 = s1 + cc;
+      u64 o2 = s2 < cc;
+      r.v[i] = s2;
+      cc = o1 + o2;
+    }
+    carry += 1;
+  }
+  n_reduce(&r);
+  return r;
+}
+
+/* p256.rs:498-534 Mul */
+static fe n_mul(fe a, fe b) {
+  u64 wide[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u128 carry = 0;
+    for (int j = 0; j < 4; ++j) {
+      u128 prod = (u128)a.v[i] * (u128)b.v[j] + (u128)wide[i + j] + carry;
+      wide[i + j] = (u64)prod;
+      carry = prod >> 64;
+    }
+    u128 sum = (u128)wide[i + 4] + carry;
+    wide[i + 4] = (u64)sum;
+    if ((sum >> 64) != 0) {
+      for (int k = i + 5; k < 8; ++k) {
+        u64 nv = wide[k] + 1;
+        int ovf = nv == 0;
+        wide[k] = nv;
+        if (!ovf) break;
+      }
+    }
+  }
+  return n_reduce_wide(wide);
+}
+static fe n_sqr(fe a) { return n_mul(a, a); }   /* p256.rs:772-776 */
+
+/* p256.rs:707-729 Neg */
+static fe n_neg(fe a) {
+  if (fe_is_zero(&a)) return a;
+  fe r;
+  u64 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 d1 = N_P[i] - a.v[i];
+    u64 b1 = N_P[i] < a.v[i];
+    u64 d2 = d1 - borrow;
+    u64 b2 = d1 < borrow;
+    r.v[i] = d2;
+    borrow = b1 + b2;
+  }
+  return r;
+}
+
+/* p256.rs:376-393 pow (LSB first), 343-370 invert (exponent p-2 by limb-wise borrow) */
+static fe n_pow(fe a, const u64 e[4]) {
+  fe result = fe_small(1);
+  fe base = a;
+  for (int w = 0; w < 4; ++w) {
+    u64 x = e[w];
+    for (int i = 0; i < 64; ++i) {
+      if (x & 1) result = n_mul(result, base);
+      base = n_sqr(base);
+      x >>= 1;
+    }
+  }
+  return result;
+}
+static fe n_inv(fe a) {
+  if (fe_is_zero(&a)) return fe_small(0);
+  u64 e[4] = {N_P[0], N_P[1], N_P[2], N_P[3]};
+  u64 borrow = 2;
+  for (int i = 0; i < 4; ++i) {
+    u64 val = e[i] - borrow;
+    int did = e[i] < borrow;
+    e[i] = val;
+    if (!did) { borrow = 0; break; }
+    borrow = 1;
+  }
+  return n_pow(a, e);
+}
+
+static jpt n_identity(void) {                   /* :1827-1829 */
+  jpt p = {fe_small(0), fe_small(1), fe_small(0)};
+  return p;
+}
+static int n_is_identity(const jpt* p) { return fe_is_zero(&p->z); }   /* :1831-1833 */
+
+/* p256.rs:1869-1912 double (a = 0 formula although a = -3; Z==1 shortcut) */
+static jpt n_double(const jpt* p) {
+  if (n_is_identity(p)) return n_identity();
+  fe xx = n_sqr(p->x);
+  fe yy = n_sqr(p->y);
+  fe yyyy = n_sqr(yy);
+  fe xy2 = n_sqr(n_add(p->x, yy));
+  fe w = n_sub(n_sub(xy2, xx), yyyy);
+  fe d = n_add(w, w);
+  fe e = n_mul(fe_small(3), xx);
+  fe ee = n_sqr(e);
+  fe x3 = n_sub(n_sub(ee, d), d);
+  fe eight_yyyy = n_mul(fe_small(8), yyyy);
+  fe y3 = n_sub(n_mul(e, n_sub(d, x3)), eight_yyyy);
+  fe z3 = n_add(p->y, p->y);
+  fe one = fe_small(1);
+  if (!fe_eq(&p->z, &one)) z3 = n_mul(z3, p->z);
+  jpt r = {x3, y3, z3};
+  return r;
+}
+
+/* p256.rs:2034-2068 ConstantTimeEq for ProjectivePoint */
+static int n_pt_eq(const jpt* p, const jpt* q) {
+  if (n_is_identity(p) && n_is_identity(q)) return 1;
+  if (n_is_identity(p) || n_is_identity(q)) return 0;
+  fe z1z1 = n_sqr(p->z);
+  fe z2z2 = n_sqr(q->z);
+  fe u1 = n_mul(p->x, z2z2);
+  fe u2 = n_mul(q->x, z1z1);
+  fe s1 = n_mul(n_mul(p->y, q->z), z2z2);
+  fe s2 = n_mul(n_mul(q->y, p->z), z1z1);
+  return fe_eq(&u1, &u2) & fe_eq(&s1, &s2);
+}
+
+/* p256.rs:1938-2007 Add */
+static jpt n_padd(const jpt* p, const jpt* q) {
+  if (n_is_identity(p)) return *q;
+  if (n_is_identity(q)) return *p;
+  if (n_pt_eq(p, q)) return n_double(p);
+  fe z1z1 = n_sqr(p->z);
+  fe z2z2 = n_sqr(q->z);
+  fe u1 = n_mul(p->x, z2z2);
+  fe u2 = n_mul(q->x, z1z1);
+  fe s1 = n_mul(n_mul(p->y, q->z), z2z2);
+  fe s2 = n_mul(n_mul(q->y, p->z), z1z1);
+  fe ns2 = n_neg(s2);
+  if (fe_eq(&u1, &u2) && fe_eq(&s1, &ns2)) return n_identity();        /* :1977 */
+  fe h = n_sub(u2, u1);
+  fe i = n_sqr(n_add(h, h));
+  fe j = n_mul(h, i);
+  fe r = n_add(n_sub(s2, s1), n_sub(s2, s1));
+  fe v = n_mul(u1, i);
+  fe x3 = n_sub(n_sub(n_sub(n_sqr(r), j), v), v);
+  fe y3 = n_sub(n_mul(r, n_sub(v, x3)), n_mul(n_add(s1, s1), j));
+  fe z3 = n_mul(n_sub(n_sub(n_sqr(n_add(p->z, q->z)), z1z1), z2z2), h);
+  jpt o = {x3, y3, z3};
+  return o;
+}
+
+static jpt n_generator(void) {                  /* :2092-2110 */
+  jpt g = {{{0xF4A13945D898C296ULL, 0x77037D812DEB33A0ULL, 0xF8BCE6E563A440F2ULL, 0x6B17D1F2E12C4247ULL}},
+           {{0xCBB6406837BF51F5ULL, 0x2BCE33576B315ECEULL, 0x8EE7EB4A7C0F9E16ULL, 0x4FE342E2FE1A7F9BULL}},
+           {{1, 0, 0, 0}}};
+  return g;
+}
+
+static int n_to_affine(const jpt* p, fe* x, fe* y) {                    /* :1835-1857 */
+  if (n_is_identity(p)) { *x = fe_small(0); *y = fe_small(0); return 1; }
+  fe zi = n_inv(p->z);
+  fe zi2 = n_sqr(zi);
+  fe zi3 = n_mul(zi2, zi);
+  *x = n_mul(p->x, zi2);
+  *y = n_mul(p->y, zi3);
+  return 0;
+}
+
+/* p256.rs:2120-2156 Curve::multiply: MSB-first double-and-add over the inherent big-endian
+ * Scalar::to_bytes (1026-1038); the add is data-dependent. */
+static jpt n_multiply(const jpt* point, const u64 k[4]) {
+  if (n_is_identity(point) || (k[0] | k[1] | k[2] | k[3]) == 0) return n_identity();
+  unsigned char bytes[32];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) bytes[31 - (i * 8 + j)] = (unsigned char)((k[i] >> (j * 8)) & 0xFF);
+  jpt result = n_identity();
+  for (int i = 0; i < 256; ++i) {
+    int bit = (bytes[i / 8] >> (7 - (i % 8))) & 1;
+    result = n_double(&result);
+    if (bit == 1) result = n_padd(&result, point);
+  }
+  return result;
+}
+
+/* =====================================================================================
+ * Ed25519  (ed25519.rs)
+ * ===================================================================================== */
+static const u64 E_P[4] = {0xFFFFFFFFFFFFFFEDULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL,
+                           0x7FFFFFFFFFFFFFFFULL};                       /* ed25519.rs:64-69 */
+static const u64 E_D[4] = {0x75EB4DCA135EDEFFULL, 0x00E0149A8283B156ULL, 0x198E80F2EEF3D130ULL,
+                           0x2406875CC61A8E3CULL};                       /* ed25519.rs:86-91 */
+
+/* ed25519.rs:214-247 reduce */
+static void e_reduce(fe* s) {
+  u64 top = s->v[3] >> 63;
+  s->v[3] &= 0x7FFFFFFFFFFFFFFFULL;
+  u64 carry = top * 19;
+  for (int i = 0; i < 4; ++i) {
+    u128 sum = (u128)s->v[i] + (u128)carry;
+    s->v[i] = (u64)sum;
+    carry = (u64)(sum >> 64);
+  }
+  u64 diff[4];
+  u64 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 d1 = s->v[i] - E_P[i];
+    u64 b1 = s->v[i] < E_P[i];
+    u64 d2 = d1 - borrow;
+    u64 b2 = d1 < borrow;
+    diff[i] = d2;
+    borrow = b1 + b2;
+  }
+  if (borrow == 0)
+    for (int i = 0; i < 4; ++i) s->v[i] = diff[i];
+}
+
+/* ed25519.rs:260-289 reduce_wide: low + 38*high; the final carry is folded with x19 (not 38) */
+static fe e_reduce_wide(const u64 l[8]) {
+  u64 low[4] = {l[0], l[1], l[2], l[3]};
+  u128 carry = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 prod = (u128)l[4 + i] * (u128)38 + (u128)low[i] + carry;
+    low[i] = (u64)prod;
+    carry = prod >> 64;
+  }
+  u64 fc = (u64)carry * 19;
+  for (int i = 0; i < 4; ++i) {
+    u128 sum = (u128)low[i] + (u128)fc;
+    low[i] = (u64)sum;
+    fc = (u64)(sum >> 64);
+  }
+  fe r = {{low[0], low[1], low[2], low[3]}};
+  e_reduce(&r);
+  return r;
+}
+
+/* ed25519.rs:458-488 Add */
+static fe e_add(fe a, fe b) {
+  u64 r[4];
+  u64 carry = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 sum = (u128)a.v[i] + (u128)b.v[i] + (u128)carry;
+    r[i] = (u64)sum;
+    carry = (u64)(sum >> 64);
+  }
+  if (carry > 0) {
+    u64 ec = carry * 19;
+    for (int i = 0; i < 4; ++i) {
+      u128 sum = (u128)r[i] + (u128)ec;
+      r[i] = (u64)sum;
+      ec = (u64)(sum >> 64);
+    }
+  }
+  fe o = {{r[0], r[1], r[2], r[3]}};
+  e_reduce(&o);
+  return o;
+}
+
+/* ed25519.rs:490-520 Sub (no final reduce) */
+static fe e_sub(fe a, fe b) {
+  u64 r[4];
+  u64 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 d1 = a.v[i] - b.v[i];
+    u64 b1 = a.v[i] < b.v[i];
+    u64 d2 = d1 - borrow;
+    u64 b2 = d1 < borrow;
+    r[i] = d2;
+    borrow = b1 + b2;
+  }
+  if (borrow > 0) {
+    u64 carry = 0;
+    for (int i = 0; i < 4; ++i) {
+      u128 sum = (u128)r[i] + (u128)E_P[i] + (u128)carry;
+      r[i] = (u64)sum;
+      carry = (u64)(sum >> 64);
+    }
+  }
+  fe o = {{r[0], r[1], r[2], r[3]}};
+  return o;
+}
+
+/* ed25519.rs:522-545 Mul */
+static fe e_mul(fe a, fe b) {
+  u64 product[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u64 carry = 0;
+    for (int j = 0; j < 4; ++j) {
+      u128 prod = (u128)a.v[i] * (u128)b.v[j] + (u128)product[i + j] + (u128)carry;
+      product[i + j] = (u64)prod;
+      carry = (u64)(prod >> 64);
+    }
+    product[i + 4] = carry;
+  }
+  return e_reduce_wide(product);
+}
+static fe e_sqr(fe a) { return e_mul(a, a); }   /* ed25519.rs:623-625 */
+
+/* ed25519.rs:547-570 Neg */
+static fe e_neg(fe a) {
+  fe r;
+  u64 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 d1 = E_P[i] - a.v[i];
+    u64 b1 = E_P[i] < a.v[i];
+    u64 d2 = d1 - borrow;
+    u64 b2 = d1 < borrow;
+    r.v[i] = d2;
+    borrow = b1 + b2;
+  }
+  if (fe_is_zero(&a)) return fe_small(0);
+  return r;
+}
+
+/* ed25519.rs:410-431 pow (mul every bit, select), 603-621 invert */
+static fe e_pow(fe a, const u64 e[4]) {
+  fe result = fe_small(1);
+  fe base = a;
+  for (int w = 0; w < 4; ++w) {
+    for (int i = 0; i < 64; ++i) {
+      int bit = (int)((e[w] >> i) & 1);
+      fe nr = e_mul(result, base);
+      result = fe_select(&result, &nr, bit);
+      base = e_sqr(base);
+    }
+  }
+  return result;
+}
+static fe e_inv(fe a) {
+  static const u64 e[4] = {0xFFFFFFFFFFFFFFEBULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL,
+                           0x7FFFFFFFFFFFFFFFULL};
+  return e_pow(a, e);                          /* CtOption is none for zero; value is pow(0) */
+}
+
+static ept e_identity(void) {                   /* :1776-1783 */
+  ept p = {fe_small(0), fe_small(1), fe_small(1), fe_small(0)};
+  return p;
+}
+static int e_is_identity(const ept* p) {        /* :1785-1791 */
+  return fe_is_zero(&p->x) & fe_eq(&p->y, &p->z) & fe_is_zero(&p->t);
+}
+
+/* ed25519.rs:1864-1928 Add (C = T1*T2*d with d not 2d; D = Z1*Z2 not 2*Z1*Z2) */
+static ept e_padd(const ept* p, const ept* q) {
+  if (e_is_identity(p)) return *q;
+  if (e_is_identity(q)) return *p;
+  fe nqx = e_neg(q->x);
+  if (fe_eq(&p->x, &nqx) && fe_eq(&p->y, &q->y)) return e_identity();  /* :1878 raw coords */
+  fe d = {{E_D[0], E_D[1], E_D[2], E_D[3]}};
+  fe a = e_mul(e_sub(p->y, p->x), e_sub(q->y, q->x));
+  fe b = e_mul(e_add(p->y, p->x), e_add(q->y, q->x));
+  fe c = e_mul(e_mul(p->t, q->t), d);
+  fe dd = e_mul(p->z, q->z);
+  fe e = e_sub(b, a);
+  fe f = e_sub(dd, c);
+  fe g = e_add(dd, c);
+  fe h = e_add(b, a);
+  ept o = {e_mul(e, f), e_mul(g, h), e_mul(f, g), e_mul(e, h)};         /* x, y, z, t */
+  return o;
+}
+static ept e_double(const ept* p) { return e_padd(p, p); }              /* :1828-1832 */
+
+/* ed25519.rs:2015-2052 generator: hard-coded x,y; t = x*y (from_affine 1813-1826) */
+static ept e_generator(void) {
+  fe y = {{0x2DFC9311D90045F9ULL, 0x0A71C760BF38C6A7ULL, 0xA6FB8EEBCEAA2C8DULL, 0x5FD9C9E6CC3CCCCCULL}};
+  fe x = {{0x1A1462FAFB9683F2ULL, 0xD2E8A68B8B30C404ULL, 0xA0C0F3A1E9E71B63ULL, 0x216936D3CD6E53FEULL}};
+  ept g = {x, y, fe_small(1), e_mul(x, y)};
+  return g;
+}
+
+static int e_to_affine(const ept* p, fe* x, fe* y) {                    /* :1793-1811 */
+  if (e_is_identity(p)) { *x = fe_small(0); *y = fe_small(0); return 1; }
+  fe zi = e_inv(p->z);
+  *x = e_mul(p->x, zi);
+  *y = e_mul(p->y, zi);
+  return 0;
+}
+
+/* ed25519.rs:2062-2097 Curve::multiply: LSB-first over scalar.to_raw(), add every bit + select */
+static ept e_multiply(const ept* point, const u64 k[4]) {
+  if (e_is_identity(point) || (k[0] | k[1] | k[2] | k[3]) == 0) return e_identity();
+  ept result = e_identity();
+  ept addend = *point;
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 64; ++j) {
+      int bit = (k[i] & ((u64)1 << j)) != 0;
+      ept rpa = e_padd(&result, &addend);
+      result = bit ? rpa : result;
+      addend = e_double(&addend);
+    }
+  }
+  return result;
+}
+
+/* =====================================================================================
+ * C entry points
+ * ===================================================================================== */
+int fo_point_limbs(int curve) {
+  return (curve == FO_SECP256K1 || curve == FO_P256) ? 12 : (curve == FO_ED25519 ? 16 : 0);
+}
+
+static fe ld(const u64* p) { fe r = {{p[0], p[1], p[2], p[3]}}; return r; }
+static void st(u64* p, fe a) { p[0] = a.v[0]; p[1] = a.v[1]; p[2] = a.v[2]; p[3] = a.v[3]; }
+static jpt ldj(const u64* p) { jpt r = {ld(p), ld(p + 4), ld(p + 8)}; return r; }
+static void stj(u64* p, jpt a) { st(p, a.x); st(p + 4, a.y); st(p + 8, a.z); }
+static ept lde(const u64* p) { ept r = {ld(p), ld(p + 4), ld(p + 8), ld(p + 12)}; return r; }
+static void ste(u64* p, ept a) { st(p, a.x); st(p + 4, a.y); st(p + 8, a.z); st(p + 12, a.t); }
+
+int fo_field_op(int curve, const char* op, const u64 a[4], const u64 b[4], u64 r[4]) {
+  fe x = ld(a), y = b ? ld(b) : fe_small(0), o;
+  int c = curve;
+  if (c != FO_SECP256K1 && c != FO_P256 && c != FO_ED25519) return -1;
+  if (!strcmp(op, "add")) o = c == 0 ? k_add(x, y) : c == 1 ? n_add(x, y) : e_add(x, y);
+  else if (!strcmp(op, "sub")) o = c == 0 ? k_sub(x, y) : c == 1 ? n_sub(x, y) : e_sub(x, y);
+  else if (!strcmp(op, "mul")) o = c == 0 ? k_mul(x, y) : c == 1 ? n_mul(x, y) : e_mul(x, y);
+  else if (!strcmp(op, "sqr")) o = c == 0 ? k_sqr(x) : c == 1 ? n_sqr(x) : e_sqr(x);
+  else if (!strcmp(op, "neg")) o = c == 0 ? k_neg(x) : c == 1 ? n_neg(x) : e_neg(x);
+  else if (!strcmp(op, "inv")) o = c == 0 ? k_inv(x) : c == 1 ? n_inv(x) : e_inv(x);
+  else return -2;
+  st(r, o);
+  return 0;
+}
+
+void fo_identity(int curve, u64* p) {
+  if (curve == FO_SECP256K1) stj(p, k_identity());
+  else if (curve == FO_P256) stj(p, n_identity());
+  else ste(p, e_identity());
+}
+void fo_generator(int curve, u64* p) {
+  if (curve == FO_SECP256K1) stj(p, k_generator());
+  else if (curve == FO_P256) stj(p, n_generator());
+  else ste(p, e_generator());
+}
+int fo_is_identity(int curve, const u64* p) {
+  if (curve == FO_SECP256K1) { jpt a = ldj(p); return k_is_identity(&a); }
+  if (curve == FO_P256) { jpt a = ldj(p); return n_is_identity(&a); }
+  ept a = lde(p);
+  return e_is_identity(&a);
+}
+void fo_point_add(int curve, const u64* p, const u64* q, u64* r) {
+  if (curve == FO_SECP256K1) { jpt a = ldj(p), b = ldj(q); stj(r, k_padd(&a, &b)); }
+  else if (curve == FO_P256) { jpt a = ldj(p), b = ldj(q); stj(r, n_padd(&a, &b)); }
+  else { ept a = lde(p), b = lde(q); ste(r, e_padd(&a, &b)); }
+}
+void fo_point_double(int curve, const u64* p, u64* r) {
+  if (curve == FO_SECP256K1) { jpt a = ldj(p); stj(r, k_double(&a)); }
+  else if (curve == FO_P256) { jpt a = ldj(p); stj(r, n_double(&a)); }
+  else { ept a = lde(p); ste(r, e_double(&a)); }
+}
+void fo_secp256k1_point_double_trait(const u64* p, u64* r) {
+  jpt a = ldj(p);
+  stj(r, k_double_trait(&a));
+}
+void fo_point_negate(int curve, const u64* p, u64* r) {
+  if (curve == FO_SECP256K1) { jpt a = ldj(p); a.y = k_neg(a.y); stj(r, a); }        /* :1420-1422 */
+  else if (curve == FO_P256) { jpt a = ldj(p); a.y = n_neg(a.y); stj(r, a); }        /* p256 :1914-1916 */
+  else { ept a = lde(p); a.x = e_neg(a.x); a.t = e_neg(a.t); ste(r, a); }            /* ed :1834-1841 */
+}
+int fo_to_affine(int curve, const u64* p, u64* xy) {
+  fe x, y;
+  int inf;
+  if (curve == FO_SECP256K1) { jpt a = ldj(p); inf = k_to_affine(&a, &x, &y); }
+  else if (curve == FO_P256) { jpt a = ldj(p); inf = n_to_affine(&a, &x, &y); }
+  else { ept a = lde(p); inf = e_to_affine(&a, &x, &y); }
+  st(xy, x);
+  st(xy + 4, y);
+  return inf;
+}
+void fo_multiply(int curve, const u64* point, const u64 scalar[4], u64* out) {
+  if (curve == FO_SECP256K1) { jpt a = ldj(point); stj(out, k_multiply(&a, scalar)); }
+  else if (curve == FO_P256) { jpt a = ldj(point); stj(out, n_multiply(&a, scalar)); }
+  else { ept a = lde(point); ste(out, e_multiply(&a, scalar)); }
+}
+
+/* ---- threaded batch drivers ---- */
+typedef struct {
+  int kind;               /* 0 mul, 1 fixed, 2 double-mul, 3 to_affine */
+  int curve;
+  const u64 *s, *s2, *pts;
+  u64* out;
+  uint8_t* inf;
+  size_t lo, hi;
+} job_t;
+
+static void* worker(void* arg) {
+  job_t* j = (job_t*)arg;
+  int pl = fo_point_limbs(j->curve);
+  u64 g[16], a[16], b[16];
+  if (j->kind == 2) fo_generator(j->curve, g);
+  for (size_t i = j->lo; i < j->hi; ++i) {
+    switch (j->kind) {
+      case 0: fo_multiply(j->curve, j->pts + i * pl, j->s + i * 4, j->out + i * pl); break;
+      case 1: fo_multiply(j->curve, j->pts, j->s + i * 4, j->out + i * pl); break;
+      case 2:
+        fo_multiply(j->curve, g, j->s + i * 4, a);
+        fo_multiply(j->curve, j->pts + i * pl, j->s2 + i * 4, b);
+        fo_point_add(j->curve, a, b, j->out + i * pl);
+        break;
+      default: j->inf[i] = (uint8_t)fo_to_affine(j->curve, j->pts + i * pl, j->out + i * 8); break;
+    }
+  }
+  return NULL;
+}
+
+static void run_jobs(job_t proto, size_t n, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+  pthread_t th[256];
+  job_t jobs[256];
+  for (int t = 0; t < nthreads; ++t) {
+    jobs[t] = proto;
+    jobs[t].lo = n * (size_t)t / (size_t)nthreads;
+    jobs[t].hi = n * (size_t)(t + 1) / (size_t)nthreads;
+  }
+  if (nthreads == 1) { worker(&jobs[0]); return; }
+  for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, worker, &jobs[t]);
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+}
+
+void fo_batch_mul(int curve, const u64* scalars, const u64* points, u64* out, size_t n, int nthreads) {
+  job_t j = {0, curve, scalars, NULL, points, out, NULL, 0, 0};
+  run_jobs(j, n, nthreads);
+}
+void fo_batch_mul_fixed(int curve, const u64* scalars, const u64* base, u64* out, size_t n, int nthreads) {
+  job_t j = {1, curve, scalars, NULL, base, out, NULL, 0, 0};
+  run_jobs(j, n, nthreads);
+}
+void fo_batch_double_mul(int curve, const u64* u1, const u64* u2, const u64* q, u64* out, size_t n,
+                         int nthreads) {
+  job_t j = {2, curve, u1, u2, q, out, NULL, 0, 0};
+  run_jobs(j, n, nthreads);
+}
+void fo_batch_to_affine(int curve, const u64* points, u64* xy, uint8_t* inf, size_t n, int nthreads) {
+  job_t j = {3, curve, NULL, NULL, points, xy, inf, 0, 0};
+  run_jobs(j, n, nthreads);
+}

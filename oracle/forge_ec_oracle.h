@@ -1,0 +1,75 @@
+/*
+ * forge_ec_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT A PRODUCT PATH)
+ *
+ * A plain-C restatement of the batched scalar-multiplication hot path of
+ * tanm-sys/forge-ec (forge-ec-curves/src/{secp256k1,p256,ed25519}.rs), written
+ * from the reference's *integer op sequences*, including its arithmetic quirks
+ * (SURVEY.md section 8a).  Each function cites the reference file:line it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The shipped library (libfecgpu.so) never links, loads or
+ * calls it, and has no CPU fallback.
+ *
+ * PARITY PINNING: the Rust reference cannot be compiled in this environment (no
+ * rustc/cargo, no network).  This oracle is therefore pinned by (1) every
+ * known-answer value the reference's own unit tests hold for this path
+ * (tests/golden/reference_kats.json, cited per vector) and (2) bit-exact
+ * agreement with an independently written Python restatement
+ * (oracle/py_model.py).  The *ladder's* numeric output is asserted by none of the
+ * reference's tests (only "not identity"), so scalar-multiplication outputs are
+ * restatement-derived: "parity pinned by KATs at the field/point level, unpinned
+ * at the full-ladder level".
+ *
+ * Layout: every field element / scalar is uint64_t[4], little-endian limbs.
+ * Weierstrass points are X,Y,Z (12 limbs, Jacobian); Ed25519 points X,Y,Z,T (16).
+ */
+#ifndef FORGE_EC_ORACLE_H
+#define FORGE_EC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { FO_SECP256K1 = 0, FO_P256 = 1, FO_ED25519 = 2 };
+
+/* number of 64-bit limbs of one projective point of `curve` (12 or 16), 0 if unknown */
+int fo_point_limbs(int curve);
+
+/* ---- field ops: op in {"add","sub","mul","sqr","neg","inv"}; b ignored for unary ops ---- */
+int fo_field_op(int curve, const char* op, const uint64_t a[4], const uint64_t b[4], uint64_t r[4]);
+
+/* ---- point ops ---- */
+void fo_identity(int curve, uint64_t* p);
+void fo_generator(int curve, uint64_t* p);
+int  fo_is_identity(int curve, const uint64_t* p);
+void fo_point_add(int curve, const uint64_t* p, const uint64_t* q, uint64_t* r);
+/* the `double` the reference's multiply actually reaches (secp256k1: inherent, 1502-1540) */
+void fo_point_double(int curve, const uint64_t* p, uint64_t* r);
+/* secp256k1 only: the trait PointProjective::double (1375-1418) */
+void fo_secp256k1_point_double_trait(const uint64_t* p, uint64_t* r);
+void fo_point_negate(int curve, const uint64_t* p, uint64_t* r);
+/* out = x,y (8 limbs) + returns 1 if infinity */
+int  fo_to_affine(int curve, const uint64_t* p, uint64_t* xy);
+
+/* ---- Curve::multiply, the reference's full work (discarded doublings included) ---- */
+void fo_multiply(int curve, const uint64_t* point, const uint64_t scalar[4], uint64_t* out);
+
+/* ---- batched drivers (nthreads host threads over contiguous shards) ---- */
+void fo_batch_mul(int curve, const uint64_t* scalars, const uint64_t* points, uint64_t* out,
+                  size_t n, int nthreads);
+void fo_batch_mul_fixed(int curve, const uint64_t* scalars, const uint64_t* base, uint64_t* out,
+                        size_t n, int nthreads);
+/* out[i] = multiply(G,u1[i]) + multiply(Q[i],u2[i])   (forge-ec-signature/src/ecdsa.rs:254-256) */
+void fo_batch_double_mul(int curve, const uint64_t* u1, const uint64_t* u2, const uint64_t* q,
+                         uint64_t* out, size_t n, int nthreads);
+/* out[i] = to_affine(points[i]) as x,y (8 limbs); inf[i] = 1 when identity */
+void fo_batch_to_affine(int curve, const uint64_t* points, uint64_t* xy, uint8_t* inf, size_t n,
+                        int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,755 @@
+"""
+py_model.py -- second, independently written CPU restatement (TEST INFRASTRUCTURE ONLY).
+
+Written from the Rust sources (forge-ec-curves/src/{secp256k1,p256,ed25519}.rs), not
+from oracle/forge_ec_oracle.c, so that agreement between the two pins the
+restatement ("agreement of two independently written
+transliterations").  Pure Python integers stand in for u64/u128/i128 with explicit
+masks; loops mirror the reference's loops.  Slow (about 50 ms per secp256k1
+scalar-mul): used for small cases and to emit tests/golden/*.json.
+
+Nothing under forge_ec_amd/ may import this module.
+"""
+M64 = (1 << 64) - 1
+M128 = (1 << 128) - 1
+
+SECP256K1, P256, ED25519 = 0, 1, 2
+
+
+def _is_zero(a):
+    return a[0] == 0 and a[1] == 0 and a[2] == 0 and a[3] == 0
+
+
+# ======================================================================================
+# secp256k1 (secp256k1.rs)
+# ======================================================================================
+class Secp:
+    P = [0xFFFFFFFEFFFFFC2F, M64, M64, M64]  # :22-23
+    N0 = 0xD838091DD2253531  # :468
+
+    @staticmethod
+    def cmp_p(l):  # :47-75
+        res = 0
+        for i in (3, 2, 1, 0):
+            if res != 0:
+                continue
+            if l[i] < Secp.P[i]:
+                res = -1
+            elif l[i] > Secp.P[i]:
+                res = 1
+        return res
+
+    @staticmethod
+    def _minus_p(l):
+        out, borrow = [0] * 4, 0
+        for i in range(4):
+            d1 = (l[i] - Secp.P[i]) & M64
+            b1 = 1 if l[i] < Secp.P[i] else 0
+            d2 = (d1 - borrow) & M64
+            b2 = 1 if d1 < borrow else 0
+            out[i] = d2
+            borrow = b1 | b2
+        return out
+
+    @staticmethod
+    def reduce(l):  # :78-102
+        return Secp._minus_p(l) if Secp.cmp_p(l) >= 0 else list(l)
+
+    @staticmethod
+    def add(a, b):  # :353-393
+        r, carry = list(a), 0
+        for i in range(4):
+            s1 = (r[i] + b[i]) & M64
+            s2 = (s1 + carry) & M64
+            c1 = 1 if r[i] > (b[i] ^ M64) else 0
+            c2 = 1 if s1 > (M64 - carry) else 0
+            r[i] = s2
+            carry = c1 | c2
+        red = Secp._minus_p(r)
+        return red if (carry > 0 or Secp.cmp_p(r) >= 0) else r
+
+    @staticmethod
+    def sub(a, b):  # :395-440
+        r, borrow = list(a), 0
+        for i in range(4):
+            d1 = (r[i] - b[i]) & M64
+            d2 = (d1 - borrow) & M64
+            b1 = 1 if r[i] < b[i] else 0
+            b2 = 1 if d1 < borrow else 0
+            r[i] = d2
+            borrow = b1 | b2
+        wp, carry = list(r), 0
+        for i in range(4):
+            s1 = (wp[i] + Secp.P[i]) & M64
+            s2 = (s1 + carry) & M64
+            c1 = 1 if wp[i] > (Secp.P[i] ^ M64) else 0
+            c2 = 1 if s1 > (M64 - carry) else 0
+            wp[i] = s2
+            carry = c1 | c2
+        return wp if borrow > 0 else r
+
+    @staticmethod
+    def mul(a, b):  # :442-507
+        t = [0] * 8
+        for i in range(4):
+            carry = 0
+            for j in range(4):
+                prod = a[i] * b[j] + t[i + j] + carry
+                assert prod <= M128
+                t[i + j] = prod & M64
+                carry = prod >> 64
+            t[i + 4] = carry
+        carry = 0  # declared once, outside the rounds (:470)
+        for i in range(4):
+            m = (t[i] * Secp.N0) & M64
+            s = t[i] + m * Secp.P[0] + carry
+            assert s <= M128
+            carry = s >> 64
+            for j in range(1, 4):
+                s = t[i + j] + m * Secp.P[j] + carry
+                assert s <= M128
+                t[i + j] = s & M64
+                carry = s >> 64
+            j = i + 4
+            while j < 8 and carry > 0:
+                s = t[j] + carry
+                t[j] = s & M64
+                carry = s >> 64
+                j += 1
+        r = t[4:8]
+        if Secp.cmp_p(r) >= 0:
+            r = Secp.reduce(r)
+        return r
+
+    @staticmethod
+    def neg(a):  # :509-539
+        r, borrow = [0] * 4, 0
+        for i in range(4):
+            d1 = (Secp.P[i] - a[i]) & M64
+            d2 = (d1 - borrow) & M64
+            b1 = 1 if Secp.P[i] < a[i] else 0
+            b2 = 1 if d1 < borrow else 0
+            r[i] = d2
+            borrow = b1 | b2
+        return list(a) if _is_zero(a) else r
+
+    @staticmethod
+    def sqr(a):  # :634-713
+        product = [0] * 8
+        for i in range(4):
+            s = a[i] * a[i]
+            product[2 * i] = s & M64
+            product[2 * i + 1] = s >> 64
+        for i in range(4):
+            for j in range(i + 1, 4):
+                cross = ((a[i] * a[j]) * 2) & M128  # u128::wrapping_mul(2)
+                lo, hi = cross & M64, cross >> 64
+                s = product[i + j] + lo
+                carry = s > M64
+                product[i + j] = s & M64
+                s = product[i + j + 1] + hi
+                carry2 = s > M64
+                product[i + j + 1] = s & M64
+                if carry or carry2:
+                    k = i + j + 2
+                    while k < 8:
+                        product[k] = (product[k] + 1) & M64
+                        if product[k] != 0:
+                            break
+                        k += 1
+        result = product[0:4]
+        carry = 0
+        for i in range(4, 8):
+            m = (product[i] * 0x1000003D1) & M64
+            t = (result[0] + m) & M64
+            t = (t + carry) & M64
+            result[0] = t
+            carry = (1 if t < m else 0) | ((1 if t < carry else 0) & (1 if m != 0 else 0))
+            for j in range(1, 4):
+                t2 = (result[j] + carry) & M64
+                result[j] = t2
+                carry = 1 if t2 < carry else 0
+        return Secp.reduce(result)
+
+    @staticmethod
+    def inv(a):  # :599-632
+        if _is_zero(a):
+            return [0, 0, 0, 0]
+        e = [0xFFFFFFFEFFFFFC2D, M64, M64, M64]
+        result = [1, 0, 0, 0]
+        for i in range(4):
+            for j in range(63, -1, -1):
+                result = Secp.sqr(result)
+                if (e[i] >> j) & 1:
+                    result = Secp.mul(result, a)
+        return result
+
+    # ---- points: tuples (x, y, z) of limb lists ----
+    @staticmethod
+    def identity():
+        return ([0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 0])
+
+    @staticmethod
+    def is_identity(p):  # :1326-1340
+        if _is_zero(p[0]) and _is_zero(p[1]) and _is_zero(p[2]):
+            return True
+        return _is_zero(p[2])
+
+    @staticmethod
+    def double(p):  # inherent, :1502-1540
+        F = Secp
+        if F.is_identity(p):
+            return F.identity()
+        x, y, z = p
+        a = F.sqr(x)
+        b = F.sqr(y)
+        c = F.sqr(b)
+        xpb2 = F.sqr(F.add(x, b))
+        t = F.sub(F.sub(xpb2, a), c)
+        d = F.add(t, t)
+        e = F.mul(a, [3, 0, 0, 0])
+        f = F.sqr(e)
+        x3 = F.sub(f, F.add(d, d))
+        y3 = F.sub(F.mul(e, F.sub(d, x3)), F.mul(c, [8, 0, 0, 0]))
+        yz = F.mul(y, z)
+        z3 = F.add(yz, yz)
+        return (x3, y3, z3)
+
+    @staticmethod
+    def double_trait(p):  # :1375-1418
+        F = Secp
+        if F.is_identity(p):
+            return F.identity()
+        x, y, z = p
+        xx = F.sqr(x)
+        yy = F.sqr(y)
+        yyyy = F.sqr(yy)
+        xy2 = F.sqr(F.add(x, yy))
+        w = F.sub(F.sub(xy2, xx), yyyy)
+        d = F.add(w, w)
+        e = F.mul([3, 0, 0, 0], xx)
+        ee = F.sqr(e)
+        x3 = F.sub(F.sub(ee, d), d)
+        y3 = F.sub(F.mul(e, F.sub(d, x3)), F.mul([8, 0, 0, 0], yyyy))
+        z3 = F.add(y, y)
+        if z != [1, 0, 0, 0]:
+            z3 = F.mul(z3, z)
+        return (x3, y3, z3)
+
+    @staticmethod
+    def padd(p, q):  # :1444-1498
+        F = Secp
+        if F.is_identity(p):
+            return q
+        if F.is_identity(q):
+            return p
+        x1, y1, z1 = p
+        x2, y2, z2 = q
+        z1s, z2s = F.sqr(z1), F.sqr(z2)
+        u1, u2 = F.mul(x1, z2s), F.mul(x2, z1s)
+        z1c, z2c = F.mul(z1s, z1), F.mul(z2s, z2)
+        s1, s2 = F.mul(y1, z2c), F.mul(y2, z1c)
+        if u1 == u2:
+            return F.double(p) if s1 == s2 else F.identity()
+        h = F.sub(u2, u1)
+        r = F.sub(s2, s1)
+        h2 = F.sqr(h)
+        h3 = F.mul(h2, h)
+        u1h2 = F.mul(u1, h2)
+        x3 = F.sub(F.sub(F.sub(F.sqr(r), h3), u1h2), u1h2)
+        y3 = F.sub(F.mul(r, F.sub(u1h2, x3)), F.mul(s1, h3))
+        z3 = F.mul(F.mul(h, z1), z2)
+        return (x3, y3, z3)
+
+    @staticmethod
+    def generator():  # :2608-2625 with to_montgomery's R_SQUARED (:225-230)
+        r2 = [0x000E9F61, 0x07A20000, 0x00000100, 0]
+        gx = [0x59F2815B16F81798, 0x029BFCDB2DCE28D9, 0x55A06295CE870B07, 0x79BE667EF9DCBBAC]
+        gy = [0x9C47D08FFB10D4B8, 0xFD17B448A6855419, 0x5DA4FBFC0E1108A8, 0x483ADA7726A3C465]
+        return (Secp.mul(gx, r2), Secp.mul(gy, r2), [1, 0, 0, 0])
+
+    @staticmethod
+    def to_affine(p):  # :1342-1363
+        F = Secp
+        if F.is_identity(p):
+            return ([0, 0, 0, 0], [0, 0, 0, 0], True)
+        zi = F.inv(p[2])
+        zi2 = F.sqr(zi)
+        zi3 = F.mul(zi2, zi)
+        return (F.mul(p[0], zi2), F.mul(p[1], zi3), False)
+
+    @staticmethod
+    def multiply(point, k):  # :2635-2692
+        F = Secp
+        if F.is_identity(point) or _is_zero(k):
+            return F.identity()
+        by = []
+        for i in range(4):  # inherent Scalar::to_bytes, little-endian (:1924-1933)
+            for j in range(8):
+                by.append((k[i] >> (8 * j)) & 0xFF)
+        r0, r1 = F.identity(), point
+        for i in range(256):
+            bit = (by[i // 8] >> (7 - (i % 8))) & 1
+            s = F.padd(r0, r1)
+            d0 = F.double(r0)
+            d1 = F.double(r1)
+            r0 = s if bit else d0
+            r1 = d1 if bit else s
+        return r0
+
+
+# ======================================================================================
+# P-256 (p256.rs)
+# ======================================================================================
+class P256c:
+    P = [M64, 0x00000000FFFFFFFF, 0, 0xFFFFFFFF00000001]  # :18-19
+
+    @staticmethod
+    def cmp(a, b):  # :70-80
+        for i in (3, 2, 1, 0):
+            if a[i] < b[i]:
+                return -1
+            if a[i] > b[i]:
+                return 1
+        return 0
+
+    @staticmethod
+    def _sub_limbs(a, b):
+        out, borrow = [0] * 4, 0
+        for i in range(4):
+            d1 = (a[i] - b[i]) & M64
+            b1 = 1 if a[i] < b[i] else 0
+            d2 = (d1 - borrow) & M64
+            b2 = 1 if d1 < borrow else 0
+            out[i] = d2
+            borrow = b1 + b2
+        return out
+
+    @staticmethod
+    def _add_limbs(a, b):
+        out, c = [0] * 4, 0
+        for i in range(4):
+            s1 = a[i] + b[i]
+            o1 = s1 >> 64
+            s1 &= M64
+            s2 = s1 + c
+            o2 = s2 >> 64
+            out[i] = s2 & M64
+            c = o1 + o2
+        return out, c
+
+    @staticmethod
+    def reduce(a):  # :88-99
+        a = list(a)
+        while P256c.cmp(a, P256c.P) >= 0:
+            a = P256c._sub_limbs(a, P256c.P)
+        return a
+
+    @staticmethod
+    def add(a, b):  # :416-468
+        r, carry = P256c._add_limbs(a, b)
+        red = [1, 0xFFFFFFFF00000000, M64, 0x00000000FFFFFFFE]
+        while carry > 0:
+            r, ac = P256c._add_limbs(r, red)
+            carry = carry - 1 + ac
+        return P256c.reduce(r)
+
+    @staticmethod
+    def sub(a, b):  # :470-496
+        r = list(a)
+        if P256c.cmp(a, b) < 0:
+            r = P256c.add(r, P256c.P)
+        return P256c._sub_limbs(r, b)
+
+    @staticmethod
+    def reduce_wide(w):  # :544-704
+        c = []
+        for i in range(8):
+            c.append(w[i] & 0xFFFFFFFF)
+            c.append(w[i] >> 32)
+        acc = [c[i] for i in range(8)]  # s1
+        for idx, k in ((3, 11), (4, 12), (5, 13), (6, 14), (7, 15)):  # 2*s2
+            acc[idx] += 2 * c[k]
+        for idx, k in ((3, 12), (4, 13), (5, 14), (6, 15)):  # 2*s3
+            acc[idx] += 2 * c[k]
+        for idx, k in ((0, 8), (1, 9), (2, 10), (6, 14), (7, 15)):  # s4
+            acc[idx] += c[k]
+        for idx, k in ((0, 9), (1, 10), (2, 11), (3, 13), (4, 14), (5, 15), (6, 13), (7, 8)):  # s5
+            acc[idx] += c[k]
+        for idx, k in ((0, 11), (1, 12), (2, 13), (6, 8), (7, 10)):  # s6
+            acc[idx] -= c[k]
+        for idx, k in ((0, 12), (1, 13), (2, 14), (3, 15), (6, 9), (7, 11)):  # s7
+            acc[idx] -= c[k]
+        for idx, k in ((0, 13), (1, 14), (2, 15), (3, 8), (4, 9), (5, 10), (7, 12)):  # s8
+            acc[idx] -= c[k]
+        for idx, k in ((0, 14), (1, 15), (3, 9), (4, 10), (5, 11), (7, 13)):  # s9
+            acc[idx] -= c[k]
+        for i in range(7):
+            carry = acc[i] >> 32  # Python >> on negative ints floors, like i128 >>
+            acc[i] &= 0xFFFFFFFF
+            acc[i + 1] += carry
+        carry = acc[7] >> 32
+        acc[7] &= 0xFFFFFFFF
+        r = [acc[0] | (acc[1] << 32), acc[2] | (acc[3] << 32), acc[4] | (acc[5] << 32), acc[6] | (acc[7] << 32)]
+        while carry > 0:
+            r = P256c._sub_limbs(r, P256c.P)
+            carry -= 1
+        while carry < 0:
+            r, _ = P256c._add_limbs(r, P256c.P)
+            carry += 1
+        return P256c.reduce(r)
+
+    @staticmethod
+    def mul(a, b):  # :498-534
+        wide = [0] * 8
+        for i in range(4):
+            carry = 0
+            for j in range(4):
+                prod = a[i] * b[j] + wide[i + j] + carry
+                wide[i + j] = prod & M64
+                carry = prod >> 64
+            s = wide[i + 4] + carry
+            wide[i + 4] = s & M64
+            if (s >> 64) != 0:
+                for k in range(i + 5, 8):
+                    nv = wide[k] + 1
+                    wide[k] = nv & M64
+                    if nv <= M64:
+                        break
+        return P256c.reduce_wide(wide)
+
+    @staticmethod
+    def sqr(a):
+        return P256c.mul(a, a)
+
+    @staticmethod
+    def neg(a):  # :707-729
+        if _is_zero(a):
+            return list(a)
+        return P256c._sub_limbs(P256c.P, a)
+
+    @staticmethod
+    def pow(a, e):  # :376-393
+        result, base = [1, 0, 0, 0], list(a)
+        for w in e:
+            for _ in range(64):
+                if w & 1:
+                    result = P256c.mul(result, base)
+                base = P256c.sqr(base)
+                w >>= 1
+        return result
+
+    @staticmethod
+    def inv(a):  # :343-370
+        if _is_zero(a):
+            return [0, 0, 0, 0]
+        e, borrow = list(P256c.P), 2
+        for i in range(4):
+            did = e[i] < borrow
+            e[i] = (e[i] - borrow) & M64
+            if not did:
+                break
+            borrow = 1
+        return P256c.pow(a, e)
+
+    @staticmethod
+    def identity():
+        return ([0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 0])
+
+    @staticmethod
+    def is_identity(p):
+        return _is_zero(p[2])
+
+    @staticmethod
+    def double(p):  # :1869-1912
+        F = P256c
+        if F.is_identity(p):
+            return F.identity()
+        x, y, z = p
+        xx = F.sqr(x)
+        yy = F.sqr(y)
+        yyyy = F.sqr(yy)
+        xy2 = F.sqr(F.add(x, yy))
+        w = F.sub(F.sub(xy2, xx), yyyy)
+        d = F.add(w, w)
+        e = F.mul([3, 0, 0, 0], xx)
+        ee = F.sqr(e)
+        x3 = F.sub(F.sub(ee, d), d)
+        y3 = F.sub(F.mul(e, F.sub(d, x3)), F.mul([8, 0, 0, 0], yyyy))
+        z3 = F.add(y, y)
+        if z != [1, 0, 0, 0]:
+            z3 = F.mul(z3, z)
+        return (x3, y3, z3)
+
+    @staticmethod
+    def pt_eq(p, q):  # :2034-2068
+        F = P256c
+        if F.is_identity(p) and F.is_identity(q):
+            return True
+        if F.is_identity(p) or F.is_identity(q):
+            return False
+        z1z1, z2z2 = F.sqr(p[2]), F.sqr(q[2])
+        u1, u2 = F.mul(p[0], z2z2), F.mul(q[0], z1z1)
+        s1 = F.mul(F.mul(p[1], q[2]), z2z2)
+        s2 = F.mul(F.mul(q[1], p[2]), z1z1)
+        return u1 == u2 and s1 == s2
+
+    @staticmethod
+    def padd(p, q):  # :1938-2007
+        F = P256c
+        if F.is_identity(p):
+            return q
+        if F.is_identity(q):
+            return p
+        if F.pt_eq(p, q):
+            return F.double(p)
+        z1z1, z2z2 = F.sqr(p[2]), F.sqr(q[2])
+        u1, u2 = F.mul(p[0], z2z2), F.mul(q[0], z1z1)
+        s1 = F.mul(F.mul(p[1], q[2]), z2z2)
+        s2 = F.mul(F.mul(q[1], p[2]), z1z1)
+        if u1 == u2 and s1 == F.neg(s2):
+            return F.identity()
+        h = F.sub(u2, u1)
+        i = F.sqr(F.add(h, h))
+        j = F.mul(h, i)
+        r = F.add(F.sub(s2, s1), F.sub(s2, s1))
+        v = F.mul(u1, i)
+        x3 = F.sub(F.sub(F.sub(F.sqr(r), j), v), v)
+        y3 = F.sub(F.mul(r, F.sub(v, x3)), F.mul(F.add(s1, s1), j))
+        z3 = F.mul(F.sub(F.sub(F.sqr(F.add(p[2], q[2])), z1z1), z2z2), h)
+        return (x3, y3, z3)
+
+    @staticmethod
+    def generator():  # :2092-2110
+        return ([0xF4A13945D898C296, 0x77037D812DEB33A0, 0xF8BCE6E563A440F2, 0x6B17D1F2E12C4247],
+                [0xCBB6406837BF51F5, 0x2BCE33576B315ECE, 0x8EE7EB4A7C0F9E16, 0x4FE342E2FE1A7F9B],
+                [1, 0, 0, 0])
+
+    @staticmethod
+    def to_affine(p):  # :1835-1857
+        F = P256c
+        if F.is_identity(p):
+            return ([0, 0, 0, 0], [0, 0, 0, 0], True)
+        zi = F.inv(p[2])
+        zi2 = F.sqr(zi)
+        zi3 = F.mul(zi2, zi)
+        return (F.mul(p[0], zi2), F.mul(p[1], zi3), False)
+
+    @staticmethod
+    def multiply(point, k):  # :2120-2156
+        F = P256c
+        if F.is_identity(point) or _is_zero(k):
+            return F.identity()
+        by = [0] * 32
+        for i in range(4):  # inherent Scalar::to_bytes, big-endian (:1026-1038)
+            for j in range(8):
+                by[31 - (i * 8 + j)] = (k[i] >> (8 * j)) & 0xFF
+        result = F.identity()
+        for i in range(256):
+            bit = (by[i // 8] >> (7 - (i % 8))) & 1
+            result = F.double(result)
+            if bit == 1:
+                result = F.padd(result, point)
+        return result
+
+
+# ======================================================================================
+# Ed25519 (ed25519.rs)
+# ======================================================================================
+class Ed:
+    P = [0xFFFFFFFFFFFFFFED, M64, M64, 0x7FFFFFFFFFFFFFFF]  # :64-69
+    D = [0x75EB4DCA135EDEFF, 0x00E0149A8283B156, 0x198E80F2EEF3D130, 0x2406875CC61A8E3C]  # :86-91
+
+    @staticmethod
+    def reduce(a):  # :214-247
+        a = list(a)
+        top = a[3] >> 63
+        a[3] &= 0x7FFFFFFFFFFFFFFF
+        carry = top * 19
+        for i in range(4):
+            s = a[i] + carry
+            a[i] = s & M64
+            carry = s >> 64
+        diff, borrow = [0] * 4, 0
+        for i in range(4):
+            d1 = (a[i] - Ed.P[i]) & M64
+            b1 = 1 if a[i] < Ed.P[i] else 0
+            d2 = (d1 - borrow) & M64
+            b2 = 1 if d1 < borrow else 0
+            diff[i] = d2
+            borrow = b1 + b2
+        return diff if borrow == 0 else a
+
+    @staticmethod
+    def reduce_wide(l):  # :260-289
+        low = list(l[0:4])
+        carry = 0
+        for i in range(4):
+            prod = l[4 + i] * 38 + low[i] + carry
+            low[i] = prod & M64
+            carry = prod >> 64
+        fc = ((carry & M64) * 19) & M64  # (carry as u64) * 19
+        for i in range(4):
+            s = low[i] + fc
+            low[i] = s & M64
+            fc = s >> 64
+        return Ed.reduce(low)
+
+    @staticmethod
+    def add(a, b):  # :458-488
+        r, carry = [0] * 4, 0
+        for i in range(4):
+            s = a[i] + b[i] + carry
+            r[i] = s & M64
+            carry = s >> 64
+        if carry > 0:
+            ec = carry * 19
+            for i in range(4):
+                s = r[i] + ec
+                r[i] = s & M64
+                ec = s >> 64
+        return Ed.reduce(r)
+
+    @staticmethod
+    def sub(a, b):  # :490-520
+        r, borrow = [0] * 4, 0
+        for i in range(4):
+            d1 = (a[i] - b[i]) & M64
+            b1 = 1 if a[i] < b[i] else 0
+            d2 = (d1 - borrow) & M64
+            b2 = 1 if d1 < borrow else 0
+            r[i] = d2
+            borrow = b1 + b2
+        if borrow > 0:
+            carry = 0
+            for i in range(4):
+                s = r[i] + Ed.P[i] + carry
+                r[i] = s & M64
+                carry = s >> 64
+        return r
+
+    @staticmethod
+    def mul(a, b):  # :522-545
+        prod = [0] * 8
+        for i in range(4):
+            carry = 0
+            for j in range(4):
+                p = a[i] * b[j] + prod[i + j] + carry
+                prod[i + j] = p & M64
+                carry = p >> 64
+            prod[i + 4] = carry
+        return Ed.reduce_wide(prod)
+
+    @staticmethod
+    def sqr(a):
+        return Ed.mul(a, a)
+
+    @staticmethod
+    def neg(a):  # :547-570
+        if _is_zero(a):
+            return [0, 0, 0, 0]
+        r, borrow = [0] * 4, 0
+        for i in range(4):
+            d1 = (Ed.P[i] - a[i]) & M64
+            b1 = 1 if Ed.P[i] < a[i] else 0
+            d2 = (d1 - borrow) & M64
+            b2 = 1 if d1 < borrow else 0
+            r[i] = d2
+            borrow = b1 + b2
+        return r
+
+    @staticmethod
+    def pow(a, e):  # :410-431
+        result, base = [1, 0, 0, 0], list(a)
+        for w in e:
+            for i in range(64):
+                nr = Ed.mul(result, base)
+                if (w >> i) & 1:
+                    result = nr
+                base = Ed.sqr(base)
+        return result
+
+    @staticmethod
+    def inv(a):  # :603-621
+        return Ed.pow(a, [0xFFFFFFFFFFFFFFEB, M64, M64, 0x7FFFFFFFFFFFFFFF])
+
+    @staticmethod
+    def identity():
+        return ([0, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 0])
+
+    @staticmethod
+    def is_identity(p):  # :1785-1791
+        return _is_zero(p[0]) and p[1] == p[2] and _is_zero(p[3])
+
+    @staticmethod
+    def padd(p, q):  # :1864-1928
+        F = Ed
+        if F.is_identity(p):
+            return q
+        if F.is_identity(q):
+            return p
+        x1, y1, z1, t1 = p
+        x2, y2, z2, t2 = q
+        if x1 == F.neg(x2) and y1 == y2:
+            return F.identity()
+        a = F.mul(F.sub(y1, x1), F.sub(y2, x2))
+        b = F.mul(F.add(y1, x1), F.add(y2, x2))
+        c = F.mul(F.mul(t1, t2), F.D)
+        d = F.mul(z1, z2)
+        e = F.sub(b, a)
+        f = F.sub(d, c)
+        g = F.add(d, c)
+        h = F.add(b, a)
+        return (F.mul(e, f), F.mul(g, h), F.mul(f, g), F.mul(e, h))
+
+    @staticmethod
+    def double(p):  # :1828-1832
+        return Ed.padd(p, p)
+
+    @staticmethod
+    def generator():  # :2015-2052
+        y = [0x2DFC9311D90045F9, 0x0A71C760BF38C6A7, 0xA6FB8EEBCEAA2C8D, 0x5FD9C9E6CC3CCCCC]
+        x = [0x1A1462FAFB9683F2, 0xD2E8A68B8B30C404, 0xA0C0F3A1E9E71B63, 0x216936D3CD6E53FE]
+        return (x, y, [1, 0, 0, 0], Ed.mul(x, y))
+
+    @staticmethod
+    def to_affine(p):  # :1793-1811
+        if Ed.is_identity(p):
+            return ([0, 0, 0, 0], [0, 0, 0, 0], True)
+        zi = Ed.inv(p[2])
+        return (Ed.mul(p[0], zi), Ed.mul(p[1], zi), False)
+
+    @staticmethod
+    def multiply(point, k):  # :2062-2097
+        F = Ed
+        if F.is_identity(point) or _is_zero(k):
+            return F.identity()
+        result, addend = F.identity(), point
+        for i in range(4):
+            for j in range(64):
+                bit = (k[i] >> j) & 1
+                rpa = F.padd(result, addend)
+                if bit:
+                    result = rpa
+                addend = F.double(addend)
+        return result
+
+
+CURVES = {SECP256K1: Secp, P256: P256c, ED25519: Ed}
+
+
+def flat(pt):
+    out = []
+    for c in pt:
+        out.extend(c)
+    return out
+
+
+def unflat(limbs):
+    return tuple(list(limbs[i:i + 4]) for i in range(0, len(limbs), 4))
+
+
+def double_mul(curve, u1, u2, q):
+    """R = multiply(G,u1) + multiply(Q,u2)  (forge-ec-signature/src/ecdsa.rs:254-256)."""
+    F = CURVES[curve]
+    return F.padd(F.multiply(F.generator(), u1), F.multiply(q, u2))
