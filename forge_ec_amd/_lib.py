@@ -1,0 +1,90 @@
+"""ctypes binding of include/fecgpu.h.  No fallback: if libfecgpu.so is missing or no gfx950
+GPU is usable, importing works but every compute call raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libfecgpu.so")
+
+SECP256K1, P256, ED25519 = 0, 1, 2
+POINT_LIMBS = {SECP256K1: 12, P256: 12, ED25519: 16}
+F_ADD, F_SUB, F_MUL, F_SQR, F_NEG = 0, 1, 2, 3, 4
+P_ADD, P_DOUBLE, P_NEGATE, P_DOUBLE_TRAIT = 0, 1, 2, 3
+
+# every symbol include/fecgpu.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "fec_point_limbs", "fec_ctx_create", "fec_ctx_destroy", "fec_generator", "fec_batch_mul", "fec_batch_mul_fixed",
+    "fec_batch_double_mul", "fec_field_op", "fec_point_op", "fec_batch_mul_dev",
+    "fec_batch_mul_fixed_dev", "fec_batch_double_mul_dev", "fec_ctx_set_timing",
+    "fec_ctx_last_kernel_ms", "fec_measure_peak_mad32", "fec_ctx_device_info", "fec_strerror",
+]
+
+
+class FecError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = "fecgpu error %d" % status
+        try:
+            msg += ": " + lib().fec_strerror(status).decode()
+        except Exception:
+            pass
+        if what:
+            msg += " (%s)" % what
+        super().__init__(msg)
+
+
+_lib = None
+
+
+def lib():
+    """Load libfecgpu.so.  Raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            "forge_ec_amd: %s is missing -- build it with `python -m forge_ec_amd.build` "
+            "(there is no CPU fallback)" % SO_PATH)
+    # PyTorch (device memory / streams / torch.distributed plumbing) bundles its own HIP runtime
+    # under the same SONAME.  Device pointers and streams handed to the *_dev entry points must
+    # come from the runtime instance libfecgpu.so itself uses, so when torch is importable it is
+    # loaded first and libfecgpu.so binds to its libamdhip64; without torch the system ROCm
+    # runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = ctypes.CDLL(SO_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.fec_point_limbs.argtypes = [ci]
+    L.fec_point_limbs.restype = ci
+    L.fec_ctx_create.argtypes = [ctypes.POINTER(vp), ci]
+    L.fec_ctx_create.restype = ci
+    L.fec_ctx_destroy.argtypes = [vp]
+    L.fec_ctx_destroy.restype = None
+    L.fec_generator.argtypes = [vp, ci, vp]
+    L.fec_generator.restype = ci
+    L.fec_batch_mul.argtypes = [vp, ci, vp, vp, vp, sz]
+    L.fec_batch_mul_fixed.argtypes = [vp, ci, vp, vp, vp, sz]
+    L.fec_batch_double_mul.argtypes = [vp, ci, vp, vp, vp, vp, sz]
+    L.fec_field_op.argtypes = [vp, ci, ci, vp, vp, vp, sz]
+    L.fec_point_op.argtypes = [vp, ci, ci, vp, vp, vp, sz]
+    L.fec_batch_mul_dev.argtypes = [vp, ci, vp, vp, vp, sz, vp]
+    L.fec_batch_mul_fixed_dev.argtypes = [vp, ci, vp, vp, vp, sz, vp]
+    L.fec_batch_double_mul_dev.argtypes = [vp, ci, vp, vp, vp, vp, sz, vp]
+    for n in ("fec_batch_mul", "fec_batch_mul_fixed", "fec_batch_double_mul", "fec_field_op",
+              "fec_point_op", "fec_batch_mul_dev", "fec_batch_mul_fixed_dev",
+              "fec_batch_double_mul_dev"):
+        getattr(L, n).restype = ci
+    L.fec_ctx_set_timing.argtypes = [vp, ci]
+    L.fec_ctx_set_timing.restype = ci
+    L.fec_ctx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p)]
+    L.fec_ctx_last_kernel_ms.restype = ci
+    L.fec_measure_peak_mad32.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+    L.fec_measure_peak_mad32.restype = ci
+    L.fec_ctx_device_info.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    L.fec_ctx_device_info.restype = ci
+    L.fec_strerror.argtypes = [ci]
+    L.fec_strerror.restype = ctypes.c_char_p
+    _lib = L
+    return L

@@ -1,0 +1,168 @@
+// ed25519.hpp -- device-side Ed25519 field / extended-point / binary method, bit-exact with
+// forge-ec-curves/src/ed25519.rs (citations are lines of that file).
+//
+// Quirks reproduced: reduce_wide folds the top carry with x19 instead of x38 (278); the
+// addition uses d (not 2d) and Z1*Z2 (not 2*Z1*Z2) (1897-1900); the negation early-out compares
+// raw projective coordinates (1878), so doubling a point with X = 0 returns the identity.
+#pragma once
+#include "limbs.hpp"
+
+namespace fecgpu {
+namespace ed {
+
+FEC_DEV fe D_() {  // 86-91
+  fe d;
+  d.w[0] = 0x135EDEFFu; d.w[1] = 0x75EB4DCAu; d.w[2] = 0x8283B156u; d.w[3] = 0x00E0149Au;
+  d.w[4] = 0xEEF3D130u; d.w[5] = 0x198E80F2u; d.w[6] = 0xC61A8E3Cu; d.w[7] = 0x2406875Cu;
+  return d;
+}
+
+// p = 2^255 - 19 (64-69).  x - p = (x + 19) with bit 255 toggled, x + p = (x - 19) with bit 255
+// toggled (mod 2^256), so every p-operand chain is a chain on the small constant 19.
+
+// reduce (214-247): clear bit 255 and add 19 if it was set (no carry out is possible); then
+// subtract p if the value is >= p, i.e. if value + 19 reaches 2^255.
+FEC_DEV fe reduce(const fe& a) {
+  u32 top = a.w[7] >> 31;
+  fe v0 = a, v;
+  v0.w[7] &= 0x7FFFFFFFu;
+  add_word256(v, v0, top * 19u);
+  // v < 2^255 + 19.  v >= p = 2^255 - 19 needs either bit 255 set again or words 1..6 all ones with
+  // w7 == 0x7FFFFFFF: ~2^-224 on random data, so the exact comparison sits behind a wave-uniform
+  // branch.
+  u32 ones = v.w[1] & v.w[2] & v.w[3] & v.w[4] & v.w[5] & v.w[6] & (v.w[7] | 0x80000000u);
+  lmask maybe = lanes_where(ones == 0xFFFFFFFFu || (v.w[7] >> 31) != 0);
+  if (maybe != 0) {
+    fe u;
+    lmask t;
+    FEC_ADDK256(u, v, t, 19, 0, 0, 0, 0, 0, 0, 0);  // u = v + 19 < 2^256
+    (void)t;
+    lmask ge = lanes_where((u.w[7] >> 31) != 0);  // v >= p
+    u.w[7] &= 0x7FFFFFFFu;                       // u - 2^255 = v - p
+    v = fe_select(v, u, ge);
+  }
+  return v;
+}
+
+// Add (458-488): a + b; if it carried out of 2^256, add 19 (wrapping); then reduce().
+FEC_DEV fe add(const fe& a, const fe& b) {
+  fe s, s2;
+  lmask carry = add256(s, a, b);
+  add_word256(s2, s, word_select(0u, 19u, carry));
+  return reduce(s2);
+}
+
+// Sub (490-520): a - b; add p (wrapping) if it borrowed.  No reduce.
+FEC_DEV fe sub(const fe& a, const fe& b) {
+  fe d, w;
+  lmask borrow = sub256(d, a, b);
+  sub_word256(w, d, word_select(0u, 19u, borrow));   // d + p = d - 19 + 2^255
+  w.w[7] ^= word_select(0u, 0x80000000u, borrow);
+  return w;
+}
+
+// Neg (547-570): p - a (wrapping), 0 -> 0.
+FEC_DEV fe neg(const fe& a) {
+  fe r;
+  lmask t;
+  FEC_KSUB256(r, a, t, 0xffffffed, -1, -1, -1, -1, -1, -1, -1);  // 2^256 - 19 - a
+  (void)t;
+  r.w[7] ^= 0x80000000u;                                         // - 2^255
+  return fe_select(r, fe_zero(), fe_is_zero(a));
+}
+
+// reduce_wide (260-289): low + 38*high with the carry chain of the reference; the carry out of
+// limb 3 is multiplied by 19 (not 38) and added back, a second carry out is dropped; reduce().
+FEC_DEV fe reduce_wide(const u32 t[16]) {
+  fe low;
+  u64 carry = 0;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    u64 p = (u64)t[8 + i] * 38u + t[i] + carry;
+    low.w[i] = (u32)p;
+    carry = p >> 32;
+  }
+  // carry == floor((low + 38*high) / 2^256) <= 38
+  fe low2;
+  add_word256(low2, low, (u32)carry * 19u);
+  return reduce(low2);
+}
+
+// Mul (522-545)
+FEC_DEV fe mul(const fe& a, const fe& b) {
+  u32 t[16];
+  mul_wide(t, a, b);
+  return reduce_wide(t);
+}
+
+struct pt {
+  fe x, y, z, t;
+};
+
+FEC_DEV pt identity() {  // 1776-1783
+  pt p;
+  p.x = fe_zero();
+  p.y = fe_small(1);
+  p.z = fe_small(1);
+  p.t = fe_zero();
+  return p;
+}
+FEC_DEV lmask is_identity(const pt& p) {  // 1785-1791
+  return fe_is_zero(p.x) & fe_eq(p.y, p.z) & fe_is_zero(p.t);
+}
+FEC_DEV pt pt_select(const pt& a, const pt& b, lmask choice) {
+  pt r;
+  r.x = fe_select(a.x, b.x, choice);
+  r.y = fe_select(a.y, b.y, choice);
+  r.z = fe_select(a.z, b.z, choice);
+  r.t = fe_select(a.t, b.t, choice);
+  return r;
+}
+
+// Add for ExtendedPoint (1864-1928); double() is add(self, self) (1828-1832).
+FEC_DEV pt padd(const pt& p, const pt& q) {
+  fe a = mul(sub(p.y, p.x), sub(q.y, q.x));
+  fe b = mul(add(p.y, p.x), add(q.y, q.x));
+  fe c = mul(mul(p.t, q.t), D_());
+  fe d = mul(p.z, q.z);
+  fe e = sub(b, a);
+  fe f = sub(d, c);
+  fe g = add(d, c);
+  fe h = add(b, a);
+  pt o;
+  o.x = mul(e, f);
+  o.y = mul(g, h);
+  o.t = mul(e, h);
+  o.z = mul(f, g);
+  lmask opposite = fe_eq(p.x, neg(q.x)) & fe_eq(p.y, q.y);  // 1878, raw coordinates
+  o = pt_select(o, identity(), opposite);
+  o = pt_select(o, p, is_identity(q));
+  o = pt_select(o, q, is_identity(p));
+  return o;
+}
+
+// Curve::multiply (2062-2097): LSB-first over scalar.to_raw(); every step computes
+// result + addend, selects it on the bit, and doubles the addend.
+FEC_DEV pt multiply(const pt& point, const u32* kw) {
+  u32 any = 0;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kw[i * KSTRIDE];
+  lmask early = is_identity(point) | lanes_where(any == 0);
+  pt result = identity();
+  pt addend = point;
+#pragma unroll 1
+  for (int i = 0; i < 256; ++i) {
+    lmask bit = lanes_where(((kw[(i >> 5) * KSTRIDE] >> (i & 31)) & 1u) != 0);
+    // one padd instance: pass 0 is result + addend (kept where the bit is set), pass 1 doubles
+    // the addend.  The reference discards pass 0 when the bit is clear (2085-2086).
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      pt lhs = pass == 0 ? result : addend;
+      pt o = padd(lhs, addend);
+      if (pass == 0) result = pt_select(result, o, bit);
+      else addend = o;
+    }
+  }
+  return pt_select(result, identity(), early);
+}
+
+}  // namespace ed
+}  // namespace fecgpu

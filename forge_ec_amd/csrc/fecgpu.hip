@@ -1,0 +1,726 @@
+// fecgpu.hip -- HIP kernels + the extern "C" ABI of include/fecgpu.h.  gfx950 only.
+//
+// Mapping: one scalar-mul per lane, 64 per wavefront, 256-thread workgroups.
+// The (scalar, point) batch is array-of-structs in HBM; each workgroup pulls its 256 elements
+// with fully coalesced 16-byte loads into LDS (transposed to word-major so the per-lane reads
+// are bank-conflict-free), every lane then runs the reference's op sequence on 8 x 32-bit
+// words in VGPRs, and results go back through LDS as coalesced 16-byte stores.  The path is
+// integer-VALU bound (~7*10^5 32-bit multiply-adds per secp256k1 scalar-mul against 224 bytes
+// of HBM traffic), so there is no MFMA and no inter-workgroup communication.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/fecgpu.h"
+#include "ed25519.hpp"
+#include "p256.hpp"
+#include "secp256k1.hpp"
+
+namespace fecgpu {
+
+constexpr int TPB = 256;  // threads per workgroup = 4 wavefronts, one per SIMD
+
+// ------------------------------------------------------------------------------------------
+// curve adaptors: a uniform static interface over the three curve headers
+// ------------------------------------------------------------------------------------------
+struct Secp {
+  static constexpr int PW = 24;  // 32-bit words per point
+  using pt = secp::pt;
+  FEC_DEV static pt load(const u32* l, int stride) {
+    pt p;
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      p.x.w[i] = l[i * stride];
+      p.y.w[i] = l[(8 + i) * stride];
+      p.z.w[i] = l[(16 + i) * stride];
+    }
+    return p;
+  }
+  FEC_DEV static void store(u32* l, int stride, const pt& p) {
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      l[i * stride] = p.x.w[i];
+      l[(8 + i) * stride] = p.y.w[i];
+      l[(16 + i) * stride] = p.z.w[i];
+    }
+  }
+  FEC_DEV static pt multiply(const pt& p, const u32* kw) { return secp::multiply(p, kw); }
+  FEC_DEV static pt padd(const pt& a, const pt& b) { return secp::padd(a, b); }
+  FEC_DEV static pt pdouble(const pt& a) { return secp::pdouble(a); }
+  FEC_DEV static pt pdouble_trait(const pt& a) { return secp::pdouble_trait(a); }
+  FEC_DEV static pt pnegate(const pt& a) {
+    pt r = a;
+    r.y = secp::neg(a.y);
+    return r;
+  }
+  FEC_DEV static fe f_add(const fe& a, const fe& b) { return secp::add(a, b); }
+  FEC_DEV static fe f_sub(const fe& a, const fe& b) { return secp::sub(a, b); }
+  FEC_DEV static fe f_mul(const fe& a, const fe& b) { return secp::mul(a, b); }
+  FEC_DEV static fe f_sqr(const fe& a) { return secp::sqr(a); }
+  FEC_DEV static fe f_neg(const fe& a) { return secp::neg(a); }
+};
+
+struct P256 {
+  static constexpr int PW = 24;
+  using pt = p256::pt;
+  FEC_DEV static pt load(const u32* l, int stride) {
+    pt p;
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      p.x.w[i] = l[i * stride];
+      p.y.w[i] = l[(8 + i) * stride];
+      p.z.w[i] = l[(16 + i) * stride];
+    }
+    return p;
+  }
+  FEC_DEV static void store(u32* l, int stride, const pt& p) {
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      l[i * stride] = p.x.w[i];
+      l[(8 + i) * stride] = p.y.w[i];
+      l[(16 + i) * stride] = p.z.w[i];
+    }
+  }
+  FEC_DEV static pt multiply(const pt& p, const u32* kw) { return p256::multiply(p, kw); }
+  FEC_DEV static pt padd(const pt& a, const pt& b) { return p256::padd(a, b); }
+  FEC_DEV static pt pdouble(const pt& a) { return p256::pdouble(a); }
+  FEC_DEV static pt pdouble_trait(const pt& a) { return p256::pdouble(a); }
+  FEC_DEV static pt pnegate(const pt& a) {
+    pt r = a;
+    r.y = p256::neg(a.y);
+    return r;
+  }
+  FEC_DEV static fe f_add(const fe& a, const fe& b) { return p256::add(a, b); }
+  FEC_DEV static fe f_sub(const fe& a, const fe& b) { return p256::sub(a, b); }
+  FEC_DEV static fe f_mul(const fe& a, const fe& b) { return p256::mul(a, b); }
+  FEC_DEV static fe f_sqr(const fe& a) { return p256::sqr(a); }
+  FEC_DEV static fe f_neg(const fe& a) { return p256::neg(a); }
+};
+
+struct Ed {
+  static constexpr int PW = 32;
+  using pt = ed::pt;
+  FEC_DEV static pt load(const u32* l, int stride) {
+    pt p;
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      p.x.w[i] = l[i * stride];
+      p.y.w[i] = l[(8 + i) * stride];
+      p.z.w[i] = l[(16 + i) * stride];
+      p.t.w[i] = l[(24 + i) * stride];
+    }
+    return p;
+  }
+  FEC_DEV static void store(u32* l, int stride, const pt& p) {
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      l[i * stride] = p.x.w[i];
+      l[(8 + i) * stride] = p.y.w[i];
+      l[(16 + i) * stride] = p.z.w[i];
+      l[(24 + i) * stride] = p.t.w[i];
+    }
+  }
+  FEC_DEV static pt multiply(const pt& p, const u32* kw) { return ed::multiply(p, kw); }
+  FEC_DEV static pt padd(const pt& a, const pt& b) { return ed::padd(a, b); }
+  FEC_DEV static pt pdouble(const pt& a) { return ed::padd(a, a); }
+  FEC_DEV static pt pdouble_trait(const pt& a) { return ed::padd(a, a); }
+  FEC_DEV static pt pnegate(const pt& a) {
+    pt r = a;
+    r.x = ed::neg(a.x);
+    r.t = ed::neg(a.t);
+    return r;
+  }
+  FEC_DEV static fe f_add(const fe& a, const fe& b) { return ed::add(a, b); }
+  FEC_DEV static fe f_sub(const fe& a, const fe& b) { return ed::sub(a, b); }
+  FEC_DEV static fe f_mul(const fe& a, const fe& b) { return ed::mul(a, b); }
+  FEC_DEV static fe f_sqr(const fe& a) { return ed::mul(a, a); }
+  FEC_DEV static fe f_neg(const fe& a) { return ed::neg(a); }
+};
+
+// ------------------------------------------------------------------------------------------
+// HBM <-> LDS staging: coalesced 16-byte accesses, word-major (transposed) LDS image
+//   word w of the workgroup's element e lives at lds[w * TPB + e]
+// ------------------------------------------------------------------------------------------
+template <int W>
+FEC_DEV void stage_in(u32* lds, const u32* g, int valid) {
+  for (int v = threadIdx.x; v < TPB * W / 4; v += TPB) {
+    int e = (v * 4) / W, w = (v * 4) % W;
+    if (e < valid) {
+      uint4 x = *reinterpret_cast<const uint4*>(g + (size_t)v * 4);
+      lds[(w + 0) * TPB + e] = x.x;
+      lds[(w + 1) * TPB + e] = x.y;
+      lds[(w + 2) * TPB + e] = x.z;
+      lds[(w + 3) * TPB + e] = x.w;
+    }
+  }
+}
+template <int W>
+FEC_DEV void stage_out(u32* g, const u32* lds, int valid) {
+  for (int v = threadIdx.x; v < TPB * W / 4; v += TPB) {
+    int e = (v * 4) / W, w = (v * 4) % W;
+    if (e < valid) {
+      uint4 x;
+      x.x = lds[(w + 0) * TPB + e];
+      x.y = lds[(w + 1) * TPB + e];
+      x.z = lds[(w + 2) * TPB + e];
+      x.w = lds[(w + 3) * TPB + e];
+      *reinterpret_cast<uint4*>(g + (size_t)v * 4) = x;
+    }
+  }
+}
+FEC_DEV fe load_fe(const u32* l, int stride) {
+  fe a;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) a.w[i] = l[i * stride];
+  return a;
+}
+FEC_DEV void store_fe(u32* l, int stride, const fe& a) {
+  FEC_UNROLL for (int i = 0; i < 8; ++i) l[i * stride] = a.w[i];
+}
+FEC_DEV int block_valid(size_t n) {
+  size_t first = (size_t)blockIdx.x * TPB;
+  size_t left = n - first;
+  return left < (size_t)TPB ? (int)left : TPB;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+// out[i] = Curve::multiply(FIXED ? base : points[i], scalars[i])
+template <class C, bool FIXED>
+__global__ __launch_bounds__(TPB) void k_batch_mul(const u32* __restrict__ scalars,
+                                                   const u32* __restrict__ points,
+                                                   u32* __restrict__ out, size_t n) {
+  __shared__ u32 lds_k[8 * TPB];
+  __shared__ u32 lds_p[C::PW * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_k, scalars + first * 8, valid);
+  if (!FIXED) stage_in<C::PW>(lds_p, points + first * C::PW, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    typename C::pt p = FIXED ? C::load(points, 1) : C::load(lds_p + e, TPB);
+    typename C::pt r = C::multiply(p, lds_k + e);
+    C::store(lds_p + e, TPB, r);
+  }
+  __syncthreads();
+  stage_out<C::PW>(out + first * C::PW, lds_p, valid);
+}
+
+// out[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])     (ecdsa.rs:254-256)
+template <class C>
+__global__ __launch_bounds__(TPB) void k_batch_double_mul(const u32* __restrict__ u1,
+                                                          const u32* __restrict__ u2,
+                                                          const u32* __restrict__ q,
+                                                          const u32* __restrict__ gen,
+                                                          u32* __restrict__ out, size_t n) {
+  __shared__ u32 lds_k[2][8 * TPB];
+  __shared__ u32 lds_p[C::PW * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_k[0], u1 + first * 8, valid);
+  stage_in<8>(lds_k[1], u2 + first * 8, valid);
+  stage_in<C::PW>(lds_p, q + first * C::PW, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    typename C::pt r[2];
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {  // one copy of the ladder in the code object
+      typename C::pt base = pass == 0 ? C::load(gen, 1) : C::load(lds_p + e, TPB);
+      typename C::pt m = C::multiply(base, lds_k[pass] + e);
+      if (pass == 0) r[0] = m; else r[1] = m;
+    }
+    typename C::pt s = C::padd(r[0], r[1]);
+    C::store(lds_p + e, TPB, s);
+  }
+  __syncthreads();
+  stage_out<C::PW>(out + first * C::PW, lds_p, valid);
+}
+
+template <class C>
+__global__ __launch_bounds__(TPB) void k_field_op(int op, const u32* __restrict__ a,
+                                                  const u32* __restrict__ b, u32* __restrict__ out,
+                                                  size_t n) {
+  __shared__ u32 lds_a[8 * TPB];
+  __shared__ u32 lds_b[8 * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_a, a + first * 8, valid);
+  if (b) stage_in<8>(lds_b, b + first * 8, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    fe x = load_fe(lds_a + e, TPB);
+    fe y = b ? load_fe(lds_b + e, TPB) : fe_zero();
+    fe r;
+    switch (op) {
+      case FEC_F_ADD: r = C::f_add(x, y); break;
+      case FEC_F_SUB: r = C::f_sub(x, y); break;
+      case FEC_F_MUL: r = C::f_mul(x, y); break;
+      case FEC_F_SQR: r = C::f_sqr(x); break;
+      default: r = C::f_neg(x); break;
+    }
+    store_fe(lds_a + e, TPB, r);
+  }
+  __syncthreads();
+  stage_out<8>(out + first * 8, lds_a, valid);
+}
+
+template <class C>
+__global__ __launch_bounds__(TPB) void k_point_op(int op, const u32* __restrict__ p,
+                                                  const u32* __restrict__ q, u32* __restrict__ out,
+                                                  size_t n) {
+  __shared__ u32 lds_p[C::PW * TPB];
+  __shared__ u32 lds_q[C::PW * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<C::PW>(lds_p, p + first * C::PW, valid);
+  if (q) stage_in<C::PW>(lds_q, q + first * C::PW, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    typename C::pt a = C::load(lds_p + e, TPB);
+    typename C::pt r;
+    switch (op) {
+      case FEC_P_ADD: {
+        typename C::pt b = C::load(lds_q + e, TPB);
+        r = C::padd(a, b);
+        break;
+      }
+      case FEC_P_DOUBLE: r = C::pdouble(a); break;
+      case FEC_P_NEGATE: r = C::pnegate(a); break;
+      default: r = C::pdouble_trait(a); break;
+    }
+    C::store(lds_p + e, TPB, r);
+  }
+  __syncthreads();
+  stage_out<C::PW>(out + first * C::PW, lds_p, valid);
+}
+
+// Peak 32x32+64 multiply-add rate: 8 independent v_mad_u64_u32 chains per lane, no memory.
+constexpr int PEAK_ITERS = 4096;
+__global__ __launch_bounds__(TPB) void k_peak_mad32(u32* out, u32 seed) {
+  u32 a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u;
+  u64 c0 = a, c1 = b, c2 = a + 1, c3 = b + 2, c4 = a + 3, c5 = b + 4, c6 = a + 5, c7 = b + 6;
+  for (int it = 0; it < PEAK_ITERS; ++it) {
+#define FEC_MAD8                                                                            \
+  "v_mad_u64_u32 %0, s[10:11], %8, %9, %0\n v_mad_u64_u32 %1, s[12:13], %8, %9, %1\n"       \
+  "v_mad_u64_u32 %2, s[14:15], %8, %9, %2\n v_mad_u64_u32 %3, s[16:17], %8, %9, %3\n"       \
+  "v_mad_u64_u32 %4, s[18:19], %8, %9, %4\n v_mad_u64_u32 %5, s[20:21], %8, %9, %5\n"       \
+  "v_mad_u64_u32 %6, s[22:23], %8, %9, %6\n v_mad_u64_u32 %7, s[24:25], %8, %9, %7\n"
+    asm volatile(FEC_MAD8 FEC_MAD8 FEC_MAD8 FEC_MAD8 FEC_MAD8 FEC_MAD8 FEC_MAD8 FEC_MAD8
+                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+                 : "v"(a), "v"(b)
+                 : "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20",
+                   "s21", "s22", "s23", "s24", "s25");
+#undef FEC_MAD8
+  }
+  u64 cs = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = (u32)cs ^ (u32)(cs >> 32);
+}
+
+}  // namespace fecgpu
+
+// ==========================================================================================
+// host side: context + extern "C" ABI
+// ==========================================================================================
+using namespace fecgpu;
+
+struct fec_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing = false, timed = false;
+  const char* last_kernel = "";
+  // device staging for the host-pointer entry points
+  void* d_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[4] = {0, 0, 0, 0};
+  u64* d_gen[3] = {nullptr, nullptr, nullptr};  // reference generator() per curve, device copy
+  hipDeviceProp_t prop;
+};
+
+namespace {
+
+// Inputs of generator() as the reference writes them.  secp256k1 (secp256k1.rs:2608-2625) pushes
+// the affine constants through its own to_montgomery(), i.e. Mul by the reference's R_SQUARED
+// (219-235); Ed25519 (ed25519.rs:2015-2052) hard-codes x, y and from_affine() sets t = x*y.  Both
+// products are evaluated on the device with the same Mul kernels at ctx creation, so the table
+// below holds only the reference's literals.  P-256 (p256.rs:2092-2110) is plain affine, Z = 1.
+const u64 SECP_GXY[8] = {0x59F2815B16F81798ULL, 0x029BFCDB2DCE28D9ULL, 0x55A06295CE870B07ULL,
+                         0x79BE667EF9DCBBACULL, 0x9C47D08FFB10D4B8ULL, 0xFD17B448A6855419ULL,
+                         0x5DA4FBFC0E1108A8ULL, 0x483ADA7726A3C465ULL};
+const u64 SECP_R2X2[8] = {0x000E9F61ULL, 0x07A20000ULL, 0x00000100ULL, 0, 0x000E9F61ULL, 0x07A20000ULL,
+                          0x00000100ULL, 0};
+const u64 GEN_P256[12] = {0xF4A13945D898C296ULL, 0x77037D812DEB33A0ULL, 0xF8BCE6E563A440F2ULL,
+                          0x6B17D1F2E12C4247ULL, 0xCBB6406837BF51F5ULL, 0x2BCE33576B315ECEULL,
+                          0x8EE7EB4A7C0F9E16ULL, 0x4FE342E2FE1A7F9BULL, 1,
+                          0,                     0,                     0};
+const u64 GEN_ED[16] = {0x1A1462FAFB9683F2ULL, 0xD2E8A68B8B30C404ULL, 0xA0C0F3A1E9E71B63ULL,
+                        0x216936D3CD6E53FEULL, 0x2DFC9311D90045F9ULL, 0x0A71C760BF38C6A7ULL,
+                        0xA6FB8EEBCEAA2C8DULL, 0x5FD9C9E6CC3CCCCCULL, 1, 0, 0, 0,
+                        0, 0, 0, 0};  // T is filled in on the device
+const u64 FE_ONE[4] = {1, 0, 0, 0};
+
+inline bool curve_ok(int c) { return c == FEC_SECP256K1 || c == FEC_P256 || c == FEC_ED25519; }
+inline int plimbs(int c) { return c == FEC_ED25519 ? 16 : 12; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int ensure(fec_ctx* ctx, int slot, size_t bytes) {
+  if (ctx->d_cap[slot] >= bytes) return FEC_OK;
+  if (ctx->d_buf[slot]) (void)hipFree(ctx->d_buf[slot]);
+  ctx->d_buf[slot] = nullptr;
+  ctx->d_cap[slot] = 0;
+  size_t cap = bytes + (bytes >> 2) + 4096;
+  if (hipMalloc(&ctx->d_buf[slot], cap) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_OOM;
+  }
+  ctx->d_cap[slot] = cap;
+  return FEC_OK;
+}
+
+struct Launch {
+  fec_ctx* ctx;
+  hipStream_t s;
+  Launch(fec_ctx* c, void* stream, const char* name) : ctx(c), s(stream ? (hipStream_t)stream : c->stream) {
+    ctx->last_kernel = name;
+    ctx->timed = false;
+    if (ctx->timing) (void)hipEventRecord(ctx->ev0, s);
+  }
+  int done() {
+    hipError_t e = hipGetLastError();
+    if (ctx->timing) {
+      (void)hipEventRecord(ctx->ev1, s);
+      ctx->timed = true;
+    }
+    return e == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
+  }
+};
+
+inline unsigned grid_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp, u64* dout, size_t n,
+               void* stream) {
+  if (n == 0) return FEC_OK;
+  const u32* s = reinterpret_cast<const u32*>(ds);
+  const u32* p = reinterpret_cast<const u32*>(dp);
+  u32* o = reinterpret_cast<u32*>(dout);
+  dim3 g(grid_for(n)), b(TPB);
+  Launch L(ctx, stream, fixed ? "k_batch_mul<fixed>" : "k_batch_mul<var>");
+  switch (curve) {
+    case FEC_SECP256K1:
+      if (fixed) hipLaunchKernelGGL((k_batch_mul<Secp, true>), g, b, 0, L.s, s, p, o, n);
+      else hipLaunchKernelGGL((k_batch_mul<Secp, false>), g, b, 0, L.s, s, p, o, n);
+      break;
+    case FEC_P256:
+      if (fixed) hipLaunchKernelGGL((k_batch_mul<P256, true>), g, b, 0, L.s, s, p, o, n);
+      else hipLaunchKernelGGL((k_batch_mul<P256, false>), g, b, 0, L.s, s, p, o, n);
+      break;
+    default:
+      if (fixed) hipLaunchKernelGGL((k_batch_mul<Ed, true>), g, b, 0, L.s, s, p, o, n);
+      else hipLaunchKernelGGL((k_batch_mul<Ed, false>), g, b, 0, L.s, s, p, o, n);
+      break;
+  }
+  return L.done();
+}
+
+int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, const u64* dq, u64* dout,
+                      size_t n, void* stream) {
+  if (n == 0) return FEC_OK;
+  const u32* a = reinterpret_cast<const u32*>(d1);
+  const u32* b2 = reinterpret_cast<const u32*>(d2);
+  const u32* q = reinterpret_cast<const u32*>(dq);
+  const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
+  u32* o = reinterpret_cast<u32*>(dout);
+  dim3 g(grid_for(n)), b(TPB);
+  Launch L(ctx, stream, "k_batch_double_mul");
+  switch (curve) {
+    case FEC_SECP256K1: hipLaunchKernelGGL((k_batch_double_mul<Secp>), g, b, 0, L.s, a, b2, q, gen, o, n); break;
+    case FEC_P256: hipLaunchKernelGGL((k_batch_double_mul<P256>), g, b, 0, L.s, a, b2, q, gen, o, n); break;
+    default: hipLaunchKernelGGL((k_batch_double_mul<Ed>), g, b, 0, L.s, a, b2, q, gen, o, n); break;
+  }
+  return L.done();
+}
+
+int launch_field(fec_ctx* ctx, int curve, int op, const u64* da, const u64* db, u64* dout, size_t n) {
+  if (n == 0) return FEC_OK;
+  const u32* a = reinterpret_cast<const u32*>(da);
+  const u32* bb = reinterpret_cast<const u32*>(db);
+  u32* o = reinterpret_cast<u32*>(dout);
+  dim3 g(grid_for(n)), b(TPB);
+  Launch L(ctx, nullptr, "k_field_op");
+  switch (curve) {
+    case FEC_SECP256K1: hipLaunchKernelGGL((k_field_op<Secp>), g, b, 0, L.s, op, a, bb, o, n); break;
+    case FEC_P256: hipLaunchKernelGGL((k_field_op<P256>), g, b, 0, L.s, op, a, bb, o, n); break;
+    default: hipLaunchKernelGGL((k_field_op<Ed>), g, b, 0, L.s, op, a, bb, o, n); break;
+  }
+  return L.done();
+}
+
+int launch_point(fec_ctx* ctx, int curve, int op, const u64* dp, const u64* dq, u64* dout, size_t n) {
+  if (n == 0) return FEC_OK;
+  const u32* p = reinterpret_cast<const u32*>(dp);
+  const u32* q = reinterpret_cast<const u32*>(dq);
+  u32* o = reinterpret_cast<u32*>(dout);
+  dim3 g(grid_for(n)), b(TPB);
+  Launch L(ctx, nullptr, "k_point_op");
+  switch (curve) {
+    case FEC_SECP256K1: hipLaunchKernelGGL((k_point_op<Secp>), g, b, 0, L.s, op, p, q, o, n); break;
+    case FEC_P256: hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, op, p, q, o, n); break;
+    default: hipLaunchKernelGGL((k_point_op<Ed>), g, b, 0, L.s, op, p, q, o, n); break;
+  }
+  return L.done();
+}
+
+// copy up to three host inputs in, run `body` on device buffers, copy the output back
+template <class F>
+int host_roundtrip(fec_ctx* ctx, const void* h0, size_t b0, const void* h1, size_t b1, const void* h2,
+                   size_t b2, void* hout, size_t bout, F body) {
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  const void* hin[3] = {h0, h1, h2};
+  size_t bin[3] = {b0, b1, b2};
+  for (int i = 0; i < 3; ++i) {
+    if (!hin[i] || bin[i] == 0) continue;
+    int rc = ensure(ctx, i, bin[i]);
+    if (rc != FEC_OK) return rc;
+    if (hipMemcpyAsync(ctx->d_buf[i], hin[i], bin[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  }
+  int rc = ensure(ctx, 3, bout);
+  if (rc != FEC_OK) return rc;
+  rc = body(h0 ? ctx->d_buf[0] : nullptr, h1 ? ctx->d_buf[1] : nullptr, h2 ? ctx->d_buf[2] : nullptr,
+            ctx->d_buf[3]);
+  if (rc != FEC_OK) return rc;
+  if (hipMemcpyAsync(hout, ctx->d_buf[3], bout, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  return FEC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fec_point_limbs(fec_curve curve) { return curve_ok(curve) ? plimbs(curve) : 0; }
+
+const char* fec_strerror(int status) {
+  switch (status) {
+    case FEC_OK: return "ok";
+    case FEC_E_ARG: return "invalid argument";
+    case FEC_E_DEVICE: return "no usable gfx950 GPU / HIP runtime error (there is no CPU fallback)";
+    case FEC_E_OOM: return "out of device memory";
+    case FEC_E_LAUNCH: return "kernel launch or execution failed";
+    case FEC_E_UNSUPPORTED: return "operation not supported for this curve";
+    default: return "unknown fecgpu status";
+  }
+}
+
+int fec_ctx_create(fec_ctx** out, int device) {
+  if (!out) return FEC_E_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return FEC_E_DEVICE;
+  }
+  if (device < 0 || device >= count) return FEC_E_ARG;
+  if (hipSetDevice(device) != hipSuccess) return FEC_E_DEVICE;
+  fec_ctx* ctx = new (std::nothrow) fec_ctx();
+  if (!ctx) return FEC_E_OOM;
+  ctx->device = device;
+  if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
+      std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0 ||
+      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    (void)hipGetLastError();
+    fec_ctx_destroy(ctx);
+    return FEC_E_DEVICE;
+  }
+  for (int c = 0; c < 3; ++c) {
+    if (hipMalloc(&ctx->d_gen[c], (size_t)plimbs(c) * 8) != hipSuccess) {
+      fec_ctx_destroy(ctx);
+      return FEC_E_OOM;
+    }
+  }
+  {
+    bool ok = ensure(ctx, 0, 64) == FEC_OK && ensure(ctx, 1, 64) == FEC_OK;
+    ok = ok && hipMemcpy(ctx->d_buf[0], SECP_GXY, 64, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(ctx->d_buf[1], SECP_R2X2, 64, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(ctx->d_gen[0] + 8, FE_ONE, 32, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(ctx->d_gen[1], GEN_P256, 96, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(ctx->d_gen[2], GEN_ED, 128, hipMemcpyHostToDevice) == hipSuccess;
+    // secp256k1: (gx, gy) * R_SQUARED;  Ed25519: t = x * y
+    ok = ok && launch_field(ctx, FEC_SECP256K1, FEC_F_MUL, (const u64*)ctx->d_buf[0],
+                            (const u64*)ctx->d_buf[1], ctx->d_gen[0], 2) == FEC_OK;
+    ok = ok && launch_field(ctx, FEC_ED25519, FEC_F_MUL, ctx->d_gen[2], ctx->d_gen[2] + 4,
+                            ctx->d_gen[2] + 12, 1) == FEC_OK;
+    ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      fec_ctx_destroy(ctx);
+      return FEC_E_LAUNCH;
+    }
+  }
+  *out = ctx;
+  return FEC_OK;
+}
+
+void fec_ctx_destroy(fec_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+  for (int i = 0; i < 4; ++i)
+    if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
+  for (int i = 0; i < 3; ++i)
+    if (ctx->d_gen[i]) (void)hipFree(ctx->d_gen[i]);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int fec_batch_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* ds, const uint64_t* dp, uint64_t* dout,
+                      size_t n, void* stream) {
+  if (!ctx || !curve_ok(curve) || (n && (!ds || !dp || !dout))) return FEC_E_ARG;
+  if (!aligned16(ds) || !aligned16(dp) || !aligned16(dout)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_mul(ctx, curve, false, ds, dp, dout, n, stream);
+}
+
+int fec_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* ds, const uint64_t* dbase,
+                            uint64_t* dout, size_t n, void* stream) {
+  if (!ctx || !curve_ok(curve) || (n && (!ds || !dbase || !dout))) return FEC_E_ARG;
+  if (!aligned16(ds) || !aligned16(dbase) || !aligned16(dout)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_mul(ctx, curve, true, ds, dbase, dout, n, stream);
+}
+
+int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d1, const uint64_t* d2,
+                             const uint64_t* dq, uint64_t* dout, size_t n, void* stream) {
+  if (!ctx || !curve_ok(curve) || (n && (!d1 || !d2 || !dq || !dout))) return FEC_E_ARG;
+  if (!aligned16(d1) || !aligned16(d2) || !aligned16(dq) || !aligned16(dout)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_double_mul(ctx, curve, d1, d2, dq, dout, n, stream);
+}
+
+int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points,
+                  uint64_t* out, size_t n) {
+  if (!ctx || !curve_ok(curve) || (n && (!scalars || !points || !out))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  size_t pb = (size_t)plimbs(curve) * 8;
+  return host_roundtrip(ctx, scalars, n * 32, points, n * pb, nullptr, 0, out, n * pb,
+                        [&](void* a, void* b, void*, void* o) {
+                          return launch_mul(ctx, curve, false, (const u64*)a, (const u64*)b, (u64*)o, n, nullptr);
+                        });
+}
+
+int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* base,
+                        uint64_t* out, size_t n) {
+  if (!ctx || !curve_ok(curve) || !base || (n && (!scalars || !out))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  size_t pb = (size_t)plimbs(curve) * 8;
+  return host_roundtrip(ctx, scalars, n * 32, base, pb, nullptr, 0, out, n * pb,
+                        [&](void* a, void* b, void*, void* o) {
+                          return launch_mul(ctx, curve, true, (const u64*)a, (const u64*)b, (u64*)o, n, nullptr);
+                        });
+}
+
+int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, const uint64_t* u2,
+                         const uint64_t* q, uint64_t* out, size_t n) {
+  if (!ctx || !curve_ok(curve) || (n && (!u1 || !u2 || !q || !out))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  size_t pb = (size_t)plimbs(curve) * 8;
+  return host_roundtrip(ctx, u1, n * 32, u2, n * 32, q, n * pb, out, n * pb,
+                        [&](void* a, void* b, void* c, void* o) {
+                          return launch_double_mul(ctx, curve, (const u64*)a, (const u64*)b, (const u64*)c,
+                                                   (u64*)o, n, nullptr);
+                        });
+}
+
+int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a, const uint64_t* b,
+                 uint64_t* out, size_t n) {
+  if (!ctx || !curve_ok(curve) || op < FEC_F_ADD || op > FEC_F_NEG || (n && (!a || !out))) return FEC_E_ARG;
+  bool binary = op == FEC_F_ADD || op == FEC_F_SUB || op == FEC_F_MUL;
+  if (binary && n && !b) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  return host_roundtrip(ctx, a, n * 32, binary ? b : nullptr, n * 32, nullptr, 0, out, n * 32,
+                        [&](void* x, void* y, void*, void* o) {
+                          return launch_field(ctx, curve, op, (const u64*)x, (const u64*)y, (u64*)o, n);
+                        });
+}
+
+int fec_point_op(fec_ctx* ctx, fec_curve curve, fec_point_opcode op, const uint64_t* p, const uint64_t* q,
+                 uint64_t* out, size_t n) {
+  if (!ctx || !curve_ok(curve) || op < FEC_P_ADD || op > FEC_P_DOUBLE_TRAIT || (n && (!p || !out)))
+    return FEC_E_ARG;
+  if (op == FEC_P_DOUBLE_TRAIT && curve != FEC_SECP256K1) return FEC_E_UNSUPPORTED;
+  if (op == FEC_P_ADD && n && !q) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  size_t pb = (size_t)plimbs(curve) * 8;
+  return host_roundtrip(ctx, p, n * pb, op == FEC_P_ADD ? q : nullptr, n * pb, nullptr, 0, out, n * pb,
+                        [&](void* x, void* y, void*, void* o) {
+                          return launch_point(ctx, curve, op, (const u64*)x, (const u64*)y, (u64*)o, n);
+                        });
+}
+
+int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out) {
+  if (!ctx || !curve_ok(curve) || !out) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  if (hipMemcpy(out, ctx->d_gen[curve], (size_t)plimbs(curve) * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_DEVICE;
+  }
+  return FEC_OK;
+}
+
+int fec_ctx_set_timing(fec_ctx* ctx, int enabled) {
+  if (!ctx) return FEC_E_ARG;
+  ctx->timing = enabled != 0;
+  ctx->timed = false;
+  return FEC_OK;
+}
+
+int fec_ctx_last_kernel_ms(fec_ctx* ctx, float* ms, const char** kernel_name) {
+  if (!ctx || !ms) return FEC_E_ARG;
+  if (!ctx->timed) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  if (hipEventSynchronize(ctx->ev1) != hipSuccess || hipEventElapsedTime(ms, ctx->ev0, ctx->ev1) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  if (kernel_name) *kernel_name = ctx->last_kernel;
+  return FEC_OK;
+}
+
+int fec_measure_peak_mad32(fec_ctx* ctx, double* mad32_per_sec) {
+  if (!ctx || !mad32_per_sec) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  const int blocks = ctx->prop.multiProcessorCount * 8;  // 8 wavefronts per SIMD
+  int rc = ensure(ctx, 3, (size_t)blocks * TPB * sizeof(u32));
+  if (rc != FEC_OK) return rc;
+  u32* out = (u32*)ctx->d_buf[3];
+  double best = 0;
+  for (int rep = 0; rep < 4; ++rep) {  // first rep warms up
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
+    hipLaunchKernelGGL(k_peak_mad32, dim3(blocks), dim3(TPB), 0, ctx->stream, out, (u32)rep);
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    if (hipGetLastError() != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess) return FEC_E_LAUNCH;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    double rate = (double)blocks * TPB * (double)PEAK_ITERS * 64.0 / (ms * 1e-3);
+    if (rep > 0 && rate > best) best = rate;
+  }
+  *mad32_per_sec = best;
+  return FEC_OK;
+}
+
+int fec_ctx_device_info(fec_ctx* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz) {
+  if (!ctx) return FEC_E_ARG;
+  if (name && name_len) {
+    std::snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  }
+  if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = ctx->prop.clockRate;
+  return FEC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,355 @@
+// limbs.hpp -- 256-bit limb primitives for gfx950 (CDNA4) integer VALU.
+//
+// Representation: a field element / scalar is 8 x uint32 little-endian words held in VGPRs (one
+// scalar-mul per lane, 64 per wavefront).  The reference's u64 limb i is the word pair
+// (w[2i], w[2i+1]).  All loops are fully unrolled with compile-time indices so nothing lands in
+// scratch.
+//
+// Per-lane predicates are LANE MASKS (`lmask`, one bit per lane, held in an SGPR pair): carry
+// chains export their carry-out as a mask, masks are combined with scalar ALU ops, selects
+// consume them with VOP3 v_cndmask, and rare paths branch on `mask != 0` (wave-uniform).
+//
+// Why inline asm for carry chains and selects (measured on MI355X, profiles/valu_rates*_r01.txt):
+//  * v_mad_u64_u32, v_add_co/v_addc_co, v_cmp and 3-operand VOP3 integer ops all issue at ~4.5
+//    cycles per wave-instruction, plain VOP2 at ~2.5: the cost model is "count instructions".
+//  * VOP2 `v_cndmask_b32_e32 ..., vcc` -- what hipcc emits for every select whose condition sits
+//    in VCC -- measures 23 cycles; the VOP3 form on an SGPR pair 4.6.
+//  * hipcc pads every VCC write->read with s_nop (6.3 vs 4.4 cycles per chained v_addc); a
+//    2*10^10-chain stress of nop-less v_addc/v_subb chains (tools/microbench/valu_rates3.hip)
+//    found no mismatch at 1..8 waves/SIMD.
+//  * ROCm 7.2 hipcc MISCOMPILES a __builtin_subc chain followed by a __builtin_addc chain: it
+//    fuses the top words into v_addc(x, borrow ? -1 : 0, carry), whose carry-out is wrong
+//    whenever the borrow reaches the top word (caught by the edge-operand parity test).
+#pragma once
+#include <stdint.h>
+#ifdef FEC_HOST_EMUL
+// Host emulation of the device headers (tools/host_emul.cpp): logic checks and sanitizers on the
+// CPU build; never part of the shipped library.  One "lane": lmask is 0 or all-ones.
+#define FEC_DEV static inline
+#else
+#include <hip/hip_runtime.h>
+#define FEC_DEV __device__ __forceinline__
+#endif
+
+namespace fecgpu {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef u64 lmask;  // one bit per lane
+
+// scalars are staged in LDS word-major: word k of this lane's scalar is kw[k * KSTRIDE]
+constexpr int KSTRIDE = 256;
+
+struct fe {
+  u32 w[8];
+};
+
+#define FEC_UNROLL _Pragma("unroll")
+
+#ifdef FEC_HOST_EMUL
+FEC_DEV lmask lanes_where(bool c) { return c ? ~0ull : 0ull; }
+#else
+FEC_DEV lmask lanes_where(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+#endif
+
+FEC_DEV fe fe_zero() {
+  fe r;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) r.w[i] = 0;
+  return r;
+}
+FEC_DEV fe fe_small(u32 x) {
+  fe r = fe_zero();
+  r.w[0] = x;
+  return r;
+}
+FEC_DEV lmask fe_eq(const fe& a, const fe& b) {
+  u32 d = 0;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) d |= a.w[i] ^ b.w[i];
+  return lanes_where(d == 0);
+}
+FEC_DEV lmask fe_is_zero(const fe& a) {
+  u32 d = 0;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) d |= a.w[i];
+  return lanes_where(d == 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// carry chains and selects
+// ------------------------------------------------------------------------------------------
+#ifdef FEC_HOST_EMUL
+
+FEC_DEV lmask add256(fe& r, const fe& a, const fe& b) {
+  u64 c = 0;
+  for (int i = 0; i < 8; ++i) {
+    u64 s = (u64)a.w[i] + b.w[i] + c;
+    r.w[i] = (u32)s;
+    c = s >> 32;
+  }
+  return c ? ~0ull : 0ull;
+}
+FEC_DEV lmask sub256(fe& r, const fe& a, const fe& b) {
+  u64 bo = 0;
+  for (int i = 0; i < 8; ++i) {
+    u64 d = (u64)a.w[i] - b.w[i] - bo;
+    r.w[i] = (u32)d;
+    bo = (d >> 32) & 1;
+  }
+  return bo ? ~0ull : 0ull;
+}
+FEC_DEV fe fe_k8(u32 k0, u32 k1, u32 k2, u32 k3, u32 k4, u32 k5, u32 k6, u32 k7) {
+  fe k;
+  k.w[0] = k0; k.w[1] = k1; k.w[2] = k2; k.w[3] = k3; k.w[4] = k4; k.w[5] = k5; k.w[6] = k6; k.w[7] = k7;
+  return k;
+}
+#define FEC_K8(k0, k1, k2, k3, k4, k5, k6, k7) \
+  fe_k8((u32)(k0), (u32)(k1), (u32)(k2), (u32)(k3), (u32)(k4), (u32)(k5), (u32)(k6), (u32)(k7))
+#define FEC_ADDK256_(r, a, c, k0, k1, k2, k3, k4, k5, k6, k7) c = add256(r, a, FEC_K8(k0, k1, k2, k3, k4, k5, k6, k7))
+#define FEC_SUBK256_(r, a, c, k0, k1, k2, k3, k4, k5, k6, k7) c = sub256(r, a, FEC_K8(k0, k1, k2, k3, k4, k5, k6, k7))
+#define FEC_KSUB256_(r, a, c, k0, k1, k2, k3, k4, k5, k6, k7) c = sub256(r, FEC_K8(k0, k1, k2, k3, k4, k5, k6, k7), a)
+// r = a - (hi:lo) mod 2^256 (lo, hi per-lane words)
+FEC_DEV lmask sub_lohi256(fe& r, const fe& a, u32 lo, u32 hi) { return sub256(r, a, FEC_K8(lo, hi, 0, 0, 0, 0, 0, 0)); }
+// r = a + k mod 2^256 (k a per-lane word)
+FEC_DEV lmask add_word256(fe& r, const fe& a, u32 k) { return add256(r, a, FEC_K8(k, 0, 0, 0, 0, 0, 0, 0)); }
+// r = a - k mod 2^256 (k a per-lane word)
+FEC_DEV lmask sub_word256(fe& r, const fe& a, u32 k) { return sub256(r, a, FEC_K8(k, 0, 0, 0, 0, 0, 0, 0)); }
+// m ? b : a on single words
+FEC_DEV u32 word_select(u32 a, u32 b, lmask m) { return m ? b : a; }
+// r = m ? b : a   (subtle::ConditionallySelectable::conditional_select(a, b, choice))
+FEC_DEV fe fe_select(const fe& a, const fe& b, lmask m) { return m ? b : a; }
+
+#else  // ---- gfx950 ----
+
+// All multi-instruction asm statements below are IN-PLACE: each output word is tied ("+v") to the
+// input word of the same index, so no instruction can overwrite a register a later instruction
+// still reads, and the allocator may reuse the first operand's registers when it is dead.
+#define FEC_RW8(x) "+v"(x.w[0]), "+v"(x.w[1]), "+v"(x.w[2]), "+v"(x.w[3]), "+v"(x.w[4]), "+v"(x.w[5]), "+v"(x.w[6]), "+v"(x.w[7])
+#define FEC_V8(x) "v"(x.w[0]), "v"(x.w[1]), "v"(x.w[2]), "v"(x.w[3]), "v"(x.w[4]), "v"(x.w[5]), "v"(x.w[6]), "v"(x.w[7])
+
+// r = a + b mod 2^256; returns the carry-out lane mask.
+FEC_DEV lmask add256(fe& r, const fe& a, const fe& b) {
+  lmask c;
+  fe x = a;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %9\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %10, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, %2, %11, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, %3, %12, vcc\n\t"
+      "v_addc_co_u32_e32 %4, vcc, %4, %13, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, %5, %14, vcc\n\t"
+      "v_addc_co_u32_e32 %6, vcc, %6, %15, vcc\n\t"
+      "v_addc_co_u32_e32 %7, vcc, %7, %16, vcc\n\t"
+      "s_mov_b64 %8, vcc"
+      : FEC_RW8(x), "=s"(c)
+      : FEC_V8(b)
+      : "vcc");
+  r = x;
+  return c;
+}
+// r = a - b mod 2^256; returns the borrow-out lane mask.
+FEC_DEV lmask sub256(fe& r, const fe& a, const fe& b) {
+  lmask c;
+  fe x = a;
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %9\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %1, %10, vcc\n\t"
+      "v_subb_co_u32_e32 %2, vcc, %2, %11, vcc\n\t"
+      "v_subb_co_u32_e32 %3, vcc, %3, %12, vcc\n\t"
+      "v_subb_co_u32_e32 %4, vcc, %4, %13, vcc\n\t"
+      "v_subb_co_u32_e32 %5, vcc, %5, %14, vcc\n\t"
+      "v_subb_co_u32_e32 %6, vcc, %6, %15, vcc\n\t"
+      "v_subb_co_u32_e32 %7, vcc, %7, %16, vcc\n\t"
+      "s_mov_b64 %8, vcc"
+      : FEC_RW8(x), "=s"(c)
+      : FEC_V8(b)
+      : "vcc");
+  r = x;
+  return c;
+}
+// r = a + K, K = {k0..k7} compile-time words riding in the VOP2 src0 slot (no registers).  k0 may
+// be any 32-bit literal; k1..k7 must be inline constants (-16..64): a literal plus the VCC
+// carry-in would be two constant-bus reads.  c receives the carry-out mask.
+#define FEC_ADDK256_(r, a, c, k0, k1, k2, k3, k4, k5, k6, k7) \
+  do { \
+    fe fec_x_ = (a); \
+    asm("v_add_co_u32_e32 %0, vcc, " #k0 ", %0\n\t" \
+        "v_addc_co_u32_e32 %1, vcc, " #k1 ", %1, vcc\n\t" \
+        "v_addc_co_u32_e32 %2, vcc, " #k2 ", %2, vcc\n\t" \
+        "v_addc_co_u32_e32 %3, vcc, " #k3 ", %3, vcc\n\t" \
+        "v_addc_co_u32_e32 %4, vcc, " #k4 ", %4, vcc\n\t" \
+        "v_addc_co_u32_e32 %5, vcc, " #k5 ", %5, vcc\n\t" \
+        "v_addc_co_u32_e32 %6, vcc, " #k6 ", %6, vcc\n\t" \
+        "v_addc_co_u32_e32 %7, vcc, " #k7 ", %7, vcc\n\t" \
+        "s_mov_b64 %8, vcc" \
+        : FEC_RW8(fec_x_), "=s"(c) : : "vcc"); \
+    (r) = fec_x_; \
+  } while (0)
+// r = a - K; c receives the borrow-out mask.
+#define FEC_SUBK256_(r, a, c, k0, k1, k2, k3, k4, k5, k6, k7) \
+  do { \
+    fe fec_x_ = (a); \
+    asm("v_subrev_co_u32_e32 %0, vcc, " #k0 ", %0\n\t" \
+        "v_subbrev_co_u32_e32 %1, vcc, " #k1 ", %1, vcc\n\t" \
+        "v_subbrev_co_u32_e32 %2, vcc, " #k2 ", %2, vcc\n\t" \
+        "v_subbrev_co_u32_e32 %3, vcc, " #k3 ", %3, vcc\n\t" \
+        "v_subbrev_co_u32_e32 %4, vcc, " #k4 ", %4, vcc\n\t" \
+        "v_subbrev_co_u32_e32 %5, vcc, " #k5 ", %5, vcc\n\t" \
+        "v_subbrev_co_u32_e32 %6, vcc, " #k6 ", %6, vcc\n\t" \
+        "v_subbrev_co_u32_e32 %7, vcc, " #k7 ", %7, vcc\n\t" \
+        "s_mov_b64 %8, vcc" \
+        : FEC_RW8(fec_x_), "=s"(c) : : "vcc"); \
+    (r) = fec_x_; \
+  } while (0)
+// r = K - a; c receives the borrow-out mask.
+#define FEC_KSUB256_(r, a, c, k0, k1, k2, k3, k4, k5, k6, k7) \
+  do { \
+    fe fec_x_ = (a); \
+    asm("v_sub_co_u32_e32 %0, vcc, " #k0 ", %0\n\t" \
+        "v_subb_co_u32_e32 %1, vcc, " #k1 ", %1, vcc\n\t" \
+        "v_subb_co_u32_e32 %2, vcc, " #k2 ", %2, vcc\n\t" \
+        "v_subb_co_u32_e32 %3, vcc, " #k3 ", %3, vcc\n\t" \
+        "v_subb_co_u32_e32 %4, vcc, " #k4 ", %4, vcc\n\t" \
+        "v_subb_co_u32_e32 %5, vcc, " #k5 ", %5, vcc\n\t" \
+        "v_subb_co_u32_e32 %6, vcc, " #k6 ", %6, vcc\n\t" \
+        "v_subb_co_u32_e32 %7, vcc, " #k7 ", %7, vcc\n\t" \
+        "s_mov_b64 %8, vcc" \
+        : FEC_RW8(fec_x_), "=s"(c) : : "vcc"); \
+    (r) = fec_x_; \
+  } while (0)
+// r = a - (hi:lo) mod 2^256 (lo, hi per-lane words); returns the borrow-out mask.
+FEC_DEV lmask sub_lohi256(fe& r, const fe& a, u32 lo, u32 hi) {
+  lmask c;
+  fe x = a;
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %9\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %1, %10, vcc\n\t"
+      "v_subbrev_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+      "v_subbrev_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+      "v_subbrev_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+      "v_subbrev_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+      "v_subbrev_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+      "v_subbrev_co_u32_e32 %7, vcc, 0, %7, vcc\n\t"
+      "s_mov_b64 %8, vcc"
+      : FEC_RW8(x), "=s"(c)
+      : "v"(lo), "v"(hi)
+      : "vcc");
+  r = x;
+  return c;
+}
+// r = a + k mod 2^256 (k a per-lane word); returns the carry-out mask.
+FEC_DEV lmask add_word256(fe& r, const fe& a, u32 k) {
+  lmask c;
+  fe x = a;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %9\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+      "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+      "v_addc_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+      "v_addc_co_u32_e32 %7, vcc, 0, %7, vcc\n\t"
+      "s_mov_b64 %8, vcc"
+      : FEC_RW8(x), "=s"(c)
+      : "v"(k)
+      : "vcc");
+  r = x;
+  return c;
+}
+// r = a - k mod 2^256 (k a per-lane word); returns the borrow-out mask.
+FEC_DEV lmask sub_word256(fe& r, const fe& a, u32 k) {
+  lmask c;
+  fe x = a;
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %9\n\t"
+      "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_subbrev_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+      "v_subbrev_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+      "v_subbrev_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+      "v_subbrev_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+      "v_subbrev_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+      "v_subbrev_co_u32_e32 %7, vcc, 0, %7, vcc\n\t"
+      "s_mov_b64 %8, vcc"
+      : FEC_RW8(x), "=s"(c)
+      : "v"(k)
+      : "vcc");
+  r = x;
+  return c;
+}
+// m ? b : a on single words
+FEC_DEV u32 word_select(u32 a, u32 b, lmask m) {
+  u32 r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+  return r;
+}
+
+// r = m ? b : a per lane (subtle::conditional_select(a, b, choice)); VOP3 v_cndmask on the mask.
+FEC_DEV fe fe_select(const fe& a, const fe& b, lmask m) {
+  fe r = a;
+  asm("v_cndmask_b32_e64 %0, %0, %8, %16\n\t"
+      "v_cndmask_b32_e64 %1, %1, %9, %16\n\t"
+      "v_cndmask_b32_e64 %2, %2, %10, %16\n\t"
+      "v_cndmask_b32_e64 %3, %3, %11, %16\n\t"
+      "v_cndmask_b32_e64 %4, %4, %12, %16\n\t"
+      "v_cndmask_b32_e64 %5, %5, %13, %16\n\t"
+      "v_cndmask_b32_e64 %6, %6, %14, %16\n\t"
+      "v_cndmask_b32_e64 %7, %7, %15, %16"
+      : FEC_RW8(r)
+      : FEC_V8(b), "s"(m));
+  return r;
+}
+#endif
+
+// one level of indirection so that a constant list passed as a single macro (FEC_SECP_C, ...)
+// is expanded before it is split into k0..k7
+#define FEC_ADDK256(r, a, c, ...) FEC_ADDK256_(r, a, c, __VA_ARGS__)
+#define FEC_SUBK256(r, a, c, ...) FEC_SUBK256_(r, a, c, __VA_ARGS__)
+#define FEC_KSUB256(r, a, c, ...) FEC_KSUB256_(r, a, c, __VA_ARGS__)
+
+// 32x32 + 32 + 32 -> 64 (never overflows)
+FEC_DEV u64 mad2(u32 a, u32 b, u32 c, u32 d) { return (u64)a * b + c + d; }
+
+// t[0..15] = a * b, exact 512-bit product, row-wise operand scanning
+FEC_DEV void mul_wide(u32 t[16], const fe& a, const fe& b) {
+  {
+    u32 carry = 0;
+    FEC_UNROLL for (int j = 0; j < 8; ++j) {
+      u64 p = (u64)a.w[0] * b.w[j] + carry;
+      t[j] = (u32)p;
+      carry = (u32)(p >> 32);
+    }
+    t[8] = carry;
+  }
+  FEC_UNROLL for (int i = 1; i < 8; ++i) {
+    u32 carry = 0;
+    FEC_UNROLL for (int j = 0; j < 8; ++j) {
+      u64 p = mad2(a.w[i], b.w[j], t[i + j], carry);
+      t[i + j] = (u32)p;
+      carry = (u32)(p >> 32);
+    }
+    t[i + 8] = carry;
+  }
+}
+
+// t[0..8] = a * k (k a 32-bit constant), t[9..15] = 0
+FEC_DEV void mul_wide_small(u32 t[16], const fe& a, u32 k) {
+  u32 carry = 0;
+  FEC_UNROLL for (int j = 0; j < 8; ++j) {
+    u64 p = (u64)a.w[j] * k + carry;
+    t[j] = (u32)p;
+    carry = (u32)(p >> 32);
+  }
+  t[8] = carry;
+  FEC_UNROLL for (int j = 9; j < 16; ++j) t[j] = 0;
+}
+
+// 64x64 -> 128 on 32-bit words: (lo, hi) of (a1:a0) * (b1:b0)
+FEC_DEV void mul64wide(u32 a0, u32 a1, u32 b0, u32 b1, u64& lo, u64& hi) {
+  u64 p00 = (u64)a0 * b0;
+  u64 p01 = (u64)a0 * b1 + (u32)(p00 >> 32);
+  u64 p10 = mad2(a1, b0, (u32)p01, 0);
+  u64 p11 = mad2(a1, b1, (u32)(p01 >> 32), (u32)(p10 >> 32));
+  lo = (u64)(u32)p00 | ((u64)(u32)p10 << 32);
+  hi = p11;
+}
+
+FEC_DEV void set_limb64(fe& a, int i, u64 v) {
+  a.w[2 * i] = (u32)v;
+  a.w[2 * i + 1] = (u32)(v >> 32);
+}
+
+}  // namespace fecgpu

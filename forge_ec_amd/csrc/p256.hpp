@@ -1,0 +1,241 @@
+// p256.hpp -- device-side NIST P-256 field / point / double-and-add, bit-exact with
+// forge-ec-curves/src/p256.rs (citations are lines of that file).
+//
+// P-256 elements are NOT always canonical in the reference: Sub (470-496) returns
+// (a-b) mod 2^256 when a < b, which is >= p with probability ~2^-32 per borrowing subtraction
+// (about once per 2^20-element batch).  Every routine here is therefore defined on arbitrary
+// 256-bit operands and follows the reference's loops; loops whose trip count is provably
+// bounded are unrolled to that bound, with the proof next to them.
+#pragma once
+#include "limbs.hpp"
+
+namespace fecgpu {
+namespace p256 {
+
+// p (18-19) and 2^256 - p (437-442) as VOP2 inline constants, word 0 first
+#define FEC_P256_P -1, -1, -1, 0, 0, 0, 1, -1
+#define FEC_P256_RED 1, 0, 0, -1, -1, -1, -2, 0
+
+// reduce (88-99): `while v >= p { v -= p }`.  p > 2^255, so v - p < p: at most one trip.
+FEC_DEV fe csub_p(const fe& v) {
+  fe w;
+  lmask borrow;
+  FEC_SUBK256(w, v, borrow, FEC_P256_P);
+  return fe_select(v, w, ~borrow);
+}
+
+// Add (416-468).  carry <= 1 after the limb loop.  `while carry > 0` (436-452): the first trip
+// adds 2^256-p; it carries again only if (a+b-2^256) >= p, and then the second trip cannot
+// (s' < 2^256-p, so s' + (2^256-p) < 2^256): at most two trips.  The second trip needs
+// a+b >= 2^256+p, impossible for canonical operands, so it sits behind a wave-uniform branch.
+FEC_DEV fe add(const fe& a, const fe& b) {
+  fe s, s1;
+  lmask carry = add256(s, a, b);
+  lmask ac;
+  FEC_ADDK256(s1, s, ac, FEC_P256_RED);
+  s = fe_select(s, s1, carry);
+  lmask again = carry & ac;  // carry - 1 + add_carry
+  if (again != 0) {
+    fe s2;
+    lmask t;
+    FEC_ADDK256(s2, s, t, FEC_P256_RED);
+    (void)t;
+    s = fe_select(s, s2, again);
+  }
+  return csub_p(s);
+}
+
+// Sub (470-496): if a < b { a = a + P  (Add reduces that back to canon(a)) }; then a wrapping
+// 256-bit subtraction.  For a < p the `+= P` is a no-op; for p <= a < b it subtracts p.
+FEC_DEV fe sub(const fe& a, const fe& b) {
+  fe d;
+  lmask borrow = sub256(d, a, b);
+  // a >= p needs a.w[7] == 0xFFFFFFFF; only then can canon(a) differ from a
+  lmask maybe = borrow & lanes_where(a.w[7] == 0xFFFFFFFFu);
+  if (maybe != 0) {
+    fe ac = csub_p(a);
+    fe d2;
+    sub256(d2, ac, b);
+    d = fe_select(d, d2, maybe);
+  }
+  return d;
+}
+
+// Neg (707-729): 0 -> 0, else p - a (wrapping).
+FEC_DEV fe neg(const fe& a) {
+  fe r;
+  lmask t;
+  FEC_KSUB256(r, a, t, FEC_P256_P);
+  (void)t;
+  return fe_select(r, a, fe_is_zero(a));
+}
+
+// reduce_wide_p256 (544-704) on the exact 512-bit product, words c0..c15.
+FEC_DEV fe reduce_wide(const u32 c[16]) {
+  typedef long long i64;
+  i64 acc[8];
+  // s1 + 2*s2 + 2*s3 + s4 + s5 - s6 - s7 - s8 - s9, word by word (582-654)
+  acc[0] = (i64)c[0] + c[8] + c[9] - c[11] - c[12] - c[13] - c[14];
+  acc[1] = (i64)c[1] + c[9] + c[10] - c[12] - c[13] - c[14] - c[15];
+  acc[2] = (i64)c[2] + c[10] + c[11] - c[13] - c[14] - c[15];
+  acc[3] = (i64)c[3] + 2 * (i64)c[11] + 2 * (i64)c[12] + c[13] - c[15] - c[8] - c[9];
+  acc[4] = (i64)c[4] + 2 * (i64)c[12] + 2 * (i64)c[13] + c[14] - c[9] - c[10];
+  acc[5] = (i64)c[5] + 2 * (i64)c[13] + 2 * (i64)c[14] + c[15] - c[10] - c[11];
+  acc[6] = (i64)c[6] + 2 * (i64)c[14] + 2 * (i64)c[15] + c[14] + c[13] - c[8] - c[9];
+  acc[7] = (i64)c[7] + 2 * (i64)c[15] + c[15] + c[8] - c[10] - c[11] - c[12] - c[13];
+  // carry propagation with arithmetic shift (657-665)
+  FEC_UNROLL for (int i = 0; i < 7; ++i) {
+    i64 carry = acc[i] >> 32;
+    acc[i] &= 0xFFFFFFFFLL;
+    acc[i + 1] += carry;
+  }
+  i64 carry = acc[7] >> 32;
+  acc[7] &= 0xFFFFFFFFLL;
+  // `while carry > 0 { r -= p }` / `while carry < 0 { r += p }` (677-698), all wrapping:
+  // r = L - carry*p mod 2^256 = L + carry*(2^224 - 2^192 - 2^96 + 1) mod 2^256.
+  acc[0] += carry;
+  acc[3] -= carry;
+  acc[6] -= carry;
+  acc[7] += carry;
+  fe r;
+  FEC_UNROLL for (int i = 0; i < 7; ++i) {
+    i64 cy = acc[i] >> 32;
+    r.w[i] = (u32)acc[i];
+    acc[i + 1] += cy;
+  }
+  r.w[7] = (u32)acc[7];
+  return csub_p(r);  // reduce() (701)
+}
+
+// Mul (498-534): exact schoolbook product, then reduce_wide_p256.
+FEC_DEV fe mul(const fe& a, const fe& b) {
+  u32 t[16];
+  mul_wide(t, a, b);
+  return reduce_wide(t);
+}
+FEC_DEV fe sqr(const fe& a) { return mul(a, a); }  // 772-776
+
+FEC_DEV fe mul_small(const fe& a, u32 k) {  // FieldElement::from(k) * a  (1893-1904)
+  u32 t[16];
+  mul_wide_small(t, a, k);
+  return reduce_wide(t);
+}
+
+struct pt {
+  fe x, y, z;
+};
+
+FEC_DEV pt identity() {  // 1827-1829
+  pt p;
+  p.x = fe_zero();
+  p.y = fe_small(1);
+  p.z = fe_zero();
+  return p;
+}
+FEC_DEV lmask is_identity(const pt& p) { return fe_is_zero(p.z); }  // 1831-1833
+FEC_DEV pt pt_select(const pt& a, const pt& b, lmask choice) {
+  pt r;
+  r.x = fe_select(a.x, b.x, choice);
+  r.y = fe_select(a.y, b.y, choice);
+  r.z = fe_select(a.z, b.z, choice);
+  return r;
+}
+
+// double (1869-1912): dbl-2009-l for a = 0 (no a*Z^4 term although a = -3); Z == 1 shortcut.
+FEC_DEV pt pdouble(const pt& p) {
+  fe xx = sqr(p.x);
+  fe yy = sqr(p.y);
+  fe yyyy = sqr(yy);
+  fe xy2 = sqr(add(p.x, yy));
+  fe w = sub(sub(xy2, xx), yyyy);
+  fe d = add(w, w);
+  fe e = mul_small(xx, 3);
+  fe ee = sqr(e);
+  pt r;
+  r.x = sub(sub(ee, d), d);
+  r.y = sub(mul(e, sub(d, r.x)), mul_small(yyyy, 8));
+  fe z3 = add(p.y, p.y);
+  r.z = fe_select(mul(z3, p.z), z3, fe_eq(p.z, fe_small(1)));
+  return pt_select(r, identity(), is_identity(p));
+}
+
+// Add (1938-2007) with ConstantTimeEq (2034-2068) folded in: the ct_eq products are the same
+// z1z1, z2z2, u1, u2, s1, s2 the addition needs, so they are computed once.  need_double is set
+// where the reference returns self.double().
+FEC_DEV pt padd_nodouble(const pt& p, const pt& q, lmask& need_double) {
+  fe z1z1 = sqr(p.z);
+  fe z2z2 = sqr(q.z);
+  fe u1 = mul(p.x, z2z2);
+  fe u2 = mul(q.x, z1z1);
+  fe s1 = mul(mul(p.y, q.z), z2z2);
+  fe s2 = mul(mul(q.y, p.z), z1z1);
+  fe h = sub(u2, u1);
+  fe i = sqr(add(h, h));
+  fe j = mul(h, i);
+  fe s21 = sub(s2, s1);
+  fe r = add(s21, s21);
+  fe v = mul(u1, i);
+  pt o;
+  o.x = sub(sub(sub(sqr(r), j), v), v);
+  o.y = sub(mul(r, sub(v, o.x)), mul(add(s1, s1), j));
+  o.z = mul(sub(sub(sqr(add(p.z, q.z)), z1z1), z2z2), h);
+  lmask idp = is_identity(p), idq = is_identity(q);
+  lmask ueq = fe_eq(u1, u2);
+  lmask same = ueq & fe_eq(s1, s2);  // ct_eq (1951)
+  lmask opposite = 0;
+  if (ueq != 0) opposite = ueq & fe_eq(s1, neg(s2));  // 1977; u1 == u2 never holds on random inputs
+  o = pt_select(o, identity(), opposite);
+  o = pt_select(o, p, idq);
+  o = pt_select(o, q, idp);
+  need_double = same & ~idp & ~idq;
+  return o;
+}
+
+FEC_DEV pt padd(const pt& p, const pt& q) {
+  lmask nd;
+  pt o = padd_nodouble(p, q, nd);
+  if (nd != 0) {
+    pt d = pdouble(p);
+    o = pt_select(o, d, nd);
+  }
+  return o;
+}
+
+// Curve::multiply (2120-2156): MSB-first over the big-endian inherent Scalar::to_bytes
+// (1026-1038), i.e. bit 255-i of the 256-bit scalar at step i; `if bit == 1 { result + point }`
+// is per-lane data dependent, so the addition is computed for the wavefront and selected.
+FEC_DEV pt multiply(const pt& point, const u32* kw) {
+  u32 any = 0;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kw[i * KSTRIDE];
+  lmask early = is_identity(point) | lanes_where(any == 0);
+  pt result = identity();
+#pragma unroll 1
+  for (int i = 0; i < 256; ++i) {
+    int b = 255 - i;
+    lmask bit = lanes_where(((kw[(b >> 5) * KSTRIDE] >> (b & 31)) & 1u) != 0);
+    // one pdouble instance in the code object; the second pass runs only when Add (1951) returns
+    // self.double() for some lane (result == point projectively) -- never on random inputs
+    pt din = result;
+    pt d, s;
+    lmask nd = 0;
+#pragma unroll 1
+    for (int pass = 0;; ++pass) {
+      pt o = pdouble(din);
+      if (pass == 0) {
+        d = o;
+        s = padd_nodouble(d, point, nd);
+        nd = nd & bit;
+        if (nd == 0) break;
+        din = d;
+      } else {
+        s = pt_select(s, o, nd);
+        break;
+      }
+    }
+    result = pt_select(d, s, bit);
+  }
+  return pt_select(result, identity(), early);
+}
+
+}  // namespace p256
+}  // namespace fecgpu

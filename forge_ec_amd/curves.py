@@ -1,0 +1,230 @@
+"""
+Host-side mirror of the forge-ec-core trait surface for the batched scalar-multiplication path.
+
+Names follow the reference (forge-ec-core/src/lib.rs): `Curve::multiply` (832), `Curve::generator`
+/ `identity` (784-830), `PointProjective::{add,double,negate,is_identity}` (699-748),
+`FieldElement::{add,sub,mul,square,neg}` (173-241).  The batched forms (`batch_multiply*`) are what
+this backend adds: each replaces a caller-side loop over `Curve::multiply` (ecdsa.rs:313-361,
+schnorr.rs:268-284, core lib.rs:944-948).
+
+Everything runs on the GPU through libfecgpu.so (include/fecgpu.h); there is no CPU path here.
+Arrays are numpy uint64, little-endian limbs: scalars/field elements (n,4); points (n,12) for
+secp256k1/P-256 (X,Y,Z) and (n,16) for Ed25519 (X,Y,Z,T) -- the reference's `to_raw()` layout.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import ED25519, P256, SECP256K1, FecError
+
+
+def _u64(a, cols=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def _check(rc, what=""):
+    if rc != 0:
+        raise FecError(rc, what)
+
+
+class Context:
+    """One fec_ctx: one GPU, one stream.  Use one per process per GPU."""
+
+    def __init__(self, device=0):
+        self._lib = L.lib()
+        h = ctypes.c_void_p()
+        _check(self._lib.fec_ctx_create(ctypes.byref(h), int(device)), "fec_ctx_create")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fec_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- host-pointer entry points ----
+    def batch_mul(self, curve, scalars, points):
+        pl = L.POINT_LIMBS[curve]
+        s, p = _u64(scalars, 4), _u64(points, pl)
+        if s.shape[0] != p.shape[0]:
+            raise ValueError("scalars and points differ in length")
+        out = np.empty_like(p)
+        _check(self._lib.fec_batch_mul(self._h, curve, _ptr(s), _ptr(p), _ptr(out), s.shape[0]), "fec_batch_mul")
+        return out
+
+    def batch_mul_fixed(self, curve, scalars, base):
+        pl = L.POINT_LIMBS[curve]
+        s, b = _u64(scalars, 4), _u64(base).reshape(pl)
+        out = np.empty((s.shape[0], pl), dtype=np.uint64)
+        _check(self._lib.fec_batch_mul_fixed(self._h, curve, _ptr(s), _ptr(b), _ptr(out), s.shape[0]),
+               "fec_batch_mul_fixed")
+        return out
+
+    def batch_double_mul(self, curve, u1, u2, q):
+        pl = L.POINT_LIMBS[curve]
+        a, b, p = _u64(u1, 4), _u64(u2, 4), _u64(q, pl)
+        if not (a.shape[0] == b.shape[0] == p.shape[0]):
+            raise ValueError("u1, u2 and q differ in length")
+        out = np.empty_like(p)
+        _check(self._lib.fec_batch_double_mul(self._h, curve, _ptr(a), _ptr(b), _ptr(p), _ptr(out), a.shape[0]),
+               "fec_batch_double_mul")
+        return out
+
+    def field_op(self, curve, op, a, b=None):
+        x = _u64(a, 4)
+        y = _u64(b, 4) if b is not None else None
+        if y is not None and y.shape != x.shape:
+            raise ValueError("operands differ in shape")
+        out = np.empty_like(x)
+        _check(self._lib.fec_field_op(self._h, curve, op, _ptr(x), _ptr(y), _ptr(out), x.shape[0]), "fec_field_op")
+        return out
+
+    def point_op(self, curve, op, p, q=None):
+        pl = L.POINT_LIMBS[curve]
+        x = _u64(p, pl)
+        y = _u64(q, pl) if q is not None else None
+        if y is not None and y.shape != x.shape:
+            raise ValueError("operands differ in shape")
+        out = np.empty_like(x)
+        _check(self._lib.fec_point_op(self._h, curve, op, _ptr(x), _ptr(y), _ptr(out), x.shape[0]), "fec_point_op")
+        return out
+
+    # ---- device-pointer entry points (raw addresses, e.g. torch.Tensor.data_ptr()) ----
+    def batch_mul_dev(self, curve, d_scalars, d_points, d_out, n, stream=None):
+        _check(self._lib.fec_batch_mul_dev(self._h, curve, d_scalars, d_points, d_out, n, stream), "fec_batch_mul_dev")
+
+    def batch_mul_fixed_dev(self, curve, d_scalars, d_base, d_out, n, stream=None):
+        _check(self._lib.fec_batch_mul_fixed_dev(self._h, curve, d_scalars, d_base, d_out, n, stream),
+               "fec_batch_mul_fixed_dev")
+
+    def batch_double_mul_dev(self, curve, d_u1, d_u2, d_q, d_out, n, stream=None):
+        _check(self._lib.fec_batch_double_mul_dev(self._h, curve, d_u1, d_u2, d_q, d_out, n, stream),
+               "fec_batch_double_mul_dev")
+
+    def generator(self, curve):
+        out = np.empty(L.POINT_LIMBS[curve], dtype=np.uint64)
+        _check(self._lib.fec_generator(self._h, curve, _ptr(out)), "fec_generator")
+        return out
+
+    # ---- measurement ----
+    def set_timing(self, enabled=True):
+        _check(self._lib.fec_ctx_set_timing(self._h, 1 if enabled else 0))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        name = ctypes.c_char_p()
+        _check(self._lib.fec_ctx_last_kernel_ms(self._h, ctypes.byref(ms), ctypes.byref(name)), "last_kernel_ms")
+        return float(ms.value), (name.value or b"").decode()
+
+    def measure_peak_mad32(self):
+        v = ctypes.c_double()
+        _check(self._lib.fec_measure_peak_mad32(self._h, ctypes.byref(v)), "fec_measure_peak_mad32")
+        return float(v.value)
+
+    def device_info(self):
+        buf = ctypes.create_string_buffer(256)
+        cus, khz = ctypes.c_int(), ctypes.c_int()
+        _check(self._lib.fec_ctx_device_info(self._h, buf, 256, ctypes.byref(cus), ctypes.byref(khz)))
+        return {"name": buf.value.decode(), "compute_units": cus.value, "clock_khz": khz.value}
+
+
+class _Curve:
+    """Common `Curve` trait surface.  Subclasses fix ID, NAME and the reference's constants."""
+    ID = None
+    NAME = None
+    POINT_LIMBS = 12
+    _IDENTITY = None
+
+    def __init__(self, ctx=None, device=0):
+        self.ctx = ctx if ctx is not None else Context(device)
+
+    # Curve::identity / generator (as the reference builds them, raw limbs)
+    @classmethod
+    def identity(cls):
+        return np.array(cls._IDENTITY, dtype=np.uint64)
+
+    def generator(self):
+        return self.ctx.generator(self.ID)
+
+    # Curve::multiply
+    def multiply(self, point, scalar):
+        return self.ctx.batch_mul(self.ID, _u64(scalar).reshape(1, 4), _u64(point).reshape(1, -1))[0]
+
+    # batched forms
+    def batch_multiply(self, points, scalars):
+        return self.ctx.batch_mul(self.ID, scalars, points)
+
+    def batch_multiply_fixed(self, base, scalars):
+        return self.ctx.batch_mul_fixed(self.ID, scalars, base)
+
+    def batch_double_multiply(self, u1, u2, q):
+        """R[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])  (ecdsa.rs:254-256)."""
+        return self.ctx.batch_double_mul(self.ID, u1, u2, q)
+
+    # PointProjective
+    def add(self, p, q):
+        return self.ctx.point_op(self.ID, L.P_ADD, p, q)
+
+    def double(self, p):
+        return self.ctx.point_op(self.ID, L.P_DOUBLE, p)
+
+    def negate(self, p):
+        return self.ctx.point_op(self.ID, L.P_NEGATE, p)
+
+    # FieldElement
+    def fe_add(self, a, b):
+        return self.ctx.field_op(self.ID, L.F_ADD, a, b)
+
+    def fe_sub(self, a, b):
+        return self.ctx.field_op(self.ID, L.F_SUB, a, b)
+
+    def fe_mul(self, a, b):
+        return self.ctx.field_op(self.ID, L.F_MUL, a, b)
+
+    def fe_square(self, a):
+        return self.ctx.field_op(self.ID, L.F_SQR, a)
+
+    def fe_neg(self, a):
+        return self.ctx.field_op(self.ID, L.F_NEG, a)
+
+
+class Secp256k1(_Curve):
+    ID, NAME, POINT_LIMBS = SECP256K1, "secp256k1", 12
+    _IDENTITY = [0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0]  # secp256k1.rs:1322-1324
+
+    def double_trait(self, p):
+        """trait PointProjective::double (secp256k1.rs:1375-1418), not the ladder's inherent one."""
+        return self.ctx.point_op(self.ID, L.P_DOUBLE_TRAIT, p)
+
+
+class P256Curve(_Curve):
+    ID, NAME, POINT_LIMBS = P256, "p256", 12
+    _IDENTITY = [0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0]  # p256.rs:1827-1829
+
+
+class Ed25519Curve(_Curve):
+    ID, NAME, POINT_LIMBS = ED25519, "ed25519", 16
+    _IDENTITY = [0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0]  # ed25519.rs:1776-1783
+
+
+CURVES = {SECP256K1: Secp256k1, P256: P256Curve, ED25519: Ed25519Curve}

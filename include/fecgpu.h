@@ -1,0 +1,124 @@
+/*
+ * fecgpu.h -- C ABI of the MI355X (gfx950) batched scalar-multiplication backend for forge-ec.
+ *
+ * This is the drop-in boundary: exactly what a Rust `extern "C"` block in a forge-ec shim crate
+ * binds (INTEGRATION.md shows that binding).  The reference has no FFI of its own; each entry
+ * point replaces a *loop over* one trait method of forge-ec-core (citations relative to
+ * /root/reference):
+ *
+ *   fec_batch_mul         out[i] = C::multiply(&points[i], &scalars[i])
+ *                         Curve::multiply, forge-ec-core/src/lib.rs:832; impls
+ *                         forge-ec-curves/src/secp256k1.rs:2635-2692, p256.rs:2120-2156,
+ *                         ed25519.rs:2062-2097; loops it replaces: forge-ec-signature/src/
+ *                         ecdsa.rs:313-361, schnorr.rs:268-284, core lib.rs:944-948.
+ *   fec_batch_mul_fixed   out[i] = C::multiply(&base, &scalars[i])       (key generation pattern,
+ *                         forge-ec-examples/src/ecdh.rs:27-49; ecdsa.rs:111)
+ *   fec_batch_double_mul  out[i] = C::multiply(&G,&u1[i]) + C::multiply(&q[i],&u2[i])
+ *                         (ECDSA verify point computation, forge-ec-signature/src/ecdsa.rs:254-256)
+ *   fec_field_op          FieldElement trait ops (core lib.rs:173-241): Add/Sub/Mul/Neg/square
+ *   fec_point_op          PointProjective trait ops (core lib.rs:699-748): Add / double / negate
+ *
+ * Data layout (same as the reference's in-memory representation):
+ *   field element / scalar : uint64_t[4], little-endian limbs (limb 0 least significant),
+ *                            == FieldElement::to_raw() / Scalar::to_raw()
+ *   Weierstrass point      : X,Y,Z  = 12 limbs (Jacobian), secp256k1 and P-256
+ *   Ed25519 point          : X,Y,Z,T = 16 limbs (extended)
+ *   Arrays are arrays-of-structs, element i at  base + i * limbs.
+ *
+ * Results are bit-exact with the reference's CPU arithmetic, including its quirks.  There is NO
+ * CPU fallback: every entry point runs hand-written HIP kernels on the ctx's GPU or fails.
+ *
+ * Threading: a fec_ctx owns one HIP device, one stream and its staging buffers; calls on one ctx
+ * must be serialised by the caller, different ctxs are independent.  One ctx per process per
+ * GPU is the intended use (multi-GPU = one process per GPU).
+ *
+ * Errors: 0 on success, negative fec_status otherwise; never aborts, never throws across the ABI.
+ */
+#ifndef FECGPU_H
+#define FECGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { FEC_SECP256K1 = 0, FEC_P256 = 1, FEC_ED25519 = 2 } fec_curve;
+
+typedef enum {
+  FEC_OK = 0,
+  FEC_E_ARG = -1,         /* null pointer, unknown curve/op, misaligned device pointer */
+  FEC_E_DEVICE = -2,      /* no such GPU / HIP runtime failure */
+  FEC_E_OOM = -3,         /* device or pinned-host allocation failed */
+  FEC_E_LAUNCH = -4,      /* kernel launch or execution failed */
+  FEC_E_UNSUPPORTED = -5  /* op not defined for this curve */
+} fec_status;
+
+typedef enum { FEC_F_ADD = 0, FEC_F_SUB = 1, FEC_F_MUL = 2, FEC_F_SQR = 3, FEC_F_NEG = 4 } fec_field_opcode;
+typedef enum {
+  FEC_P_ADD = 0,          /* impl Add for ProjectivePoint / ExtendedPoint */
+  FEC_P_DOUBLE = 1,       /* the double() that Curve::multiply reaches (secp256k1: inherent) */
+  FEC_P_NEGATE = 2,
+  FEC_P_DOUBLE_TRAIT = 3  /* secp256k1 only: trait PointProjective::double (secp256k1.rs:1375) */
+} fec_point_opcode;
+
+typedef struct fec_ctx fec_ctx;
+
+/* limbs per point: 12 (secp256k1, P-256), 16 (Ed25519); 0 for an unknown curve */
+int fec_point_limbs(fec_curve curve);
+
+/* device = HIP device ordinal (honours HIP_VISIBLE_DEVICES).  Fails with FEC_E_DEVICE when no
+ * gfx950 GPU is usable -- there is no host fallback. */
+int fec_ctx_create(fec_ctx** out, int device);
+void fec_ctx_destroy(fec_ctx* ctx);
+
+/* Curve::generator() exactly as the reference builds it (secp256k1.rs:2608-2625 through its own
+ * to_montgomery; p256.rs:2092-2110; ed25519.rs:2015-2052 with t = x*y), evaluated on the device
+ * with the same field kernels at ctx creation.  out: fec_point_limbs(curve) limbs. */
+int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out);
+
+/* ---- host-pointer entry points (caller-owned memory; nothing retained after return) ---- */
+int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars /* n*4 */,
+                  const uint64_t* points /* n*limbs */, uint64_t* out /* n*limbs */, size_t n);
+int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars /* n*4 */,
+                        const uint64_t* base /* limbs */, uint64_t* out /* n*limbs */, size_t n);
+int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1 /* n*4 */,
+                         const uint64_t* u2 /* n*4 */, const uint64_t* q /* n*limbs */,
+                         uint64_t* out /* n*limbs */, size_t n);
+int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a /* n*4 */,
+                 const uint64_t* b /* n*4, may be NULL for unary ops */, uint64_t* out /* n*4 */,
+                 size_t n);
+int fec_point_op(fec_ctx* ctx, fec_curve curve, fec_point_opcode op, const uint64_t* p /* n*limbs */,
+                 const uint64_t* q /* n*limbs, may be NULL for unary ops */,
+                 uint64_t* out /* n*limbs */, size_t n);
+
+/* ---- device-pointer entry points: pointers are HIP device pointers on the ctx's device,
+ * 16-byte aligned; the launch is enqueued on `stream` (a hipStream_t; NULL = the ctx's own
+ * stream) and NOT synchronised -- the caller orders it like any other stream work. ---- */
+int fec_batch_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars,
+                      const uint64_t* d_points, uint64_t* d_out, size_t n, void* stream);
+int fec_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars,
+                            const uint64_t* d_base, uint64_t* d_out, size_t n, void* stream);
+int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1,
+                             const uint64_t* d_u2, const uint64_t* d_q, uint64_t* d_out, size_t n,
+                             void* stream);
+
+/* ---- measurement hooks ---- */
+/* When enabled, every kernel launched through this ctx is bracketed by HIP events recorded on
+ * the launch stream. */
+int fec_ctx_set_timing(fec_ctx* ctx, int enabled);
+/* Synchronises the last timed launch and returns its duration in milliseconds and its name. */
+int fec_ctx_last_kernel_ms(fec_ctx* ctx, float* ms, const char** kernel_name);
+/* Dependency-free v_mad_u64_u32 micro-kernel: measured peak 32x32->64 multiply-adds per second
+ * of this GPU (the integer-VALU roofline the scalar-mul kernels are priced against). */
+int fec_measure_peak_mad32(fec_ctx* ctx, double* mad32_per_sec);
+/* name / CU count / clock of the ctx's device */
+int fec_ctx_device_info(fec_ctx* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz);
+
+const char* fec_strerror(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FECGPU_H */

@@ -1,0 +1,41 @@
+// Host build of the device headers: exposes the same field/point/multiply routines the kernels
+// inline, as a C shared library, so tests can diff them against the oracle WITHOUT a GPU and
+// under -fsanitize=address,undefined.  Test infrastructure only.
+#define FEC_HOST_EMUL 1
+#include "../forge_ec_amd/csrc/secp256k1.hpp"
+#include "../forge_ec_amd/csrc/p256.hpp"
+#include "../forge_ec_amd/csrc/ed25519.hpp"
+#include <string.h>
+using namespace fecgpu;
+
+static fe ld(const uint64_t* a) { fe r; for (int i = 0; i < 4; ++i) { r.w[2*i] = (u32)a[i]; r.w[2*i+1] = (u32)(a[i] >> 32); } return r; }
+static void st(uint64_t* o, const fe& a) { for (int i = 0; i < 4; ++i) o[i] = (u64)a.w[2*i] | ((u64)a.w[2*i+1] << 32); }
+
+extern "C" int he_field_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  fe x = ld(a), y = b ? ld(b) : fe_zero(), r;
+  if (curve == 0) r = op == 0 ? secp::add(x, y) : op == 1 ? secp::sub(x, y) : op == 2 ? secp::mul(x, y) : op == 3 ? secp::sqr(x) : secp::neg(x);
+  else if (curve == 1) r = op == 0 ? p256::add(x, y) : op == 1 ? p256::sub(x, y) : op == 2 ? p256::mul(x, y) : op == 3 ? p256::sqr(x) : p256::neg(x);
+  else r = op == 0 ? ed::add(x, y) : op == 1 ? ed::sub(x, y) : op == 2 ? ed::mul(x, y) : op == 3 ? ed::mul(x, x) : ed::neg(x);
+  st(out, r);
+  return 0;
+}
+template <class PT> static PT ldp3(const uint64_t* p) { PT r; r.x = ld(p); r.y = ld(p + 4); r.z = ld(p + 8); return r; }
+template <class PT> static void stp3(uint64_t* o, const PT& p) { st(o, p.x); st(o + 4, p.y); st(o + 8, p.z); }
+static ed::pt ldp4(const uint64_t* p) { ed::pt r; r.x = ld(p); r.y = ld(p + 4); r.z = ld(p + 8); r.t = ld(p + 12); return r; }
+static void stp4(uint64_t* o, const ed::pt& p) { st(o, p.x); st(o + 4, p.y); st(o + 8, p.z); st(o + 12, p.t); }
+
+// op: 0 add, 1 double
+extern "C" int he_point_op(int curve, int op, const uint64_t* p, const uint64_t* q, uint64_t* out) {
+  if (curve == 0) { auto a = ldp3<secp::pt>(p); stp3(out, op == 0 ? secp::padd(a, ldp3<secp::pt>(q)) : secp::pdouble(a)); }
+  else if (curve == 1) { auto a = ldp3<p256::pt>(p); stp3(out, op == 0 ? p256::padd(a, ldp3<p256::pt>(q)) : p256::pdouble(a)); }
+  else { auto a = ldp4(p); stp4(out, op == 0 ? ed::padd(a, ldp4(q)) : ed::padd(a, a)); }
+  return 0;
+}
+extern "C" int he_multiply(int curve, const uint64_t* point, const uint64_t* scalar, uint64_t* out) {
+  static thread_local u32 kw[8 * KSTRIDE];
+  for (int i = 0; i < 4; ++i) { kw[(2*i) * KSTRIDE] = (u32)scalar[i]; kw[(2*i+1) * KSTRIDE] = (u32)(scalar[i] >> 32); }
+  if (curve == 0) stp3(out, secp::multiply(ldp3<secp::pt>(point), kw));
+  else if (curve == 1) stp3(out, p256::multiply(ldp3<p256::pt>(point), kw));
+  else stp4(out, ed::multiply(ldp4(point), kw));
+  return 0;
+}
