@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the batched scalar-multiplication hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W        (N > 1, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): 2^20 secp256k1 variable-base scalar multiplications per
+GPU on synthetic seeded inputs (forge_ec_amd/synth.py), inputs resident in HBM before the timed
+region.  One "step" = one pass of the hot path over one 2^20 batch.  With N > 1 ranks every rank
+runs its own 2^20 shard (weak scaling, no collective on the compute path) and the result shards
+are all-gathered over RCCL/xGMI on a side stream, overlapped with the next step's kernel.
+
+Prints ONE JSON line on rank 0: metric/value (whole-job scalar-muls/s), roofline (integer-VALU:
+algorithmic 32x32 multiply-adds per second against the chip's peak; kernel time from HIP events
+on the launch stream) and cpu_baseline (the C oracle timed on this box's host cores on a bounded
+sample of the same inputs, which doubles as a parity spot-check of the GPU output).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic work per scalar-mul, SURVEY.md section 8(d) "needed MAD32" column
+NEEDED_MAD32 = {"secp256k1": 693248, "p256": 278528, "ed25519": 248832}
+HBM_BYTES = {"secp256k1": 224, "p256": 224, "ed25519": 288}
+CURVE_ID = {"secp256k1": 0, "p256": 1, "ed25519": 2}
+# guide-derived integer-VALU peak: 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per
+# v_mad_u64_u32 wave-instruction (MI355X_MICROARCH.md chip parameters; issue cost measured,
+# profiles/valu_rates2_r01.txt) = 39.3e12 MAD32/s
+PEAK_MAD32_FORMULA = 256 * 4 * 64 * 2.4e9 / 4.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--curve", default="secp256k1", choices=list(CURVE_ID))
+    ap.add_argument("--log2-batch", type=int, default=20, help="scalar-muls per GPU per step = 2^this")
+    ap.add_argument("--gather", default="all", choices=["all", "none"],
+                    help="N>1: all-gather result shards over RCCL (overlapped) or not")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def host_cores():
+    """Usable host cores: the affinity mask, capped by the cgroup CPU quota (a one-GPU box exposes
+    every logical CPU but grants a share of them)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(cores, 64))
+
+
+def cpu_baseline(curve_name, k, p, gpu_out, target_s):
+    """Time the C oracle (the reference's full work, discarded doublings included) on this box's
+    cores over a bounded prefix of the same inputs; compare with the GPU output (parity sample)."""
+    from oracle import c_oracle
+    cid = CURVE_ID[curve_name]
+    cores = host_cores()
+    probe = 64 * cores
+    t0 = time.perf_counter()
+    c_oracle.batch_mul(cid, k[:probe], p[:probe], nthreads=cores)
+    dt = time.perf_counter() - t0
+    rate = probe / max(dt, 1e-9)
+    n = int(min(k.shape[0], max(probe, rate * target_s)))
+    t0 = time.perf_counter()
+    ref = c_oracle.batch_mul(cid, k[:n], p[:n], nthreads=cores)
+    dt = time.perf_counter() - t0
+    ok = bool(np.array_equal(ref, gpu_out[:n]))
+    return {"value": n / dt, "unit": "scalar-muls/s", "cores": cores, "kind": "port",
+            "sample": "first %d of the rank-0 batch (%s variable-base), C oracle oracle/forge_ec_oracle.c, "
+                      "%d threads, %.1f s" % (n, curve_name, cores, dt),
+            "parity_sample_bit_exact": ok}
+
+
+def main():
+    args = parse()
+    import torch
+    import forge_ec_amd as F
+    from forge_ec_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    curve = args.curve
+    cid = CURVE_ID[curve]
+    n = 1 << args.log2_batch
+    limbs = F.POINT_LIMBS[cid]
+    ctx = F.Context(local_rank)
+
+    # synthetic seeded inputs, one stream pair per rank; resident in HBM before timing
+    k = synth.scalars(n, cid, 1000 + 2 * rank)
+    p = synth.points(n, cid, 1001 + 2 * rank)
+    d_k = torch.from_numpy(k.view(np.int64)).cuda()
+    d_p = torch.from_numpy(p.view(np.int64)).cuda()
+    d_out = [torch.empty((n, limbs), dtype=torch.int64, device="cuda") for _ in range(2)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    gather = None
+    if world > 1 and args.gather == "all":
+        from forge_ec_amd.dist import ResultGather
+        gather = [ResultGather(n * world, limbs, torch.device("cuda", local_rank)) for _ in range(2)]
+
+    def step(i, timed):
+        buf = i & 1
+        if gather is not None:
+            gather[buf].finish()  # the collective that last read d_out[buf] has completed
+        ctx.batch_mul_dev(cid, d_k.data_ptr(), d_p.data_ptr(), d_out[buf].data_ptr(), n, stream)
+        ms = None
+        if timed:
+            ms = ctx.last_kernel_ms()[0]  # HIP events on the launch stream (syncs this launch)
+        if gather is not None:
+            gather[buf].start(d_out[buf])
+        return ms
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.set_timing(False)
+    for i in range(args.warmup):
+        step(i, False)
+    if gather is not None:
+        for g in gather:
+            g.finish()
+    barrier()
+    # timed region: exactly K steps, barrier + synchronize on both sides
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, False)
+    if gather is not None:
+        for g in gather:
+            g.finish()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel duration from HIP events on the launch stream (separate passes, not in `value`)
+    ctx.set_timing(True)
+    kms = [step(i, True) for i in range(min(args.steps, 5))]
+    if gather is not None:
+        for g in gather:
+            g.finish()
+    ctx.set_timing(False)
+    torch.cuda.synchronize()
+    kernel_ms = float(np.mean(kms))
+    peak_measured = ctx.measure_peak_mad32()
+    info = ctx.device_info()
+
+    if rank == 0:
+        total = n * world * args.steps
+        value = total / elapsed
+        alg = NEEDED_MAD32[curve]
+        achieved = n * alg / (kernel_ms * 1e-3)
+        out = {
+            "metric": "%s variable-base scalar-muls/sec (batched, bit-exact vs CPU oracle)" % curve,
+            "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "2^%d %s variable-base scalar-muls per GPU per step (BASELINE.json configs[1])"
+                                   % (args.log2_batch, curve),
+                       "curve": curve, "batch_per_gpu": n, "global_batch": n * world,
+                       "result_gather": (args.gather if world > 1 else "n/a"),
+                       "device": info["name"], "compute_units": info["compute_units"]},
+            "roofline": {
+                "bound": "int-valu", "achieved": achieved / 1e12, "peak": PEAK_MAD32_FORMULA / 1e12,
+                "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_FORMULA, "traffic": None,
+                "kernel": "k_batch_mul<%s,var>" % curve, "kernel_ms": kernel_ms,
+                "algorithmic_mad32_per_unit": alg, "units_per_launch": n,
+                "peak_measured": peak_measured / 1e12, "frac_of_measured_peak": achieved / peak_measured,
+                "hbm": {"achieved_GBps": n * HBM_BYTES[curve] / (kernel_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                        "algorithmic_bytes_per_unit": HBM_BYTES[curve]},
+            },
+        }
+        if not args.no_cpu_baseline:
+            gpu_out = d_out[(min(args.steps, 5) - 1) & 1].cpu().numpy().view(np.uint64)
+            out["cpu_baseline"] = cpu_baseline(curve, k, p, gpu_out, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""
+Multi-GPU sharding for the batched scalar-multiplication path: one process per GPU,
+torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+The path shards trivially -- scalar-muls are independent -- so there is NO collective on the
+compute path.  The only exchange is the one BASELINE.json's north_star names: gathering the
+result shards.  It is one all-gather of the contiguous per-rank result block, issued on its own
+stream (async) so it overlaps the next batch's kernel.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous shard [lo, hi) of n units for `rank` of `world` (sizes differ by at most 1)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def shard_sizes(n, world):
+    return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+
+
+class ResultGather:
+    """All-gather of per-rank result shards into the full (n, limbs) result on every rank.
+
+    Shards may differ in size by one row; they are padded to the largest shard for the collective
+    and trimmed afterwards.  `start()` enqueues the collective and returns immediately (async);
+    `finish()` waits and returns the assembled tensor.
+    """
+
+    def __init__(self, n_total, limbs, device, dtype=torch.int64, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_total = n_total
+        self.limbs = limbs
+        self.sizes = shard_sizes(n_total, self.world)
+        self.pad = max(self.sizes)
+        self.buf = torch.empty((self.world * self.pad, limbs), dtype=dtype, device=device)
+        self.send = torch.zeros((self.pad, limbs), dtype=dtype, device=device)
+        self.handle = None
+
+    def start(self, local):
+        if local.shape[0] != self.sizes[self.rank]:
+            raise ValueError("local shard has %d rows, expected %d" % (local.shape[0], self.sizes[self.rank]))
+        if local.shape[0] == self.pad:
+            src = local
+        else:
+            self.send[:local.shape[0]].copy_(local)
+            src = self.send
+        self.handle = dist.all_gather_into_tensor(self.buf, src.contiguous(), group=self.group, async_op=True)
+        return self.handle
+
+    def finish(self):
+        if self.handle is not None:
+            self.handle.wait()
+            self.handle = None
+        if all(s == self.pad for s in self.sizes):
+            return self.buf
+        parts = [self.buf[r * self.pad: r * self.pad + self.sizes[r]] for r in range(self.world)]
+        return torch.cat(parts, dim=0)

@@ -69,7 +69,10 @@ def reference_kats():
         {"curve": 0, "name": "g_plus_g_affine_eq_double_affine", "src": "secp256k1.rs:2769-2776"},
         {"curve": 0, "name": "g_minus_g_is_identity", "src": "secp256k1.rs:2785-2786"},
         {"curve": 1, "name": "two_g_eq_double", "src": "p256.rs:2494-2499"},
-        {"curve": 1, "name": "three_g_eq_g_plus_2g", "src": "p256.rs:2526"},
+        {"curve": 1, "name": "three_g_eq_g_plus_2g", "src": "p256.rs:2526",
+         "holds_for_reference_arithmetic": False,
+         "why": "multiply(G,3) = Add(2G,G) but the test builds Add(G,2G); Add is not symmetric because "
+                "Sub (470-496) is off by 2^256-p whenever it borrows"},
         {"curve": 2, "name": "mul_small_scalars", "src": "ed25519.rs:2405-2436"},
     ]
     note = ("Known-divergent (recorded, not asserted): p256.rs:2472 expects the TRUE x^3-3x+b; the "

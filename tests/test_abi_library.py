@@ -1,0 +1,65 @@
+"""CPU tests of the drop-in boundary: libfecgpu.so builds for gfx950, loads, exports every symbol
+include/fecgpu.h declares, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from forge_ec_amd import build
+    build.build()
+    from forge_ec_amd import _lib
+    return _lib.lib()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fecgpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fec_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_library_agree(lib):
+    from forge_ec_amd import _lib
+    declared = _declared_symbols()
+    assert declared == sorted(_lib.ABI_SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_point_limbs_and_strerror(lib):
+    assert lib.fec_point_limbs(0) == 12 and lib.fec_point_limbs(1) == 12 and lib.fec_point_limbs(2) == 16
+    assert lib.fec_point_limbs(9) == 0
+    assert lib.fec_strerror(0) == b"ok"
+    assert b"no CPU fallback" in lib.fec_strerror(-2)
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    """On a box without a gfx950 GPU, ctx creation fails loudly instead of computing on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    assert lib.fec_ctx_create(ctypes.byref(h), 0) == -2
+    assert not h.value
+    import forge_ec_amd as F
+    with pytest.raises(F.FecError):
+        F.Context(0)
+
+
+def test_product_code_never_touches_the_oracle():
+    """The shipped package must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "forge_ec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("CPU oracle", "").replace("the oracle", "").replace(
+                    "oracle-checked", "").replace("oracles", ""), os.path.join(dirpath, f)
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pkg, "libfecgpu.so")], capture_output=True, text=True).stdout
+    assert "forge_ec_oracle" not in out
