@@ -303,20 +303,13 @@ FEC_DEV fe fe_select(const fe& a, const fe& b, lmask m) {
 // 32x32 + 32 + 32 -> 64 (never overflows)
 FEC_DEV u64 mad2(u32 a, u32 b, u32 c, u32 d) { return (u64)a * b + c + d; }
 
-// t[0..15] = a * b, exact 512-bit product, row-wise operand scanning
+// t[0..15] = a * b, exact 512-bit product.
+#ifdef FEC_HOST_EMUL
 FEC_DEV void mul_wide(u32 t[16], const fe& a, const fe& b) {
-  {
+  for (int i = 0; i < 16; ++i) t[i] = 0;
+  for (int i = 0; i < 8; ++i) {
     u32 carry = 0;
-    FEC_UNROLL for (int j = 0; j < 8; ++j) {
-      u64 p = (u64)a.w[0] * b.w[j] + carry;
-      t[j] = (u32)p;
-      carry = (u32)(p >> 32);
-    }
-    t[8] = carry;
-  }
-  FEC_UNROLL for (int i = 1; i < 8; ++i) {
-    u32 carry = 0;
-    FEC_UNROLL for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 8; ++j) {
       u64 p = mad2(a.w[i], b.w[j], t[i + j], carry);
       t[i + j] = (u32)p;
       carry = (u32)(p >> 32);
@@ -324,6 +317,38 @@ FEC_DEV void mul_wide(u32 t[16], const fe& a, const fe& b) {
     t[i + 8] = carry;
   }
 }
+#else
+// Product scanning: column k accumulates its (up to 8) partial products into a 96-bit
+// accumulator {acc (64-bit VGPR pair), ovf}.  Each product is TWO instructions:
+//   v_mad_u64_u32 acc, vcc, a_i, b_j, acc      ; acc += a_i*b_j, carry-out -> vcc
+//   v_addc_co_u32 ovf, vcc, 0, ovf, vcc        ; ovf += carry
+// The accumulator is only ever written by the mad (as a 64-bit pair) and only read in halves, so
+// no 64-bit pair has to be assembled from separate registers inside a column -- that assembly
+// cost hipcc's own lowering of the same arithmetic 179 v_mov per multiplication.
+FEC_DEV void mac96(u64& acc, u32& ovf, u32 x, u32 y) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(ovf)
+      : "v"(x), "v"(y)
+      : "vcc");
+}
+FEC_DEV void mul_wide(u32 t[16], const fe& a, const fe& b) {
+  u64 acc = (u64)a.w[0] * b.w[0];  // column 0: one product, cannot overflow
+  u32 ovf = 0;
+  t[0] = (u32)acc;
+  acc >>= 32;
+  FEC_UNROLL for (int k = 1; k < 15; ++k) {
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      const int j = k - i;
+      if (j >= 0 && j < 8) mac96(acc, ovf, a.w[i], b.w[j]);
+    }
+    t[k] = (u32)acc;
+    acc = (acc >> 32) | ((u64)ovf << 32);
+    ovf = 0;
+  }
+  t[15] = (u32)acc;
+}
+#endif
 
 // t[0..8] = a * k (k a 32-bit constant), t[9..15] = 0
 FEC_DEV void mul_wide_small(u32 t[16], const fe& a, u32 k) {
