@@ -26,9 +26,11 @@
 // Host emulation of the device headers (tools/host_emul.cpp): logic checks and sanitizers on the
 // CPU build; never part of the shipped library.  One "lane": lmask is 0 or all-ones.
 #define FEC_DEV static inline
+#define FEC_DEV_NOINLINE static __attribute__((noinline))
 #else
 #include <hip/hip_runtime.h>
 #define FEC_DEV __device__ __forceinline__
+#define FEC_DEV_NOINLINE __device__ __attribute__((noinline))
 #endif
 
 namespace fecgpu {
@@ -108,6 +110,8 @@ FEC_DEV fe fe_k8(u32 k0, u32 k1, u32 k2, u32 k3, u32 k4, u32 k5, u32 k6, u32 k7)
 #define FEC_KSUB256_(r, a, c, k0, k1, k2, k3, k4, k5, k6, k7) c = sub256(r, FEC_K8(k0, k1, k2, k3, k4, k5, k6, k7), a)
 // r = a - (hi:lo) mod 2^256 (lo, hi per-lane words)
 FEC_DEV lmask sub_lohi256(fe& r, const fe& a, u32 lo, u32 hi) { return sub256(r, a, FEC_K8(lo, hi, 0, 0, 0, 0, 0, 0)); }
+// r = a + (hi:lo) mod 2^256 (lo, hi per-lane words)
+FEC_DEV lmask add_lohi256(fe& r, const fe& a, u32 lo, u32 hi) { return add256(r, a, FEC_K8(lo, hi, 0, 0, 0, 0, 0, 0)); }
 // r = a + k mod 2^256 (k a per-lane word)
 FEC_DEV lmask add_word256(fe& r, const fe& a, u32 k) { return add256(r, a, FEC_K8(k, 0, 0, 0, 0, 0, 0, 0)); }
 // r = a - k mod 2^256 (k a per-lane word)
@@ -232,6 +236,25 @@ FEC_DEV lmask sub_lohi256(fe& r, const fe& a, u32 lo, u32 hi) {
   r = x;
   return c;
 }
+// r = a + (hi:lo) mod 2^256 (lo, hi per-lane words); returns the carry-out mask.
+FEC_DEV lmask add_lohi256(fe& r, const fe& a, u32 lo, u32 hi) {
+  lmask c;
+  fe x = a;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %9\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %10, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+      "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+      "v_addc_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+      "v_addc_co_u32_e32 %7, vcc, 0, %7, vcc\n\t"
+      "s_mov_b64 %8, vcc"
+      : FEC_RW8(x), "=s"(c)
+      : "v"(lo), "v"(hi)
+      : "vcc");
+  r = x;
+  return c;
+}
 // r = a + k mod 2^256 (k a per-lane word); returns the carry-out mask.
 FEC_DEV lmask add_word256(fe& r, const fe& a, u32 k) {
   lmask c;
@@ -332,21 +355,42 @@ FEC_DEV void mac96(u64& acc, u32& ovf, u32 x, u32 y) {
       : "v"(x), "v"(y)
       : "vcc");
 }
+// First product of a column: a FRESH accumulator {acc, ovf} = x*y + cin.  Starting every column
+// in new registers leaves the finished word t[k] where the previous column's mad put it and needs
+// no re-zeroing of the overflow word; only the carry-in pair {acc_prev.hi, ovf_prev} is assembled
+// (2 v_mov per column instead of 4).  All inputs are consumed by the first instruction.
+FEC_DEV void mac96_first(u64& acc, u32& ovf, u32 x, u32 y, u64 cin) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %4\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc"
+      : "=v"(acc), "=v"(ovf)
+      : "v"(x), "v"(y), "v"(cin)
+      : "vcc");
+}
 FEC_DEV void mul_wide(u32 t[16], const fe& a, const fe& b) {
   u64 acc = (u64)a.w[0] * b.w[0];  // column 0: one product, cannot overflow
   u32 ovf = 0;
   t[0] = (u32)acc;
-  acc >>= 32;
   FEC_UNROLL for (int k = 1; k < 15; ++k) {
+    u64 cin = (acc >> 32) | ((u64)ovf << 32);
+    bool first = true;
     FEC_UNROLL for (int i = 0; i < 8; ++i) {
       const int j = k - i;
-      if (j >= 0 && j < 8) mac96(acc, ovf, a.w[i], b.w[j]);
+      if (j >= 0 && j < 8) {
+        if (first) {
+          u64 nacc;
+          u32 novf;
+          mac96_first(nacc, novf, a.w[i], b.w[j], cin);
+          acc = nacc;
+          ovf = novf;
+          first = false;
+        } else {
+          mac96(acc, ovf, a.w[i], b.w[j]);
+        }
+      }
     }
     t[k] = (u32)acc;
-    acc = (acc >> 32) | ((u64)ovf << 32);
-    ovf = 0;
   }
-  t[15] = (u32)acc;
+  t[15] = (u32)(acc >> 32);
 }
 #endif
 
@@ -361,6 +405,28 @@ FEC_DEV void mul_wide_small(u32 t[16], const fe& a, u32 k) {
   t[8] = carry;
   FEC_UNROLL for (int j = 9; j < 16; ++j) t[j] = 0;
 }
+
+// p[0..3] = (x1:x0) * (y1:y0), exact 128-bit product as four words (product scanning: the first
+// product of a column cannot overflow the 64-bit accumulator, and the top column is bounded by
+// the true product, so only one overflow count is needed).
+#ifdef FEC_HOST_EMUL
+FEC_DEV void mul64_words(u32 p[4], u32 x0, u32 x1, u32 y0, u32 y1) {
+  unsigned __int128 v = (unsigned __int128)(((u64)x1 << 32) | x0) * (((u64)y1 << 32) | y0);
+  for (int i = 0; i < 4; ++i) p[i] = (u32)(v >> (32 * i));
+}
+#else
+FEC_DEV void mul64_words(u32 p[4], u32 x0, u32 x1, u32 y0, u32 y1) {
+  u64 c0 = (u64)x0 * y0;
+  p[0] = (u32)c0;
+  u64 acc = (u64)x0 * y1 + (c0 >> 32);
+  u32 ovf = 0;
+  mac96(acc, ovf, x1, y0);
+  p[1] = (u32)acc;
+  u64 top = (u64)x1 * y1 + ((acc >> 32) | ((u64)ovf << 32));
+  p[2] = (u32)top;
+  p[3] = (u32)(top >> 32);
+}
+#endif
 
 // 64x64 -> 128 on 32-bit words: (lo, hi) of (a1:a0) * (b1:b0)
 FEC_DEV void mul64wide(u32 a0, u32 a1, u32 b0, u32 b1, u64& lo, u64& hi) {

@@ -31,24 +31,39 @@ FEC_DEV fe csub_p(const fe& v) {
   FEC_ADDK256(w, v, ov, FEC_SECP_C);
   return fe_select(v, w, ov);
 }
-
-// Add (353-393): s = a + b mod 2^256; subtract p once if the add carried or s >= p.
-FEC_DEV fe add(const fe& a, const fe& b) {
-  fe s, w;
-  lmask carry = add256(s, a, b);
-  lmask ov;
-  FEC_ADDK256(w, s, ov, FEC_SECP_C);  // w = s - p mod 2^256
-  return fe_select(s, w, carry | ov);
+// lanes where v >= p is possible at all: p = 2^256 - 2^32 - 977 has words 2..7 all ones
+FEC_DEV lmask maybe_ge_p(const fe& v) {
+  u32 ones = v.w[2] & v.w[3] & v.w[4] & v.w[5] & v.w[6] & v.w[7];
+  return lanes_where(ones == 0xFFFFFFFFu);
+}
+// the same reduce where v >= p is improbable (2^-224 for a Mul/square result): the chain and the
+// select sit behind a wave-uniform branch
+FEC_DEV fe csub_p_unlikely(const fe& v) {
+  if (__builtin_expect(maybe_ge_p(v) != 0, 0)) return csub_p(v);
+  return v;
 }
 
-// Sub (395-440): d = a - b mod 2^256; add p (wrapping) if it borrowed.
+// Add (353-393): s = a + b mod 2^256; subtract p once if the add carried or s >= p.
+// With a carry the result is s + c; without one it is s unless s >= p (improbable: rare branch).
+FEC_DEV fe add(const fe& a, const fe& b) {
+  fe s, r;
+  lmask carry = add256(s, a, b);
+  add_lohi256(r, s, word_select(0u, 0x3D1u, carry), word_select(0u, 1u, carry));
+  if (__builtin_expect((maybe_ge_p(s) & ~carry) != 0, 0)) {
+    fe w;
+    lmask ov;
+    FEC_ADDK256(w, s, ov, FEC_SECP_C);  // w = s - p mod 2^256
+    r = fe_select(s, w, carry | ov);
+  }
+  return r;
+}
+
+// Sub (395-440): d = a - b mod 2^256; add p (wrapping), i.e. subtract c, if it borrowed.
 FEC_DEV fe sub(const fe& a, const fe& b) {
-  fe d, w;
+  fe d, r;
   lmask borrow = sub256(d, a, b);
-  lmask t;
-  FEC_SUBK256(w, d, t, FEC_SECP_C);  // d + p mod 2^256
-  (void)t;
-  return fe_select(d, w, borrow);
+  sub_lohi256(r, d, word_select(0u, 0x3D1u, borrow), word_select(0u, 1u, borrow));
+  return r;
 }
 
 // Neg (509-539): p - a (wrapping), 0 -> 0.
@@ -81,7 +96,7 @@ FEC_DEV fe mont_reduce(const u32 t[16]) {
   }
   add256(v, th, mm);
   sub_lohi256(v2, v, e_lo, e_hi);
-  return csub_p(v2);
+  return csub_p_unlikely(v2);
 }
 
 // Mul (442-507)
@@ -98,48 +113,159 @@ FEC_DEV fe mul_small(const fe& a, u32 k) {
   return mont_reduce(t);
 }
 
-// square (634-713), literal on 64-bit limbs
+// ---- square() (634-713) ---------------------------------------------------------------------
+// NOT Montgomery and NOT mul(x,x).  Restated on 16 words w[] (the reference's product[0..8]):
+//   * limb squares into w (643-649);
+//   * each cross term a_i*a_j, doubled mod 2^128 (bit 127 lost), is added as TWO independent
+//     64-bit adds at limbs i+j and i+j+1 -- the first add's carry is not fed to the second -- and
+//     if either carried a single +1 ripples from limb i+j+2, dropped past limb 7 (652-679);
+//   * every high limb h is folded into limb 0 (always limb 0) as the low 64 bits of
+//     h * 0x1000003D1, with the reference's carry rule (693-707), then one conditional subtract.
+// The data-dependent ripples almost never travel (a +1 leaves a limb only if it was 2^64-1), so
+// each ripple is performed into its first limb and continued under a wave-uniform unlikely branch;
+// likewise the fold's incoming carry (692) is 0 unless a ripple crossed limbs 1..3, in which case
+// that fold step runs the reference's general rule.  Every branch is exact; none is taken on
+// random data (tests/golden/secp256k1_sqr_ripple_operands.json forces them).
+#ifdef FEC_HOST_EMUL
+static unsigned long fec_host_rare_sqr = 0;  // coverage counter for tests (host emulation only)
+FEC_DEV lmask cross_add(u32& w0, u32& w1, u32& w2, u32& w3, u32& w4, u32& w5, u32 x0, u32 x1, u32 x2, u32 x3) {
+  u64 lo = ((u64)w1 << 32) | w0, hi = ((u64)w3 << 32) | w2, nx = ((u64)w5 << 32) | w4;
+  u64 xl = ((u64)x1 << 32) | x0, xh = ((u64)x3 << 32) | x2;
+  u64 s0 = lo + xl, s1 = hi + xh;
+  u64 inc = (s0 < xl) | (s1 < xh);
+  u64 n2 = nx + inc;
+  w0 = (u32)s0; w1 = (u32)(s0 >> 32); w2 = (u32)s1; w3 = (u32)(s1 >> 32); w4 = (u32)n2; w5 = (u32)(n2 >> 32);
+  return (n2 < inc) ? ~0ull : 0ull;
+}
+FEC_DEV lmask fold_add(u32& r0, u32& r1, u32& r2, u32& r3, u32 m0, u32 m1) {
+  u64 l0 = ((u64)r1 << 32) | r0, l1 = ((u64)r3 << 32) | r2, m = ((u64)m1 << 32) | m0;
+  u64 t = l0 + m;
+  u64 c = t < m;
+  u64 t1 = l1 + c;
+  r0 = (u32)t; r1 = (u32)(t >> 32); r2 = (u32)t1; r3 = (u32)(t1 >> 32);
+  return (t1 < c) ? ~0ull : 0ull;
+}
+FEC_DEV lmask ripple2(u32& a, u32& b, lmask cin) {
+  u64 v = ((u64)b << 32) | a, c = cin ? 1 : 0;
+  u64 n = v + c;
+  a = (u32)n; b = (u32)(n >> 32);
+  return (n < c) ? ~0ull : 0ull;
+}
+#else
+// words w0..w3 += (x0..x3) as two independent 64-bit adds; +1 (if either carried) into limb
+// (w4,w5); returns the lanes where that limb carried out.
+FEC_DEV lmask cross_add(u32& w0, u32& w1, u32& w2, u32& w3, u32& w4, u32& w5, u32 x0, u32 x1, u32 x2, u32 x3) {
+  lmask more;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %7\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %8, vcc\n\t"
+      "s_mov_b64 %6, vcc\n\t"
+      "v_add_co_u32_e32 %2, vcc, %2, %9\n\t"
+      "v_addc_co_u32_e32 %3, vcc, %3, %10, vcc\n\t"
+      "s_or_b64 vcc, vcc, %6\n\t"
+      "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+      "s_mov_b64 %6, vcc"
+      : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "=&s"(more)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(x3)
+      : "vcc");
+  return more;
+}
+// limb0 (r0,r1) += (m1:m0); its carry-out goes into limb1 (r2,r3); returns limb1's carry-out.
+FEC_DEV lmask fold_add(u32& r0, u32& r1, u32& r2, u32& r3, u32 m0, u32 m1) {
+  lmask more;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %5\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %6, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+      "s_mov_b64 %4, vcc"
+      : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "=s"(more)
+      : "v"(m0), "v"(m1)
+      : "vcc");
+  return more;
+}
+// limb (a,b) += cin (one bit per lane); returns its carry-out.
+FEC_DEV lmask ripple2(u32& a, u32& b, lmask cin) {
+  lmask cout;
+  asm("s_mov_b64 vcc, %3\n\t"
+      "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "s_mov_b64 %2, vcc"
+      : "+v"(a), "+v"(b), "=s"(cout)
+      : "s"(cin)
+      : "vcc");
+  return cout;
+}
+#endif
+
+// One fold step in the reference's full generality (693-707): r[0..7] are the words of result[0..4],
+// cin the per-lane incoming carry.  Returns the carry out of limb 3.
+FEC_DEV lmask fold_general(u32 r[8], u32 m0, u32 m1, lmask cin) {
+  u64 m = ((u64)m1 << 32) | m0;
+  u64 carry = word_select(0u, 1u, cin);
+  u64 res0 = ((u64)r[1] << 32) | r[0];
+  u64 t = res0 + m;
+  t = t + carry;
+  carry = (u64)(t < m) | ((u64)(t < carry) & (u64)(m != 0));  // 698-699
+  r[0] = (u32)t;
+  r[1] = (u32)(t >> 32);
+  lmask c = lanes_where(carry != 0);
+  FEC_UNROLL for (int j = 1; j < 4; ++j) c = ripple2(r[2 * j], r[2 * j + 1], c);  // 702-706
+  return c;
+}
+
 FEC_DEV fe sqr(const fe& a) {
-  u64 pr[8];
-  FEC_UNROLL for (int i = 0; i < 4; ++i)  // 643-649
-      mul64wide(a.w[2 * i], a.w[2 * i + 1], a.w[2 * i], a.w[2 * i + 1], pr[2 * i], pr[2 * i + 1]);
-  FEC_UNROLL for (int i = 0; i < 4; ++i) {  // 652-679
+  u32 w[16];
+  FEC_UNROLL for (int i = 0; i < 4; ++i)  // 643-649: limb squares
+      mul64_words(&w[4 * i], a.w[2 * i], a.w[2 * i + 1], a.w[2 * i], a.w[2 * i + 1]);
+  FEC_UNROLL for (int i = 0; i < 4; ++i) {  // 652-679: doubled cross terms
     FEC_UNROLL for (int j = i + 1; j < 4; ++j) {
-      u64 lo, hi;
-      mul64wide(a.w[2 * i], a.w[2 * i + 1], a.w[2 * j], a.w[2 * j + 1], lo, hi);
-      hi = (hi << 1) | (lo >> 63);  // u128 wrapping_mul(2): bit 127 is lost
-      lo = lo << 1;
-      u64 s0 = pr[i + j] + lo;
-      u32 c1 = s0 < lo;
-      pr[i + j] = s0;
-      u64 s1 = pr[i + j + 1] + hi;  // c1 is not added here
-      u32 c2 = s1 < hi;
-      pr[i + j + 1] = s1;
-      u64 inc = c1 | c2;  // a single +1 rippling from limb i+j+2, lost past limb 7
-      FEC_UNROLL for (int k = i + j + 2; k < 8; ++k) {
-        u64 v = pr[k] + inc;
-        inc = (v < inc) ? 1 : 0;
-        pr[k] = v;
+      u32 p[4];
+      mul64_words(p, a.w[2 * i], a.w[2 * i + 1], a.w[2 * j], a.w[2 * j + 1]);
+      u32 x0 = p[0] << 1;  // u128 wrapping_mul(2): bit 127 is lost
+      u32 x1 = (p[1] << 1) | (p[0] >> 31);
+      u32 x2 = (p[2] << 1) | (p[1] >> 31);
+      u32 x3 = (p[3] << 1) | (p[2] >> 31);
+      const int B = 2 * (i + j);
+      lmask more = cross_add(w[B], w[B + 1], w[B + 2], w[B + 3], w[B + 4], w[B + 5], x0, x1, x2, x3);
+      if (B + 6 < 16) {  // the ripple may continue into limbs i+j+3 .. 7
+        if (__builtin_expect(more != 0, 0)) {
+#ifdef FEC_HOST_EMUL
+          ++fec_host_rare_sqr;
+#endif
+          FEC_UNROLL for (int k = B + 6; k < 16; k += 2) more = ripple2(w[k], w[k + 1], more);
+        }
       }
     }
   }
-  u64 res[4] = {pr[0], pr[1], pr[2], pr[3]};
-  u64 carry = 0;  // 692
+  // 681-707: every high limb folded into limb 0 with the low 64 bits of limb * 0x1000003D1
+  u32 r[8];
+  FEC_UNROLL for (int i = 0; i < 8; ++i) r[i] = w[i];
+  lmask carry = 0;  // 692: carry out of limb 3 of the previous fold step
   FEC_UNROLL for (int i = 4; i < 8; ++i) {
-    u64 m = pr[i] * 0x1000003D1ULL;  // low 64 bits only
-    u64 t = res[0] + m;              // always into limb 0
-    t = t + carry;
-    res[0] = t;
-    carry = (u64)(t < m) | ((u64)(t < carry) & (u64)(m != 0));  // 698-699
-    FEC_UNROLL for (int j = 1; j < 4; ++j) {
-      u64 t2 = res[j] + carry;
-      res[j] = t2;
-      carry = (u64)(t2 < carry);
+    u32 h0 = w[2 * i], h1 = w[2 * i + 1];
+    u64 q = (u64)h0 * 977u;
+    u32 m0 = (u32)q;
+    u32 m1 = (u32)(q >> 32) + h1 * 977u + h0;
+    if (__builtin_expect(carry == 0, 1)) {
+      // incoming carry 0: the rule at 698-699 is the plain carry-out of limb0 + m
+      lmask more = fold_add(r[0], r[1], r[2], r[3], m0, m1);
+      if (__builtin_expect(more != 0, 0)) {
+#ifdef FEC_HOST_EMUL
+        ++fec_host_rare_sqr;
+#endif
+        more = ripple2(r[4], r[5], more);
+        carry = ripple2(r[6], r[7], more);
+      }
+    } else {
+#ifdef FEC_HOST_EMUL
+      ++fec_host_rare_sqr;
+#endif
+      carry = fold_general(r, m0, m1, carry);
     }
   }
-  fe r;
-  FEC_UNROLL for (int i = 0; i < 4; ++i) set_limb64(r, i, res[i]);
-  return csub_p(r);
+  fe o;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) o.w[i] = r[i];
+  return csub_p_unlikely(o);
 }
 
 struct pt {
@@ -178,7 +304,9 @@ FEC_DEV pt pdouble(const pt& p) {
   r.y = sub(mul(e, sub(d, r.x)), mul_small(c, 8));
   fe yz = mul(p.y, p.z);
   r.z = add(yz, yz);
-  return pt_select(r, identity(), is_identity(p));
+  lmask idp = is_identity(p);
+  if (__builtin_expect(idp != 0, 0)) r = pt_select(r, identity(), idp);
+  return r;
 }
 
 // Add for ProjectivePoint (1444-1498) without the equal-points branch: sets need_double when
@@ -203,11 +331,15 @@ FEC_DEV pt padd_nodouble(const pt& p, const pt& q, lmask& need_double) {
   o.y = sub(mul(r, sub(u1h2, o.x)), mul(s1, h3));
   o.z = mul(mul(h, p.z), q.z);
   lmask idp = is_identity(p), idq = is_identity(q);
-  lmask ueq = fe_eq(u1, u2), seq = fe_eq(s1, s2);
-  o = pt_select(o, identity(), ueq & ~seq);
-  o = pt_select(o, p, idq);
-  o = pt_select(o, q, idp);
-  need_double = ueq & seq & ~idp & ~idq;
+  lmask ueq = fe_eq(u1, u2);
+  need_double = 0;
+  if (__builtin_expect((idp | idq | ueq) != 0, 0)) {  // early-outs: only the ladder's first steps
+    lmask seq = fe_eq(s1, s2);
+    o = pt_select(o, identity(), ueq & ~seq);
+    o = pt_select(o, p, idq);
+    o = pt_select(o, q, idp);
+    need_double = ueq & seq & ~idp & ~idq;
+  }
   return o;
 }
 

@@ -58,6 +58,22 @@ def test_field_ops_match_oracle(gpu_ctx, oracle, curve, op):
     _assert_same(got, want, "%s field %s" % (NAMES[curve], OPNAME[op]))
 
 
+def test_secp256k1_square_ripple_operands(gpu_ctx, oracle):
+    """square() operands whose carries ripple past the first limb: the kernel's fast path must fall
+    back to the literal routine for the wavefront.  Mixed with ordinary operands so fast and slow
+    lanes share wavefronts."""
+    import json
+    import os
+    ops = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                      "secp256k1_sqr_ripple_operands.json")))["operands"]
+    rare = np.array(ops, dtype=np.uint64)
+    plain = V.field_elements(1000, 0, 881)
+    a = np.ascontiguousarray(np.concatenate([rare, plain, rare[:7], plain[:300], rare[40:41]]))
+    got = gpu_ctx.field_op(0, F_SQR, a)
+    want = _oracle_field(oracle, 0, F_SQR, a)
+    _assert_same(got, want, "secp256k1 square with travelling ripples")
+
+
 def test_field_reference_kats(gpu_ctx):
     """The reference's own unit-test vectors, through the GPU kernels."""
     import json

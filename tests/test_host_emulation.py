@@ -79,3 +79,21 @@ def test_point_ops_and_multiply(emu, oracle, curve):
         base = np.ascontiguousarray(base)
         emu.he_multiply(curve, _p(base), _p(k), _p(out))
         assert np.array_equal(out, oracle.multiply(curve, base, k)), (curve, [hex(int(v)) for v in k])
+
+
+def test_secp256k1_square_fallback_is_exercised(emu, oracle):
+    """Operands whose ripples travel (tests/golden/secp256k1_sqr_ripple_operands.json) must reach
+    sqr()'s cold continuation blocks and still match the oracle."""
+    import json
+    ops = json.load(open(os.path.join(ROOT, "tests", "golden", "secp256k1_sqr_ripple_operands.json")))["operands"]
+    emu.he_rare_sqr_count.restype = ctypes.c_ulong
+    out = np.zeros(4, dtype=np.uint64)
+    taken = 0
+    for limbs in ops:
+        a = np.array(limbs, dtype=np.uint64)
+        before = emu.he_rare_sqr_count()
+        emu.he_field_op(0, OPS["sqr"], _p(a), None, _p(out))
+        assert emu.he_rare_sqr_count() > before, "operand does not reach a cold block any more"
+        taken += 1
+        assert np.array_equal(out, oracle.field_op(0, "sqr", a))
+    assert taken == len(ops)

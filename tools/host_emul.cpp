@@ -11,6 +11,7 @@ using namespace fecgpu;
 static fe ld(const uint64_t* a) { fe r; for (int i = 0; i < 4; ++i) { r.w[2*i] = (u32)a[i]; r.w[2*i+1] = (u32)(a[i] >> 32); } return r; }
 static void st(uint64_t* o, const fe& a) { for (int i = 0; i < 4; ++i) o[i] = (u64)a.w[2*i] | ((u64)a.w[2*i+1] << 32); }
 
+extern "C" unsigned long he_rare_sqr_count() { return secp::fec_host_rare_sqr; }
 extern "C" int he_field_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
   fe x = ld(a), y = b ? ld(b) : fe_zero(), r;
   if (curve == 0) r = op == 0 ? secp::add(x, y) : op == 1 ? secp::sub(x, y) : op == 2 ? secp::mul(x, y) : op == 3 ? secp::sqr(x) : secp::neg(x);
