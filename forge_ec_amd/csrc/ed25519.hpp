@@ -164,5 +164,52 @@ FEC_DEV pt multiply(const pt& point, const u32* kw) {
   return pt_select(result, identity(), early);
 }
 
+// Fixed-base Curve::multiply (BASELINE config 3).  The reference's addend sequence
+// B, B+B, (B+B)+(B+B), ... (2089: `addend = addend.double()`) does not depend on the scalar, so
+// the 256 addends are computed once (k_ed_build_table, the same padd chain) and staged in LDS;
+// each lane then performs only the additions its set bits select, in the reference's order
+// (ascending bit index), from its own position in the table: `result + addend` is computed for
+// every bit by the reference but kept only where the bit is set (2085-2086).  Entry j, word w of
+// the table sits at tab[j * ED_TSTRIDE + w]; the odd stride spreads lanes reading different
+// entries over the LDS banks.
+constexpr int ED_TSTRIDE = 33;
+
+FEC_DEV pt table_entry(const u32* tab, u32 j) {
+  const u32* e = tab + j * ED_TSTRIDE;
+  pt p;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    p.x.w[i] = e[i];
+    p.y.w[i] = e[8 + i];
+    p.z.w[i] = e[16 + i];
+    p.t.w[i] = e[24 + i];
+  }
+  return p;
+}
+
+FEC_DEV pt multiply_fixed(const pt& base, const u32* tab, const u32* kw) {
+  u32 any = 0;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kw[i * KSTRIDE];
+  lmask early = is_identity(base) | lanes_where(any == 0);
+  pt result = identity();
+  int wi = 0;
+  u32 cur = kw[0];
+#pragma unroll 1
+  for (;;) {
+    while (cur == 0 && wi < 7) {  // advance to this lane's next non-zero scalar word
+      ++wi;
+      cur = kw[wi * KSTRIDE];
+    }
+    bool have = cur != 0;
+    lmask active = lanes_where(have);
+    if (active == 0) break;  // every lane of the wavefront has consumed its set bits
+    u32 b = have ? (u32)__builtin_ctz(cur) : 0u;
+    cur &= cur - 1;
+    pt addend = table_entry(tab, have ? (u32)wi * 32u + b : 0u);
+    pt sum = padd(result, addend);
+    result = pt_select(result, sum, active);
+  }
+  return pt_select(result, identity(), early);
+}
+
 }  // namespace ed
 }  // namespace fecgpu

@@ -203,6 +203,46 @@ __global__ __launch_bounds__(TPB) void k_batch_mul(const u32* __restrict__ scala
   stage_out<C::PW>(out + first * C::PW, lds_p, valid);
 }
 
+// table[j] = 2^j * base by the reference's own doubling chain (ed25519.rs:2089): one lane, 255
+// sequential additions; 32 words per entry, dense.  Runs once per base point.
+__global__ __launch_bounds__(64) void k_ed_build_table(const u32* __restrict__ base, u32* __restrict__ table) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ed::pt a = Ed::load(base, 1);
+#pragma unroll 1
+  for (int j = 0; j < 256; ++j) {
+    Ed::store(table + j * 32, 1, a);
+    a = ed::padd(a, a);
+  }
+}
+
+// Ed25519 fixed-base: out[i] = multiply(base, scalars[i]) from the LDS addend table.
+__global__ __launch_bounds__(TPB) void k_ed_fixed_base(const u32* __restrict__ scalars,
+                                                       const u32* __restrict__ base,
+                                                       const u32* __restrict__ table,
+                                                       u32* __restrict__ out, size_t n) {
+  __shared__ u32 lds_k[8 * TPB];
+  __shared__ u32 lds_t[256 * ed::ED_TSTRIDE];
+  __shared__ u32 lds_o[Ed::PW * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_k, scalars + first * 8, valid);
+  for (int v = threadIdx.x; v < 256 * 32 / 4; v += TPB) {  // 32 KiB table, 16-byte loads (L2-resident)
+    uint4 x = *reinterpret_cast<const uint4*>(table + (size_t)v * 4);
+    int j = (v * 4) / 32, w = (v * 4) % 32;
+    u32* d = lds_t + j * ed::ED_TSTRIDE + w;
+    d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+  }
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    ed::pt b = Ed::load(base, 1);
+    ed::pt r = ed::multiply_fixed(b, lds_t, lds_k + e);
+    Ed::store(lds_o + e, TPB, r);
+  }
+  __syncthreads();
+  stage_out<Ed::PW>(out + first * Ed::PW, lds_o, valid);
+}
+
 // out[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])     (ecdsa.rs:254-256)
 template <class C>
 __global__ __launch_bounds__(TPB) void k_batch_double_mul(const u32* __restrict__ u1,
@@ -333,6 +373,10 @@ struct fec_ctx {
   void* d_buf[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t d_cap[4] = {0, 0, 0, 0};
   u64* d_gen[3] = {nullptr, nullptr, nullptr};  // reference generator() per curve, device copy
+  u32* d_ed_table = nullptr;                    // Ed25519 fixed-base addend table (256 x 32 words)
+  u64 ed_table_base[16] = {0};                  // the base point the table was built for
+  bool ed_table_valid = false;
+  u64 h_gen_ed[16] = {0};                       // host copy of the Ed25519 generator (table cache key)
   hipDeviceProp_t prop;
 };
 
@@ -395,6 +439,34 @@ struct Launch {
 };
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+// Build (or reuse) the Ed25519 addend table for the base at device address d_base.  `host_base`
+// (may be null) is the same point on the host and lets repeated calls with one base skip the build.
+int ensure_ed_table(fec_ctx* ctx, const u64* d_base, const u64* host_base, hipStream_t s) {
+  if (!ctx->d_ed_table && hipMalloc(&ctx->d_ed_table, 256 * 32 * sizeof(u32)) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_OOM;
+  }
+  if (host_base && ctx->ed_table_valid && std::memcmp(host_base, ctx->ed_table_base, 128) == 0) return FEC_OK;
+  hipLaunchKernelGGL(k_ed_build_table, dim3(1), dim3(64), 0, s, reinterpret_cast<const u32*>(d_base),
+                     ctx->d_ed_table);
+  if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
+  ctx->ed_table_valid = host_base != nullptr;
+  if (host_base) std::memcpy(ctx->ed_table_base, host_base, 128);
+  return FEC_OK;
+}
+
+int launch_ed_fixed(fec_ctx* ctx, const u64* ds, const u64* dbase, const u64* host_base, u64* dout, size_t n,
+                    void* stream) {
+  if (n == 0) return FEC_OK;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  int rc = ensure_ed_table(ctx, dbase, host_base, s);
+  if (rc != FEC_OK) return rc;
+  Launch L(ctx, stream, "k_ed_fixed_base");
+  hipLaunchKernelGGL(k_ed_fixed_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(ds),
+                     reinterpret_cast<const u32*>(dbase), ctx->d_ed_table, reinterpret_cast<u32*>(dout), n);
+  return L.done();
+}
 
 int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp, u64* dout, size_t n,
                void* stream) {
@@ -555,6 +627,7 @@ int fec_ctx_create(fec_ctx** out, int device) {
     ok = ok && launch_field(ctx, FEC_ED25519, FEC_F_MUL, ctx->d_gen[2], ctx->d_gen[2] + 4,
                             ctx->d_gen[2] + 12, 1) == FEC_OK;
     ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    ok = ok && hipMemcpy(ctx->h_gen_ed, ctx->d_gen[2], 128, hipMemcpyDeviceToHost) == hipSuccess;
     if (!ok) {
       (void)hipGetLastError();
       fec_ctx_destroy(ctx);
@@ -572,6 +645,7 @@ void fec_ctx_destroy(fec_ctx* ctx) {
     if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
   for (int i = 0; i < 3; ++i)
     if (ctx->d_gen[i]) (void)hipFree(ctx->d_gen[i]);
+  if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -591,6 +665,11 @@ int fec_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* ds, c
   if (!ctx || !curve_ok(curve) || (n && (!ds || !dbase || !dout))) return FEC_E_ARG;
   if (!aligned16(ds) || !aligned16(dbase) || !aligned16(dout)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  if (curve == FEC_ED25519) {
+    // the ctx's own generator (fec_generator_dev) is recognised by address, so its table is built once
+    const u64* host_base = dbase == ctx->d_gen[FEC_ED25519] ? ctx->h_gen_ed : nullptr;
+    return launch_ed_fixed(ctx, ds, dbase, host_base, dout, n, stream);
+  }
   return launch_mul(ctx, curve, true, ds, dbase, dout, n, stream);
 }
 
@@ -620,6 +699,8 @@ int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, 
   size_t pb = (size_t)plimbs(curve) * 8;
   return host_roundtrip(ctx, scalars, n * 32, base, pb, nullptr, 0, out, n * pb,
                         [&](void* a, void* b, void*, void* o) {
+                          if (curve == FEC_ED25519)
+                            return launch_ed_fixed(ctx, (const u64*)a, (const u64*)b, base, (u64*)o, n, nullptr);
                           return launch_mul(ctx, curve, true, (const u64*)a, (const u64*)b, (u64*)o, n, nullptr);
                         });
 }
@@ -670,6 +751,11 @@ int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out) {
     return FEC_E_DEVICE;
   }
   return FEC_OK;
+}
+
+const uint64_t* fec_generator_dev(fec_ctx* ctx, fec_curve curve) {
+  if (!ctx || !curve_ok(curve)) return nullptr;
+  return ctx->d_gen[curve];
 }
 
 int fec_ctx_set_timing(fec_ctx* ctx, int enabled) {

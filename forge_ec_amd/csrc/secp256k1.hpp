@@ -44,18 +44,12 @@ FEC_DEV fe csub_p_unlikely(const fe& v) {
 }
 
 // Add (353-393): s = a + b mod 2^256; subtract p once if the add carried or s >= p.
-// With a carry the result is s + c; without one it is s unless s >= p (improbable: rare branch).
 FEC_DEV fe add(const fe& a, const fe& b) {
-  fe s, r;
+  fe s, w;
   lmask carry = add256(s, a, b);
-  add_lohi256(r, s, word_select(0u, 0x3D1u, carry), word_select(0u, 1u, carry));
-  if (__builtin_expect((maybe_ge_p(s) & ~carry) != 0, 0)) {
-    fe w;
-    lmask ov;
-    FEC_ADDK256(w, s, ov, FEC_SECP_C);  // w = s - p mod 2^256
-    r = fe_select(s, w, carry | ov);
-  }
-  return r;
+  lmask ov;
+  FEC_ADDK256(w, s, ov, FEC_SECP_C);  // w = s - p mod 2^256
+  return fe_select(s, w, carry | ov);
 }
 
 // Sub (395-440): d = a - b mod 2^256; add p (wrapping), i.e. subtract c, if it borrowed.

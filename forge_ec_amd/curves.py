@@ -126,6 +126,10 @@ class Context:
         _check(self._lib.fec_generator(self._h, curve, _ptr(out)), "fec_generator")
         return out
 
+    def generator_dev(self, curve):
+        """Device address of the ctx's generator (pass it to batch_mul_fixed_dev)."""
+        return self._lib.fec_generator_dev(self._h, curve)
+
     # ---- measurement ----
     def set_timing(self, enabled=True):
         _check(self._lib.fec_ctx_set_timing(self._h, 1 if enabled else 0))

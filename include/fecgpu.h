@@ -78,6 +78,10 @@ void fec_ctx_destroy(fec_ctx* ctx);
  * with the same field kernels at ctx creation.  out: fec_point_limbs(curve) limbs. */
 int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out);
 
+/* Device address of that generator (valid for the ctx's lifetime), for the *_dev entry points.
+ * Passing it to fec_batch_mul_fixed_dev lets the Ed25519 fixed-base addend table be built once. */
+const uint64_t* fec_generator_dev(fec_ctx* ctx, fec_curve curve);
+
 /* ---- host-pointer entry points (caller-owned memory; nothing retained after return) ---- */
 int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars /* n*4 */,
                   const uint64_t* points /* n*limbs */, uint64_t* out /* n*limbs */, size_t n);

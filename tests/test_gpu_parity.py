@@ -226,6 +226,26 @@ def test_abi_argument_errors(gpu_ctx):
     assert L.fec_batch_mul_dev(h, 0, ctypes.c_void_p(8), ctypes.c_void_p(16), ctypes.c_void_p(16), 1, None) == -1
 
 
+def test_ed25519_fixed_base_device_path_reuses_table(gpu_ctx, oracle):
+    """fec_batch_mul_fixed_dev on the ctx's own generator (table built once, recognised by address),
+    then on another base (table rebuilt), then the generator again."""
+    import torch
+    n = 900
+    k = V.scalars(n, 2, 351)
+    dk = torch.from_numpy(k.view(np.int64)).cuda()
+    do = torch.empty((n, 16), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    g = oracle.generator(2)
+    other = V.points(1, 2, 352)[0]
+    d_other = torch.from_numpy(other.view(np.int64)).cuda()
+    for base_host, base_dev in ((g, gpu_ctx.generator_dev(2)), (other, d_other.data_ptr()),
+                                (g, gpu_ctx.generator_dev(2))):
+        gpu_ctx.batch_mul_fixed_dev(2, dk.data_ptr(), base_dev, do.data_ptr(), n, stream)
+        torch.cuda.synchronize()
+        got = do.cpu().numpy().view(np.uint64)
+        _assert_same(got, oracle.batch_mul_fixed(2, k, base_host, nthreads=8), "ed25519 fixed-base dev path")
+
+
 def test_device_pointer_path_with_torch(gpu_ctx, oracle):
     """The *_dev entry points on torch-owned HBM buffers and torch's current stream."""
     import torch

@@ -97,3 +97,19 @@ def test_secp256k1_square_fallback_is_exercised(emu, oracle):
         taken += 1
         assert np.array_equal(out, oracle.field_op(0, "sqr", a))
     assert taken == len(ops)
+
+
+def test_ed25519_fixed_base_table_walk(emu, oracle):
+    """multiply_fixed (LDS addend table, set bits only) == the reference's 256-step loop."""
+    g = oracle.generator(2)
+    ks = [V.limbs_of(v) for v in (0, 1, 2, 3, 1 << 255, (1 << 256) - 1, 0x80, 1 << 31, 1 << 32, 0x8000000100000000)]
+    ks += [list(r) for r in V.scalars(10, 2, 31)]
+    bases = [g] * len(ks)
+    bases[-3:] = list(V.points(3, 2, 32))
+    bases[4] = oracle.identity(2)
+    out = np.zeros(16, dtype=np.uint64)
+    for k, base in zip(ks, bases):
+        k = np.array(k, dtype=np.uint64)
+        base = np.ascontiguousarray(base)
+        emu.he_ed_multiply_fixed(_p(base), _p(k), _p(out))
+        assert np.array_equal(out, oracle.multiply(2, base, k)), [hex(int(v)) for v in k]

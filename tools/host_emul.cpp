@@ -40,3 +40,18 @@ extern "C" int he_multiply(int curve, const uint64_t* point, const uint64_t* sca
   else stp4(out, ed::multiply(ldp4(point), kw));
   return 0;
 }
+
+// Ed25519 fixed-base through the same table walk the kernel uses (table built by the same chain)
+extern "C" int he_ed_multiply_fixed(const uint64_t* base, const uint64_t* scalar, uint64_t* out) {
+  static thread_local u32 kw[8 * KSTRIDE];
+  static thread_local u32 tab[256 * ed::ED_TSTRIDE];
+  for (int i = 0; i < 4; ++i) { kw[(2*i) * KSTRIDE] = (u32)scalar[i]; kw[(2*i+1) * KSTRIDE] = (u32)(scalar[i] >> 32); }
+  ed::pt a = ldp4(base);
+  for (int j = 0; j < 256; ++j) {
+    u32* e = tab + j * ed::ED_TSTRIDE;
+    for (int i = 0; i < 8; ++i) { e[i] = a.x.w[i]; e[8+i] = a.y.w[i]; e[16+i] = a.z.w[i]; e[24+i] = a.t.w[i]; }
+    a = ed::padd(a, a);
+  }
+  stp4(out, ed::multiply_fixed(ldp4(base), tab, kw));
+  return 0;
+}

@@ -17,8 +17,21 @@ def main():
     print("peak MAD32/s: %.3e" % peak, flush=True)
     ctx.set_timing(True)
     need = {0: 693248, 1: 278528, 2: 248832}
+    mode = sys.argv[3] if len(sys.argv) > 3 else "var"
+    need_fixed = {0: 693248, 1: 278528, 2: 82944}
     for curve in curves:
         k = V.scalars(n, curve, 1); p = V.points(n, curve, 2)
+        if mode == "fixed":
+            dk = torch.from_numpy(k.view(np.int64)).cuda()
+            do = torch.empty((n, V.POINT_LIMBS[curve]), dtype=torch.int64, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            for rep in range(3):
+                ctx.batch_mul_fixed_dev(curve, dk.data_ptr(), ctx.generator_dev(curve), do.data_ptr(), n, st)
+                ms, name = ctx.last_kernel_ms()
+                rate = n / (ms * 1e-3)
+                print("curve %d n=2^%d FIXED %s: %.3f ms  %.3f M scalar-mul/s  alg-MAD32 %.2f T/s (%.1f%% of peak)" % (
+                    curve, logn, name, ms, rate / 1e6, rate * need_fixed[curve] / 1e12, 100 * rate * need_fixed[curve] / peak), flush=True)
+            continue
         dk = torch.from_numpy(k.view(np.int64)).cuda(); dp = torch.from_numpy(p.view(np.int64)).cuda()
         do = torch.empty_like(dp)
         st = torch.cuda.current_stream().cuda_stream
