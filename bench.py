@@ -103,7 +103,10 @@ def main():
         raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
     dist = None
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # FEC_BENCH_FORCE_DIST=1 rehearses the N>1 code path (RCCL init, overlapped gather, max-reduce)
+    # with a single rank on a one-GPU box
+    force_dist = os.environ.get("FEC_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -122,7 +125,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     gather = None
-    if world > 1 and args.gather == "all":
+    if dist is not None and args.gather == "all":
         from forge_ec_amd.dist import ResultGather
         gather = [ResultGather(n * world, limbs, torch.device("cuda", local_rank)) for _ in range(2)]
 
@@ -190,7 +193,7 @@ def main():
             "config": {"workload": "2^%d %s variable-base scalar-muls per GPU per step (BASELINE.json configs[1])"
                                    % (args.log2_batch, curve),
                        "curve": curve, "batch_per_gpu": n, "global_batch": n * world,
-                       "result_gather": (args.gather if world > 1 else "n/a"),
+                       "result_gather": (args.gather if dist is not None else "n/a"),
                        "device": info["name"], "compute_units": info["compute_units"]},
             "roofline": {
                 "bound": "int-valu", "achieved": achieved / 1e12, "peak": PEAK_MAD32_FORMULA / 1e12,

@@ -140,6 +140,33 @@ FEC_DEV pt padd(const pt& p, const pt& q) {
   return o;
 }
 
+// pow (410-431): every bit computes result * base and selects it on the bit; base = base.square().
+// invert (603-621): a^(p-2) (for zero the CtOption is none; the value pow returns is 0).
+FEC_DEV fe inv(const fe& a) {
+  const u64 e[4] = {0xFFFFFFFFFFFFFFEBULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0x7FFFFFFFFFFFFFFFULL};
+  fe result = fe_small(1);
+  fe base = a;
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+      // the discarded product (bit clear) is dead work in the reference; the bit is uniform
+      if ((e[w] >> i) & 1) result = mul(result, base);
+      base = mul(base, base);
+    }
+  }
+  return result;
+}
+
+// to_affine (1793-1811): x = X * Z^-1, y = Y * Z^-1; identity -> (0, 0, infinity).
+FEC_DEV lmask to_affine(const pt& p, fe& x, fe& y) {
+  lmask inf = is_identity(p);
+  fe zi = inv(p.z);
+  x = fe_select(mul(p.x, zi), fe_zero(), inf);
+  y = fe_select(mul(p.y, zi), fe_zero(), inf);
+  return inf;
+}
+
 // Curve::multiply (2062-2097): LSB-first over scalar.to_raw(); every step computes
 // result + addend, selects it on the bit, and doubles the addend.
 FEC_DEV pt multiply(const pt& point, const u32* kw) {

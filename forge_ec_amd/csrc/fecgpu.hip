@@ -45,6 +45,7 @@ struct Secp {
     }
   }
   FEC_DEV static pt multiply(const pt& p, const u32* kw) { return secp::multiply(p, kw); }
+  FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return secp::to_affine(p, x, y); }
   FEC_DEV static pt padd(const pt& a, const pt& b) { return secp::padd(a, b); }
   FEC_DEV static pt pdouble(const pt& a) { return secp::pdouble(a); }
   FEC_DEV static pt pdouble_trait(const pt& a) { return secp::pdouble_trait(a); }
@@ -80,6 +81,7 @@ struct P256 {
     }
   }
   FEC_DEV static pt multiply(const pt& p, const u32* kw) { return p256::multiply(p, kw); }
+  FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return p256::to_affine(p, x, y); }
   FEC_DEV static pt padd(const pt& a, const pt& b) { return p256::padd(a, b); }
   FEC_DEV static pt pdouble(const pt& a) { return p256::pdouble(a); }
   FEC_DEV static pt pdouble_trait(const pt& a) { return p256::pdouble(a); }
@@ -117,6 +119,7 @@ struct Ed {
     }
   }
   FEC_DEV static pt multiply(const pt& p, const u32* kw) { return ed::multiply(p, kw); }
+  FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return ed::to_affine(p, x, y); }
   FEC_DEV static pt padd(const pt& a, const pt& b) { return ed::padd(a, b); }
   FEC_DEV static pt pdouble(const pt& a) { return ed::padd(a, a); }
   FEC_DEV static pt pdouble_trait(const pt& a) { return ed::padd(a, a); }
@@ -334,6 +337,29 @@ __global__ __launch_bounds__(TPB) void k_point_op(int op, const u32* __restrict_
   stage_out<C::PW>(out + first * C::PW, lds_p, valid);
 }
 
+// xy[i] = to_affine(points[i]) as (x, y); inf[i] = 1 where the point is the identity
+template <class C>
+__global__ __launch_bounds__(TPB) void k_to_affine(const u32* __restrict__ points, u32* __restrict__ xy,
+                                                   unsigned char* __restrict__ inf, size_t n) {
+  __shared__ u32 lds_p[C::PW * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<C::PW>(lds_p, points + first * C::PW, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    typename C::pt p = C::load(lds_p + e, TPB);
+    fe x, y;
+    lmask m = C::to_affine(p, x, y);
+    bool mine = (m >> (threadIdx.x & 63)) & 1;
+    store_fe(lds_p + e, TPB, x);  // a lane reads and writes only its own LDS column
+    store_fe(lds_p + 8 * TPB + e, TPB, y);
+    inf[first + e] = mine ? 1 : 0;
+  }
+  __syncthreads();
+  stage_out<16>(xy + first * 16, lds_p, valid);
+}
+
 // Peak 32x32+64 multiply-add rate: 8 independent v_mad_u64_u32 chains per lane, no memory.
 constexpr int PEAK_ITERS = 4096;
 __global__ __launch_bounds__(TPB) void k_peak_mad32(u32* out, u32 seed) {
@@ -507,6 +533,20 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
     case FEC_SECP256K1: hipLaunchKernelGGL((k_batch_double_mul<Secp>), g, b, 0, L.s, a, b2, q, gen, o, n); break;
     case FEC_P256: hipLaunchKernelGGL((k_batch_double_mul<P256>), g, b, 0, L.s, a, b2, q, gen, o, n); break;
     default: hipLaunchKernelGGL((k_batch_double_mul<Ed>), g, b, 0, L.s, a, b2, q, gen, o, n); break;
+  }
+  return L.done();
+}
+
+int launch_to_affine(fec_ctx* ctx, int curve, const u64* dp, u64* dxy, unsigned char* dinf, size_t n, void* stream) {
+  if (n == 0) return FEC_OK;
+  const u32* p = reinterpret_cast<const u32*>(dp);
+  u32* o = reinterpret_cast<u32*>(dxy);
+  dim3 g(grid_for(n)), b(TPB);
+  Launch L(ctx, stream, "k_to_affine");
+  switch (curve) {
+    case FEC_SECP256K1: hipLaunchKernelGGL((k_to_affine<Secp>), g, b, 0, L.s, p, o, dinf, n); break;
+    case FEC_P256: hipLaunchKernelGGL((k_to_affine<P256>), g, b, 0, L.s, p, o, dinf, n); break;
+    default: hipLaunchKernelGGL((k_to_affine<Ed>), g, b, 0, L.s, p, o, dinf, n); break;
   }
   return L.done();
 }
@@ -715,6 +755,39 @@ int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
                           return launch_double_mul(ctx, curve, (const u64*)a, (const u64*)b, (const u64*)c,
                                                    (u64*)o, n, nullptr);
                         });
+}
+
+int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
+                            uint8_t* d_inf, size_t n, void* stream) {
+  if (!ctx || !curve_ok(curve) || (n && (!d_points || !d_xy || !d_inf))) return FEC_E_ARG;
+  if (!aligned16(d_points) || !aligned16(d_xy)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_to_affine(ctx, curve, d_points, d_xy, d_inf, n, stream);
+}
+
+int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points, uint64_t* xy, uint8_t* inf,
+                        size_t n) {
+  if (!ctx || !curve_ok(curve) || (n && (!points || !xy || !inf))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  size_t pb = (size_t)plimbs(curve) * 8;
+  int rc = ensure(ctx, 0, n * pb);
+  if (rc == FEC_OK) rc = ensure(ctx, 3, n * 64);
+  if (rc == FEC_OK) rc = ensure(ctx, 1, n);
+  if (rc != FEC_OK) return rc;
+  if (hipMemcpyAsync(ctx->d_buf[0], points, n * pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    return FEC_E_DEVICE;
+  rc = launch_to_affine(ctx, curve, (const u64*)ctx->d_buf[0], (u64*)ctx->d_buf[3],
+                        (unsigned char*)ctx->d_buf[1], n, nullptr);
+  if (rc != FEC_OK) return rc;
+  if (hipMemcpyAsync(xy, ctx->d_buf[3], n * 64, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(inf, ctx->d_buf[1], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  return FEC_OK;
 }
 
 int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a, const uint64_t* b,

@@ -24,11 +24,11 @@ FEC_DEV fe csub_p(const fe& v) {
   return fe_select(v, w, ~borrow);
 }
 
-// Add (416-468).  carry <= 1 after the limb loop.  `while carry > 0` (436-452): the first trip
-// adds 2^256-p; it carries again only if (a+b-2^256) >= p, and then the second trip cannot
-// (s' < 2^256-p, so s' + (2^256-p) < 2^256): at most two trips.  The second trip needs
-// a+b >= 2^256+p, impossible for canonical operands, so it sits behind a wave-uniform branch.
-FEC_DEV fe add(const fe& a, const fe& b) {
+// Add (416-468), literal for arbitrary 256-bit operands.  carry <= 1 after the limb loop.
+// `while carry > 0` (436-452): the first trip adds 2^256-p; it carries again only if
+// (a+b-2^256) >= p, and then the second trip cannot (s' < 2^256-p, so s' + (2^256-p) < 2^256): at
+// most two trips; then reduce() (one trip).
+FEC_DEV fe add_general(const fe& a, const fe& b) {
   fe s, s1;
   lmask carry = add256(s, a, b);
   lmask ac;
@@ -43,6 +43,21 @@ FEC_DEV fe add(const fe& a, const fe& b) {
     s = fe_select(s, s2, again);
   }
   return csub_p(s);
+}
+
+// Add for the common case.  For canonical operands (a, b < p) the loops above collapse to
+// (a + b) mod p: with a carry, s + (2^256-p) = a+b-p < p and nothing else fires; without one the
+// result is s - p if s >= p.  Both are w = s - p (mod 2^256), selected on carry | (s >= p).
+// A non-canonical operand (possible after the reference's Sub, ~2^-32 per subtraction) needs a
+// top word of 0xFFFFFFFF; such wavefronts take the literal routine.
+FEC_DEV fe add(const fe& a, const fe& b) {
+  lmask noncanon = lanes_where(a.w[7] == 0xFFFFFFFFu || b.w[7] == 0xFFFFFFFFu);
+  if (__builtin_expect(noncanon != 0, 0)) return add_general(a, b);
+  fe s, w;
+  lmask carry = add256(s, a, b);
+  lmask borrow;
+  FEC_SUBK256(w, s, borrow, FEC_P256_P);
+  return fe_select(s, w, carry | ~borrow);
 }
 
 // Sub (470-496): if a < b { a = a + P  (Add reduces that back to canon(a)) }; then a wrapping
@@ -199,6 +214,34 @@ FEC_DEV pt padd(const pt& p, const pt& q) {
     o = pt_select(o, d, nd);
   }
   return o;
+}
+
+// pow (376-393), LSB first: `if e & 1 { result *= base }; base = base.square()`
+// invert (343-370): zero -> none (value zero); exponent p - 2 from the limb-wise borrow loop.
+FEC_DEV fe inv(const fe& a) {
+  const u64 e[4] = {0xFFFFFFFFFFFFFFFDULL, 0x00000000FFFFFFFFULL, 0x0000000000000000ULL, 0xFFFFFFFF00000001ULL};
+  fe result = fe_small(1);
+  fe base = a;
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+      if ((e[w] >> i) & 1) result = mul(result, base);  // exponent bits are uniform
+      base = sqr(base);
+    }
+  }
+  return fe_select(result, fe_zero(), fe_is_zero(a));
+}
+
+// to_affine (1835-1857)
+FEC_DEV lmask to_affine(const pt& p, fe& x, fe& y) {
+  lmask inf = is_identity(p);
+  fe zi = inv(p.z);
+  fe zi2 = sqr(zi);
+  fe zi3 = mul(zi2, zi);
+  x = fe_select(mul(p.x, zi2), fe_zero(), inf);
+  y = fe_select(mul(p.y, zi3), fe_zero(), inf);
+  return inf;
 }
 
 // Curve::multiply (2120-2156): MSB-first over the big-endian inherent Scalar::to_bytes

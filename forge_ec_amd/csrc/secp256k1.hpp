@@ -365,6 +365,33 @@ FEC_DEV pt pdouble_trait(const pt& p) {
   return pt_select(r, identity(), is_identity(p));
 }
 
+// invert (599-632): square-and-multiply over p-2, limbs visited LS->MS, bits MS->LS inside a limb;
+// zero has no inverse (CtOption none; the value is zero).
+FEC_DEV fe inv(const fe& a) {
+  const u64 e[4] = {0xFFFFFFFEFFFFFC2DULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL};
+  fe result = fe_small(1);
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll 1
+    for (int j = 63; j >= 0; --j) {
+      result = sqr(result);
+      if ((e[i] >> j) & 1) result = mul(result, a);  // exponent bits are uniform
+    }
+  }
+  return fe_select(result, fe_zero(), fe_is_zero(a));
+}
+
+// to_affine (1342-1363): x = X * (Z^-1)^2, y = Y * (Z^-1)^2 * Z^-1; identity -> (0, 0, infinity)
+FEC_DEV lmask to_affine(const pt& p, fe& x, fe& y) {
+  lmask inf = is_identity(p);
+  fe zi = inv(p.z);
+  fe zi2 = sqr(zi);
+  fe zi3 = mul(zi2, zi);
+  x = fe_select(mul(p.x, zi2), fe_zero(), inf);
+  y = fe_select(mul(p.y, zi3), fe_zero(), inf);
+  return inf;
+}
+
 // Bit i of the ladder (2655-2659): byte i/8 of the little-endian bytes, MSB first in the byte.
 FEC_DEV u32 ladder_bit(const u32* kw, int i) {
   u32 w = kw[(i >> 5) * KSTRIDE];

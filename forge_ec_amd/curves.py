@@ -90,6 +90,16 @@ class Context:
                "fec_batch_double_mul")
         return out
 
+    def batch_to_affine(self, curve, points):
+        """(xy, inf): xy (n,8) affine limbs, inf (n,) uint8 -- Curve::to_affine per element."""
+        pl = L.POINT_LIMBS[curve]
+        p = _u64(points, pl)
+        xy = np.empty((p.shape[0], 8), dtype=np.uint64)
+        inf = np.empty(p.shape[0], dtype=np.uint8)
+        _check(self._lib.fec_batch_to_affine(self._h, curve, _ptr(p), _ptr(xy), _ptr(inf), p.shape[0]),
+               "fec_batch_to_affine")
+        return xy, inf
+
     def field_op(self, curve, op, a, b=None):
         x = _u64(a, 4)
         y = _u64(b, 4) if b is not None else None
@@ -184,6 +194,10 @@ class _Curve:
     def batch_double_multiply(self, u1, u2, q):
         """R[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])  (ecdsa.rs:254-256)."""
         return self.ctx.batch_double_mul(self.ID, u1, u2, q)
+
+    # Curve::to_affine, batched
+    def batch_to_affine(self, points):
+        return self.ctx.batch_to_affine(self.ID, points)
 
     # PointProjective
     def add(self, p, q):

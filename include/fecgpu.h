@@ -15,6 +15,10 @@
  *                         forge-ec-examples/src/ecdh.rs:27-49; ecdsa.rs:111)
  *   fec_batch_double_mul  out[i] = C::multiply(&G,&u1[i]) + C::multiply(&q[i],&u2[i])
  *                         (ECDSA verify point computation, forge-ec-signature/src/ecdsa.rs:254-256)
+ *   fec_batch_to_affine   xy[i] = C::to_affine(&points[i])  (Curve::to_affine, core lib.rs:820-826; impls
+ *                         secp256k1.rs:1342-1363 + invert 599-632, p256.rs:1835-1857 + 343-393,
+ *                         ed25519.rs:1793-1811 + 410-431/603-621) -- what every caller does right
+ *                         after multiply (ecdsa.rs:112, 264)
  *   fec_field_op          FieldElement trait ops (core lib.rs:173-241): Add/Sub/Mul/Neg/square
  *   fec_point_op          PointProjective trait ops (core lib.rs:699-748): Add / double / negate
  *
@@ -90,6 +94,12 @@ int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars /
 int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1 /* n*4 */,
                          const uint64_t* u2 /* n*4 */, const uint64_t* q /* n*limbs */,
                          uint64_t* out /* n*limbs */, size_t n);
+/* xy[i] = (x, y) limbs of to_affine(points[i]) (8 limbs per element); inf[i] = 1 for the identity
+ * (x = y = 0 then).  Uses the reference's own field inversion, so results are bit-identical to the
+ * reference even where its arithmetic is not a field.  A non-identity input with Z = 0 (the
+ * reference would panic on CtOption::unwrap) yields x = y = 0, inf = 0 for Ed25519. */
+int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points /* n*limbs */,
+                        uint64_t* xy /* n*8 */, uint8_t* inf /* n */, size_t n);
 int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a /* n*4 */,
                  const uint64_t* b /* n*4, may be NULL for unary ops */, uint64_t* out /* n*4 */,
                  size_t n);
@@ -107,6 +117,9 @@ int fec_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_sca
 int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1,
                              const uint64_t* d_u2, const uint64_t* d_q, uint64_t* d_out, size_t n,
                              void* stream);
+
+int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
+                            uint8_t* d_inf, size_t n, void* stream);
 
 /* ---- measurement hooks ---- */
 /* When enabled, every kernel launched through this ctx is bracketed by HIP events recorded on

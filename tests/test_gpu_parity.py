@@ -246,6 +246,21 @@ def test_ed25519_fixed_base_device_path_reuses_table(gpu_ctx, oracle):
         _assert_same(got, oracle.batch_mul_fixed(2, k, base_host, nthreads=8), "ed25519 fixed-base dev path")
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_batch_to_affine_matches_oracle(gpu_ctx, oracle, curve):
+    """Curve::to_affine with the reference's own field inversion (next row of SURVEY section 8f)."""
+    n = 700
+    p = V.points(n, curve, 361)
+    g = oracle.generator(curve)
+    sp = _special_points(oracle, curve)[:6]
+    mult = oracle.batch_mul(curve, V.scalars(40, curve, 362), V.points(40, curve, 363), nthreads=8)
+    p = np.ascontiguousarray(np.concatenate([np.array(sp, dtype=np.uint64), mult, p]))
+    xy, inf = gpu_ctx.batch_to_affine(curve, p)
+    wxy, winf = oracle.batch_to_affine(curve, p, nthreads=8)
+    assert np.array_equal(inf, winf)
+    _assert_same(xy, wxy, "%s to_affine" % NAMES[curve])
+
+
 def test_device_pointer_path_with_torch(gpu_ctx, oracle):
     """The *_dev entry points on torch-owned HBM buffers and torch's current stream."""
     import torch

@@ -113,3 +113,16 @@ def test_ed25519_fixed_base_table_walk(emu, oracle):
         base = np.ascontiguousarray(base)
         emu.he_ed_multiply_fixed(_p(base), _p(k), _p(out))
         assert np.array_equal(out, oracle.multiply(2, base, k)), [hex(int(v)) for v in k]
+
+
+@pytest.mark.parametrize("curve", [0, 1, 2])
+def test_to_affine(emu, oracle, curve):
+    g = oracle.generator(curve)
+    pts = [g, oracle.point_double(curve, g), oracle.identity(curve)] + list(V.points(4, curve, 41))
+    pts.append(oracle.multiply(curve, g, V.limbs_of(0x123456789ABCDEF)))
+    out = np.zeros(8, dtype=np.uint64)
+    for p in pts:
+        p = np.ascontiguousarray(p)
+        inf = emu.he_to_affine(curve, _p(p), _p(out))
+        want, winf = oracle.to_affine(curve, p)
+        assert bool(inf) == winf and np.array_equal(out, want)

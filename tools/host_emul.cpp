@@ -55,3 +55,12 @@ extern "C" int he_ed_multiply_fixed(const uint64_t* base, const uint64_t* scalar
   stp4(out, ed::multiply_fixed(ldp4(base), tab, kw));
   return 0;
 }
+
+extern "C" int he_to_affine(int curve, const uint64_t* p, uint64_t* xy) {
+  fe x, y; lmask inf;
+  if (curve == 0) inf = secp::to_affine(ldp3<secp::pt>(p), x, y);
+  else if (curve == 1) inf = p256::to_affine(ldp3<p256::pt>(p), x, y);
+  else inf = ed::to_affine(ldp4(p), x, y);
+  st(xy, x); st(xy + 4, y);
+  return inf ? 1 : 0;
+}
