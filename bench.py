@@ -6,8 +6,8 @@ bench.py -- headline benchmark of the batched scalar-multiplication hot path on 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W        (N > 1, one rank per GPU)
 
-Workload (BASELINE.json configs[1]): 2^20 secp256k1 variable-base scalar multiplications per
-GPU on synthetic seeded inputs (forge_ec_amd/synth.py), inputs resident in HBM before the timed
+Default workload (BASELINE.json configs[1], the headline): 2^20 secp256k1 variable-base scalar
+multiplications per GPU (--workload selects the other BASELINE configurations) on synthetic seeded inputs (forge_ec_amd/synth.py), inputs resident in HBM before the timed
 region.  One "step" = one pass of the hot path over one 2^20 batch.  With N > 1 ranks every rank
 runs its own 2^20 shard (weak scaling, no collective on the compute path) and the result shards
 are all-gathered over RCCL/xGMI on a side stream, overlapped with the next step's kernel.
@@ -29,9 +29,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic work per scalar-mul, SURVEY.md section 8(d) "needed MAD32" column
-NEEDED_MAD32 = {"secp256k1": 693248, "p256": 278528, "ed25519": 248832}
-HBM_BYTES = {"secp256k1": 224, "p256": 224, "ed25519": 288}
+# workload -> (curve, kind, algorithmic MAD32 per unit, algorithmic HBM bytes per unit, BASELINE config)
+# MAD32 counts are SURVEY.md section 8(d)'s "needed" column (popcount-128 averages for P-256/Ed25519)
+WORKLOADS = {
+    "secp256k1-var": ("secp256k1", "var", 693248, 224, "configs[1]"),
+    "ed25519-fixed": ("ed25519", "fixed", 82944, 160, "configs[2]"),
+    "p256-var": ("p256", "var", 278528, 224, "configs[3] (per-GPU shard)"),
+    "secp256k1-double": ("secp256k1", "double", 1388384, 256, "configs[4] (per-GPU shard)"),
+    "ed25519-var": ("ed25519", "var", 248832, 288, "-"),
+    "secp256k1-fixed": ("secp256k1", "fixed", 693248, 128, "north_star fixed-base target"),
+}
 CURVE_ID = {"secp256k1": 0, "p256": 1, "ed25519": 2}
 # guide-derived integer-VALU peak: 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per
 # v_mad_u64_u32 wave-instruction (MI355X_MICROARCH.md chip parameters; issue cost measured,
@@ -44,7 +51,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--curve", default="secp256k1", choices=list(CURVE_ID))
+    ap.add_argument("--workload", default="secp256k1-var", choices=list(WORKLOADS),
+                    help="default = the headline (BASELINE.json configs[1])")
     ap.add_argument("--log2-batch", type=int, default=20, help="scalar-muls per GPU per step = 2^this")
     ap.add_argument("--gather", default="all", choices=["all", "none"],
                     help="N>1: all-gather result shards over RCCL (overlapped) or not")
@@ -66,26 +74,46 @@ def host_cores():
     return max(1, min(cores, 64))
 
 
-def cpu_baseline(curve_name, k, p, gpu_out, target_s):
+def cpu_baseline(workload, inputs, gpu_out, target_s):
     """Time the C oracle (the reference's full work, discarded doublings included) on this box's
     cores over a bounded prefix of the same inputs; compare with the GPU output (parity sample)."""
     from oracle import c_oracle
+    curve_name, kind = WORKLOADS[workload][0], WORKLOADS[workload][1]
     cid = CURVE_ID[curve_name]
     cores = host_cores()
+
+    def run(m):
+        if kind == "var":
+            return c_oracle.batch_mul(cid, inputs[0][:m], inputs[1][:m], nthreads=cores)
+        if kind == "fixed":
+            return c_oracle.batch_mul_fixed(cid, inputs[0][:m], c_oracle.generator(cid), nthreads=cores)
+        return c_oracle.batch_double_mul(cid, inputs[0][:m], inputs[1][:m], inputs[2][:m], nthreads=cores)
+
     probe = 64 * cores
     t0 = time.perf_counter()
-    c_oracle.batch_mul(cid, k[:probe], p[:probe], nthreads=cores)
+    run(probe)
     dt = time.perf_counter() - t0
     rate = probe / max(dt, 1e-9)
-    n = int(min(k.shape[0], max(probe, rate * target_s)))
+    n = int(min(inputs[0].shape[0], max(probe, rate * target_s)))
     t0 = time.perf_counter()
-    ref = c_oracle.batch_mul(cid, k[:n], p[:n], nthreads=cores)
+    ref = run(n)
     dt = time.perf_counter() - t0
     ok = bool(np.array_equal(ref, gpu_out[:n]))
     return {"value": n / dt, "unit": "scalar-muls/s", "cores": cores, "kind": "port",
-            "sample": "first %d of the rank-0 batch (%s variable-base), C oracle oracle/forge_ec_oracle.c, "
-                      "%d threads, %.1f s" % (n, curve_name, cores, dt),
+            "sample": "first %d of the rank-0 batch (%s), C oracle oracle/forge_ec_oracle.c, "
+                      "%d threads, %.1f s" % (n, workload, cores, dt),
             "parity_sample_bit_exact": ok}
+
+
+def measured_traffic(workload, n):
+    """HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMC itself)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01", "traffic.json")))
+        if t["workload"] == workload and t["units_per_launch"] == n:
+            return t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -110,17 +138,21 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    curve = args.curve
+    workload = args.workload
+    curve, kind, alg, hbm_bytes, cfg = WORKLOADS[workload]
     cid = CURVE_ID[curve]
     n = 1 << args.log2_batch
     limbs = F.POINT_LIMBS[cid]
     ctx = F.Context(local_rank)
 
     # synthetic seeded inputs, one stream pair per rank; resident in HBM before timing
-    k = synth.scalars(n, cid, 1000 + 2 * rank)
-    p = synth.points(n, cid, 1001 + 2 * rank)
-    d_k = torch.from_numpy(k.view(np.int64)).cuda()
-    d_p = torch.from_numpy(p.view(np.int64)).cuda()
+    k = synth.scalars(n, cid, 1000 + 3 * rank)
+    inputs = [k]
+    if kind in ("var", "double"):
+        inputs.append(synth.points(n, cid, 1001 + 3 * rank) if kind == "var" else synth.scalars(n, cid, 1001 + 3 * rank))
+    if kind == "double":
+        inputs.append(synth.points(n, cid, 1002 + 3 * rank))
+    d_in = [torch.from_numpy(a.view(np.int64)).cuda() for a in inputs]
     d_out = [torch.empty((n, limbs), dtype=torch.int64, device="cuda") for _ in range(2)]
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -133,7 +165,13 @@ def main():
         buf = i & 1
         if gather is not None:
             gather[buf].finish()  # the collective that last read d_out[buf] has completed
-        ctx.batch_mul_dev(cid, d_k.data_ptr(), d_p.data_ptr(), d_out[buf].data_ptr(), n, stream)
+        if kind == "var":
+            ctx.batch_mul_dev(cid, d_in[0].data_ptr(), d_in[1].data_ptr(), d_out[buf].data_ptr(), n, stream)
+        elif kind == "fixed":
+            ctx.batch_mul_fixed_dev(cid, d_in[0].data_ptr(), ctx.generator_dev(cid), d_out[buf].data_ptr(), n, stream)
+        else:
+            ctx.batch_double_mul_dev(cid, d_in[0].data_ptr(), d_in[1].data_ptr(), d_in[2].data_ptr(),
+                                     d_out[buf].data_ptr(), n, stream)
         ms = None
         if timed:
             ms = ctx.last_kernel_ms()[0]  # HIP events on the launch stream (syncs this launch)
@@ -182,32 +220,35 @@ def main():
     if rank == 0:
         total = n * world * args.steps
         value = total / elapsed
-        alg = NEEDED_MAD32[curve]
         achieved = n * alg / (kernel_ms * 1e-3)
+        kname = {"var": "k_batch_mul<%s,var>", "fixed": "k_batch_mul<%s,fixed>",
+                 "double": "k_batch_double_mul<%s>"}[kind] % curve
+        if workload == "ed25519-fixed":
+            kname = "k_ed_fixed_base"
         out = {
-            "metric": "%s variable-base scalar-muls/sec (batched, bit-exact vs CPU oracle)" % curve,
+            "metric": "%s scalar-muls/sec (batched, bit-exact vs CPU oracle)" % workload,
             "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "2^%d %s variable-base scalar-muls per GPU per step (BASELINE.json configs[1])"
-                                   % (args.log2_batch, curve),
-                       "curve": curve, "batch_per_gpu": n, "global_batch": n * world,
+            "config": {"workload": "2^%d %s scalar-muls per GPU per step (BASELINE.json %s)"
+                                   % (args.log2_batch, workload, cfg),
+                       "curve": curve, "kind": kind, "batch_per_gpu": n, "global_batch": n * world,
                        "result_gather": (args.gather if dist is not None else "n/a"),
                        "device": info["name"], "compute_units": info["compute_units"]},
             "roofline": {
                 "bound": "int-valu", "achieved": achieved / 1e12, "peak": PEAK_MAD32_FORMULA / 1e12,
-                "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_FORMULA, "traffic": None,
-                "kernel": "k_batch_mul<%s,var>" % curve, "kernel_ms": kernel_ms,
+                "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_FORMULA, "traffic": measured_traffic(workload, n),
+                "kernel": kname, "kernel_ms": kernel_ms,
                 "algorithmic_mad32_per_unit": alg, "units_per_launch": n,
                 "peak_measured": peak_measured / 1e12, "frac_of_measured_peak": achieved / peak_measured,
-                "hbm": {"achieved_GBps": n * HBM_BYTES[curve] / (kernel_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
-                        "algorithmic_bytes_per_unit": HBM_BYTES[curve]},
+                "hbm": {"achieved_GBps": n * hbm_bytes / (kernel_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                        "algorithmic_bytes_per_unit": hbm_bytes},
             },
         }
         if not args.no_cpu_baseline:
             gpu_out = d_out[(min(args.steps, 5) - 1) & 1].cpu().numpy().view(np.uint64)
-            out["cpu_baseline"] = cpu_baseline(curve, k, p, gpu_out, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(workload, inputs, gpu_out, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
     if dist is not None:
