@@ -1,0 +1,197 @@
+// forge_ec_gpu.hpp -- C++17 host-side mirror of forge-ec's trait surface for the batched
+// scalar-multiplication path, over the C ABI of fecgpu.h (header-only; link libfecgpu.so).
+//
+// The reference is Rust and no Rust toolchain exists in the build image, so this header plays the
+// role of the `forge-ec-gpu` shim crate: same names, argument meaning and error
+// behaviour as forge-ec-core (citations relative to /root/reference):
+//   FieldElement / Scalar        from_raw / to_raw          secp256k1.rs:36-43, 1914-1921
+//   FieldElement operators       + - * square() -a          forge-ec-core/src/lib.rs:173-241
+//   PointProjective              identity / add / double / negate / is_identity   lib.rs:699-748
+//   Curve                        generator / identity / multiply / to_affine      lib.rs:784-952
+//   new, fallible batch API      batch_multiply, batch_multiply_fixed, batch_double_multiply
+// Every operation runs on the GPU (there is no CPU fallback); single-element trait calls are
+// batches of one and exist so that tests can be written like the reference's unit tests.
+// Failures surface as forge_ec::Error (GenericError, like forge-ec-core's Error::GenericError).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "fecgpu.h"
+
+namespace forge_ec {
+
+struct Error : std::runtime_error {
+  int status;
+  explicit Error(int st) : std::runtime_error(std::string("forge_ec GenericError: ") + fec_strerror(st)), status(st) {}
+};
+
+class GpuContext {
+ public:
+  explicit GpuContext(int device = 0) {
+    int rc = fec_ctx_create(&ctx_, device);
+    if (rc != FEC_OK) throw Error(rc);
+  }
+  ~GpuContext() { fec_ctx_destroy(ctx_); }
+  GpuContext(const GpuContext&) = delete;
+  GpuContext& operator=(const GpuContext&) = delete;
+  fec_ctx* raw() const { return ctx_; }
+  static GpuContext& global() {  // process-wide default context on device 0
+    static GpuContext g(0);
+    return g;
+  }
+
+ private:
+  fec_ctx* ctx_ = nullptr;
+};
+
+inline void check(int rc) {
+  if (rc != FEC_OK) throw Error(rc);
+}
+
+using Limbs = std::array<uint64_t, 4>;
+
+template <fec_curve C>
+struct FieldElement {
+  Limbs raw{};
+  static FieldElement from_raw(const Limbs& l) { return FieldElement{l}; }
+  const Limbs& to_raw() const { return raw; }
+  static FieldElement zero() { return FieldElement{}; }
+  static FieldElement one() { return FieldElement{{1, 0, 0, 0}}; }
+  bool is_zero() const { return (raw[0] | raw[1] | raw[2] | raw[3]) == 0; }
+  bool ct_eq(const FieldElement& o) const { return raw == o.raw; }
+  FieldElement op(fec_field_opcode code, const FieldElement* rhs) const {
+    FieldElement r;
+    check(fec_field_op(GpuContext::global().raw(), C, code, raw.data(), rhs ? rhs->raw.data() : nullptr,
+                       r.raw.data(), 1));
+    return r;
+  }
+  FieldElement operator+(const FieldElement& o) const { return op(FEC_F_ADD, &o); }
+  FieldElement operator-(const FieldElement& o) const { return op(FEC_F_SUB, &o); }
+  FieldElement operator*(const FieldElement& o) const { return op(FEC_F_MUL, &o); }
+  FieldElement operator-() const { return op(FEC_F_NEG, nullptr); }
+  FieldElement square() const { return op(FEC_F_SQR, nullptr); }
+};
+
+template <fec_curve C>
+struct Scalar {
+  Limbs raw{};
+  static Scalar from_raw(const Limbs& l) { return Scalar{l}; }
+  static Scalar from(uint64_t v) { return Scalar{{v, 0, 0, 0}}; }
+  const Limbs& to_raw() const { return raw; }
+  bool is_zero() const { return (raw[0] | raw[1] | raw[2] | raw[3]) == 0; }
+};
+
+template <fec_curve C>
+struct AffinePoint {
+  FieldElement<C> x_, y_;
+  bool infinity = false;
+  const FieldElement<C>& x() const { return x_; }
+  const FieldElement<C>& y() const { return y_; }
+  bool is_identity() const { return infinity; }
+};
+
+// X,Y,Z (secp256k1 / P-256, Jacobian) or X,Y,Z,T (Ed25519, extended), exactly the ABI layout
+template <fec_curve C>
+struct ProjectivePoint {
+  static constexpr int LIMBS = C == FEC_ED25519 ? 16 : 12;
+  std::array<uint64_t, LIMBS> c{};
+  static ProjectivePoint from_raw_coords(const std::array<uint64_t, LIMBS>& l) { return ProjectivePoint{l}; }
+  const std::array<uint64_t, LIMBS>& to_raw_coords() const { return c; }
+  FieldElement<C> coord(int i) const { return FieldElement<C>{{c[4 * i], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3]}}; }
+  static ProjectivePoint identity() {
+    ProjectivePoint p;
+    p.c[4] = 1;                       // Y = one()
+    if (C == FEC_ED25519) p.c[8] = 1; // Z = one() for the extended identity (0,1,1,0)
+    return p;
+  }
+  bool is_identity() const {
+    if (C == FEC_ED25519) return coord(0).is_zero() && coord(1).ct_eq(coord(2)) && coord(3).is_zero();
+    return coord(2).is_zero();
+  }
+  ProjectivePoint op(fec_point_opcode code, const ProjectivePoint* rhs) const {
+    ProjectivePoint r;
+    check(fec_point_op(GpuContext::global().raw(), C, code, c.data(), rhs ? rhs->c.data() : nullptr, r.c.data(), 1));
+    return r;
+  }
+  ProjectivePoint operator+(const ProjectivePoint& o) const { return op(FEC_P_ADD, &o); }
+  ProjectivePoint double_() const { return op(FEC_P_DOUBLE, nullptr); }  // `double` is a C++ keyword
+  ProjectivePoint negate() const { return op(FEC_P_NEGATE, nullptr); }
+  ProjectivePoint operator-(const ProjectivePoint& o) const {
+    // impl Sub (secp256k1.rs:1549-1566): equal coordinates short-circuit to the identity
+    if (C == FEC_SECP256K1 && c == o.c) return identity();
+    return *this + o.negate();
+  }
+  bool ct_eq(const ProjectivePoint& o) const { return c == o.c; }
+};
+
+template <fec_curve C>
+struct Curve {
+  using Field = FieldElement<C>;
+  using ScalarT = Scalar<C>;
+  using PointProjective = ProjectivePoint<C>;
+  using PointAffine = AffinePoint<C>;
+  static constexpr int LIMBS = PointProjective::LIMBS;
+
+  static PointProjective identity() { return PointProjective::identity(); }
+  static PointProjective generator() {
+    PointProjective g;
+    check(fec_generator(GpuContext::global().raw(), C, g.c.data()));
+    return g;
+  }
+  // Curve::multiply -- infallible in the reference; a GPU failure throws Error here
+  static PointProjective multiply(const PointProjective& p, const ScalarT& k) {
+    PointProjective r;
+    check(fec_batch_mul(GpuContext::global().raw(), C, k.raw.data(), p.c.data(), r.c.data(), 1));
+    return r;
+  }
+  static PointAffine to_affine(const PointProjective& p) {
+    uint64_t xy[8];
+    uint8_t inf = 0;
+    check(fec_batch_to_affine(GpuContext::global().raw(), C, p.c.data(), xy, &inf, 1));
+    PointAffine a;
+    a.x_ = Field{{xy[0], xy[1], xy[2], xy[3]}};
+    a.y_ = Field{{xy[4], xy[5], xy[6], xy[7]}};
+    a.infinity = inf != 0;
+    return a;
+  }
+  // ---- the batched API this backend adds ----
+  static std::vector<PointProjective> batch_multiply(GpuContext& ctx, const std::vector<PointProjective>& points,
+                                                     const std::vector<ScalarT>& scalars) {
+    if (points.size() != scalars.size()) throw Error(FEC_E_ARG);
+    std::vector<PointProjective> out(points.size());
+    static_assert(sizeof(PointProjective) == LIMBS * 8 && sizeof(ScalarT) == 32, "ABI layout");
+    check(fec_batch_mul(ctx.raw(), C, reinterpret_cast<const uint64_t*>(scalars.data()),
+                        reinterpret_cast<const uint64_t*>(points.data()), reinterpret_cast<uint64_t*>(out.data()),
+                        points.size()));
+    return out;
+  }
+  static std::vector<PointProjective> batch_multiply_fixed(GpuContext& ctx, const PointProjective& base,
+                                                           const std::vector<ScalarT>& scalars) {
+    std::vector<PointProjective> out(scalars.size());
+    check(fec_batch_mul_fixed(ctx.raw(), C, reinterpret_cast<const uint64_t*>(scalars.data()), base.c.data(),
+                              reinterpret_cast<uint64_t*>(out.data()), scalars.size()));
+    return out;
+  }
+  // R[i] = multiply(G, u1[i]) + multiply(Q[i], u2[i])   (forge-ec-signature/src/ecdsa.rs:254-256)
+  static std::vector<PointProjective> batch_double_multiply(GpuContext& ctx, const std::vector<ScalarT>& u1,
+                                                            const std::vector<ScalarT>& u2,
+                                                            const std::vector<PointProjective>& q) {
+    if (u1.size() != u2.size() || u1.size() != q.size()) throw Error(FEC_E_ARG);
+    std::vector<PointProjective> out(q.size());
+    check(fec_batch_double_mul(ctx.raw(), C, reinterpret_cast<const uint64_t*>(u1.data()),
+                               reinterpret_cast<const uint64_t*>(u2.data()),
+                               reinterpret_cast<const uint64_t*>(q.data()), reinterpret_cast<uint64_t*>(out.data()),
+                               q.size()));
+    return out;
+  }
+};
+
+using Secp256k1 = Curve<FEC_SECP256K1>;
+using P256 = Curve<FEC_P256>;
+using Ed25519 = Curve<FEC_ED25519>;
+
+}  // namespace forge_ec

@@ -1,0 +1,120 @@
+// GPU test program written like the reference's own unit tests (forge-ec-curves/src/
+// {secp256k1,p256,ed25519}.rs `mod tests`), through the C++ mirror of the trait surface.
+// Each check cites the reference assertion it reproduces.  Asserts that the reference's own code
+// does not satisfy (p256.rs:2472, 2526, 2538) are replaced by what its code actually computes.
+// build: g++ -std=c++17 -I include tests/cpp/test_traits.cpp -L forge_ec_amd -lfecgpu -o test_traits
+#include <cstdio>
+#include <cstdlib>
+
+#include "forge_ec_gpu.hpp"
+using namespace forge_ec;
+
+static int failures = 0;
+#define CHECK(cond, what) do { if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, what); ++failures; } } while (0)
+
+static void secp256k1_field_arithmetic() {  // secp256k1.rs:2737-2761
+  using F = Secp256k1::Field;
+  F a = F::from_raw({1, 0, 0, 0}), b = F::from_raw({2, 0, 0, 0});
+  F c = a + b;
+  CHECK(c.to_raw()[0] == 3, "1 + 2 == 3");
+  F d = c - a;
+  CHECK(d.to_raw()[0] == 2, "3 - 1 == 2");
+  F e = a * b;
+  CHECK(e.to_raw()[0] == 12713681792961361445ULL, "Mul KAT raw1*raw2 (2750-2751)");
+  F g = a + (-a);
+  CHECK(g.is_zero(), "a + (-a) == 0");
+  F h = b.square();
+  CHECK(h.to_raw()[0] == 4, "square KAT raw2 (2759-2760)");
+}
+static void secp256k1_point_arithmetic() {  // secp256k1.rs:2763-2787
+  auto g = Secp256k1::generator();
+  auto g2 = g + g;
+  auto g2_double = g.double_();
+  auto a1 = Secp256k1::to_affine(g2), a2 = Secp256k1::to_affine(g2_double);
+  CHECK(a1.x().to_raw() == a2.x().to_raw(), "(g+g).x == g.double().x (2775)");
+  CHECK(a1.y().to_raw() == a2.y().to_raw(), "(g+g).y == g.double().y (2776)");
+  auto g_again = g2 - g;
+  CHECK(!g_again.is_identity(), "2G - G is not the identity (2782)");
+  auto inf = g - g;
+  CHECK(inf.is_identity(), "G - G is the identity (2785-2786)");
+}
+static void secp256k1_scalar_multiplication() {  // secp256k1.rs:2789-2821
+  auto g = Secp256k1::generator();
+  auto g2 = Secp256k1::multiply(g, Secp256k1::ScalarT::from(2));
+  CHECK(!g2.is_identity(), "2*G is not the identity (2805)");
+  auto g3 = Secp256k1::multiply(g, Secp256k1::ScalarT::from(3));
+  CHECK(!g3.is_identity(), "3*G is not the identity (2819)");
+  CHECK(Secp256k1::multiply(Secp256k1::identity(), Secp256k1::ScalarT::from(5)).is_identity(), "identity * k");
+  CHECK(Secp256k1::multiply(g, Secp256k1::ScalarT::from(0)).is_identity(), "P * 0 (2637-2639)");
+}
+static void p256_field_and_point_arithmetic() {  // p256.rs:2354-2484
+  using F = P256::Field;
+  F a = F::from_raw({5, 0, 0, 0}), b = F::from_raw({7, 0, 0, 0});
+  CHECK((a + b).to_raw() == (Limbs{12, 0, 0, 0}), "5 + 7 == 12");
+  CHECK((b - a).to_raw() == (Limbs{2, 0, 0, 0}), "7 - 5 == 2");
+  CHECK((a * b).to_raw() == (Limbs{35, 0, 0, 0}), "5 * 7 == 35");
+  CHECK(a.square().to_raw() == (Limbs{25, 0, 0, 0}), "5^2 == 25");
+  auto g = P256::generator();
+  F x = g.coord(0), y = g.coord(1);
+  F x2 = x.square();
+  CHECK(x2.to_raw() == (Limbs{12074202155401100ULL, 3726334282074508753ULL, 9331909631644438744ULL, 11022199779588240050ULL}), "Gx^2 (2457)");
+  CHECK((x2 * x).to_raw() == (Limbs{6985818112209442057ULL, 5293983511093485517ULL, 13285487596276262425ULL, 4350650246863171228ULL}), "Gx^3 (2458)");
+  CHECK((F::from_raw({3, 0, 0, 0}) * x).to_raw() == (Limbs{15988812018543642563ULL, 7280764249650076386ULL, 16876875322344915671ULL, 4703857913423513302ULL}), "3*Gx (2459)");
+  CHECK(y.square().to_raw() == (Limbs{13753198298469232017ULL, 5299206390010787296ULL, 9373276401007028734ULL, 6187767046927055789ULL}), "Gy^2 (2480)");
+  // p256.rs:2494-2499: multiply(G, 2) == G.double()
+  auto g2 = P256::multiply(g, P256::ScalarT::from(2));
+  CHECK(P256::to_affine(g2).x().to_raw() == P256::to_affine(g.double_()).x().to_raw(), "2*G == G.double() (2499)");
+  // p256.rs:2526 (3G == G + 2G) does not hold for the reference's own arithmetic; what its code
+  // computes is multiply(G,3) == Add(double(G), G) bit for bit
+  auto g3 = P256::multiply(g, P256::ScalarT::from(3));
+  CHECK(g3.ct_eq(g.double_() + g), "3*G == Add(2G, G) (what p256.rs:2120-2156 computes)");
+}
+static void ed25519_field_and_scalar_multiplication() {  // ed25519.rs:2126-2166, 2405-2436
+  using F = Ed25519::Field;
+  F a = F::from_raw({1, 0, 0, 0}), b = F::from_raw({2, 0, 0, 0});
+  CHECK((a + b).ct_eq(F::from_raw({3, 0, 0, 0})), "1 + 2 == 3");
+  CHECK((b - a).ct_eq(F::from_raw({1, 0, 0, 0})), "2 - 1 == 1");
+  CHECK((a * b).ct_eq(F::from_raw({2, 0, 0, 0})), "1 * 2 == 2");
+  CHECK((a + (-a)).is_zero(), "a + (-a) == 0");
+  CHECK(a.square().ct_eq(a * a), "square == self * self (623-625)");
+  auto g = Ed25519::generator();
+  CHECK(Ed25519::multiply(g, Ed25519::ScalarT::from(0)).is_identity(), "g * 0 is the identity (2436)");
+  CHECK(Ed25519::multiply(Ed25519::identity(), Ed25519::ScalarT::from(5)).is_identity(), "identity * 5 (2428)");
+  CHECK(Ed25519::multiply(g, Ed25519::ScalarT::from(1)).ct_eq(g), "g * 1 == g");
+  CHECK(Ed25519::multiply(g, Ed25519::ScalarT::from(2)).ct_eq(g.double_()), "g * 2 == g.double()");
+  CHECK(Ed25519::multiply(g, Ed25519::ScalarT::from(3)).ct_eq(g + g.double_()), "g * 3 == g + 2g (result + addend order)");
+}
+static void batch_api() {
+  GpuContext ctx(0);
+  auto g = Secp256k1::generator();
+  std::vector<Secp256k1::ScalarT> ks;
+  std::vector<Secp256k1::PointProjective> ps;
+  for (uint64_t i = 1; i <= 300; ++i) { ks.push_back(Secp256k1::ScalarT::from_raw({i * 0x9E3779B97F4A7C15ULL, i, ~i, i << 7})); ps.push_back(g); }
+  auto out = Secp256k1::batch_multiply(ctx, ps, ks);
+  auto fixed = Secp256k1::batch_multiply_fixed(ctx, g, ks);
+  bool same = true;
+  for (size_t i = 0; i < out.size(); ++i) same = same && out[i].ct_eq(fixed[i]) && out[i].ct_eq(Secp256k1::multiply(ps[i], ks[i]));
+  CHECK(same, "batch_multiply == batch_multiply_fixed == per-element multiply");
+  // ecdsa.rs:254-256: R = u1*G + u2*Q
+  auto r = Secp256k1::batch_double_multiply(ctx, ks, ks, ps);
+  CHECK(r[7].ct_eq(Secp256k1::multiply(g, ks[7]) + Secp256k1::multiply(ps[7], ks[7])), "double-mul == r1 + r2");
+  bool threw = false;
+  try { ks.pop_back(); Secp256k1::batch_multiply(ctx, ps, ks); } catch (const Error&) { threw = true; }
+  CHECK(threw, "length mismatch -> Error");
+}
+
+int main() {
+  try {
+    secp256k1_field_arithmetic();
+    secp256k1_point_arithmetic();
+    secp256k1_scalar_multiplication();
+    p256_field_and_point_arithmetic();
+    ed25519_field_and_scalar_multiplication();
+    batch_api();
+  } catch (const Error& e) {
+    std::printf("FAIL: %s\n", e.what());
+    return 2;
+  }
+  std::printf(failures ? "%d check(s) failed\n" : "all trait-surface checks passed\n", failures);
+  return failures ? 1 : 0;
+}
