@@ -15,7 +15,7 @@ P_ADD, P_DOUBLE, P_NEGATE, P_DOUBLE_TRAIT = 0, 1, 2, 3
 ABI_SYMBOLS = [
     "fec_point_limbs", "fec_ctx_create", "fec_ctx_destroy", "fec_generator", "fec_generator_dev", "fec_batch_mul", "fec_batch_mul_fixed",
     "fec_batch_double_mul", "fec_batch_to_affine", "fec_batch_to_affine_dev", "fec_field_op", "fec_point_op", "fec_batch_mul_dev",
-    "fec_batch_mul_fixed_dev", "fec_batch_double_mul_dev", "fec_ctx_set_timing",
+    "fec_batch_mul_fixed_dev", "fec_batch_double_mul_dev", "fec_ctx_set_chunk", "fec_ctx_set_timing",
     "fec_ctx_last_kernel_ms", "fec_measure_peak_mad32", "fec_ctx_device_info", "fec_strerror",
 ]
 
@@ -82,6 +82,8 @@ def lib():
               "fec_point_op", "fec_batch_mul_dev", "fec_batch_mul_fixed_dev",
               "fec_batch_double_mul_dev"):
         getattr(L, n).restype = ci
+    L.fec_ctx_set_chunk.argtypes = [vp, sz]
+    L.fec_ctx_set_chunk.restype = ci
     L.fec_ctx_set_timing.argtypes = [vp, ci]
     L.fec_ctx_set_timing.restype = ci
     L.fec_ctx_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p)]

@@ -395,9 +395,12 @@ struct fec_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false, timed = false;
   const char* last_kernel = "";
-  // device staging for the host-pointer entry points
-  void* d_buf[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[4] = {0, 0, 0, 0};
+  // device staging for the host-pointer entry points: slots 0-3 serve pipeline lane 0 (and the
+  // small one-shot calls), slots 4-7 pipeline lane 1
+  void* d_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipStream_t stream2 = nullptr;
+  size_t chunk = (size_t)1 << 18;  // elements per pipeline chunk
   u64* d_gen[3] = {nullptr, nullptr, nullptr};  // reference generator() per curve, device copy
   u32* d_ed_table = nullptr;                    // Ed25519 fixed-base addend table (256 x 32 words)
   u64 ed_table_base[16] = {0};                  // the base point the table was built for
@@ -551,13 +554,14 @@ int launch_to_affine(fec_ctx* ctx, int curve, const u64* dp, u64* dxy, unsigned 
   return L.done();
 }
 
-int launch_field(fec_ctx* ctx, int curve, int op, const u64* da, const u64* db, u64* dout, size_t n) {
+int launch_field(fec_ctx* ctx, int curve, int op, const u64* da, const u64* db, u64* dout, size_t n,
+                 void* stream = nullptr) {
   if (n == 0) return FEC_OK;
   const u32* a = reinterpret_cast<const u32*>(da);
   const u32* bb = reinterpret_cast<const u32*>(db);
   u32* o = reinterpret_cast<u32*>(dout);
   dim3 g(grid_for(n)), b(TPB);
-  Launch L(ctx, nullptr, "k_field_op");
+  Launch L(ctx, stream, "k_field_op");
   switch (curve) {
     case FEC_SECP256K1: hipLaunchKernelGGL((k_field_op<Secp>), g, b, 0, L.s, op, a, bb, o, n); break;
     case FEC_P256: hipLaunchKernelGGL((k_field_op<P256>), g, b, 0, L.s, op, a, bb, o, n); break;
@@ -566,13 +570,14 @@ int launch_field(fec_ctx* ctx, int curve, int op, const u64* da, const u64* db, 
   return L.done();
 }
 
-int launch_point(fec_ctx* ctx, int curve, int op, const u64* dp, const u64* dq, u64* dout, size_t n) {
+int launch_point(fec_ctx* ctx, int curve, int op, const u64* dp, const u64* dq, u64* dout, size_t n,
+                 void* stream = nullptr) {
   if (n == 0) return FEC_OK;
   const u32* p = reinterpret_cast<const u32*>(dp);
   const u32* q = reinterpret_cast<const u32*>(dq);
   u32* o = reinterpret_cast<u32*>(dout);
   dim3 g(grid_for(n)), b(TPB);
-  Launch L(ctx, nullptr, "k_point_op");
+  Launch L(ctx, stream, "k_point_op");
   switch (curve) {
     case FEC_SECP256K1: hipLaunchKernelGGL((k_point_op<Secp>), g, b, 0, L.s, op, p, q, o, n); break;
     case FEC_P256: hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, op, p, q, o, n); break;
@@ -581,28 +586,57 @@ int launch_point(fec_ctx* ctx, int curve, int op, const u64* dp, const u64* dq, 
   return L.done();
 }
 
-// copy up to three host inputs in, run `body` on device buffers, copy the output back
+// Host-pointer batches run as a two-lane software pipeline over chunks of ctx->chunk elements:
+//   H2D(c) K(c) on lane c%2, then D2H(c-1) on the other lane -- so while the host waits for
+// chunk c-1's results the GPU is already running chunk c.  Copies from/to pageable caller memory
+// overlap the kernels of the other lane; device staging is bounded by two chunks however large n
+// is.  An input with stride 0 is shared by all elements (a fixed base) and copied once per lane.
+struct HostIn {
+  const void* ptr;
+  size_t stride;  // bytes per element; 0 = one shared value of `bytes` bytes
+  size_t bytes;   // only for stride == 0
+};
 template <class F>
-int host_roundtrip(fec_ctx* ctx, const void* h0, size_t b0, const void* h1, size_t b1, const void* h2,
-                   size_t b2, void* hout, size_t bout, F body) {
+int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, size_t out_stride, F body) {
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  const void* hin[3] = {h0, h1, h2};
-  size_t bin[3] = {b0, b1, b2};
-  for (int i = 0; i < 3; ++i) {
-    if (!hin[i] || bin[i] == 0) continue;
-    int rc = ensure(ctx, i, bin[i]);
-    if (rc != FEC_OK) return rc;
-    if (hipMemcpyAsync(ctx->d_buf[i], hin[i], bin[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+  const size_t chunk = ctx->chunk;
+  const size_t nchunks = (n + chunk - 1) / chunk;
+  hipStream_t lanes[2] = {ctx->stream, ctx->stream2};
+  auto copy_back = [&](size_t c) -> int {
+    const int lane = (int)(c & 1);
+    const size_t lo = c * chunk, cnt = (lo + chunk <= n ? chunk : n - lo);
+    if (hipMemcpyAsync((char*)hout + lo * out_stride, ctx->d_buf[lane * 4 + 3], cnt * out_stride,
+                       hipMemcpyDeviceToHost, lanes[lane]) != hipSuccess)
       return FEC_E_DEVICE;
+    return FEC_OK;
+  };
+  for (size_t c = 0; c < nchunks; ++c) {
+    const int lane = (int)(c & 1);
+    const size_t lo = c * chunk, cnt = (lo + chunk <= n ? chunk : n - lo);
+    void* d_in[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; ++i) {
+      if (!in[i].ptr) continue;
+      const size_t bytes = in[i].stride ? cnt * in[i].stride : in[i].bytes;
+      int rc = ensure(ctx, lane * 4 + i, in[i].stride ? (chunk < n ? chunk : n) * in[i].stride : in[i].bytes);
+      if (rc != FEC_OK) return rc;
+      d_in[i] = ctx->d_buf[lane * 4 + i];
+      if (in[i].stride == 0 && c >= 2) continue;  // the shared value is already on this lane
+      const char* src = (const char*)in[i].ptr + (in[i].stride ? lo * in[i].stride : 0);
+      if (hipMemcpyAsync(d_in[i], src, bytes, hipMemcpyHostToDevice, lanes[lane]) != hipSuccess)
+        return FEC_E_DEVICE;
+    }
+    int rc = ensure(ctx, lane * 4 + 3, (chunk < n ? chunk : n) * out_stride);
+    if (rc != FEC_OK) return rc;
+    rc = body(d_in[0], d_in[1], d_in[2], ctx->d_buf[lane * 4 + 3], cnt, (void*)lanes[lane]);
+    if (rc != FEC_OK) return rc;
+    if (c > 0) {
+      rc = copy_back(c - 1);
+      if (rc != FEC_OK) return rc;
+    }
   }
-  int rc = ensure(ctx, 3, bout);
+  int rc = copy_back(nchunks - 1);
   if (rc != FEC_OK) return rc;
-  rc = body(h0 ? ctx->d_buf[0] : nullptr, h1 ? ctx->d_buf[1] : nullptr, h2 ? ctx->d_buf[2] : nullptr,
-            ctx->d_buf[3]);
-  if (rc != FEC_OK) return rc;
-  if (hipMemcpyAsync(hout, ctx->d_buf[3], bout, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-    return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream2) != hipSuccess) {
     (void)hipGetLastError();
     return FEC_E_LAUNCH;
   }
@@ -643,6 +677,7 @@ int fec_ctx_create(fec_ctx** out, int device) {
   if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
       std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0 ||
       hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
     (void)hipGetLastError();
     fec_ctx_destroy(ctx);
@@ -681,8 +716,9 @@ int fec_ctx_create(fec_ctx** out, int device) {
 void fec_ctx_destroy(fec_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
     if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   for (int i = 0; i < 3; ++i)
     if (ctx->d_gen[i]) (void)hipFree(ctx->d_gen[i]);
   if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
@@ -726,10 +762,10 @@ int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const 
   if (!ctx || !curve_ok(curve) || (n && (!scalars || !points || !out))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   size_t pb = (size_t)plimbs(curve) * 8;
-  return host_roundtrip(ctx, scalars, n * 32, points, n * pb, nullptr, 0, out, n * pb,
-                        [&](void* a, void* b, void*, void* o) {
-                          return launch_mul(ctx, curve, false, (const u64*)a, (const u64*)b, (u64*)o, n, nullptr);
-                        });
+  const HostIn in[3] = {{scalars, 32, 0}, {points, pb, 0}, {nullptr, 0, 0}};
+  return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void*, void* o, size_t cnt, void* s) {
+    return launch_mul(ctx, curve, false, (const u64*)a, (const u64*)b, (u64*)o, cnt, s);
+  });
 }
 
 int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* base,
@@ -737,12 +773,21 @@ int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, 
   if (!ctx || !curve_ok(curve) || !base || (n && (!scalars || !out))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   size_t pb = (size_t)plimbs(curve) * 8;
-  return host_roundtrip(ctx, scalars, n * 32, base, pb, nullptr, 0, out, n * pb,
-                        [&](void* a, void* b, void*, void* o) {
-                          if (curve == FEC_ED25519)
-                            return launch_ed_fixed(ctx, (const u64*)a, (const u64*)b, base, (u64*)o, n, nullptr);
-                          return launch_mul(ctx, curve, true, (const u64*)a, (const u64*)b, (u64*)o, n, nullptr);
-                        });
+  if (curve == FEC_ED25519) {
+    // the addend table is built once, on the ctx's first stream, before the pipeline starts
+    if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+    int rc = ensure(ctx, 1, pb);
+    if (rc != FEC_OK) return rc;
+    if (hipMemcpyAsync(ctx->d_buf[1], base, pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+    rc = ensure_ed_table(ctx, (const u64*)ctx->d_buf[1], base, ctx->stream);
+    if (rc != FEC_OK) return rc;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return FEC_E_LAUNCH;
+  }
+  const HostIn in[3] = {{scalars, 32, 0}, {base, 0, pb}, {nullptr, 0, 0}};
+  return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void*, void* o, size_t cnt, void* s) {
+    if (curve == FEC_ED25519) return launch_ed_fixed(ctx, (const u64*)a, (const u64*)b, base, (u64*)o, cnt, s);
+    return launch_mul(ctx, curve, true, (const u64*)a, (const u64*)b, (u64*)o, cnt, s);
+  });
 }
 
 int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, const uint64_t* u2,
@@ -750,11 +795,10 @@ int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
   if (!ctx || !curve_ok(curve) || (n && (!u1 || !u2 || !q || !out))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   size_t pb = (size_t)plimbs(curve) * 8;
-  return host_roundtrip(ctx, u1, n * 32, u2, n * 32, q, n * pb, out, n * pb,
-                        [&](void* a, void* b, void* c, void* o) {
-                          return launch_double_mul(ctx, curve, (const u64*)a, (const u64*)b, (const u64*)c,
-                                                   (u64*)o, n, nullptr);
-                        });
+  const HostIn in[3] = {{u1, 32, 0}, {u2, 32, 0}, {q, pb, 0}};
+  return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void* c, void* o, size_t cnt, void* s) {
+    return launch_double_mul(ctx, curve, (const u64*)a, (const u64*)b, (const u64*)c, (u64*)o, cnt, s);
+  });
 }
 
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
@@ -796,10 +840,10 @@ int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint6
   bool binary = op == FEC_F_ADD || op == FEC_F_SUB || op == FEC_F_MUL;
   if (binary && n && !b) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
-  return host_roundtrip(ctx, a, n * 32, binary ? b : nullptr, n * 32, nullptr, 0, out, n * 32,
-                        [&](void* x, void* y, void*, void* o) {
-                          return launch_field(ctx, curve, op, (const u64*)x, (const u64*)y, (u64*)o, n);
-                        });
+  const HostIn in[3] = {{a, 32, 0}, {binary ? b : nullptr, 32, 0}, {nullptr, 0, 0}};
+  return host_pipeline(ctx, n, in, out, 32, [&](void* x, void* y, void*, void* o, size_t cnt, void* s) {
+    return launch_field(ctx, curve, op, (const u64*)x, (const u64*)y, (u64*)o, cnt, s);
+  });
 }
 
 int fec_point_op(fec_ctx* ctx, fec_curve curve, fec_point_opcode op, const uint64_t* p, const uint64_t* q,
@@ -810,10 +854,10 @@ int fec_point_op(fec_ctx* ctx, fec_curve curve, fec_point_opcode op, const uint6
   if (op == FEC_P_ADD && n && !q) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   size_t pb = (size_t)plimbs(curve) * 8;
-  return host_roundtrip(ctx, p, n * pb, op == FEC_P_ADD ? q : nullptr, n * pb, nullptr, 0, out, n * pb,
-                        [&](void* x, void* y, void*, void* o) {
-                          return launch_point(ctx, curve, op, (const u64*)x, (const u64*)y, (u64*)o, n);
-                        });
+  const HostIn in[3] = {{p, pb, 0}, {op == FEC_P_ADD ? q : nullptr, pb, 0}, {nullptr, 0, 0}};
+  return host_pipeline(ctx, n, in, out, pb, [&](void* x, void* y, void*, void* o, size_t cnt, void* s) {
+    return launch_point(ctx, curve, op, (const u64*)x, (const u64*)y, (u64*)o, cnt, s);
+  });
 }
 
 int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out) {
@@ -829,6 +873,12 @@ int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out) {
 const uint64_t* fec_generator_dev(fec_ctx* ctx, fec_curve curve) {
   if (!ctx || !curve_ok(curve)) return nullptr;
   return ctx->d_gen[curve];
+}
+
+int fec_ctx_set_chunk(fec_ctx* ctx, size_t elements) {
+  if (!ctx || elements == 0) return FEC_E_ARG;
+  ctx->chunk = elements;
+  return FEC_OK;
 }
 
 int fec_ctx_set_timing(fec_ctx* ctx, int enabled) {

@@ -140,6 +140,10 @@ class Context:
         """Device address of the ctx's generator (pass it to batch_mul_fixed_dev)."""
         return self._lib.fec_generator_dev(self._h, curve)
 
+    def set_chunk(self, elements):
+        """Elements per pipeline chunk of the host-pointer entry points (default 2^18)."""
+        _check(self._lib.fec_ctx_set_chunk(self._h, int(elements)))
+
     # ---- measurement ----
     def set_timing(self, enabled=True):
         _check(self._lib.fec_ctx_set_timing(self._h, 1 if enabled else 0))

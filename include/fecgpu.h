@@ -121,6 +121,11 @@ int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
                             uint8_t* d_inf, size_t n, void* stream);
 
+/* Host-pointer batches are processed as a two-lane pipeline of `elements`-sized chunks (default
+ * 2^18): copies of one chunk overlap the kernel of the other, and device staging memory is bounded
+ * by two chunks for any n.  Tuning/test knob; results do not depend on it. */
+int fec_ctx_set_chunk(fec_ctx* ctx, size_t elements);
+
 /* ---- measurement hooks ---- */
 /* When enabled, every kernel launched through this ctx is bracketed by HIP events recorded on
  * the launch stream. */

@@ -211,6 +211,28 @@ def test_ragged_sizes_config1(gpu_ctx, oracle, n):
         _assert_same(got, want, "secp256k1 n=%d" % n)
 
 
+def test_host_pipeline_chunking_is_invisible(gpu_ctx, oracle):
+    """The host-pointer path pipelines chunks over two streams; results must not depend on the
+    chunk size (1 chunk, many chunks, ragged last chunk, odd and even chunk counts)."""
+    n = 1000
+    try:
+        for curve in (0, 2):
+            k, p = V.scalars(n, curve, 371), V.points(n, curve, 372)
+            want = oracle.batch_mul(curve, k, p, nthreads=8)
+            g = oracle.generator(curve)
+            wantf = oracle.batch_mul_fixed(curve, k, g, nthreads=8)
+            for chunk in (1 << 18, 256, 333, 64, 999, 1000, 1001):
+                gpu_ctx.set_chunk(chunk)
+                _assert_same(gpu_ctx.batch_mul(curve, k, p), want, "chunk %d curve %d" % (chunk, curve))
+                _assert_same(gpu_ctx.batch_mul_fixed(curve, k, g), wantf, "fixed chunk %d curve %d" % (chunk, curve))
+        u1, u2, q = V.scalars(300, 0, 373), V.scalars(300, 0, 374), V.points(300, 0, 375)
+        gpu_ctx.set_chunk(128)
+        _assert_same(gpu_ctx.batch_double_mul(0, u1, u2, q), oracle.batch_double_mul(0, u1, u2, q, nthreads=8),
+                     "double-mul chunked")
+    finally:
+        gpu_ctx.set_chunk(1 << 18)
+
+
 def test_abi_argument_errors(gpu_ctx):
     import ctypes
     import forge_ec_amd as F
