@@ -360,6 +360,65 @@ __global__ __launch_bounds__(TPB) void k_to_affine(const u32* __restrict__ point
   stage_out<16>(xy + first * 16, lds_p, valid);
 }
 
+// Ecdsa::<Secp256k1, D>::verify (forge-ec-signature/src/ecdsa.rs:213-281) with the digest given:
+// status[i] = 1 valid, 0 invalid, 2 where the reference panics (CtOption::unwrap on None: the
+// digest or the affine x read as a scalar is >= n).  Everything after the hash runs here: the
+// range checks, h, s^-1, u1, u2 in the reference's scalar field (its Mul keeps only the low 256
+// bits of the product), u1*G + u2*Q with one ladder instance, to_affine, FieldElement::to_bytes
+// (a Montgomery reduction of x) and the comparison with r.
+__global__ __launch_bounds__(TPB) void k_ecdsa_verify_secp(const u32* __restrict__ digests,
+                                                           const u32* __restrict__ rs, const u32* __restrict__ ss,
+                                                           const u32* __restrict__ pk, const unsigned char* __restrict__ pk_inf,
+                                                           const u32* __restrict__ gen, unsigned char* __restrict__ status,
+                                                           size_t n) {
+  __shared__ u32 lds_a[8 * TPB];      // digest words, then u1
+  __shared__ u32 lds_b[8 * TPB];      // r (kept), 
+  __shared__ u32 lds_c[8 * TPB];      // s, then u2
+  __shared__ u32 lds_p[16 * TPB];     // public key x, y
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_a, digests + first * 8, valid);
+  stage_in<8>(lds_b, rs + first * 8, valid);
+  stage_in<8>(lds_c, ss + first * 8, valid);
+  stage_in<16>(lds_p, pk + first * 16, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    fe r = load_fe(lds_b + e, TPB), s = load_fe(lds_c + e, TPB), h;
+    // trait Scalar::from_bytes (2270-2297): big-endian bytes -> little-endian limbs
+    FEC_UNROLL for (int w = 0; w < 8; ++w) h.w[w] = __builtin_bswap32(lds_a[(7 - w) * TPB + e]);
+    lmask bad = fe_is_zero(r) | fe_is_zero(s) | secp::sc_ge_n(r) | secp::sc_ge_n(s);  // 215-228 -> false
+    lmask panic = secp::sc_ge_n(h) & ~bad;                                            // 239 unwrap
+    fe s_inv = secp::sc_inv(s);
+    fe u1 = secp::sc_mul(h, s_inv), u2 = secp::sc_mul(r, s_inv);                      // 250-251
+    store_fe(lds_a + e, TPB, u1);   // a lane reads and writes only its own LDS column
+    store_fe(lds_c + e, TPB, u2);
+    secp::pt q;                                                                        // from_affine 1365-1373
+    q.x = load_fe(lds_p + e, TPB);
+    q.y = load_fe(lds_p + 8 * TPB + e, TPB);
+    q.z = fe_small(1);
+    const bool inf = pk_inf != nullptr && pk_inf[first + e] != 0;
+    q = secp::pt_select(q, secp::identity(), lanes_where(inf));
+    secp::pt acc[2];
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {  // one copy of the ladder in the code object
+      secp::pt base = pass == 0 ? Secp::load(gen, 1) : q;
+      secp::pt m = secp::multiply(base, pass == 0 ? lds_a + e : lds_c + e);
+      if (pass == 0) acc[0] = m; else acc[1] = m;
+    }
+    secp::pt rp = secp::padd(acc[0], acc[1]);                                          // 254-256
+    lmask ident = secp::is_identity(rp);                                               // 259-262 -> false
+    fe x, y;
+    secp::to_affine(rp, x, y);                                                         // 264
+    fe xr = secp::mul(x, fe_small(1));           // FieldElement::to_bytes (138-178) = mont_reduce(x)
+    lmask panic2 = secp::sc_ge_n(xr) & ~(bad | panic | ident);                         // 271 unwrap
+    lmask ok = fe_eq(xr, r) & ~(bad | panic | ident | panic2);                         // 274
+    const int lane = threadIdx.x & 63;
+    unsigned char st = ((ok >> lane) & 1) ? 1 : ((((panic | panic2) >> lane) & 1) ? 2 : 0);
+    status[first + e] = st;
+  }
+}
+
 // Peak 32x32+64 multiply-add rate: 8 independent v_mad_u64_u32 chains per lane, no memory.
 constexpr int PEAK_ITERS = 4096;
 __global__ __launch_bounds__(TPB) void k_peak_mad32(u32* out, u32 seed) {
@@ -551,6 +610,17 @@ int launch_to_affine(fec_ctx* ctx, int curve, const u64* dp, u64* dxy, unsigned 
     case FEC_P256: hipLaunchKernelGGL((k_to_affine<P256>), g, b, 0, L.s, p, o, dinf, n); break;
     default: hipLaunchKernelGGL((k_to_affine<Ed>), g, b, 0, L.s, p, o, dinf, n); break;
   }
+  return L.done();
+}
+
+int launch_ecdsa_verify(fec_ctx* ctx, const unsigned char* dd, const u64* dr, const u64* ds, const u64* dpk,
+                        const unsigned char* dinf, unsigned char* dstatus, size_t n, void* stream) {
+  if (n == 0) return FEC_OK;
+  Launch L(ctx, stream, "k_ecdsa_verify_secp");
+  hipLaunchKernelGGL(k_ecdsa_verify_secp, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(dd),
+                     reinterpret_cast<const u32*>(dr), reinterpret_cast<const u32*>(ds),
+                     reinterpret_cast<const u32*>(dpk), dinf, reinterpret_cast<const u32*>(ctx->d_gen[FEC_SECP256K1]),
+                     dstatus, n);
   return L.done();
 }
 
@@ -799,6 +869,44 @@ int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
   return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void* c, void* o, size_t cnt, void* s) {
     return launch_double_mul(ctx, curve, (const u64*)a, (const u64*)b, (const u64*)c, (u64*)o, cnt, s);
   });
+}
+
+int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
+                                   const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
+                                   void* stream) {
+  if (!ctx || (n && (!d_digests || !d_r || !d_s || !d_pk_xy || !d_status))) return FEC_E_ARG;
+  if (!aligned16(d_digests) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_pk_xy)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_ecdsa_verify(ctx, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream);
+}
+
+int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
+                               const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) {
+  if (!ctx || (n && (!digests || !r || !s || !pk_xy || !status))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  const void* hin[5] = {digests, r, s, pk_xy, pk_inf};
+  const size_t bytes[5] = {n * 32, n * 32, n * 32, n * 64, n};
+  const int slot[5] = {0, 1, 2, 4, 5};
+  for (int i = 0; i < 5; ++i) {
+    if (!hin[i]) continue;
+    int rc = ensure(ctx, slot[i], bytes[i]);
+    if (rc != FEC_OK) return rc;
+    if (hipMemcpyAsync(ctx->d_buf[slot[i]], hin[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  }
+  int rc = ensure(ctx, 3, n);
+  if (rc != FEC_OK) return rc;
+  rc = launch_ecdsa_verify(ctx, (const unsigned char*)ctx->d_buf[0], (const u64*)ctx->d_buf[1], (const u64*)ctx->d_buf[2],
+                           (const u64*)ctx->d_buf[4], pk_inf ? (const unsigned char*)ctx->d_buf[5] : nullptr,
+                           (unsigned char*)ctx->d_buf[3], n, nullptr);
+  if (rc != FEC_OK) return rc;
+  if (hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  return FEC_OK;
 }
 
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,

@@ -394,6 +394,39 @@ FEC_DEV void mul_wide(u32 t[16], const fe& a, const fe& b) {
 }
 #endif
 
+// t[0..7] = low 256 bits of a * b (columns 0..7 of the same product scanning)
+#ifdef FEC_HOST_EMUL
+FEC_DEV void mul_low256(u32 t[8], const fe& a, const fe& b) {
+  u32 w[16];
+  mul_wide(w, a, b);
+  for (int i = 0; i < 8; ++i) t[i] = w[i];
+}
+#else
+FEC_DEV void mul_low256(u32 t[8], const fe& a, const fe& b) {
+  u64 acc = (u64)a.w[0] * b.w[0];
+  u32 ovf = 0;
+  t[0] = (u32)acc;
+  FEC_UNROLL for (int k = 1; k < 8; ++k) {
+    u64 cin = (acc >> 32) | ((u64)ovf << 32);
+    bool first = true;
+    FEC_UNROLL for (int i = 0; i <= k; ++i) {
+      const int j = k - i;
+      if (first) {
+        u64 nacc;
+        u32 novf;
+        mac96_first(nacc, novf, a.w[i], b.w[j], cin);
+        acc = nacc;
+        ovf = novf;
+        first = false;
+      } else {
+        mac96(acc, ovf, a.w[i], b.w[j]);
+      }
+    }
+    t[k] = (u32)acc;
+  }
+}
+#endif
+
 // t[0..8] = a * k (k a 32-bit constant), t[9..15] = 0
 FEC_DEV void mul_wide_small(u32 t[16], const fe& a, u32 k) {
   u32 carry = 0;

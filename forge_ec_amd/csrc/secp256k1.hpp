@@ -434,5 +434,52 @@ FEC_DEV pt multiply(const pt& point, const u32* kw) {
   return pt_select(r0, identity(), early);
 }
 
+// ---- scalar field (mod n) as the reference implements it, for ECDSA verify -------------------
+// The reference's N (27-28) is [0xBFD25E8CD0364141, 0xBAAEDCE6AF48A03B, 0xFFFFFFFFFFFFFFFF,
+// 0xFFFFFFFFFFFFFFFE] in little-endian limbs: its two top limbs are SWAPPED relative to the true
+// group order (which has 0x...FFFE in limb 2).  Every scalar-field routine of the reference
+// (reduce, Mul, invert's exponent n-2, from_bytes, ct_lt against get_order()) uses that constant,
+// so parity means using it too.
+FEC_DEV fe N_() {
+  fe n;
+  n.w[0] = 0xD0364141u; n.w[1] = 0xBFD25E8Cu; n.w[2] = 0xAF48A03Bu; n.w[3] = 0xBAAEDCE6u;
+  n.w[4] = 0xFFFFFFFFu; n.w[5] = 0xFFFFFFFFu; n.w[6] = 0xFFFFFFFEu; n.w[7] = 0xFFFFFFFFu;
+  return n;
+}
+// a >= n (the comparison spelled out at 1955-1958), and Scalar::reduce (1953-1969)
+FEC_DEV lmask sc_ge_n(const fe& a) {
+  fe t;
+  return ~sub256(t, a, N_());
+}
+FEC_DEV fe sc_reduce(const fe& a) {
+  fe t;
+  lmask borrow = sub256(t, a, N_());
+  return fe_select(a, t, ~borrow);
+}
+// Mul for Scalar (2410-2456): the exact product of which ONLY the low 256 bits are kept, then
+// reduce() and `while >= n { reduce() }` -- after one subtraction the value is < 2^256 - n < n, so
+// the loop never runs a second time.
+FEC_DEV fe sc_mul(const fe& a, const fe& b) {
+  u32 t[8];
+  mul_low256(t, a, b);
+  fe r;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) r.w[i] = t[i];
+  return sc_reduce(r);
+}
+// invert for Scalar (2162-2195): a^(n-2), limbs LS->MS, bits MS->LS; `square()` is s * s
+FEC_DEV fe sc_inv(const fe& a) {
+  const u64 e[4] = {0xBFD25E8CD036413FULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFEULL};
+  fe result = fe_small(1);
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll 1
+    for (int j = 63; j >= 0; --j) {
+      result = sc_mul(result, result);
+      if ((e[i] >> j) & 1) result = sc_mul(result, a);  // exponent bits are uniform
+    }
+  }
+  return result;
+}
+
 }  // namespace secp
 }  // namespace fecgpu

@@ -100,6 +100,21 @@ class Context:
                "fec_batch_to_affine")
         return xy, inf
 
+    def ecdsa_verify_secp256k1(self, digests, r, s, pk_xy, pk_inf=None):
+        """Ecdsa::<Secp256k1, D>::verify per signature with the digests supplied (ecdsa.rs:213-281).
+        digests (n,32) uint8; r, s (n,4); pk_xy (n,8) raw limbs; pk_inf (n,) uint8 or None.
+        Returns (n,) uint8: 1 valid, 0 invalid, 2 = the reference panics."""
+        d = np.ascontiguousarray(np.asarray(digests, dtype=np.uint8)).reshape(-1, 32)
+        rr, ss, pk = _u64(r, 4), _u64(s, 4), _u64(pk_xy, 8)
+        n = d.shape[0]
+        if not (rr.shape[0] == ss.shape[0] == pk.shape[0] == n):
+            raise ValueError("inputs differ in length")
+        inf = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+        out = np.empty(n, dtype=np.uint8)
+        _check(self._lib.fec_ecdsa_verify_secp256k1(self._h, _ptr(d), _ptr(rr), _ptr(ss), _ptr(pk), _ptr(inf),
+                                                    _ptr(out), n), "fec_ecdsa_verify_secp256k1")
+        return out
+
     def field_op(self, curve, op, a, b=None):
         x = _u64(a, 4)
         y = _u64(b, 4) if b is not None else None

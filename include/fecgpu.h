@@ -19,6 +19,9 @@
  *                         secp256k1.rs:1342-1363 + invert 599-632, p256.rs:1835-1857 + 343-393,
  *                         ed25519.rs:1793-1811 + 410-431/603-621) -- what every caller does right
  *                         after multiply (ecdsa.rs:112, 264)
+ *   fec_ecdsa_verify_secp256k1   Ecdsa::<Secp256k1, D>::verify per signature, digest supplied
+ *                         (forge-ec-signature/src/ecdsa.rs:213-281; scalar field secp256k1.rs:1953-1969,
+ *                         2162-2195, 2270-2297, 2410-2456; FieldElement::to_bytes 138-178)
  *   fec_field_op          FieldElement trait ops (core lib.rs:173-241): Add/Sub/Mul/Neg/square
  *   fec_point_op          PointProjective trait ops (core lib.rs:699-748): Add / double / negate
  *
@@ -100,6 +103,14 @@ int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1 /* n*
  * reference would panic on CtOption::unwrap) yields x = y = 0, inf = 0 for Ed25519. */
 int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points /* n*limbs */,
                         uint64_t* xy /* n*8 */, uint8_t* inf /* n */, size_t n);
+/* ECDSA verification as the reference computes it, one signature per element, everything after the
+ * hash on the GPU.  digests: n*32 bytes exactly as the hash emits them (the reference reads them
+ * big-endian); r, s: raw scalar limbs; pk_xy: the AffinePoint's x and y raw field limbs (8 per
+ * element); pk_inf: its infinity flag per element, or NULL for none.  status[i] = 1 valid, 0 invalid,
+ * 2 where the reference panics (CtOption::unwrap on None: digest or affine x >= n as a scalar). */
+int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests /* n*32 */, const uint64_t* r /* n*4 */,
+                               const uint64_t* s /* n*4 */, const uint64_t* pk_xy /* n*8 */,
+                               const uint8_t* pk_inf /* n or NULL */, uint8_t* status /* n */, size_t n);
 int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a /* n*4 */,
                  const uint64_t* b /* n*4, may be NULL for unary ops */, uint64_t* out /* n*4 */,
                  size_t n);
@@ -118,6 +129,9 @@ int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1
                              const uint64_t* d_u2, const uint64_t* d_q, uint64_t* d_out, size_t n,
                              void* stream);
 
+int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
+                                   const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
+                                   void* stream);
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
                             uint8_t* d_inf, size_t n, void* stream);
 

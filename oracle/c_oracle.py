@@ -62,6 +62,12 @@ def lib():
         L.fo_batch_double_mul.restype = None
         L.fo_batch_to_affine.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t, ctypes.c_int]
         L.fo_batch_to_affine.restype = None
+        L.fo_secp256k1_scalar_op.argtypes = [ctypes.c_char_p, p, p, p]
+        L.fo_secp256k1_scalar_op.restype = ctypes.c_int
+        L.fo_secp256k1_ecdsa_verify.argtypes = [p, p, p, p, ctypes.c_int]
+        L.fo_secp256k1_ecdsa_verify.restype = ctypes.c_int
+        L.fo_batch_secp256k1_ecdsa_verify.argtypes = [p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_secp256k1_ecdsa_verify.restype = None
         _lib = L
     return _lib
 
@@ -174,3 +180,25 @@ def batch_to_affine(curve, points, nthreads=1):
     inf = np.zeros(n, dtype=np.uint8)
     lib().fo_batch_to_affine(curve, _ptr(points), _ptr(xy), _ptr(inf), n, nthreads)
     return xy, inf
+
+
+def secp256k1_scalar_op(op, a, b=None):
+    a = _u64(a)
+    b = _u64(b if b is not None else [0, 0, 0, 0])
+    r = np.zeros(4, dtype=np.uint64)
+    rc = lib().fo_secp256k1_scalar_op(op.encode(), _ptr(a), _ptr(b), _ptr(r))
+    if rc < 0:
+        raise ValueError("fo_secp256k1_scalar_op rc=%d" % rc)
+    return r, rc == 0
+
+
+def batch_secp256k1_ecdsa_verify(digests, r, s, pk_xy, pk_inf=None, nthreads=1):
+    """digests (n,32) uint8 big-endian; r, s (n,4); pk_xy (n,8) raw field limbs; -> (n,) uint8 status."""
+    digests = np.ascontiguousarray(np.asarray(digests, dtype=np.uint8)).reshape(-1, 32)
+    r, s, pk_xy = _u64(r), _u64(s), _u64(pk_xy)
+    n = digests.shape[0]
+    inf = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+    out = np.zeros(n, dtype=np.uint8)
+    lib().fo_batch_secp256k1_ecdsa_verify(_ptr(digests), _ptr(r), _ptr(s), _ptr(pk_xy),
+                                          _ptr(inf) if inf is not None else None, _ptr(out), n, nthreads)
+    return out

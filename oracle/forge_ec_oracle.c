@@ -346,6 +346,118 @@ static jpt k_multiply(const jpt* point, const u64 k[4]) {
   return r0;
 }
 
+/* ---- secp256k1 scalar field as the reference implements it, and ECDSA verify ---------------- */
+/* secp256k1.rs:27-28, literally: note that the two top limbs are swapped relative to the true
+ * group order (true n has 0xFFFFFFFFFFFFFFFE in limb 2); the reference uses this constant everywhere */
+static const u64 K_N[4] = {0xBFD25E8CD0364141ULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFFULL,
+                           0xFFFFFFFFFFFFFFFEULL};
+
+/* the >= n comparison written out at 1955-1958 / 2443-2449 */
+static int ks_ge_n(const u64 a[4]) {
+  return a[3] > K_N[3] || (a[3] == K_N[3] && a[2] > K_N[2]) ||
+         (a[3] == K_N[3] && a[2] == K_N[2] && a[1] > K_N[1]) ||
+         (a[3] == K_N[3] && a[2] == K_N[2] && a[1] == K_N[1] && a[0] >= K_N[0]);
+}
+/* secp256k1.rs:1953-1969 Scalar::reduce: one subtraction of n if >= n */
+static void ks_reduce(u64 a[4]) {
+  if (ks_ge_n(a)) {
+    u64 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+      u64 d1 = a[i] - K_N[i];
+      u64 b1 = a[i] < K_N[i];
+      u64 d2 = d1 - borrow;
+      u64 b2 = d1 < borrow;
+      a[i] = d2;
+      borrow = (b1 || b2) ? 1 : 0;
+    }
+  }
+}
+/* secp256k1.rs:2410-2456 Mul for Scalar: exact 512-bit product, of which ONLY the low 256 bits are
+ * kept, then reduce() and a while-loop of further reduce() */
+static void ks_mul(const u64 a[4], const u64 b[4], u64 r[4]) {
+  u64 t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u64 carry = 0;
+    for (int j = 0; j < 4; ++j) {
+      u128 product = (u128)a[i] * (u128)b[j];
+      u64 lo = (u64)product, hi = (u64)(product >> 64);
+      u64 res1 = t[i + j] + lo;
+      u64 c1 = res1 < lo;
+      u64 res2 = res1 + carry;
+      u64 c2 = res2 < carry;
+      t[i + j] = res2;
+      carry = hi + c1 + c2;
+      if (j == 3) t[i + j + 1] = carry;
+    }
+  }
+  r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3];
+  ks_reduce(r);
+  while (ks_ge_n(r)) ks_reduce(r);
+}
+/* secp256k1.rs:2162-2195 invert: a^(n-2), limbs LS->MS, bits MS->LS; zero -> none */
+static int ks_inv(const u64 a[4], u64 r[4]) {
+  if ((a[0] | a[1] | a[2] | a[3]) == 0) { r[0] = r[1] = r[2] = r[3] = 0; return 0; }
+  static const u64 e[4] = {0xBFD25E8CD036413FULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFFULL,
+                           0xFFFFFFFFFFFFFFFEULL};
+  u64 result[4] = {1, 0, 0, 0};
+  for (int i = 0; i < 4; ++i)
+    for (int j = 63; j >= 0; --j) {
+      u64 sq[4];
+      ks_mul(result, result, sq);               /* square() = s * s (2197-2200) */
+      memcpy(result, sq, sizeof sq);
+      if ((e[i] >> j) & 1) { ks_mul(result, a, sq); memcpy(result, sq, sizeof sq); }
+    }
+  memcpy(r, result, sizeof result);
+  return 1;
+}
+/* trait Scalar::from_bytes (2270-2297): big-endian; valid iff < n */
+static int ks_from_bytes_be(const unsigned char b[32], u64 l[4]) {
+  l[0] = l[1] = l[2] = l[3] = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) l[i] |= (u64)b[31 - (i * 8 + j)] << (j * 8);
+  return !ks_ge_n(l);
+}
+
+/* forge-ec-signature/src/ecdsa.rs:213-281 Ecdsa::<Secp256k1, D>::verify with the digest given.
+ * Returns 1 valid, 0 invalid, 2 where the reference panics (CtOption::unwrap on None: the digest
+ * or the affine x, read as a scalar, is >= n). */
+int fo_secp256k1_ecdsa_verify(const unsigned char digest[32], const u64 r[4], const u64 s[4],
+                              const u64 pk_xy[8], int pk_inf) {
+  if ((r[0] | r[1] | r[2] | r[3]) == 0 || (s[0] | s[1] | s[2] | s[3]) == 0) return 0;   /* 215-217 */
+  if (ks_ge_n(r) || ks_ge_n(s)) return 0;                   /* 223-228, ct_lt override 2321-2347 */
+  u64 h[4];
+  if (!ks_from_bytes_be(digest, h)) return 2;               /* 239 unwrap */
+  u64 s_inv[4];
+  if (!ks_inv(s, s_inv)) return 0;                          /* 243-247 */
+  u64 u1[4], u2[4];
+  ks_mul(h, s_inv, u1);                                      /* 250 */
+  ks_mul(r, s_inv, u2);                                      /* 251 */
+  jpt g = k_generator();
+  jpt q = k_identity();                                     /* from_affine 1365-1373 */
+  if (!pk_inf) {
+    for (int i = 0; i < 4; ++i) { q.x.v[i] = pk_xy[i]; q.y.v[i] = pk_xy[4 + i]; }
+    q.z = fe_small(1);
+  }
+  jpt r1 = k_multiply(&g, u1);
+  jpt r2 = k_multiply(&q, u2);
+  jpt rp = k_padd(&r1, &r2);                                 /* 254-256 */
+  if (k_is_identity(&rp)) return 0;                          /* 259-262 */
+  fe x, y;
+  k_to_affine(&rp, &x, &y);                                  /* 264 */
+  /* field_to_bytes -> FieldElement::to_bytes (138-178): mont_reduce(x) = Mul(x, raw 1), big-endian;
+   * then Scalar::from_bytes of those bytes: the same limbs, valid iff < n (271 unwrap) */
+  fe xr = k_mul(x, fe_small(1));
+  if (ks_ge_n(xr.v)) return 2;
+  return xr.v[0] == r[0] && xr.v[1] == r[1] && xr.v[2] == r[2] && xr.v[3] == r[3];   /* 274 */
+}
+
+/* scalar-field ops for tests: op in {"mul","inv"} */
+int fo_secp256k1_scalar_op(const char* op, const u64 a[4], const u64 b[4], u64 r[4]) {
+  if (!strcmp(op, "mul")) { ks_mul(a, b, r); return 0; }
+  if (!strcmp(op, "inv")) { return ks_inv(a, r) ? 0 : 1; }
+  return -2;
+}
+
 /* =====================================================================================
  * P-256  (p256.rs)
  * ===================================================================================== */
@@ -1031,6 +1143,30 @@ void fo_batch_double_mul(int curve, const u64* u1, const u64* u2, const u64* q, 
   job_t j = {2, curve, u1, u2, q, out, NULL, 0, 0};
   run_jobs(j, n, nthreads);
 }
+typedef struct { const unsigned char* dg; const u64 *r, *s, *pk; const uint8_t* inf; uint8_t* out; size_t lo, hi; } vjob_t;
+static void* vworker(void* arg) {
+  vjob_t* j = (vjob_t*)arg;
+  for (size_t i = j->lo; i < j->hi; ++i)
+    j->out[i] = (uint8_t)fo_secp256k1_ecdsa_verify(j->dg + 32 * i, j->r + 4 * i, j->s + 4 * i, j->pk + 8 * i,
+                                                   j->inf ? j->inf[i] : 0);
+  return NULL;
+}
+void fo_batch_secp256k1_ecdsa_verify(const unsigned char* digests, const u64* r, const u64* s, const u64* pk_xy,
+                                     const uint8_t* pk_inf, uint8_t* out, size_t n, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+  pthread_t th[256];
+  vjob_t jobs[256];
+  for (int t = 0; t < nthreads; ++t) {
+    vjob_t v = {digests, r, s, pk_xy, pk_inf, out, n * (size_t)t / (size_t)nthreads, n * (size_t)(t + 1) / (size_t)nthreads};
+    jobs[t] = v;
+  }
+  if (nthreads == 1) { vworker(&jobs[0]); return; }
+  for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, vworker, &jobs[t]);
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+}
+
 void fo_batch_to_affine(int curve, const u64* points, u64* xy, uint8_t* inf, size_t n, int nthreads) {
   job_t j = {3, curve, NULL, NULL, points, xy, inf, 0, 0};
   run_jobs(j, n, nthreads);

@@ -57,6 +57,15 @@ int  fo_to_affine(int curve, const uint64_t* p, uint64_t* xy);
 /* ---- Curve::multiply, the reference's full work (discarded doublings included) ---- */
 void fo_multiply(int curve, const uint64_t* point, const uint64_t scalar[4], uint64_t* out);
 
+/* ---- secp256k1 scalar field + ECDSA verify (forge-ec-signature/src/ecdsa.rs:213-281) ---- */
+int fo_secp256k1_scalar_op(const char* op, const uint64_t a[4], const uint64_t b[4], uint64_t r[4]);
+/* 1 valid, 0 invalid, 2 = the reference panics (CtOption::unwrap on None) */
+int fo_secp256k1_ecdsa_verify(const unsigned char digest[32], const uint64_t r[4], const uint64_t s[4],
+                              const uint64_t pk_xy[8], int pk_inf);
+void fo_batch_secp256k1_ecdsa_verify(const unsigned char* digests, const uint64_t* r, const uint64_t* s,
+                                     const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* out, size_t n,
+                                     int nthreads);
+
 /* ---- batched drivers (nthreads host threads over contiguous shards) ---- */
 void fo_batch_mul(int curve, const uint64_t* scalars, const uint64_t* points, uint64_t* out,
                   size_t n, int nthreads);

@@ -735,6 +735,103 @@ class Ed:
         return result
 
 
+# ======================================================================================
+# secp256k1 scalar field as implemented (secp256k1.rs) and ECDSA verify (ecdsa.rs:213-281)
+# ======================================================================================
+class SecpScalar:
+    N = [0xBFD25E8CD0364141, 0xBAAEDCE6AF48A03B, M64, 0xFFFFFFFFFFFFFFFE]  # :27-28
+
+    @staticmethod
+    def ge_n(a):  # the comparison spelled out at :1955-1958
+        N = SecpScalar.N
+        return (a[3] > N[3] or (a[3] == N[3] and a[2] > N[2]) or (a[3] == N[3] and a[2] == N[2] and a[1] > N[1])
+                or (a[3] == N[3] and a[2] == N[2] and a[1] == N[1] and a[0] >= N[0]))
+
+    @staticmethod
+    def reduce(a):  # :1953-1969
+        a = list(a)
+        if SecpScalar.ge_n(a):
+            borrow = 0
+            for i in range(4):
+                d1 = (a[i] - SecpScalar.N[i]) & M64
+                b1 = a[i] < SecpScalar.N[i]
+                d2 = (d1 - borrow) & M64
+                b2 = d1 < borrow
+                a[i] = d2
+                borrow = 1 if (b1 or b2) else 0
+        return a
+
+    @staticmethod
+    def mul(a, b):  # :2410-2456 -- keeps only t[0..4] of the 512-bit product
+        t = [0] * 8
+        for i in range(4):
+            carry = 0
+            for j in range(4):
+                product = a[i] * b[j]
+                lo, hi = product & M64, product >> 64
+                res1 = t[i + j] + lo
+                c1 = res1 >> 64
+                res1 &= M64
+                res2 = res1 + carry
+                c2 = res2 >> 64
+                t[i + j] = res2 & M64
+                carry = hi + c1 + c2
+                assert carry <= M64
+                if j == 3:
+                    t[i + j + 1] = carry
+        r = SecpScalar.reduce(t[0:4])
+        while SecpScalar.ge_n(r):
+            r = SecpScalar.reduce(r)
+        return r
+
+    @staticmethod
+    def inv(a):  # :2162-2195
+        if _is_zero(a):
+            return None
+        e = [0xBFD25E8CD036413F, 0xBAAEDCE6AF48A03B, M64, 0xFFFFFFFFFFFFFFFE]
+        result = [1, 0, 0, 0]
+        for i in range(4):
+            for j in range(63, -1, -1):
+                result = SecpScalar.mul(result, result)
+                if (e[i] >> j) & 1:
+                    result = SecpScalar.mul(result, a)
+        return result
+
+    @staticmethod
+    def from_bytes_be(b):  # trait Scalar::from_bytes :2270-2297
+        l = [0] * 4
+        for i in range(4):
+            for j in range(8):
+                l[i] |= b[31 - (i * 8 + j)] << (8 * j)
+        return l, not SecpScalar.ge_n(l)
+
+
+def secp256k1_ecdsa_verify(digest, r, s, pk_xy, pk_inf=False):
+    """ecdsa.rs:213-281 with the digest supplied.  1 valid, 0 invalid, 2 = the reference panics."""
+    S, F = SecpScalar, Secp
+    if _is_zero(r) or _is_zero(s):
+        return 0
+    if S.ge_n(r) or S.ge_n(s):
+        return 0
+    h, ok = S.from_bytes_be(list(digest))
+    if not ok:
+        return 2
+    s_inv = S.inv(s)
+    if s_inv is None:
+        return 0
+    u1 = S.mul(h, s_inv)
+    u2 = S.mul(r, s_inv)
+    q = F.identity() if pk_inf else (list(pk_xy[0:4]), list(pk_xy[4:8]), [1, 0, 0, 0])
+    rp = F.padd(F.multiply(F.generator(), u1), F.multiply(q, u2))
+    if F.is_identity(rp):
+        return 0
+    x, _, _ = F.to_affine(rp)
+    xr = F.mul(x, [1, 0, 0, 0])  # FieldElement::to_bytes = mont_reduce (:138-178), then Scalar::from_bytes
+    if S.ge_n(xr):
+        return 2
+    return 1 if xr == list(r) else 0
+
+
 CURVES = {SECP256K1: Secp, P256: P256c, ED25519: Ed}
 
 

@@ -283,6 +283,65 @@ def test_batch_to_affine_matches_oracle(gpu_ctx, oracle, curve):
     _assert_same(xy, wxy, "%s to_affine" % NAMES[curve])
 
 
+def _ecdsa_cases(oracle, n_random, n_valid):
+    """digests, r, s, pk_xy, pk_inf covering: random (invalid) signatures, constructed VALID ones,
+    zero / out-of-range r and s, and digests >= n (where the reference panics)."""
+    rng = np.random.default_rng(99)
+    # the reference's own N (secp256k1.rs:27-28) has its two top limbs swapped w.r.t. the true order
+    order = 0xFFFFFFFFFFFFFFFEFFFFFFFFFFFFFFFFBAAEDCE6AF48A03BBFD25E8CD0364141
+    total = n_random + n_valid + 8
+    dg = rng.integers(0, 256, size=(total, 32), dtype=np.uint8)
+    dg[:, 0] &= 0x7F                                   # keep the digest below N unless stated otherwise
+    r = V.scalars(total, 0, 381)
+    s = V.scalars(total, 0, 382)
+    pk = np.ascontiguousarray(np.concatenate([V.field_elements(total, 0, 383), V.field_elements(total, 0, 384)], axis=1))
+    inf = np.zeros(total, dtype=np.uint8)
+    g = oracle.generator(0)
+    one = np.array([1, 0, 0, 0], dtype=np.uint64)
+    made = 0
+    for i in range(n_random, n_random + n_valid):
+        # with the public key at infinity R = multiply(G, h * s^-1) does not depend on r, so r can be
+        # set to the x the reference will derive: these verify as VALID under the reference's rules
+        inf[i] = 1
+        h = np.array([int.from_bytes(dg[i].tobytes(), "big") >> (64 * k) & ((1 << 64) - 1) for k in range(4)], dtype=np.uint64)
+        s_inv, ok = oracle.secp256k1_scalar_op("inv", s[i])
+        u1 = oracle.secp256k1_scalar_op("mul", h, s_inv)[0]
+        rp = oracle.multiply(0, g, u1)
+        xy, is_inf = oracle.to_affine(0, rp)
+        xr = oracle.field_op(0, "mul", xy[:4], one)
+        if not is_inf and 0 < V.int_of(xr) < order:
+            r[i] = xr
+            made += 1
+    base = n_random + n_valid
+    r[base + 0] = 0                                     # r == 0            -> 0
+    s[base + 1] = 0                                     # s == 0            -> 0
+    r[base + 2] = V.limbs_of(order)                     # r == n            -> 0
+    s[base + 3] = V.limbs_of((1 << 256) - 1)            # s >= n            -> 0
+    dg[base + 4] = 0xFF                                 # digest >= n       -> 2 (unwrap panics)
+    dg[base + 5] = np.frombuffer(order.to_bytes(32, "big"), dtype=np.uint8)  # digest == n -> 2
+    inf[base + 6] = 1                                   # Q at infinity, random r -> 0
+    dg[base + 7] = 0                                    # h == 0: u1 == 0, R = u2*Q
+    return dg, r, s, pk, inf, made
+
+
+def test_ecdsa_verify_secp256k1_matches_oracle(gpu_ctx, oracle):
+    """Ecdsa::<Secp256k1,_>::verify end to end (next row of SURVEY section 8f): every status the
+    reference can produce, including signatures that VERIFY under its arithmetic."""
+    # (under the reference's scalar arithmetic s^-1 collapses to 0 for about half of all s, which
+    # makes R the identity; the construction only succeeds for the rest)
+    dg, r, s, pk, inf, made = _ecdsa_cases(oracle, 300, 80)
+    assert made >= 20
+    want = oracle.batch_secp256k1_ecdsa_verify(dg, r, s, pk, inf, nthreads=8)
+    got = gpu_ctx.ecdsa_verify_secp256k1(dg, r, s, pk, inf)
+    assert set(int(v) for v in want) == {0, 1, 2}
+    assert int((want == 1).sum()) == made
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, "first mismatch at %d: got %d want %d" % (bad[0], got[bad[0]], want[bad[0]])
+    # without the infinity flags (NULL pk_inf) every key is a finite point
+    want2 = oracle.batch_secp256k1_ecdsa_verify(dg, r, s, pk, None, nthreads=8)
+    assert np.array_equal(gpu_ctx.ecdsa_verify_secp256k1(dg, r, s, pk, None), want2)
+
+
 def test_device_pointer_path_with_torch(gpu_ctx, oracle):
     """The *_dev entry points on torch-owned HBM buffers and torch's current stream."""
     import torch

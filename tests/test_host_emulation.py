@@ -126,3 +126,25 @@ def test_to_affine(emu, oracle, curve):
         inf = emu.he_to_affine(curve, _p(p), _p(out))
         want, winf = oracle.to_affine(curve, p)
         assert bool(inf) == winf and np.array_equal(out, want)
+
+
+def test_secp256k1_scalar_field(emu, oracle):
+    """Scalar Mul (low 256 bits of the product, then reduce) and invert, vs the oracle."""
+    n = V.ORDER[0]
+    nref = 0xFFFFFFFFFFFFFFFEFFFFFFFFFFFFFFFFBAAEDCE6AF48A03BBFD25E8CD0364141  # the reference's N (limbs swapped)
+    vals = [1, 2, n - 1, n, n + 1, nref - 1, nref, nref + 1, (1 << 256) - 1, 1 << 128, (1 << 128) - 1, 1 << 255]
+    a = np.concatenate([np.array([V.limbs_of(v) for v in vals], dtype=np.uint64), V.scalars(60, 0, 51),
+                        V.splitmix64(120, V.SEED, 52).reshape(-1, 4)])
+    b = np.concatenate([np.array([V.limbs_of(v) for v in reversed(vals)], dtype=np.uint64), V.scalars(60, 0, 53),
+                        V.splitmix64(120, V.SEED, 54).reshape(-1, 4)])
+    out = np.zeros(4, dtype=np.uint64)
+    for i in range(a.shape[0]):
+        ai, bi = np.ascontiguousarray(a[i]), np.ascontiguousarray(b[i])
+        emu.he_secp_scalar_op(0, _p(ai), _p(bi), _p(out))
+        assert np.array_equal(out, oracle.secp256k1_scalar_op("mul", ai, bi)[0])
+    for i in range(0, 20):
+        ai = np.ascontiguousarray(a[i])
+        want, ok = oracle.secp256k1_scalar_op("inv", ai)
+        if ok:
+            emu.he_secp_scalar_op(1, _p(ai), None, _p(out))
+            assert np.array_equal(out, want)

@@ -131,3 +131,28 @@ def test_batch_drivers_match_single_calls(oracle):
         fx = oracle.batch_mul_fixed(curve, k, g, nthreads=2)
         for i in range(9):
             assert np.array_equal(fx[i], oracle.multiply(curve, g, k[i]))
+
+
+def test_ecdsa_verify_two_restatements_agree(oracle):
+    """secp256k1 scalar field + Ecdsa::verify: C oracle vs the independent Python model."""
+    from oracle import py_model as M
+    S = M.SecpScalar
+    a = V.splitmix64(80, V.SEED, 601).reshape(-1, 4)
+    b = V.scalars(20, 0, 602)
+    for i in range(20):
+        la, lb = [int(v) for v in a[i]], [int(v) for v in b[i]]
+        assert S.mul(la, lb) == [int(v) for v in oracle.secp256k1_scalar_op("mul", la, lb)[0]]
+    assert S.inv([int(v) for v in b[0]]) == [int(v) for v in oracle.secp256k1_scalar_op("inv", b[0])[0]]
+    rng = np.random.default_rng(7)
+    for i in range(3):
+        dg = rng.integers(0, 256, size=32, dtype=np.uint8)
+        dg[0] &= 0x7F
+        r, s = [int(v) for v in b[2 * i + 1]], [int(v) for v in b[2 * i + 2]]
+        pk = [int(v) for v in V.field_elements(2, 0, 603 + i).reshape(-1)]
+        want = M.secp256k1_ecdsa_verify(bytes(dg), r, s, pk, pk_inf=(i == 2))
+        got = int(oracle.batch_secp256k1_ecdsa_verify(dg, [r], [s], [pk], [1 if i == 2 else 0])[0])
+        assert want == got
+    # a digest >= n makes the reference panic (status 2) in both
+    dg = np.full(32, 0xFF, dtype=np.uint8)
+    assert M.secp256k1_ecdsa_verify(bytes(dg), r, s, pk) == 2
+    assert int(oracle.batch_secp256k1_ecdsa_verify(dg, [r], [s], [pk])[0]) == 2

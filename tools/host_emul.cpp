@@ -64,3 +64,11 @@ extern "C" int he_to_affine(int curve, const uint64_t* p, uint64_t* xy) {
   st(xy, x); st(xy + 4, y);
   return inf ? 1 : 0;
 }
+
+// secp256k1 scalar field (mod n) as the reference implements it: op 0 = mul, 1 = inv
+extern "C" int he_secp_scalar_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  fe x = ld(a), r;
+  if (op == 0) r = secp::sc_mul(x, ld(b)); else r = secp::sc_inv(x);
+  st(out, r);
+  return 0;
+}
