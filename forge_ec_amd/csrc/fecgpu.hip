@@ -46,6 +46,7 @@ struct Secp {
   }
   FEC_DEV static pt multiply(const pt& p, const u32* kw) { return secp::multiply(p, kw); }
   FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return secp::to_affine(p, x, y); }
+  FEC_DEV static pt identity() { return secp::identity(); }
   FEC_DEV static pt padd(const pt& a, const pt& b) { return secp::padd(a, b); }
   FEC_DEV static pt pdouble(const pt& a) { return secp::pdouble(a); }
   FEC_DEV static pt pdouble_trait(const pt& a) { return secp::pdouble_trait(a); }
@@ -82,6 +83,7 @@ struct P256 {
   }
   FEC_DEV static pt multiply(const pt& p, const u32* kw) { return p256::multiply(p, kw); }
   FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return p256::to_affine(p, x, y); }
+  FEC_DEV static pt identity() { return p256::identity(); }
   FEC_DEV static pt padd(const pt& a, const pt& b) { return p256::padd(a, b); }
   FEC_DEV static pt pdouble(const pt& a) { return p256::pdouble(a); }
   FEC_DEV static pt pdouble_trait(const pt& a) { return p256::pdouble(a); }
@@ -120,6 +122,7 @@ struct Ed {
   }
   FEC_DEV static pt multiply(const pt& p, const u32* kw) { return ed::multiply(p, kw); }
   FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return ed::to_affine(p, x, y); }
+  FEC_DEV static pt identity() { return ed::identity(); }
   FEC_DEV static pt padd(const pt& a, const pt& b) { return ed::padd(a, b); }
   FEC_DEV static pt pdouble(const pt& a) { return ed::padd(a, a); }
   FEC_DEV static pt pdouble_trait(const pt& a) { return ed::padd(a, a); }
@@ -335,6 +338,22 @@ __global__ __launch_bounds__(TPB) void k_point_op(int op, const u32* __restrict_
   }
   __syncthreads();
   stage_out<C::PW>(out + first * C::PW, lds_p, valid);
+}
+
+// Curve::multi_scalar_multiply's fold (forge-ec-core/src/lib.rs:944-948, p256.rs:2204-2208):
+//   result = identity; for i in 0..n { result += product[i] }
+// The reference's Add is neither associative nor commutative, so the order is part of the result:
+// one lane folds the n products (already computed by k_batch_mul) strictly left to right.
+template <class C>
+__global__ __launch_bounds__(64) void k_fold_sum(const u32* __restrict__ products, u32* __restrict__ out, size_t n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  typename C::pt acc = C::identity();
+#pragma unroll 1
+  for (size_t i = 0; i < n; ++i) {
+    typename C::pt p = C::load(products + i * C::PW, 1);
+    acc = C::padd(acc, p);
+  }
+  C::store(out, 1, acc);
 }
 
 // xy[i] = to_affine(points[i]) as (x, y); inf[i] = 1 where the point is the identity
@@ -869,6 +888,46 @@ int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
   return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void* c, void* o, size_t cnt, void* s) {
     return launch_double_mul(ctx, curve, (const u64*)a, (const u64*)b, (const u64*)c, (u64*)o, cnt, s);
   });
+}
+
+int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points,
+                         uint64_t* out, size_t n) {
+  if (!ctx || !curve_ok(curve) || !out || (n && (!scalars || !points))) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  const size_t pb = (size_t)plimbs(curve) * 8;
+  int rc = ensure(ctx, 6, (n ? n : 1) * pb);   // products stay on the device
+  if (rc == FEC_OK) rc = ensure(ctx, 7, pb);
+  if (rc != FEC_OK) return rc;
+  for (size_t lo = 0; lo < n; lo += ctx->chunk) {  // the independent products, chunked
+    const size_t cnt = lo + ctx->chunk <= n ? ctx->chunk : n - lo;
+    rc = ensure(ctx, 0, cnt * 32);
+    if (rc == FEC_OK) rc = ensure(ctx, 1, cnt * pb);
+    if (rc != FEC_OK) return rc;
+    if (hipMemcpyAsync(ctx->d_buf[0], scalars + lo * 4, cnt * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(ctx->d_buf[1], points + lo * (pb / 8), cnt * pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+    rc = launch_mul(ctx, curve, false, (const u64*)ctx->d_buf[0], (const u64*)ctx->d_buf[1],
+                    (u64*)((char*)ctx->d_buf[6] + lo * pb), cnt, nullptr);
+    if (rc != FEC_OK) return rc;
+  }
+  {
+    Launch L(ctx, nullptr, "k_fold_sum");
+    const u32* prod = reinterpret_cast<const u32*>(ctx->d_buf[6]);
+    u32* o = reinterpret_cast<u32*>(ctx->d_buf[7]);
+    switch (curve) {
+      case FEC_SECP256K1: hipLaunchKernelGGL((k_fold_sum<Secp>), dim3(1), dim3(64), 0, L.s, prod, o, n); break;
+      case FEC_P256: hipLaunchKernelGGL((k_fold_sum<P256>), dim3(1), dim3(64), 0, L.s, prod, o, n); break;
+      default: hipLaunchKernelGGL((k_fold_sum<Ed>), dim3(1), dim3(64), 0, L.s, prod, o, n); break;
+    }
+    rc = L.done();
+    if (rc != FEC_OK) return rc;
+  }
+  if (hipMemcpyAsync(out, ctx->d_buf[7], pb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  return FEC_OK;
 }
 
 int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,

@@ -100,6 +100,17 @@ class Context:
                "fec_batch_to_affine")
         return xy, inf
 
+    def multi_scalar_mul(self, curve, scalars, points):
+        """Curve::multi_scalar_multiply: sum_i multiply(points[i], scalars[i]) in the reference's order."""
+        pl = L.POINT_LIMBS[curve]
+        s, p = _u64(scalars, 4), _u64(points, pl)
+        if s.shape[0] != p.shape[0]:
+            raise ValueError("scalars and points differ in length")
+        out = np.empty(pl, dtype=np.uint64)
+        _check(self._lib.fec_multi_scalar_mul(self._h, curve, _ptr(s), _ptr(p), _ptr(out), s.shape[0]),
+               "fec_multi_scalar_mul")
+        return out
+
     def ecdsa_verify_secp256k1(self, digests, r, s, pk_xy, pk_inf=None):
         """Ecdsa::<Secp256k1, D>::verify per signature with the digests supplied (ecdsa.rs:213-281).
         digests (n,32) uint8; r, s (n,4); pk_xy (n,8) raw limbs; pk_inf (n,) uint8 or None.
@@ -213,6 +224,13 @@ class _Curve:
     def batch_double_multiply(self, u1, u2, q):
         """R[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])  (ecdsa.rs:254-256)."""
         return self.ctx.batch_double_mul(self.ID, u1, u2, q)
+
+    def multi_scalar_multiply(self, points, scalars):
+        """Curve::multi_scalar_multiply (core lib.rs:934-951): identity for empty or mismatched input."""
+        pts, ks = _u64(points, self.POINT_LIMBS), _u64(scalars, 4)
+        if pts.shape[0] != ks.shape[0] or pts.shape[0] == 0:
+            return self.identity()
+        return self.ctx.multi_scalar_mul(self.ID, ks, pts)
 
     # Curve::to_affine, batched
     def batch_to_affine(self, points):

@@ -19,6 +19,10 @@
  *                         secp256k1.rs:1342-1363 + invert 599-632, p256.rs:1835-1857 + 343-393,
  *                         ed25519.rs:1793-1811 + 410-431/603-621) -- what every caller does right
  *                         after multiply (ecdsa.rs:112, 264)
+ *   fec_multi_scalar_mul  C::multi_scalar_multiply(&points, &scalars): the products on the GPU in
+ *                         parallel, then the reference's strictly sequential `result += product`
+ *                         fold (core lib.rs:934-951, p256.rs:2193-2211) -- the order is part of the
+ *                         result because the reference's Add is not associative
  *   fec_ecdsa_verify_secp256k1   Ecdsa::<Secp256k1, D>::verify per signature, digest supplied
  *                         (forge-ec-signature/src/ecdsa.rs:213-281; scalar field secp256k1.rs:1953-1969,
  *                         2162-2195, 2270-2297, 2410-2456; FieldElement::to_bytes 138-178)
@@ -103,6 +107,11 @@ int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1 /* n*
  * reference would panic on CtOption::unwrap) yields x = y = 0, inf = 0 for Ed25519. */
 int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points /* n*limbs */,
                         uint64_t* xy /* n*8 */, uint8_t* inf /* n */, size_t n);
+/* out (one point) = sum over i of multiply(points[i], scalars[i]), folded left to right from the
+ * identity exactly as the reference does; n == 0 gives the identity.  The fold is inherently serial
+ * (about 7 us per term on one lane): meant for the moderate n the trait method is used with. */
+int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars /* n*4 */,
+                         const uint64_t* points /* n*limbs */, uint64_t* out /* limbs */, size_t n);
 /* ECDSA verification as the reference computes it, one signature per element, everything after the
  * hash on the GPU.  digests: n*32 bytes exactly as the hash emits them (the reference reads them
  * big-endian); r, s: raw scalar limbs; pk_xy: the AffinePoint's x and y raw field limbs (8 per

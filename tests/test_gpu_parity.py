@@ -342,6 +342,25 @@ def test_ecdsa_verify_secp256k1_matches_oracle(gpu_ctx, oracle):
     assert np.array_equal(gpu_ctx.ecdsa_verify_secp256k1(dg, r, s, pk, None), want2)
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_multi_scalar_multiply_matches_sequential_fold(gpu_ctx, oracle, curve):
+    """Curve::multi_scalar_multiply (core lib.rs:934-951): result = identity; result += product[i]
+    strictly in order (the reference's Add is not associative)."""
+    n = 300
+    k, p = V.scalars(n, curve, 391), V.points(n, curve, 392)
+    prods = oracle.batch_mul(curve, k, p, nthreads=8)
+    acc = oracle.identity(curve)
+    for i in range(n):
+        acc = oracle.point_add(curve, acc, prods[i])
+    assert np.array_equal(gpu_ctx.multi_scalar_mul(curve, k, p), acc)
+    # order matters: the reversed batch gives a different point
+    rev = gpu_ctx.multi_scalar_mul(curve, k[::-1].copy(), p[::-1].copy())
+    assert not np.array_equal(rev, acc)
+    assert np.array_equal(gpu_ctx.multi_scalar_mul(curve, k[:1], p[:1]), prods[0] if not oracle.is_identity(curve, prods[0]) else acc)
+    import forge_ec_amd as F
+    assert np.array_equal(F.CURVES[curve](gpu_ctx).multi_scalar_multiply(p[:0], k[:0]), oracle.identity(curve))
+
+
 def test_device_pointer_path_with_torch(gpu_ctx, oracle):
     """The *_dev entry points on torch-owned HBM buffers and torch's current stream."""
     import torch
