@@ -167,6 +167,30 @@ def test_batch_mul_matches_oracle(gpu_ctx, oracle, curve):
     _assert_same(got, want, "%s batch_mul" % NAMES[curve])
 
 
+def test_p256_ladder_takes_the_equal_points_branch(gpu_ctx, oracle):
+    """P = (0, 2^63, z) satisfies double(P) ~ P under the reference's P-256 arithmetic (its Sub wraps
+    mod 2^256: Y3 = 0 - 8*y^4 = 2^256 - 2^255), so `result + *point` finds projectively equal
+    operands and returns self.double() (p256.rs:1951-1953).  In the compacted kernel that verdict
+    travels from the worker lane back to the owner lane; mix such lanes with ordinary ones."""
+    n = 700
+    k, p = V.scalars(n, 1, 395), V.points(n, 1, 396)
+    rng = np.random.default_rng(3)
+    special = rng.choice(n, size=90, replace=False)
+    for j, i in enumerate(special):
+        p[i] = np.array([0, 0, 0, 0] + V.limbs_of(1 << 63) + V.limbs_of(1 + 977 * j), dtype=np.uint64)
+        if j % 3 == 0:
+            k[i] = V.limbs_of(3 + 4 * j)
+    # the premise: double(P) is projectively P, so Add(double(P), P) == double(double(P))
+    d = oracle.point_double(1, p[special[0]])
+    assert np.array_equal(oracle.point_add(1, d, p[special[0]]), oracle.point_double(1, d))
+    got = gpu_ctx.batch_mul(1, k, p)
+    want = oracle.batch_mul(1, k, p, nthreads=8)
+    _assert_same(got, want, "p256 ladder with equal-points lanes")
+    base = p[special[1]]
+    _assert_same(gpu_ctx.batch_mul_fixed(1, k[:300], base), oracle.batch_mul_fixed(1, k[:300], base, nthreads=8),
+                 "p256 fixed-base on a self-doubling base")
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_batch_mul_fixed_matches_oracle(gpu_ctx, oracle, curve):
     n = 1000
