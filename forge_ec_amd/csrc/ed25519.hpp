@@ -133,10 +133,15 @@ FEC_DEV pt padd(const pt& p, const pt& q) {
   o.y = mul(g, h);
   o.t = mul(e, h);
   o.z = mul(f, g);
+  // the three early-outs (1869-1880) are improbable after the first addition of a lane (whose
+  // accumulator is still the identity): selects only when some lane of the wavefront needs them
   lmask opposite = fe_eq(p.x, neg(q.x)) & fe_eq(p.y, q.y);  // 1878, raw coordinates
-  o = pt_select(o, identity(), opposite);
-  o = pt_select(o, p, is_identity(q));
-  o = pt_select(o, q, is_identity(p));
+  lmask idp = is_identity(p), idq = is_identity(q);
+  if (__builtin_expect((opposite | idp | idq) != 0, 0)) {
+    o = pt_select(o, identity(), opposite);
+    o = pt_select(o, p, idq);
+    o = pt_select(o, q, idp);
+  }
   return o;
 }
 
