@@ -18,6 +18,12 @@ ABI_SYMBOLS = [
     "fec_batch_mul_fixed_dev", "fec_batch_double_mul_dev", "fec_ctx_set_chunk", "fec_ctx_set_timing",
     "fec_ctx_last_kernel_ms", "fec_measure_peak_mad32", "fec_ctx_device_info", "fec_strerror",
 ]
+# include/fecgpu_canon.h: the canonical-math mode (NOT reference parity)
+CANON_ABI_SYMBOLS = [
+    "fec_canon_secp256k1_mul_base", "fec_canon_secp256k1_mul_base_dev", "fec_canon_secp256k1_mul",
+    "fec_canon_secp256k1_mul_dev", "fec_canon_secp256k1_field_op",
+]
+F_INV = 5
 
 
 class FecError(RuntimeError):
@@ -100,5 +106,12 @@ def lib():
     L.fec_ctx_device_info.restype = ci
     L.fec_strerror.argtypes = [ci]
     L.fec_strerror.restype = ctypes.c_char_p
+    L.fec_canon_secp256k1_mul_base.argtypes = [vp, vp, vp, vp, sz]
+    L.fec_canon_secp256k1_mul_base_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.fec_canon_secp256k1_mul.argtypes = [vp, vp, vp, vp, vp, sz]
+    L.fec_canon_secp256k1_mul_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    L.fec_canon_secp256k1_field_op.argtypes = [vp, ci, vp, vp, vp, sz]
+    for n in CANON_ABI_SYMBOLS:
+        getattr(L, n).restype = ci
     _lib = L
     return L

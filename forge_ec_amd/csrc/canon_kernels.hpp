@@ -1,0 +1,135 @@
+// canon_kernels.hpp -- kernels of the CANONICAL-MATH MODE (secp256k1), included by fecgpu.hip.
+//
+// NOT reference parity (see canon_secp256k1.hpp).  Same mapping as the parity kernels: one scalar
+// per lane, 256-thread workgroups, coalesced 16-byte HBM<->LDS staging of word-major columns.
+#pragma once
+#include "canon_secp256k1.hpp"
+
+namespace fecgpu {
+
+enum { CANON_FINITE = 0, CANON_INFINITY = 1, CANON_BAD_POINT = 2 };
+
+// table[(i * 15 + j - 1) * COMB_STRIDE ...] = affine j * 16^i * G, i = 0..63, j = 1..15.
+// One wavefront, once per context: lane 0 walks the 16^i * G chain (252 doublings), then lane i
+// derives its 15 multiples by repeated addition and normalises each.
+__global__ __launch_bounds__(64) void k_csecp_build_comb(u32* __restrict__ table) {
+  __shared__ u32 lds_b[24 * 64];
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    csecp::aff g = csecp::generator();
+    csecp::jac b;
+    b.x = g.x;
+    b.y = g.y;
+    b.z = fe_small(1);
+#pragma unroll 1
+    for (int i = 0; i < csecp::COMB_WINDOWS; ++i) {
+      store_fe(lds_b + i, 64, b.x);
+      store_fe(lds_b + 8 * 64 + i, 64, b.y);
+      store_fe(lds_b + 16 * 64 + i, 64, b.z);
+#pragma unroll 1
+      for (int d = 0; d < 4; ++d) b = csecp::jdouble(b);
+    }
+  }
+  __syncthreads();
+  csecp::jac acc;
+  acc.x = load_fe(lds_b + lane, 64);
+  acc.y = load_fe(lds_b + 8 * 64 + lane, 64);
+  acc.z = load_fe(lds_b + 16 * 64 + lane, 64);
+  csecp::aff base;
+  csecp::to_affine(acc, base);
+  csecp::comb_fill_window(table, lane, base);
+}
+
+// out_xy[i] = affine scalars[i] * G (x then y, 4 limbs each); status[i] = CANON_INFINITY when
+// scalars[i] = 0 (mod n), and then out_xy[i] = 0.
+__global__ __launch_bounds__(TPB) void k_csecp_mul_base(const u32* __restrict__ scalars,
+                                                        const u32* __restrict__ table,
+                                                        u32* __restrict__ out_xy,
+                                                        unsigned char* __restrict__ status, size_t n) {
+  __shared__ u32 lds_io[16 * TPB];  // scalars in (8 words), affine points out (16 words), per-lane columns
+  __shared__ u32 lds_t[csecp::COMB_WORDS];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_io, scalars + first * 8, valid);
+  for (int v = threadIdx.x; v < csecp::COMB_WORDS; v += TPB) lds_t[v] = table[v];
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    csecp::jac r = csecp::mul_base_comb(lds_t, lds_io + e);
+    csecp::aff a;
+    lmask inf = csecp::to_affine(r, a);
+    store_fe(lds_io + e, TPB, a.x);
+    store_fe(lds_io + 8 * TPB + e, TPB, a.y);
+    const bool is_inf = lane_of(inf);
+    status[first + e] = is_inf ? CANON_INFINITY : CANON_FINITE;
+  }
+  __syncthreads();
+  stage_out<16>(out_xy + first * 16, lds_io, valid);
+}
+
+// out_xy[i] = affine scalars[i] * points_xy[i].  `scratch` holds one 15-entry window table per
+// element (WIN_ENTRIES * WIN_ENTRY_WORDS words each), private to the lane that builds it.
+__global__ __launch_bounds__(TPB) void k_csecp_mul(const u32* __restrict__ scalars,
+                                                   const u32* __restrict__ points_xy,
+                                                   u32* __restrict__ scratch, u32* __restrict__ out_xy,
+                                                   unsigned char* __restrict__ status, size_t n) {
+  __shared__ u32 lds_k[8 * TPB];
+  __shared__ u32 lds_p[16 * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_k, scalars + first * 8, valid);
+  stage_in<16>(lds_p, points_xy + first * 16, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    csecp::aff base;
+    base.x = load_fe(lds_p + e, TPB);
+    base.y = load_fe(lds_p + 8 * TPB + e, TPB);
+    lmask ok = csecp::on_curve(base);
+    // a bad point still runs the ladder (on garbage; the arithmetic is total) and is zeroed below
+    u32* table = scratch + (first + e) * (size_t)(csecp::WIN_ENTRIES * csecp::WIN_ENTRY_WORDS);
+    csecp::jac r = csecp::mul_window(base, lds_k + e, table);
+    csecp::aff a;
+    lmask inf = csecp::to_affine(r, a);
+    a.x = fe_select(fe_zero(), a.x, ok);
+    a.y = fe_select(fe_zero(), a.y, ok);
+    store_fe(lds_p + e, TPB, a.x);
+    store_fe(lds_p + 8 * TPB + e, TPB, a.y);
+    const bool is_ok = lane_of(ok), is_inf = lane_of(inf);
+    status[first + e] = !is_ok ? CANON_BAD_POINT : (is_inf ? CANON_INFINITY : CANON_FINITE);
+  }
+  __syncthreads();
+  stage_out<16>(out_xy + first * 16, lds_p, valid);
+}
+
+// canonical field ops for tests and callers: op = fec_field_opcode, plus FEC_F_NEG + 1 = inverse
+__global__ __launch_bounds__(TPB) void k_csecp_field_op(int op, const u32* __restrict__ a,
+                                                        const u32* __restrict__ b, u32* __restrict__ out,
+                                                        size_t n) {
+  __shared__ u32 lds_a[8 * TPB];
+  __shared__ u32 lds_b[8 * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_a, a + first * 8, valid);
+  if (b) stage_in<8>(lds_b, b + first * 8, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    fe x = load_fe(lds_a + e, TPB);
+    fe y = b ? load_fe(lds_b + e, TPB) : fe_zero();
+    fe r;
+    switch (op) {
+      case FEC_F_ADD: r = csecp::add(x, y); break;
+      case FEC_F_SUB: r = csecp::sub(x, y); break;
+      case FEC_F_MUL: r = csecp::mul(x, y); break;
+      case FEC_F_SQR: r = csecp::sqr(x); break;
+      case FEC_F_NEG: r = csecp::neg(x); break;
+      default: r = csecp::inv(x); break;
+    }
+    store_fe(lds_a + e, TPB, r);
+  }
+  __syncthreads();
+  stage_out<8>(out + first * 8, lds_a, valid);
+}
+
+}  // namespace fecgpu

@@ -1,0 +1,392 @@
+// canon_secp256k1.hpp -- CANONICAL-MATH MODE for secp256k1.
+//
+// NOT reference parity.  The reference's secp256k1 arithmetic is not a field and its point layer is
+// not a group, so its outputs are not secp256k1 public keys.  This header implements the real
+// curve y^2 = x^3 + 7 over F_p, p = 2^256 - 2^32 - 977, for callers who want standard results
+// (key generation, ECDH) at GPU speed: plain (non-Montgomery) canonical field elements, Jacobian
+// coordinates, a 4-bit fixed-base comb for k*G, a batched Montgomery-trick normalisation to affine.
+// It is validated against an independent big-integer model kept with the tests and public
+// standard vectors (BIP-340 / SEC2 multiples of G), never against the reference.
+//
+// Field elements are 8 x u32 little-endian words, always in [0, p).
+#pragma once
+#include "secp256k1.hpp"
+
+namespace fecgpu {
+namespace csecp {
+
+// add / sub / neg of the reference ARE correct modulo p for canonical operands (secp256k1.rs
+// 353-440, 509-539 restate the textbook conditional-subtract forms); they are reused.
+FEC_DEV fe add(const fe& a, const fe& b) { return secp::add(a, b); }
+FEC_DEV fe sub(const fe& a, const fe& b) { return secp::sub(a, b); }
+FEC_DEV fe neg(const fe& a) { return secp::neg(a); }
+FEC_DEV fe dbl(const fe& a) { return secp::add(a, a); }
+
+// t (512 bits) mod p.  2^256 = c (mod p), c = 2^32 + 977:  t = lo + hi * c.
+FEC_DEV fe reduce512(const u32 t[16]) {
+  // u = hi * 977  (9 words)
+  u32 u[9];
+  {
+    u32 carry = 0;
+    FEC_UNROLL for (int k = 0; k < 8; ++k) {
+      u64 p = (u64)t[8 + k] * 977u + carry;
+      u[k] = (u32)p;
+      carry = (u32)(p >> 32);
+    }
+    u[8] = carry;
+  }
+  fe lo, ul, hs, v, w;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    lo.w[i] = t[i];
+    ul.w[i] = u[i];
+  }
+  hs.w[0] = 0;  // (hi << 32), low 8 words
+  FEC_UNROLL for (int i = 1; i < 8; ++i) hs.w[i] = t[7 + i];
+  lmask c1 = add256(v, lo, ul);
+  lmask c2 = add256(w, v, hs);
+  // what spilled past 2^256: u[8] + hi[7] + carries  (< 2^34)
+  u64 top = (u64)u[8] + t[15] + word_select(0u, 1u, c1) + word_select(0u, 1u, c2);
+  // fold it once more: w += top * c = top * 977 + (top << 32)
+  u64 f0 = (u64)(u32)top * 977u;                 // top_lo * 977
+  u64 f1 = (u64)(u32)(top >> 32) * 977u;         // top_hi * 977 (top_hi <= 3)
+  // addend words: a0 = lo(f0); a1 = hi(f0) + lo(f1) + top_lo; a2 = carries + top_hi  (all small)
+  u64 a1 = (f0 >> 32) + (u32)f1 + (u32)top;
+  u64 a2 = (a1 >> 32) + (f1 >> 32) + (top >> 32);
+  fe addend = fe_zero();
+  addend.w[0] = (u32)f0;
+  addend.w[1] = (u32)a1;
+  addend.w[2] = (u32)a2;
+  fe r;
+  lmask c3 = add256(r, w, addend);
+  if (__builtin_expect(c3 != 0, 0)) {  // wrapped past 2^256 once more (probability ~2^-190): add c
+    fe r2;
+    lmask t2;
+    FEC_ADDK256(r2, r, t2, FEC_SECP_C);
+    (void)t2;
+    r = fe_select(r, r2, c3);
+  }
+  return secp::csub_p_unlikely(r);
+}
+
+FEC_DEV fe mul(const fe& a, const fe& b) {
+  u32 t[16];
+  mul_wide(t, a, b);
+  return reduce512(t);
+}
+FEC_DEV fe sqr(const fe& a) { return mul(a, a); }
+FEC_DEV fe mul3(const fe& a) { return add(add(a, a), a); }
+FEC_DEV fe mul8(const fe& a) { return dbl(dbl(dbl(a))); }
+
+// a^(p-2): the standard addition chain for p = 2^256 - 2^32 - 977 (255 squarings, 15 multiplications)
+FEC_DEV fe sqr_n(fe a, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) a = sqr(a);
+  return a;
+}
+FEC_DEV fe inv(const fe& a) {
+  fe x2 = mul(sqr(a), a);
+  fe x3 = mul(sqr(x2), a);
+  fe x6 = mul(sqr_n(x3, 3), x3);
+  fe x9 = mul(sqr_n(x6, 3), x3);
+  fe x11 = mul(sqr_n(x9, 2), x2);
+  fe x22 = mul(sqr_n(x11, 11), x11);
+  fe x44 = mul(sqr_n(x22, 22), x22);
+  fe x88 = mul(sqr_n(x44, 44), x44);
+  fe x176 = mul(sqr_n(x88, 88), x88);
+  fe x220 = mul(sqr_n(x176, 44), x44);
+  fe x223 = mul(sqr_n(x220, 3), x3);
+  // p - 2 = 2^256 - 2^32 - 979: binary = 223 ones, 0, 22 ones, 0000, 1, 0, 11, 0, 1  (1..1 0 1..1 0000101101)
+  fe t = sqr_n(x223, 23);
+  t = mul(t, x22);
+  t = sqr_n(t, 5);
+  t = mul(t, a);
+  t = sqr_n(t, 3);
+  t = mul(t, x2);
+  t = sqr_n(t, 2);
+  t = mul(t, a);
+  return t;
+}
+
+struct jac {
+  fe x, y, z;
+};  // Z == 0 <=> point at infinity
+struct aff {
+  fe x, y;
+};
+
+FEC_DEV jac jac_infinity() {
+  jac p;
+  p.x = fe_small(1);
+  p.y = fe_small(1);
+  p.z = fe_zero();
+  return p;
+}
+FEC_DEV jac jac_select(const jac& a, const jac& b, lmask m) {
+  jac r;
+  r.x = fe_select(a.x, b.x, m);
+  r.y = fe_select(a.y, b.y, m);
+  r.z = fe_select(a.z, b.z, m);
+  return r;
+}
+
+// dbl-2009-l (a = 0): 2M + 5S.  Infinity (Z = 0) doubles to Z3 = 0; Y = 0 cannot occur on this
+// curve (odd prime order).
+FEC_DEV jac jdouble(const jac& p) {
+  fe A = sqr(p.x), B = sqr(p.y), C = sqr(B);
+  fe t = sqr(add(p.x, B));
+  fe D = dbl(sub(sub(t, A), C));
+  fe E = mul3(A);
+  fe F = sqr(E);
+  jac r;
+  r.x = sub(F, dbl(D));
+  r.y = sub(mul(E, sub(D, r.x)), mul8(C));
+  r.z = dbl(mul(p.y, p.z));
+  return r;
+}
+
+// madd-2007-bl: Jacobian + affine, 7M + 4S, with the exceptional cases (P infinite; P == +-Q)
+// behind wave-uniform branches.  `skip` lanes return p unchanged (a zero comb digit).
+FEC_DEV jac jadd_affine(const jac& p, const aff& q, lmask skip) {
+  fe z1z1 = sqr(p.z);
+  fe u2 = mul(q.x, z1z1);
+  fe s2 = mul(mul(q.y, p.z), z1z1);
+  fe h = sub(u2, p.x);
+  fe hh = sqr(h);
+  fe i = dbl(dbl(hh));
+  fe j = mul(h, i);
+  fe rr = dbl(sub(s2, p.y));
+  fe v = mul(p.x, i);
+  jac o;
+  o.x = sub(sub(sqr(rr), j), dbl(v));
+  o.y = sub(mul(rr, sub(v, o.x)), dbl(mul(p.y, j)));
+  o.z = sub(sub(sqr(add(p.z, h)), z1z1), hh);
+  lmask pinf = fe_is_zero(p.z);
+  lmask hzero = fe_is_zero(h) & ~pinf;
+  if (__builtin_expect((pinf | hzero) != 0, 0)) {
+    jac qa;
+    qa.x = q.x;
+    qa.y = q.y;
+    qa.z = fe_small(1);
+    o = jac_select(o, qa, pinf);
+    if (hzero != 0) {  // same x: either P == Q (double) or P == -Q (infinity)
+      lmask same = hzero & fe_is_zero(rr);
+      jac d = jdouble(qa);
+      o = jac_select(o, jac_infinity(), hzero & ~same);
+      o = jac_select(o, d, same);
+    }
+  }
+  return jac_select(o, p, skip);
+}
+
+// general Jacobian + Jacobian (add-2007-bl), 11M + 5S; used only while building tables
+FEC_DEV jac jadd(const jac& p, const jac& q) {
+  fe z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+  fe u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+  fe s1 = mul(mul(p.y, q.z), z2z2), s2 = mul(mul(q.y, p.z), z1z1);
+  fe h = sub(u2, u1);
+  fe i = sqr(dbl(h));
+  fe j = mul(h, i);
+  fe rr = dbl(sub(s2, s1));
+  fe v = mul(u1, i);
+  jac o;
+  o.x = sub(sub(sqr(rr), j), dbl(v));
+  o.y = sub(mul(rr, sub(v, o.x)), dbl(mul(s1, j)));
+  o.z = mul(sub(sub(sqr(add(p.z, q.z)), z1z1), z2z2), h);
+  lmask pinf = fe_is_zero(p.z), qinf = fe_is_zero(q.z);
+  lmask hzero = fe_is_zero(h) & ~pinf & ~qinf;
+  lmask same = hzero & fe_is_zero(rr);
+  jac d = jdouble(p);
+  o = jac_select(o, jac_infinity(), hzero & ~same);
+  o = jac_select(o, d, same);
+  o = jac_select(o, q, pinf);
+  o = jac_select(o, p, qinf & ~pinf);
+  return o;
+}
+
+// Jacobian + Jacobian for the windowed ladder: q is a table entry (never infinite); `skip` lanes
+// keep p (zero digit).  P infinite / P == +-Q are fixed up behind a wave-uniform branch.
+FEC_DEV jac jadd_window(const jac& p, const jac& q, lmask skip) {
+  fe z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+  fe u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+  fe s1 = mul(mul(p.y, q.z), z2z2), s2 = mul(mul(q.y, p.z), z1z1);
+  fe h = sub(u2, u1);
+  fe i = sqr(dbl(h));
+  fe j = mul(h, i);
+  fe rr = dbl(sub(s2, s1));
+  fe v = mul(u1, i);
+  jac o;
+  o.x = sub(sub(sqr(rr), j), dbl(v));
+  o.y = sub(mul(rr, sub(v, o.x)), dbl(mul(s1, j)));
+  o.z = mul(sub(sub(sqr(add(p.z, q.z)), z1z1), z2z2), h);
+  lmask pinf = fe_is_zero(p.z) & ~skip;
+  lmask hzero = fe_is_zero(h) & ~pinf & ~skip;
+  if (__builtin_expect((pinf | hzero) != 0, 0)) {
+    o = jac_select(o, q, pinf);
+    if (hzero != 0) {
+      lmask same = hzero & fe_is_zero(rr);
+      jac d = jdouble(q);
+      o = jac_select(o, jac_infinity(), hzero & ~same);
+      o = jac_select(o, d, same);
+    }
+  }
+  return jac_select(o, p, skip);
+}
+
+// x, y < p and y^2 == x^3 + 7
+FEC_DEV lmask ge_p(const fe& v) {  // v >= p  <=>  v + c carries out of 2^256
+  fe w;
+  lmask ov;
+  FEC_ADDK256(w, v, ov, FEC_SECP_C);
+  return ov;
+}
+FEC_DEV lmask on_curve(const aff& q) {
+  lmask xlt = ~ge_p(q.x), ylt = ~ge_p(q.y);
+  fe rhs = add(mul(sqr(q.x), q.x), fe_small(7));
+  return uniform_mask(xlt & ylt & fe_eq(sqr(q.y), rhs));
+}
+
+// Windowed variable-base k*P, 4-bit fixed windows, most significant first.  The lane's table of
+// 1P..15P (Jacobian, 32 words per entry: X, Y, Z, pad) lives in its own slice of a global scratch
+// buffer -- written and read only by this lane, one 128-byte line per lookup.
+constexpr int WIN_ENTRY_WORDS = 32, WIN_ENTRIES = 15;
+#ifdef FEC_HOST_EMUL
+FEC_DEV void win_store(u32* slot, const jac& p) {
+  for (int i = 0; i < 8; ++i) {
+    slot[i] = p.x.w[i];
+    slot[8 + i] = p.y.w[i];
+    slot[16 + i] = p.z.w[i];
+  }
+}
+FEC_DEV jac win_load(const u32* slot) {
+  jac p;
+  for (int i = 0; i < 8; ++i) {
+    p.x.w[i] = slot[i];
+    p.y.w[i] = slot[8 + i];
+    p.z.w[i] = slot[16 + i];
+  }
+  return p;
+}
+#else
+FEC_DEV void win_store(u32* slot, const jac& p) {
+  uint4* d = reinterpret_cast<uint4*>(slot);
+  d[0] = make_uint4(p.x.w[0], p.x.w[1], p.x.w[2], p.x.w[3]);
+  d[1] = make_uint4(p.x.w[4], p.x.w[5], p.x.w[6], p.x.w[7]);
+  d[2] = make_uint4(p.y.w[0], p.y.w[1], p.y.w[2], p.y.w[3]);
+  d[3] = make_uint4(p.y.w[4], p.y.w[5], p.y.w[6], p.y.w[7]);
+  d[4] = make_uint4(p.z.w[0], p.z.w[1], p.z.w[2], p.z.w[3]);
+  d[5] = make_uint4(p.z.w[4], p.z.w[5], p.z.w[6], p.z.w[7]);
+}
+FEC_DEV jac win_load(const u32* slot) {
+  const uint4* s = reinterpret_cast<const uint4*>(slot);
+  uint4 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5];
+  jac p;
+  p.x.w[0] = a.x; p.x.w[1] = a.y; p.x.w[2] = a.z; p.x.w[3] = a.w;
+  p.x.w[4] = b.x; p.x.w[5] = b.y; p.x.w[6] = b.z; p.x.w[7] = b.w;
+  p.y.w[0] = c.x; p.y.w[1] = c.y; p.y.w[2] = c.z; p.y.w[3] = c.w;
+  p.y.w[4] = d.x; p.y.w[5] = d.y; p.y.w[6] = d.z; p.y.w[7] = d.w;
+  p.z.w[0] = e.x; p.z.w[1] = e.y; p.z.w[2] = e.z; p.z.w[3] = e.w;
+  p.z.w[4] = f.x; p.z.w[5] = f.y; p.z.w[6] = f.z; p.z.w[7] = f.w;
+  return p;
+}
+#endif
+
+FEC_DEV jac mul_window(const aff& base, const u32* kw, u32* table /* this lane's 15 x 32 words */) {
+  jac t;
+  t.x = base.x;
+  t.y = base.y;
+  t.z = fe_small(1);
+  win_store(table, t);
+  t = jdouble(t);
+  win_store(table + WIN_ENTRY_WORDS, t);
+#pragma unroll 1
+  for (int j = 3; j <= WIN_ENTRIES; ++j) {
+    t = jadd_affine(t, base, 0);
+    win_store(table + (j - 1) * WIN_ENTRY_WORDS, t);
+  }
+  jac acc = jac_infinity();
+#pragma unroll 1
+  for (int w = 63; w >= 0; --w) {
+    u32 digit = (kw[(w >> 3) * KSTRIDE] >> ((w & 7) * 4)) & 15u;
+    jac q = win_load(table + ((digit == 0 ? 1u : digit) - 1) * WIN_ENTRY_WORDS);
+#pragma unroll 1
+    for (int d = 0; d < 4; ++d) acc = jdouble(acc);
+    acc = jadd_window(acc, q, lanes_where(digit == 0));
+  }
+  return acc;
+}
+
+// affine generator (SEC2)
+FEC_DEV aff generator() {
+  aff g;
+  const u32 gx[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu, 0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
+  const u32 gy[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u, 0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    g.x.w[i] = gx[i];
+    g.y.w[i] = gy[i];
+  }
+  return g;
+}
+
+// Comb table for k*G with 4-bit digits: entry (i, j), j = 1..15, is the AFFINE point j * 16^i * G.
+// 64 windows x 15 entries x 16 words, entry stride COMB_STRIDE words (odd, spreads LDS banks).
+constexpr int COMB_WINDOWS = 64, COMB_ENTRIES = 15, COMB_STRIDE = 17;
+constexpr int COMB_WORDS = COMB_WINDOWS * COMB_ENTRIES * COMB_STRIDE;
+
+FEC_DEV aff comb_entry(const u32* tab, int window, u32 digit /* 1..15 */) {
+  const u32* e = tab + (window * COMB_ENTRIES + (int)digit - 1) * COMB_STRIDE;
+  aff q;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    q.x.w[i] = e[i];
+    q.y.w[i] = e[8 + i];
+  }
+  return q;
+}
+
+// Jacobian -> affine.  inv(0) = 0, so the point at infinity comes out as (0, 0) with the mask set.
+FEC_DEV lmask to_affine(const jac& p, aff& a) {
+  fe zi = inv(p.z);
+  fe zi2 = sqr(zi);
+  a.x = mul(p.x, zi2);
+  a.y = mul(mul(p.y, zi2), zi);
+  return fe_is_zero(p.z);
+}
+
+// the 15 entries of one comb window: j * base for j = 1..15, base = 16^window * G (affine)
+FEC_DEV void comb_fill_window(u32* table, int window, const aff& base) {
+  jac acc;
+  acc.x = base.x;
+  acc.y = base.y;
+  acc.z = fe_small(1);
+#pragma unroll 1
+  for (int j = 1; j <= COMB_ENTRIES; ++j) {
+    aff e = base;
+    if (j > 1) {
+      acc = jadd_affine(acc, base, 0);  // j == 2 goes through the P == Q branch
+      to_affine(acc, e);
+    }
+    u32* dst = table + (size_t)(window * COMB_ENTRIES + j - 1) * COMB_STRIDE;
+    FEC_UNROLL for (int w = 0; w < 8; ++w) {
+      dst[w] = e.x.w[w];
+      dst[8 + w] = e.y.w[w];
+    }
+    dst[16] = 0;
+  }
+}
+
+// k*G: one mixed addition per non-zero 4-bit digit of k (64 digits), no doublings.
+// kw: the lane's scalar in LDS (word j at kw[j * KSTRIDE]); any 256-bit k is accepted (k*G with k
+// taken modulo the group order, as the group law gives).
+FEC_DEV jac mul_base_comb(const u32* tab, const u32* kw) {
+  jac acc = jac_infinity();
+#pragma unroll 1
+  for (int w = 0; w < COMB_WINDOWS; ++w) {
+    u32 digit = (kw[(w >> 3) * KSTRIDE] >> ((w & 7) * 4)) & 15u;
+    lmask skip = lanes_where(digit == 0);
+    aff q = comb_entry(tab, w, digit == 0 ? 1u : digit);
+    acc = jadd_affine(acc, q, skip);
+  }
+  return acc;
+}
+
+}  // namespace csecp
+}  // namespace fecgpu

@@ -14,6 +14,7 @@
 #include <new>
 
 #include "../../include/fecgpu.h"
+#include "../../include/fecgpu_canon.h"
 #include "ed25519.hpp"
 #include "p256.hpp"
 #include "secp256k1.hpp"
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(TPB) void k_to_affine(const u32* __restrict__ point
     typename C::pt p = C::load(lds_p + e, TPB);
     fe x, y;
     lmask m = C::to_affine(p, x, y);
-    bool mine = (m >> (threadIdx.x & 63)) & 1;
+    bool mine = lane_of(m);
     store_fe(lds_p + e, TPB, x);  // a lane reads and writes only its own LDS column
     store_fe(lds_p + 8 * TPB + e, TPB, y);
     inf[first + e] = mine ? 1 : 0;
@@ -561,6 +562,8 @@ __global__ __launch_bounds__(TPB) void k_peak_mad32(u32* out, u32 seed) {
 
 }  // namespace fecgpu
 
+#include "canon_kernels.hpp"  // canonical-math mode (NOT reference parity)
+
 // ==========================================================================================
 // host side: context + extern "C" ABI
 // ==========================================================================================
@@ -583,6 +586,11 @@ struct fec_ctx {
   u64 ed_table_base[16] = {0};                  // the base point the table was built for
   bool ed_table_valid = false;
   u64 h_gen_ed[16] = {0};                       // host copy of the Ed25519 generator (table cache key)
+  // canonical-math mode: comb table of affine multiples of G, per-element window-table scratch
+  u32* d_csecp_comb = nullptr;
+  bool csecp_comb_ready = false;
+  void* d_win_scratch = nullptr;
+  size_t win_scratch_cap = 0;
   hipDeviceProp_t prop;
 };
 
@@ -831,6 +839,94 @@ int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, siz
   return FEC_OK;
 }
 
+// ---- canonical-math mode -------------------------------------------------------------------
+int ensure_csecp_comb(fec_ctx* ctx, hipStream_t s) {
+  if (ctx->csecp_comb_ready) return FEC_OK;
+  if (!ctx->d_csecp_comb &&
+      hipMalloc(&ctx->d_csecp_comb, (size_t)csecp::COMB_WORDS * sizeof(u32)) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_OOM;
+  }
+  hipLaunchKernelGGL(k_csecp_build_comb, dim3(1), dim3(64), 0, s, ctx->d_csecp_comb);
+  if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
+  // the table is read by kernels on either pipeline stream: finish it before anyone can race
+  if (hipStreamSynchronize(s) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  ctx->csecp_comb_ready = true;
+  return FEC_OK;
+}
+
+int launch_csecp_mul_base(fec_ctx* ctx, const u64* ds, u64* dxy, unsigned char* dst, size_t n, void* stream) {
+  if (n == 0) return FEC_OK;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  int rc = ensure_csecp_comb(ctx, s);
+  if (rc != FEC_OK) return rc;
+  Launch L(ctx, stream, "k_csecp_mul_base");
+  hipLaunchKernelGGL(k_csecp_mul_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(ds),
+                     ctx->d_csecp_comb, reinterpret_cast<u32*>(dxy), dst, n);
+  return L.done();
+}
+
+int launch_csecp_mul(fec_ctx* ctx, const u64* ds, const u64* dp, u64* dxy, unsigned char* dst, size_t n,
+                     void* stream) {
+  if (n == 0) return FEC_OK;
+  const size_t need = n * (size_t)(csecp::WIN_ENTRIES * csecp::WIN_ENTRY_WORDS) * sizeof(u32);
+  if (ctx->win_scratch_cap < need) {
+    // a kernel of an earlier call may still be using the old buffer
+    if (hipDeviceSynchronize() != hipSuccess) return FEC_E_LAUNCH;
+    if (ctx->d_win_scratch) (void)hipFree(ctx->d_win_scratch);
+    ctx->d_win_scratch = nullptr;
+    ctx->win_scratch_cap = 0;
+    if (hipMalloc(&ctx->d_win_scratch, need) != hipSuccess) {
+      (void)hipGetLastError();
+      return FEC_E_OOM;
+    }
+    ctx->win_scratch_cap = need;
+  }
+  Launch L(ctx, stream, "k_csecp_mul");
+  hipLaunchKernelGGL(k_csecp_mul, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(ds),
+                     reinterpret_cast<const u32*>(dp), reinterpret_cast<u32*>(ctx->d_win_scratch),
+                     reinterpret_cast<u32*>(dxy), dst, n);
+  return L.done();
+}
+
+// one-shot host-pointer call with up to three inputs and two outputs (not pipelined)
+template <class F>
+int host_oneshot(fec_ctx* ctx, const void* const in[3], const size_t in_bytes[3], void* const out[2],
+                 const size_t out_bytes[2], F body) {
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  void* d_in[3] = {nullptr, nullptr, nullptr};
+  void* d_out[2] = {nullptr, nullptr};
+  for (int i = 0; i < 3; ++i) {
+    if (!in[i]) continue;
+    int rc = ensure(ctx, i, in_bytes[i]);
+    if (rc != FEC_OK) return rc;
+    d_in[i] = ctx->d_buf[i];
+    if (hipMemcpyAsync(d_in[i], in[i], in_bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (!out[i]) continue;
+    int rc = ensure(ctx, 3 + i, out_bytes[i]);
+    if (rc != FEC_OK) return rc;
+    d_out[i] = ctx->d_buf[3 + i];
+  }
+  int rc = body(d_in[0], d_in[1], d_in[2], d_out[0], d_out[1]);
+  if (rc != FEC_OK) return rc;
+  for (int i = 0; i < 2; ++i) {
+    if (!out[i]) continue;
+    if (hipMemcpyAsync(out[i], d_out[i], out_bytes[i], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  return FEC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -910,6 +1006,8 @@ void fec_ctx_destroy(fec_ctx* ctx) {
   for (int i = 0; i < 3; ++i)
     if (ctx->d_gen[i]) (void)hipFree(ctx->d_gen[i]);
   if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
+  if (ctx->d_csecp_comb) (void)hipFree(ctx->d_csecp_comb);
+  if (ctx->d_win_scratch) (void)hipFree(ctx->d_win_scratch);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1196,6 +1294,67 @@ int fec_ctx_device_info(fec_ctx* ctx, char* name, size_t name_len, int* compute_
   if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
   if (clock_khz) *clock_khz = ctx->prop.clockRate;
   return FEC_OK;
+}
+
+// ---- canonical-math mode (include/fecgpu_canon.h): NOT reference parity ----------------------
+int fec_canon_secp256k1_mul_base_dev(fec_ctx* ctx, const uint64_t* d_scalars, uint64_t* d_out_xy,
+                                     uint8_t* d_status, size_t n, void* stream) {
+  if (!ctx || (n && (!d_scalars || !d_out_xy || !d_status))) return FEC_E_ARG;
+  if (!aligned16(d_scalars) || !aligned16(d_out_xy)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_csecp_mul_base(ctx, d_scalars, d_out_xy, d_status, n, stream);
+}
+
+int fec_canon_secp256k1_mul_base(fec_ctx* ctx, const uint64_t* scalars, uint64_t* out_xy, uint8_t* status,
+                                 size_t n) {
+  if (!ctx || (n && (!scalars || !out_xy || !status))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const void* const in[3] = {scalars, nullptr, nullptr};
+  const size_t in_bytes[3] = {n * 32, 0, 0};
+  void* const out[2] = {out_xy, status};
+  const size_t out_bytes[2] = {n * 64, n};
+  return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void*, void*, void* o, void* st) {
+    return launch_csecp_mul_base(ctx, (const u64*)a, (u64*)o, (unsigned char*)st, n, nullptr);
+  });
+}
+
+int fec_canon_secp256k1_mul_dev(fec_ctx* ctx, const uint64_t* d_scalars, const uint64_t* d_points_xy,
+                                uint64_t* d_out_xy, uint8_t* d_status, size_t n, void* stream) {
+  if (!ctx || (n && (!d_scalars || !d_points_xy || !d_out_xy || !d_status))) return FEC_E_ARG;
+  if (!aligned16(d_scalars) || !aligned16(d_points_xy) || !aligned16(d_out_xy)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_csecp_mul(ctx, d_scalars, d_points_xy, d_out_xy, d_status, n, stream);
+}
+
+int fec_canon_secp256k1_mul(fec_ctx* ctx, const uint64_t* scalars, const uint64_t* points_xy, uint64_t* out_xy,
+                            uint8_t* status, size_t n) {
+  if (!ctx || (n && (!scalars || !points_xy || !out_xy || !status))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const void* const in[3] = {scalars, points_xy, nullptr};
+  const size_t in_bytes[3] = {n * 32, n * 64, 0};
+  void* const out[2] = {out_xy, status};
+  const size_t out_bytes[2] = {n * 64, n};
+  return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void* b, void*, void* o, void* st) {
+    return launch_csecp_mul(ctx, (const u64*)a, (const u64*)b, (u64*)o, (unsigned char*)st, n, nullptr);
+  });
+}
+
+int fec_canon_secp256k1_field_op(fec_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
+                                 size_t n) {
+  if (!ctx || op < FEC_F_ADD || op > FEC_F_INV || (n && (!a || !out))) return FEC_E_ARG;
+  const bool binary = op == FEC_F_ADD || op == FEC_F_SUB || op == FEC_F_MUL;
+  if (binary && n && !b) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const void* const in[3] = {a, binary ? b : nullptr, nullptr};
+  const size_t in_bytes[3] = {n * 32, n * 32, 0};
+  void* const outs[2] = {out, nullptr};
+  const size_t out_bytes[2] = {n * 32, 0};
+  return host_oneshot(ctx, in, in_bytes, outs, out_bytes, [&](void* x, void* y, void*, void* o, void*) {
+    Launch L(ctx, nullptr, "k_csecp_field_op");
+    hipLaunchKernelGGL(k_csecp_field_op, dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y,
+                       (u32*)o, n);
+    return L.done();
+  });
 }
 
 }  // extern "C"

@@ -317,6 +317,24 @@ FEC_DEV fe fe_select(const fe& a, const fe& b, lmask m) {
 }
 #endif
 
+// The compiler treats the mask outputs of the multi-output asm chains as divergent values and may
+// evaluate boolean combinations of them on the VALU; uniform_mask() pins such a combination back
+// into SGPRs (it IS wave-uniform) before it is used as an "s" operand.  Only needed for
+// combinations the instruction selector turns into VALU-only forms (and-not chains -> v_bfi).
+#ifdef FEC_HOST_EMUL
+FEC_DEV lmask uniform_mask(lmask m) { return m; }
+#else
+FEC_DEV lmask uniform_mask(lmask m) {
+  u32 lo = __builtin_amdgcn_readfirstlane((u32)m), hi = __builtin_amdgcn_readfirstlane((u32)(m >> 32));
+  return ((u64)hi << 32) | lo;
+}
+#endif
+
+// this lane's bit of a lane mask.  Goes through word_select so that the mask stays in SGPRs: a
+// 64-bit shift by the lane id would let the compiler move the whole mask computation to the VALU,
+// and the "s" operands of the asm selects above would then be handed VGPRs.
+FEC_DEV bool lane_of(lmask m) { return word_select(0u, 1u, m) != 0; }
+
 // one level of indirection so that a constant list passed as a single macro (FEC_SECP_C, ...)
 // is expanded before it is split into k0..k7
 #define FEC_ADDK256(r, a, c, ...) FEC_ADDK256_(r, a, c, __VA_ARGS__)

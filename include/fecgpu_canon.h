@@ -1,0 +1,62 @@
+/*
+ * fecgpu_canon.h -- CANONICAL-MATH MODE of libfecgpu.so.
+ *
+ * *** NOT REFERENCE PARITY. ***  Everything in fecgpu.h reproduces forge-ec's CPU arithmetic bit
+ * for bit, and that arithmetic is not the secp256k1 group: its outputs are
+ * not public keys any other library would accept.  The entry points below compute the REAL curve
+ * -- y^2 = x^3 + 7 over F_p, p = 2^256 - 2^32 - 977, group order n -- for callers that want
+ * standard results at GPU speed.  They replace the same loops as fec_batch_mul_fixed /
+ * fec_batch_mul + fec_batch_to_affine (key generation forge-ec-examples/src/ecdh.rs:27-49,
+ * forge-ec-signature/src/ecdsa.rs:111-112; ECDH ecdh.rs:51-70), but their results differ from the
+ * reference's by design; they are validated against an independent big-integer model
+ * (oracle/canon_model.py) and public standard vectors (SEC2 / BIP-340 multiples of G), never
+ * against the reference.  A maintainer adopts them only together with a fix of the reference's
+ * field arithmetic.
+ *
+ * Layout: scalars and coordinates are uint64_t[4] little-endian limbs holding the plain integer
+ * (no Montgomery form); an affine point is x then y = 8 limbs; arrays are arrays-of-structs.
+ * status[i]: 0 = finite point in out_xy[i]; 1 = the result is the point at infinity
+ * (out_xy[i] = 0); 2 = input point i is not on the curve / not canonical (out_xy[i] = 0).
+ *
+ * Scalars may be any 256-bit value; k*P is computed for k as given (the group law reduces it
+ * modulo n).  These routines are NOT constant-time with respect to the scalar: table lookups are
+ * indexed by scalar digits.  Use them for public or batch-verification workloads, or accept the
+ * GPU's threat model explicitly.
+ */
+#ifndef FECGPU_CANON_H
+#define FECGPU_CANON_H
+
+#include "fecgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { FEC_CANON_FINITE = 0, FEC_CANON_INFINITY = 1, FEC_CANON_BAD_POINT = 2 } fec_canon_status;
+
+/* field opcode for fec_canon_secp256k1_field_op beyond fec_field_opcode: modular inverse (0 -> 0) */
+#define FEC_F_INV 5
+
+/* out_xy[i] = scalars[i] * G, affine.  Fixed-base 4-bit comb (64 mixed additions, no doublings)
+ * from a 61 KiB table of affine multiples of G built on the device at first use and kept in LDS. */
+int fec_canon_secp256k1_mul_base(fec_ctx* ctx, const uint64_t* scalars /* n*4 */, uint64_t* out_xy /* n*8 */,
+                                 uint8_t* status /* n */, size_t n);
+int fec_canon_secp256k1_mul_base_dev(fec_ctx* ctx, const uint64_t* d_scalars, uint64_t* d_out_xy,
+                                     uint8_t* d_status, size_t n, void* stream);
+
+/* out_xy[i] = scalars[i] * points_xy[i], affine in, affine out (ECDH).  Input points are checked
+ * (coordinates < p, on the curve); a failing element gets status 2 and zero output. */
+int fec_canon_secp256k1_mul(fec_ctx* ctx, const uint64_t* scalars /* n*4 */, const uint64_t* points_xy /* n*8 */,
+                            uint64_t* out_xy /* n*8 */, uint8_t* status /* n */, size_t n);
+int fec_canon_secp256k1_mul_dev(fec_ctx* ctx, const uint64_t* d_scalars, const uint64_t* d_points_xy,
+                                uint64_t* d_out_xy, uint8_t* d_status, size_t n, void* stream);
+
+/* element-wise F_p arithmetic on canonical values (inputs must be < p): op is a fec_field_opcode
+ * or FEC_F_INV; b is ignored for unary ops */
+int fec_canon_secp256k1_field_op(fec_ctx* ctx, int op, const uint64_t* a /* n*4 */, const uint64_t* b /* n*4 */,
+                                 uint64_t* out /* n*4 */, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -17,8 +17,8 @@ def lib():
     return _lib.lib()
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "fecgpu.h")).read()
+def _declared_symbols(header="fecgpu.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fec_[a-z0-9_]+)\s*\(", text)))
 
@@ -28,6 +28,10 @@ def test_header_and_library_agree(lib):
     declared = _declared_symbols()
     assert declared == sorted(_lib.ABI_SYMBOLS)
     for s in declared:
+        assert hasattr(lib, s), s
+    canon = _declared_symbols("fecgpu_canon.h")
+    assert canon == sorted(_lib.CANON_ABI_SYMBOLS)
+    for s in canon:
         assert hasattr(lib, s), s
 
 

@@ -72,3 +72,71 @@ extern "C" int he_secp_scalar_op(int op, const uint64_t* a, const uint64_t* b, u
   st(out, r);
   return 0;
 }
+
+// ---- canonical-math mode (canon_secp256k1.hpp): checked against oracle/canon_model.py ----
+#include "../forge_ec_amd/csrc/canon_secp256k1.hpp"
+// op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 inv
+extern "C" int he_canon_field_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  fe x = ld(a), y = b ? ld(b) : fe_zero(), r;
+  r = op == 0 ? csecp::add(x, y) : op == 1 ? csecp::sub(x, y) : op == 2 ? csecp::mul(x, y)
+    : op == 3 ? csecp::sqr(x) : op == 4 ? csecp::neg(x) : csecp::inv(x);
+  st(out, r);
+  return 0;
+}
+static u32* canon_comb_table() {
+  static u32* tab = nullptr;
+  if (!tab) {
+    tab = new u32[csecp::COMB_WORDS];
+    csecp::aff g = csecp::generator();
+    csecp::jac b; b.x = g.x; b.y = g.y; b.z = fe_small(1);
+    for (int i = 0; i < csecp::COMB_WINDOWS; ++i) {
+      csecp::aff base;
+      csecp::to_affine(b, base);
+      csecp::comb_fill_window(tab, i, base);
+      for (int d = 0; d < 4; ++d) b = csecp::jdouble(b);
+    }
+  }
+  return tab;
+}
+extern "C" const u32* he_canon_comb_table() { return canon_comb_table(); }
+static void canon_kw(u32* kw, const uint64_t* scalar) {
+  for (int i = 0; i < 4; ++i) { kw[(2*i) * KSTRIDE] = (u32)scalar[i]; kw[(2*i+1) * KSTRIDE] = (u32)(scalar[i] >> 32); }
+}
+// returns status: 0 finite, 1 infinity
+extern "C" int he_canon_mul_base(const uint64_t* scalar, uint64_t* xy) {
+  static thread_local u32 kw[8 * KSTRIDE];
+  canon_kw(kw, scalar);
+  csecp::jac r = csecp::mul_base_comb(canon_comb_table(), kw);
+  csecp::aff a;
+  lmask inf = csecp::to_affine(r, a);
+  st(xy, a.x); st(xy + 4, a.y);
+  return inf ? 1 : 0;
+}
+// returns status: 0 finite, 1 infinity, 2 bad point
+extern "C" int he_canon_mul(const uint64_t* scalar, const uint64_t* pxy, uint64_t* xy) {
+  static thread_local u32 kw[8 * KSTRIDE];
+  static thread_local u32 table[csecp::WIN_ENTRIES * csecp::WIN_ENTRY_WORDS];
+  canon_kw(kw, scalar);
+  csecp::aff base; base.x = ld(pxy); base.y = ld(pxy + 4);
+  lmask ok = csecp::on_curve(base);
+  csecp::jac r = csecp::mul_window(base, kw, table);
+  csecp::aff a;
+  lmask inf = csecp::to_affine(r, a);
+  if (!ok) { a.x = fe_zero(); a.y = fe_zero(); }
+  st(xy, a.x); st(xy + 4, a.y);
+  return !ok ? 2 : inf ? 1 : 0;
+}
+// Jacobian ops for exceptional-case tests: op 0 = jdouble, 1 = jadd (general), 2 = jadd_affine(p, q.xy), 3 = jadd_window
+extern "C" int he_canon_point_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* out_xy) {
+  csecp::jac a; a.x = ld(p); a.y = ld(p + 4); a.z = ld(p + 8);
+  csecp::jac b; if (q) { b.x = ld(q); b.y = ld(q + 4); b.z = ld(q + 8); }
+  csecp::jac r;
+  if (op == 0) r = csecp::jdouble(a);
+  else if (op == 1) r = csecp::jadd(a, b);
+  else if (op == 2) { csecp::aff qa; qa.x = b.x; qa.y = b.y; r = csecp::jadd_affine(a, qa, 0); }
+  else r = csecp::jadd_window(a, b, 0);
+  csecp::aff o;
+  lmask inf = csecp::to_affine(r, o);
+  st(out_xy, o.x); st(out_xy + 4, o.y);
+  return inf ? 1 : 0;
+}
