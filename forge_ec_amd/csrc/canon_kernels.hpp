@@ -7,7 +7,7 @@
 
 namespace fecgpu {
 
-enum { CANON_FINITE = 0, CANON_INFINITY = 1, CANON_BAD_POINT = 2 };
+enum { CANON_FINITE = csecp::ST_FINITE, CANON_INFINITY = csecp::ST_INFINITY, CANON_BAD_POINT = csecp::ST_BAD_POINT };
 
 // table[(i * 15 + j - 1) * COMB_STRIDE ...] = affine j * 16^i * G, i = 0..63, j = 1..15.
 // One wavefront, once per context: lane 0 walks the 16^i * G chain (252 doublings), then lane i
@@ -40,39 +40,37 @@ __global__ __launch_bounds__(64) void k_csecp_build_comb(u32* __restrict__ table
   csecp::comb_fill_window(table, lane, base);
 }
 
-// out_xy[i] = affine scalars[i] * G (x then y, 4 limbs each); status[i] = CANON_INFINITY when
-// scalars[i] = 0 (mod n), and then out_xy[i] = 0.
+// Phase 1 of key generation: Jacobian scalars[i] * G by the comb; X, Y go to out_xy[i], Z to zbuf[i].
 __global__ __launch_bounds__(TPB) void k_csecp_mul_base(const u32* __restrict__ scalars,
                                                         const u32* __restrict__ table,
-                                                        u32* __restrict__ out_xy,
+                                                        u32* __restrict__ out_xy, u32* __restrict__ zbuf,
                                                         unsigned char* __restrict__ status, size_t n) {
-  __shared__ u32 lds_io[16 * TPB];  // scalars in (8 words), affine points out (16 words), per-lane columns
+  __shared__ u32 lds_k[8 * TPB];
   __shared__ u32 lds_t[csecp::COMB_WORDS];
   const int valid = block_valid(n);
   const size_t first = (size_t)blockIdx.x * TPB;
-  stage_in<8>(lds_io, scalars + first * 8, valid);
+  stage_in<8>(lds_k, scalars + first * 8, valid);
   for (int v = threadIdx.x; v < csecp::COMB_WORDS; v += TPB) lds_t[v] = table[v];
   __syncthreads();
   const int e = threadIdx.x;
   if (e < valid) {
-    csecp::jac r = csecp::mul_base_comb(lds_t, lds_io + e);
-    csecp::aff a;
-    lmask inf = csecp::to_affine(r, a);
-    store_fe(lds_io + e, TPB, a.x);
-    store_fe(lds_io + 8 * TPB + e, TPB, a.y);
-    const bool is_inf = lane_of(inf);
-    status[first + e] = is_inf ? CANON_INFINITY : CANON_FINITE;
+    csecp::jac r = csecp::mul_base_comb(lds_t, lds_k + e);
+    const size_t i = first + e;
+    csecp::st8(out_xy + i * 16, r.x);
+    csecp::st8(out_xy + i * 16 + 8, r.y);
+    csecp::st8(zbuf + i * 8, r.z);
+    status[i] = CANON_FINITE;
   }
-  __syncthreads();
-  stage_out<16>(out_xy + first * 16, lds_io, valid);
 }
 
-// out_xy[i] = affine scalars[i] * points_xy[i].  `scratch` holds one 15-entry window table per
-// element (WIN_ENTRIES * WIN_ENTRY_WORDS words each), private to the lane that builds it.
-__global__ __launch_bounds__(TPB) void k_csecp_mul(const u32* __restrict__ scalars,
+// Phase 1 of ECDH: Jacobian scalars[i] * points_xy[i] by the windowed ladder.  `scratch` holds one
+// 15-entry window table per element (WIN_ENTRIES * WIN_ENTRY_WORDS words each), private to the lane
+// that builds it.  Rejected input points get status CANON_BAD_POINT (phase 2 zeroes them).
+__global__ __launch_bounds__(TPB, 2) void k_csecp_mul(const u32* __restrict__ scalars,
                                                    const u32* __restrict__ points_xy,
                                                    u32* __restrict__ scratch, u32* __restrict__ out_xy,
-                                                   unsigned char* __restrict__ status, size_t n) {
+                                                   u32* __restrict__ zbuf, unsigned char* __restrict__ status,
+                                                   size_t n) {
   __shared__ u32 lds_k[8 * TPB];
   __shared__ u32 lds_p[16 * TPB];
   const int valid = block_valid(n);
@@ -85,21 +83,24 @@ __global__ __launch_bounds__(TPB) void k_csecp_mul(const u32* __restrict__ scala
     csecp::aff base;
     base.x = load_fe(lds_p + e, TPB);
     base.y = load_fe(lds_p + 8 * TPB + e, TPB);
-    lmask ok = csecp::on_curve(base);
-    // a bad point still runs the ladder (on garbage; the arithmetic is total) and is zeroed below
-    u32* table = scratch + (first + e) * (size_t)(csecp::WIN_ENTRIES * csecp::WIN_ENTRY_WORDS);
+    const lmask ok = csecp::on_curve(base);
+    // a bad point still runs the ladder (on garbage; the arithmetic is total) and is zeroed in phase 2
+    const size_t i = first + e;
+    u32* table = scratch + i * (size_t)(csecp::WIN_ENTRIES * csecp::WIN_ENTRY_WORDS);
     csecp::jac r = csecp::mul_window(base, lds_k + e, table);
-    csecp::aff a;
-    lmask inf = csecp::to_affine(r, a);
-    a.x = fe_select(fe_zero(), a.x, ok);
-    a.y = fe_select(fe_zero(), a.y, ok);
-    store_fe(lds_p + e, TPB, a.x);
-    store_fe(lds_p + 8 * TPB + e, TPB, a.y);
-    const bool is_ok = lane_of(ok), is_inf = lane_of(inf);
-    status[first + e] = !is_ok ? CANON_BAD_POINT : (is_inf ? CANON_INFINITY : CANON_FINITE);
+    csecp::st8(out_xy + i * 16, r.x);
+    csecp::st8(out_xy + i * 16 + 8, r.y);
+    csecp::st8(zbuf + i * 8, r.z);
+    status[i] = lane_of(ok) ? CANON_FINITE : CANON_BAD_POINT;
   }
-  __syncthreads();
-  stage_out<16>(out_xy + first * 16, lds_p, valid);
+}
+
+// Phase 2: Jacobian -> affine in place, one inversion per NORM_GROUP elements per lane.
+__global__ __launch_bounds__(TPB, 2) void k_csecp_normalize(u32* __restrict__ xy, const u32* __restrict__ zbuf,
+                                                         unsigned char* __restrict__ status, size_t n,
+                                                         size_t stride) {
+  const size_t g = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (g < stride) csecp::normalize_group(xy, zbuf, status, g, stride, n);
 }
 
 // canonical field ops for tests and callers: op = fec_field_opcode, plus FEC_F_NEG + 1 = inverse

@@ -22,8 +22,8 @@ FEC_DEV fe sub(const fe& a, const fe& b) { return secp::sub(a, b); }
 FEC_DEV fe neg(const fe& a) { return secp::neg(a); }
 FEC_DEV fe dbl(const fe& a) { return secp::add(a, a); }
 
-// t (512 bits) mod p.  2^256 = c (mod p), c = 2^32 + 977:  t = lo + hi * c.
-FEC_DEV fe reduce512(const u32 t[16]) {
+// t (512 bits) mod p for any t.  2^256 = c (mod p), c = 2^32 + 977:  t = lo + hi * c.
+FEC_DEV fe reduce512_general(const u32 t[16]) {
   // u = hi * 977  (9 words)
   u32 u[9];
   {
@@ -66,6 +66,42 @@ FEC_DEV fe reduce512(const u32 t[16]) {
     r = fe_select(r, r2, c3);
   }
   return secp::csub_p_unlikely(r);
+}
+
+// The same reduction for the common case, 27 VALU instructions.  Column k of  lo + hi * c  is
+//   p_k = l_k + h_k * 977 + h_k * 2^32  =  mad(h_k, 977, {l_k, h_k})          (one v_mad_u64_u32)
+// which fits 64 bits whenever h_k <= 2^32 - 978; the 9-word sum of the columns is one carry
+// chain, and its top word r8 <= h_7 + 978 folds the same way.  Lanes with any h_k >= 2^32 - 4096
+// (about one multiplication in 2^17) take reduce512_general instead.
+FEC_DEV fe reduce512(const u32 t[16]) {
+  u32 hmax = t[8];
+  FEC_UNROLL for (int k = 9; k < 16; ++k) hmax = hmax > t[k] ? hmax : t[k];
+  if (__builtin_expect(lanes_where(hmax >= 0xFFFFF000u) != 0, 0)) return reduce512_general(t);
+  fe a, b;
+  u32 top;
+  {
+    u64 p[8];
+    FEC_UNROLL for (int k = 0; k < 8; ++k) p[k] = (u64)t[8 + k] * 977u + (((u64)t[8 + k] << 32) | t[k]);
+    FEC_UNROLL for (int k = 0; k < 8; ++k) a.w[k] = (u32)p[k];
+    b.w[0] = 0;
+    FEC_UNROLL for (int k = 1; k < 8; ++k) b.w[k] = (u32)(p[k - 1] >> 32);
+    top = (u32)(p[7] >> 32);
+  }
+  fe r;
+  lmask c = add256(r, a, b);
+  top += word_select(0u, 1u, c);  // <= h_7 + 978: no wrap
+  u64 q = (u64)top * 977u + (((u64)top << 32) | r.w[0]);
+  r.w[0] = (u32)q;
+  fe r2;
+  lmask c2 = add_lohi256(r2, r, 0u, (u32)(q >> 32));
+  if (__builtin_expect(c2 != 0, 0)) {  // wrapped past 2^256 (probability ~2^-190): add c once more
+    fe r3;
+    lmask t2;
+    FEC_ADDK256(r3, r2, t2, FEC_SECP_C);
+    (void)t2;
+    r2 = fe_select(r2, r3, c2);
+  }
+  return secp::csub_p_unlikely(r2);
 }
 
 FEC_DEV fe mul(const fe& a, const fe& b) {
@@ -313,6 +349,88 @@ FEC_DEV jac mul_window(const aff& base, const u32* kw, u32* table /* this lane's
     acc = jadd_window(acc, q, lanes_where(digit == 0));
   }
   return acc;
+}
+
+// ---- batched normalisation (Montgomery's trick) ------------------------------------------------
+// The scalar-multiplication kernels leave Jacobian results in memory -- X, Y in the caller's
+// out_xy slots (16 words per element), Z in a side buffer (8 words per element); one lane then
+// normalises NORM_GROUP of them with a single inversion:  c_j = z_0 ... z_j,  u = 1 / c_last,
+// walking back  1/z_j = u * c_{j-1},  u *= z_j.   (270 + 3 (G-1)) / G + 5 multiplications per
+// element instead of 275.  Elements with Z = 0 (infinity) or a rejected input take z = 1 in the
+// chain and are written as zeros.
+constexpr int NORM_GROUP = 8;
+#ifdef FEC_HOST_EMUL
+FEC_DEV fe ld8(const u32* p) {
+  fe a;
+  for (int i = 0; i < 8; ++i) a.w[i] = p[i];
+  return a;
+}
+FEC_DEV void st8(u32* p, const fe& a) {
+  for (int i = 0; i < 8; ++i) p[i] = a.w[i];
+}
+#else
+FEC_DEV fe ld8(const u32* p) {
+  const uint4* s = reinterpret_cast<const uint4*>(p);
+  uint4 a = s[0], b = s[1];
+  fe r;
+  r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+  r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+  return r;
+}
+FEC_DEV void st8(u32* p, const fe& a) {
+  uint4* d = reinterpret_cast<uint4*>(p);
+  d[0] = make_uint4(a.w[0], a.w[1], a.w[2], a.w[3]);
+  d[1] = make_uint4(a.w[4], a.w[5], a.w[6], a.w[7]);
+}
+#endif
+
+// status values shared with the kernels / the ABI (fec_canon_status)
+constexpr unsigned char ST_FINITE = 0, ST_INFINITY = 1, ST_BAD_POINT = 2;
+
+// This lane's group: elements first, first + stride, ... (NORM_GROUP of them, those < n).
+// status[i] on entry: ST_BAD_POINT for rejected inputs, anything else is recomputed here.
+FEC_DEV void normalize_group(u32* xy, const u32* zbuf, unsigned char* status, size_t first, size_t stride,
+                             size_t n) {
+  fe c[NORM_GROUP];
+  fe run = fe_small(1);
+  FEC_UNROLL for (int j = 0; j < NORM_GROUP; ++j) {
+    const size_t i = first + (size_t)j * stride;
+    fe z = fe_small(1);
+    if (i < n && status[i] != ST_BAD_POINT) z = ld8(zbuf + i * 8);
+    z = fe_select(z, fe_small(1), fe_is_zero(z));
+    run = j == 0 ? z : mul(run, z);
+    c[j] = run;
+  }
+  fe u = inv(run);
+#pragma unroll 1
+  for (int j = NORM_GROUP - 1; j >= 0; --j) {
+    const size_t i = first + (size_t)j * stride;
+    const bool live = i < n;
+    fe z = fe_small(1);
+    bool bad = false;
+    if (live) {
+      bad = status[i] == ST_BAD_POINT;
+      if (!bad) z = ld8(zbuf + i * 8);
+    }
+    const lmask zero = fe_is_zero(z);
+    z = fe_select(z, fe_small(1), zero);
+    fe prev = fe_small(1);
+    FEC_UNROLL for (int t = 0; t < NORM_GROUP - 1; ++t) prev = fe_select(prev, c[t], lanes_where(t == j - 1));
+    fe zi = mul(u, prev);  // 1 / z_j
+    u = mul(u, z);
+    if (live) {
+      fe x = ld8(xy + i * 16), y = ld8(xy + i * 16 + 8);
+      fe zi2 = sqr(zi);
+      x = mul(x, zi2);
+      y = mul(mul(y, zi2), zi);
+      const lmask wipe = zero | lanes_where(bad);
+      x = fe_select(x, fe_zero(), wipe);
+      y = fe_select(y, fe_zero(), wipe);
+      st8(xy + i * 16, x);
+      st8(xy + i * 16 + 8, y);
+      status[i] = bad ? ST_BAD_POINT : (lane_of(zero) ? ST_INFINITY : ST_FINITE);
+    }
+  }
 }
 
 // affine generator (SEC2)

@@ -591,6 +591,8 @@ struct fec_ctx {
   bool csecp_comb_ready = false;
   void* d_win_scratch = nullptr;
   size_t win_scratch_cap = 0;
+  void* d_zbuf = nullptr;  // Jacobian Z of the batch between the ladder and the batched normalisation
+  size_t zbuf_cap = 0;
   hipDeviceProp_t prop;
 };
 
@@ -858,38 +860,57 @@ int ensure_csecp_comb(fec_ctx* ctx, hipStream_t s) {
   return FEC_OK;
 }
 
+// grow-only device buffer owned by the ctx (kernels of earlier calls may still use the old one)
+int ensure_owned(void** buf, size_t* cap, size_t need) {
+  if (*cap >= need) return FEC_OK;
+  if (hipDeviceSynchronize() != hipSuccess) return FEC_E_LAUNCH;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr;
+  *cap = 0;
+  if (hipMalloc(buf, need) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_OOM;
+  }
+  *cap = need;
+  return FEC_OK;
+}
+
+int launch_csecp_normalize(fec_ctx* ctx, u64* dxy, unsigned char* dst, size_t n, hipStream_t s) {
+  const size_t lanes = (n + csecp::NORM_GROUP - 1) / csecp::NORM_GROUP;
+  const size_t stride = (lanes + 63) / 64 * 64;
+  hipLaunchKernelGGL(k_csecp_normalize, dim3(grid_for(stride)), dim3(TPB), 0, s, reinterpret_cast<u32*>(dxy),
+                     reinterpret_cast<const u32*>(ctx->d_zbuf), dst, n, stride);
+  return hipGetLastError() == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
+}
+
 int launch_csecp_mul_base(fec_ctx* ctx, const u64* ds, u64* dxy, unsigned char* dst, size_t n, void* stream) {
   if (n == 0) return FEC_OK;
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int rc = ensure_csecp_comb(ctx, s);
+  if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
   if (rc != FEC_OK) return rc;
-  Launch L(ctx, stream, "k_csecp_mul_base");
+  Launch L(ctx, stream, "k_csecp_mul_base+k_csecp_normalize");
   hipLaunchKernelGGL(k_csecp_mul_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(ds),
-                     ctx->d_csecp_comb, reinterpret_cast<u32*>(dxy), dst, n);
-  return L.done();
+                     ctx->d_csecp_comb, reinterpret_cast<u32*>(dxy), reinterpret_cast<u32*>(ctx->d_zbuf), dst, n);
+  rc = launch_csecp_normalize(ctx, dxy, dst, n, L.s);
+  int rc2 = L.done();
+  return rc != FEC_OK ? rc : rc2;
 }
 
 int launch_csecp_mul(fec_ctx* ctx, const u64* ds, const u64* dp, u64* dxy, unsigned char* dst, size_t n,
                      void* stream) {
   if (n == 0) return FEC_OK;
-  const size_t need = n * (size_t)(csecp::WIN_ENTRIES * csecp::WIN_ENTRY_WORDS) * sizeof(u32);
-  if (ctx->win_scratch_cap < need) {
-    // a kernel of an earlier call may still be using the old buffer
-    if (hipDeviceSynchronize() != hipSuccess) return FEC_E_LAUNCH;
-    if (ctx->d_win_scratch) (void)hipFree(ctx->d_win_scratch);
-    ctx->d_win_scratch = nullptr;
-    ctx->win_scratch_cap = 0;
-    if (hipMalloc(&ctx->d_win_scratch, need) != hipSuccess) {
-      (void)hipGetLastError();
-      return FEC_E_OOM;
-    }
-    ctx->win_scratch_cap = need;
-  }
-  Launch L(ctx, stream, "k_csecp_mul");
+  int rc = ensure_owned(&ctx->d_win_scratch, &ctx->win_scratch_cap,
+                        n * (size_t)(csecp::WIN_ENTRIES * csecp::WIN_ENTRY_WORDS) * sizeof(u32));
+  if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
+  if (rc != FEC_OK) return rc;
+  Launch L(ctx, stream, "k_csecp_mul+k_csecp_normalize");
   hipLaunchKernelGGL(k_csecp_mul, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(ds),
                      reinterpret_cast<const u32*>(dp), reinterpret_cast<u32*>(ctx->d_win_scratch),
-                     reinterpret_cast<u32*>(dxy), dst, n);
-  return L.done();
+                     reinterpret_cast<u32*>(dxy), reinterpret_cast<u32*>(ctx->d_zbuf), dst, n);
+  rc = launch_csecp_normalize(ctx, dxy, dst, n, L.s);
+  int rc2 = L.done();
+  return rc != FEC_OK ? rc : rc2;
 }
 
 // one-shot host-pointer call with up to three inputs and two outputs (not pipelined)
@@ -1008,6 +1029,7 @@ void fec_ctx_destroy(fec_ctx* ctx) {
   if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
   if (ctx->d_csecp_comb) (void)hipFree(ctx->d_csecp_comb);
   if (ctx->d_win_scratch) (void)hipFree(ctx->d_win_scratch);
+  if (ctx->d_zbuf) (void)hipFree(ctx->d_zbuf);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

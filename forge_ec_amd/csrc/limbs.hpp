@@ -384,6 +384,7 @@ FEC_DEV void mac96_first(u64& acc, u32& ovf, u32 x, u32 y, u64 cin) {
       : "v"(x), "v"(y), "v"(cin)
       : "vcc");
 }
+#ifdef FEC_MAC_PER_PRODUCT
 FEC_DEV void mul_wide(u32 t[16], const fe& a, const fe& b) {
   u64 acc = (u64)a.w[0] * b.w[0];  // column 0: one product, cannot overflow
   u32 ovf = 0;
@@ -410,6 +411,160 @@ FEC_DEV void mul_wide(u32 t[16], const fe& a, const fe& b) {
   }
   t[15] = (u32)(acc >> 32);
 }
+#else
+// A whole column in ONE asm statement: {acc, ovf} = cin + sum of N products.  Keeping the column's
+// mad/addc pairs inside one statement keeps the compiler's hazard padding (an s_nop after every
+// asm statement that clobbers VCC) to one per column instead of one per product.  acc/ovf are
+// early-clobber: the first instruction writes them while later ones still read their operands.
+template <int N>
+FEC_DEV void mcol(u64& acc, u32& ovf, u64 cin, const u32* x, const u32* y);
+template <>
+FEC_DEV void mcol<1>(u64& acc, u32& ovf, u64 cin, const u32* x, const u32* y) {
+  asm("v_mad_u64_u32 %0, vcc, %3, %4, %2\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc"
+      : "=&v"(acc), "=&v"(ovf)
+      : "v"(cin), "v"(x[0]), "v"(y[0])
+      : "vcc");
+}
+template <>
+FEC_DEV void mcol<2>(u64& acc, u32& ovf, u64 cin, const u32* x, const u32* y) {
+  asm("v_mad_u64_u32 %0, vcc, %3, %4, %2\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "=&v"(acc), "=&v"(ovf)
+      : "v"(cin), "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1])
+      : "vcc");
+}
+template <>
+FEC_DEV void mcol<3>(u64& acc, u32& ovf, u64 cin, const u32* x, const u32* y) {
+  asm("v_mad_u64_u32 %0, vcc, %3, %4, %2\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "=&v"(acc), "=&v"(ovf)
+      : "v"(cin), "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2])
+      : "vcc");
+}
+template <>
+FEC_DEV void mcol<4>(u64& acc, u32& ovf, u64 cin, const u32* x, const u32* y) {
+  asm("v_mad_u64_u32 %0, vcc, %3, %4, %2\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "=&v"(acc), "=&v"(ovf)
+      : "v"(cin), "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3])
+      : "vcc");
+}
+template <>
+FEC_DEV void mcol<5>(u64& acc, u32& ovf, u64 cin, const u32* x, const u32* y) {
+  asm("v_mad_u64_u32 %0, vcc, %3, %4, %2\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "=&v"(acc), "=&v"(ovf)
+      : "v"(cin), "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4])
+      : "vcc");
+}
+template <>
+FEC_DEV void mcol<6>(u64& acc, u32& ovf, u64 cin, const u32* x, const u32* y) {
+  asm("v_mad_u64_u32 %0, vcc, %3, %4, %2\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "=&v"(acc), "=&v"(ovf)
+      : "v"(cin), "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5])
+      : "vcc");
+}
+template <>
+FEC_DEV void mcol<7>(u64& acc, u32& ovf, u64 cin, const u32* x, const u32* y) {
+  asm("v_mad_u64_u32 %0, vcc, %3, %4, %2\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "=&v"(acc), "=&v"(ovf)
+      : "v"(cin), "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6])
+      : "vcc");
+}
+template <>
+FEC_DEV void mcol<8>(u64& acc, u32& ovf, u64 cin, const u32* x, const u32* y) {
+  asm("v_mad_u64_u32 %0, vcc, %3, %4, %2\n\t"
+      "v_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "=&v"(acc), "=&v"(ovf)
+      : "v"(cin), "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7])
+      : "vcc");
+}
+FEC_DEV void mul_wide(u32 t[16], const fe& a, const fe& b) {
+  u64 acc = (u64)a.w[0] * b.w[0];  // column 0: one product, cannot overflow
+  u32 ovf = 0;
+  t[0] = (u32)acc;
+  FEC_UNROLL for (int k = 1; k < 15; ++k) {
+    const u64 cin = (acc >> 32) | ((u64)ovf << 32);
+    const int lo = k < 8 ? 0 : k - 7, n = (k < 8 ? k : 7) - lo + 1;
+    u32 x[8], y[8];
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      x[i] = i < n ? a.w[lo + i] : 0;
+      y[i] = i < n ? b.w[k - lo - i] : 0;
+    }
+    switch (n) {
+      case 1: mcol<1>(acc, ovf, cin, x, y); break;
+      case 2: mcol<2>(acc, ovf, cin, x, y); break;
+      case 3: mcol<3>(acc, ovf, cin, x, y); break;
+      case 4: mcol<4>(acc, ovf, cin, x, y); break;
+      case 5: mcol<5>(acc, ovf, cin, x, y); break;
+      case 6: mcol<6>(acc, ovf, cin, x, y); break;
+      case 7: mcol<7>(acc, ovf, cin, x, y); break;
+      default: mcol<8>(acc, ovf, cin, x, y); break;
+    }
+    t[k] = (u32)acc;
+  }
+  t[15] = (u32)(acc >> 32);
+}
+#endif
 #endif
 
 // t[0..7] = low 256 bits of a * b (columns 0..7 of the same product scanning)

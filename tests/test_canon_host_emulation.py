@@ -187,3 +187,37 @@ def test_bad_points_are_rejected(emu):
         pin = np.array(M.limbs(bad[0]) + M.limbs(bad[1]), dtype=np.uint64)
         st = emu.he_canon_mul(_p(_arr(5)), _p(pin), _p(out))
         assert st == 2 and not out.any(), bad
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 64, 515, 1100])
+def test_batched_normalisation(emu, n):
+    """Montgomery-trick Jacobian -> affine over ragged group sizes, with infinities and rejected inputs."""
+    rng = random.Random(n)
+    base = [M.mul(rng.randrange(1, M.N), M.G) for _ in range(6)]
+    xy = np.zeros((n, 16), dtype=np.uint32)
+    zb = np.zeros((n, 8), dtype=np.uint32)
+    st = np.zeros(n, dtype=np.uint8)
+    want = []
+    for i in range(n):
+        kind = rng.random()
+        pt = base[i % 6]
+        z = rng.randrange(1, M.P)
+        if kind < 0.1:      # infinity: Z = 0, X and Y arbitrary
+            X, Y, z, w = rng.randrange(M.P), rng.randrange(M.P), 0, (M.INF, 1)
+        elif kind < 0.2:    # rejected input: status preset, contents arbitrary
+            X, Y, z, w = rng.randrange(M.P), rng.randrange(M.P), rng.randrange(M.P), (M.INF, 2)
+            st[i] = 2
+        else:
+            X, Y, w = pt[0] * z * z % M.P, pt[1] * z * z * z % M.P, (pt, 0)
+        for wd in range(8):
+            xy[i, wd] = (X >> (32 * wd)) & 0xFFFFFFFF
+            xy[i, 8 + wd] = (Y >> (32 * wd)) & 0xFFFFFFFF
+            zb[i, wd] = (z >> (32 * wd)) & 0xFFFFFFFF
+        want.append(w)
+    emu.he_canon_normalize(_p(xy), _p(zb), _p(st), ctypes.c_size_t(n))
+    for i in range(n):
+        pt, status = want[i]
+        assert st[i] == status, i
+        x = sum(int(xy[i, w]) << (32 * w) for w in range(8))
+        y = sum(int(xy[i, 8 + w]) << (32 * w) for w in range(8))
+        assert (x, y) == ((0, 0) if pt is M.INF else pt), i

@@ -140,3 +140,10 @@ extern "C" int he_canon_point_op(int op, const uint64_t* p, const uint64_t* q, u
   st(out_xy, o.x); st(out_xy + 4, o.y);
   return inf ? 1 : 0;
 }
+// the batched normalisation exactly as k_csecp_normalize drives it
+extern "C" int he_canon_normalize(uint32_t* xy, const uint32_t* zbuf, unsigned char* status, size_t n) {
+  const size_t lanes = (n + csecp::NORM_GROUP - 1) / csecp::NORM_GROUP;
+  const size_t stride = (lanes + 63) / 64 * 64;
+  for (size_t g = 0; g < stride; ++g) csecp::normalize_group(xy, zbuf, status, g, stride, n);
+  return 0;
+}
