@@ -61,6 +61,9 @@ struct Secp {
   FEC_DEV static fe f_mul(const fe& a, const fe& b) { return secp::mul(a, b); }
   FEC_DEV static fe f_sqr(const fe& a) { return secp::sqr(a); }
   FEC_DEV static fe f_neg(const fe& a) { return secp::neg(a); }
+  // FieldElement::to_bytes (138-178): mont_reduce, i.e. Mul by raw 1; big-endian bytes
+  FEC_DEV static fe bytes_value(const fe& a) { return secp::mul(a, fe_small(1)); }
+  static constexpr bool BYTES_BIG_ENDIAN = true;
 };
 
 struct P256 {
@@ -98,6 +101,9 @@ struct P256 {
   FEC_DEV static fe f_mul(const fe& a, const fe& b) { return p256::mul(a, b); }
   FEC_DEV static fe f_sqr(const fe& a) { return p256::sqr(a); }
   FEC_DEV static fe f_neg(const fe& a) { return p256::neg(a); }
+  // FieldElement::to_bytes (p256.rs:288-300): the raw limbs; big-endian bytes
+  FEC_DEV static fe bytes_value(const fe& a) { return a; }
+  static constexpr bool BYTES_BIG_ENDIAN = true;
 };
 
 struct Ed {
@@ -138,6 +144,9 @@ struct Ed {
   FEC_DEV static fe f_mul(const fe& a, const fe& b) { return ed::mul(a, b); }
   FEC_DEV static fe f_sqr(const fe& a) { return ed::mul(a, a); }
   FEC_DEV static fe f_neg(const fe& a) { return ed::neg(a); }
+  // FieldElement::to_bytes (ed25519.rs:295-310): reduce(); LITTLE-endian bytes
+  FEC_DEV static fe bytes_value(const fe& a) { return ed::reduce(a); }
+  static constexpr bool BYTES_BIG_ENDIAN = false;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -538,6 +547,148 @@ __global__ __launch_bounds__(TPB) void k_ecdsa_verify_secp(const u32* __restrict
   }
 }
 
+// schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290), the per-signature
+// terms of the two folds at 262-281, challenges e_i and weights a_i supplied by the caller:
+//   A_i = multiply(G, s_i * a_i)                                           (266-268)
+//   B_i = multiply(from_affine(R_i) + multiply(from_affine(P_i), e_i), a_i) (273-280)
+// One lane per signature; the three ladders share one instance of the ladder code.
+__global__ __launch_bounds__(TPB) void k_schnorr_terms_secp(const u32* __restrict__ pk_xy,
+                                                            const u32* __restrict__ r_xy,
+                                                            const u32* __restrict__ ss, const u32* __restrict__ as,
+                                                            const u32* __restrict__ es, const u32* __restrict__ gen,
+                                                            u32* __restrict__ out_a, u32* __restrict__ out_b,
+                                                            size_t n) {
+  __shared__ u32 lds_k[3][8 * TPB];   // s (then s*a), e, a
+  __shared__ u32 lds_p[16 * TPB];     // public key x, y; then the A / B results (12 words)
+  __shared__ u32 lds_r[16 * TPB];     // signature point x, y
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_k[0], ss + first * 8, valid);
+  stage_in<8>(lds_k[1], es + first * 8, valid);
+  stage_in<8>(lds_k[2], as + first * 8, valid);
+  stage_in<16>(lds_p, pk_xy + first * 16, valid);
+  stage_in<16>(lds_r, r_xy + first * 16, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  secp::pt ta = secp::identity(), tb = secp::identity();
+  if (e < valid) {
+    fe sa = secp::sc_mul(load_fe(lds_k[0] + e, TPB), load_fe(lds_k[2] + e, TPB));   // impl Mul for Scalar
+    store_fe(lds_k[0] + e, TPB, sa);
+    secp::pt t = secp::identity();
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+      secp::pt base;
+      if (pass == 0) {
+        base = Secp::load(gen, 1);
+      } else if (pass == 1) {  // from_affine (1365-1373): the caller has rejected identities
+        base.x = load_fe(lds_p + e, TPB);
+        base.y = load_fe(lds_p + 8 * TPB + e, TPB);
+        base.z = fe_small(1);
+      } else {
+        base = t;
+      }
+      secp::pt m = secp::multiply(base, lds_k[pass] + e);
+      if (pass == 0) {
+        ta = m;
+      } else if (pass == 1) {
+        secp::pt r;
+        r.x = load_fe(lds_r + e, TPB);
+        r.y = load_fe(lds_r + 8 * TPB + e, TPB);
+        r.z = fe_small(1);
+        t = secp::padd(r, m);
+      } else {
+        tb = m;
+      }
+    }
+  }
+  __syncthreads();
+  if (e < valid) Secp::store(lds_p + e, TPB, ta);
+  __syncthreads();
+  stage_out<Secp::PW>(out_a + first * Secp::PW, lds_p, valid);
+  __syncthreads();
+  if (e < valid) Secp::store(lds_p + e, TPB, tb);
+  __syncthreads();
+  stage_out<Secp::PW>(out_b + first * Secp::PW, lds_p, valid);
+}
+
+// The two strictly sequential folds (s_g += ..., r_e_p += ...: 268, 281) and the comparison at 286:
+// block 0 folds the A terms, block 1 the B terms, each on one lane; the last block to finish
+// converts both sums with to_affine and applies AffinePoint::ct_eq (1292-1296).
+// out: [0..7] = x, y of to_affine(s_g), [8..15] of to_affine(r_e_p) (64-bit limbs as u32 pairs);
+// flags: [0] = result, [1], [2] = the two infinity flags.
+__global__ __launch_bounds__(64) void k_schnorr_fold_compare_secp(const u32* __restrict__ terms_a,
+                                                                  const u32* __restrict__ terms_b,
+                                                                  u32* __restrict__ sums, u32* __restrict__ out_xy,
+                                                                  unsigned char* __restrict__ flags,
+                                                                  unsigned int* __restrict__ done, size_t n) {
+  if (threadIdx.x != 0) return;
+  const u32* terms = blockIdx.x == 0 ? terms_a : terms_b;
+  secp::pt acc = secp::identity();
+#pragma unroll 1
+  for (size_t i = 0; i < n; ++i) {
+    secp::pt p = Secp::load(terms + i * Secp::PW, 1);
+    acc = secp::padd(acc, p);
+  }
+  Secp::store(sums + blockIdx.x * Secp::PW, 1, acc);
+  __threadfence();
+  if (atomicAdd(done, 1u) != 1u) return;  // the other fold is still running: it will finish the job
+  __threadfence();
+  fe x[2], y[2];
+  bool inf[2];
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    secp::pt p = Secp::load(sums + k * Secp::PW, 1);
+    fe xx, yy;
+    inf[k] = lane_of(secp::to_affine(p, xx, yy));
+    x[k] = xx;
+    y[k] = yy;
+    store_fe(out_xy + k * 16, 1, xx);
+    store_fe(out_xy + k * 16 + 8, 1, yy);
+  }
+  const bool same = lane_of(fe_eq(x[0], x[1]) & fe_eq(y[0], y[1]));
+  flags[0] = (same || (inf[0] && inf[1])) ? 1 : 0;
+  flags[1] = inf[0] ? 1 : 0;
+  flags[2] = inf[1] ? 1 : 0;
+}
+
+// PointAffine::to_bytes -> [u8; 33] (secp256k1.rs:875-896, p256.rs:1558-1578, ed25519.rs:1505-1525;
+// the same bytes as forge-ec-encoding CompressedPoint::from_affine, point.rs:38-67): 0x00 + zeros
+// for the identity, else 0x02 | (y.to_bytes()[31] & 1), then x.to_bytes().  For Ed25519 to_bytes is
+// little-endian, so byte 31 is the top byte and the "parity" is bit 248 of y -- reproduced as is.
+// The workgroup's 256 x 33 bytes are assembled in LDS and written as coalesced dwords.
+template <class C>
+__global__ __launch_bounds__(TPB) void k_compress(const u32* __restrict__ xy, const unsigned char* __restrict__ inf,
+                                                  unsigned char* __restrict__ out, size_t n) {
+  __shared__ u32 lds_p[16 * TPB];
+  __shared__ u32 lds_o[TPB * 33 / 4];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<16>(lds_p, xy + first * 16, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    unsigned char* o = reinterpret_cast<unsigned char*>(lds_o) + e * 33;
+    const bool is_inf = inf != nullptr && inf[first + e] != 0;
+    fe x = C::bytes_value(load_fe(lds_p + e, TPB));
+    fe y = C::bytes_value(load_fe(lds_p + 8 * TPB + e, TPB));
+    // y.to_bytes()[31]: the least significant byte when big-endian, the most significant otherwise
+    const u32 odd = C::BYTES_BIG_ENDIAN ? (y.w[0] & 1u) : ((y.w[7] >> 24) & 1u);
+    o[0] = is_inf ? 0 : (unsigned char)(2u + odd);
+    FEC_UNROLL for (int k = 0; k < 32; ++k) {
+      const u32 byte = (x.w[k >> 2] >> (8 * (k & 3))) & 0xFFu;  // byte k of the value, little-endian
+      o[1 + (C::BYTES_BIG_ENDIAN ? 31 - k : k)] = is_inf ? 0 : (unsigned char)byte;
+    }
+  }
+  __syncthreads();
+  // first * 33 is a multiple of 4 (TPB * 33 = 8448)
+  const int bytes = valid * 33, words = bytes >> 2;
+  u32* g = reinterpret_cast<u32*>(out + first * 33);
+  for (int v = threadIdx.x; v < words; v += TPB) g[v] = lds_o[v];
+  if (threadIdx.x < (bytes & 3))
+    out[first * 33 + (size_t)(words * 4 + threadIdx.x)] =
+        reinterpret_cast<const unsigned char*>(lds_o)[words * 4 + threadIdx.x];
+}
+
 // Peak 32x32+64 multiply-add rate: 8 independent v_mad_u64_u32 chains per lane, no memory.
 constexpr int PEAK_ITERS = 4096;
 __global__ __launch_bounds__(TPB) void k_peak_mad32(u32* out, u32 seed) {
@@ -737,6 +888,20 @@ int launch_to_affine(fec_ctx* ctx, int curve, const u64* dp, u64* dxy, unsigned 
     case FEC_SECP256K1: hipLaunchKernelGGL((k_to_affine<Secp>), g, b, 0, L.s, p, o, dinf, n); break;
     case FEC_P256: hipLaunchKernelGGL((k_to_affine<P256>), g, b, 0, L.s, p, o, dinf, n); break;
     default: hipLaunchKernelGGL((k_to_affine<Ed>), g, b, 0, L.s, p, o, dinf, n); break;
+  }
+  return L.done();
+}
+
+int launch_compress(fec_ctx* ctx, int curve, const u64* dxy, const unsigned char* dinf, unsigned char* dout, size_t n,
+                    void* stream) {
+  if (n == 0) return FEC_OK;
+  const u32* p = reinterpret_cast<const u32*>(dxy);
+  dim3 g(grid_for(n)), b(TPB);
+  Launch L(ctx, stream, "k_compress");
+  switch (curve) {
+    case FEC_SECP256K1: hipLaunchKernelGGL((k_compress<Secp>), g, b, 0, L.s, p, dinf, dout, n); break;
+    case FEC_P256: hipLaunchKernelGGL((k_compress<P256>), g, b, 0, L.s, p, dinf, dout, n); break;
+    default: hipLaunchKernelGGL((k_compress<Ed>), g, b, 0, L.s, p, dinf, dout, n); break;
   }
   return L.done();
 }
@@ -1185,6 +1350,86 @@ int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests, const uint6
     return FEC_E_LAUNCH;
   }
   return FEC_OK;
+}
+
+// schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290)
+int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, const uint8_t* pk_inf,
+                                       const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s,
+                                       const uint64_t* a, const uint64_t* e, size_t n, uint8_t* result,
+                                       uint64_t* sides_xy, uint8_t* sides_inf) {
+  if (!ctx || !result || (n && (!pk_xy || !r_xy || !s || !a || !e))) return FEC_E_ARG;
+  *result = 0;
+  if (sides_xy) std::memset(sides_xy, 0, 16 * sizeof(uint64_t));
+  if (sides_inf) sides_inf[0] = sides_inf[1] = 0;
+  if (n == 0) return FEC_OK;                                   // 197-199
+  for (size_t i = 0; i < n; ++i)                               // 204-225 (only the identity tests can reject)
+    if ((pk_inf && pk_inf[i]) || (r_inf && r_inf[i])) return FEC_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  const size_t pb = 96;
+  // slots: 0 pk, 1 r, 2 s, 3 a, 4 e, 5 A terms, 6 B terms, 7 sums + affine sides + flags + counter
+  const size_t bytes[5] = {n * 64, n * 64, n * 32, n * 32, n * 32};
+  const void* src[5] = {pk_xy, r_xy, s, a, e};
+  int rc = FEC_OK;
+  for (int i = 0; i < 5 && rc == FEC_OK; ++i) rc = ensure(ctx, i, bytes[i]);
+  if (rc == FEC_OK) rc = ensure(ctx, 5, n * pb);
+  if (rc == FEC_OK) rc = ensure(ctx, 6, n * pb);
+  if (rc == FEC_OK) rc = ensure(ctx, 7, 2 * pb + 128 + 16);
+  if (rc != FEC_OK) return rc;
+  for (int i = 0; i < 5; ++i)
+    if (hipMemcpyAsync(ctx->d_buf[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  char* tail = (char*)ctx->d_buf[7];
+  u32* d_sums = (u32*)tail;
+  u32* d_sides = (u32*)(tail + 2 * pb);
+  unsigned char* d_flags = (unsigned char*)(tail + 2 * pb + 128);
+  unsigned int* d_done = (unsigned int*)(tail + 2 * pb + 128 + 8);
+  if (hipMemsetAsync(tail + 2 * pb + 128, 0, 16, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  {
+    Launch L(ctx, nullptr, "k_schnorr_terms_secp");
+    hipLaunchKernelGGL(k_schnorr_terms_secp, dim3(grid_for(n)), dim3(TPB), 0, L.s, (const u32*)ctx->d_buf[0],
+                       (const u32*)ctx->d_buf[1], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3],
+                       (const u32*)ctx->d_buf[4], reinterpret_cast<const u32*>(ctx->d_gen[FEC_SECP256K1]),
+                       (u32*)ctx->d_buf[5], (u32*)ctx->d_buf[6], n);
+    rc = L.done();
+    if (rc != FEC_OK) return rc;
+  }
+  hipLaunchKernelGGL(k_schnorr_fold_compare_secp, dim3(2), dim3(64), 0, ctx->stream, (const u32*)ctx->d_buf[5],
+                     (const u32*)ctx->d_buf[6], d_sums, d_sides, d_flags, d_done, n);
+  if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
+  unsigned char flags[8] = {0};
+  uint64_t sides[16];
+  if (hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(sides, d_sides, 128, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  *result = flags[0];
+  if (sides_xy) std::memcpy(sides_xy, sides, 128);
+  if (sides_inf) { sides_inf[0] = flags[1]; sides_inf[1] = flags[2]; }
+  return FEC_OK;
+}
+
+int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf,
+                           uint8_t* d_out, size_t n, void* stream) {
+  if (!ctx || !curve_ok(curve) || (n && (!d_xy || !d_out))) return FEC_E_ARG;
+  if (!aligned16(d_xy) || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_compress(ctx, curve, d_xy, d_inf, d_out, n, stream);
+}
+
+int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* out,
+                       size_t n) {
+  if (!ctx || !curve_ok(curve) || (n && (!xy || !out))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const void* const in[3] = {xy, inf, nullptr};
+  const size_t in_bytes[3] = {n * 64, n, 0};
+  void* const outs[2] = {out, nullptr};
+  const size_t out_bytes[2] = {n * 33, 0};
+  return host_oneshot(ctx, in, in_bytes, outs, out_bytes, [&](void* a, void* f, void*, void* o, void*) {
+    return launch_compress(ctx, curve, (const u64*)a, (const unsigned char*)f, (unsigned char*)o, n, nullptr);
+  });
 }
 
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,

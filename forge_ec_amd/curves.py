@@ -126,6 +126,35 @@ class Context:
                                                     _ptr(out), n), "fec_ecdsa_verify_secp256k1")
         return out
 
+    def batch_compress(self, curve, xy, inf=None):
+        """PointAffine::to_bytes of each affine point (x, y, infinity) -> (n, 33) uint8."""
+        p = _u64(xy, 8)
+        n = p.shape[0]
+        fl = np.ascontiguousarray(np.asarray(inf, dtype=np.uint8)) if inf is not None else None
+        if fl is not None and fl.shape[0] != n:
+            raise ValueError("flags and points differ in length")
+        out = np.zeros((n, 33), dtype=np.uint8)
+        _check(self._lib.fec_batch_compress(self._h, curve, _ptr(p), _ptr(fl), _ptr(out), n), "fec_batch_compress")
+        return out
+
+    def schnorr_batch_verify_secp256k1(self, pk_xy, r_xy, s, a, e, pk_inf=None, r_inf=None):
+        """schnorr::batch_verify::<Secp256k1, D> (schnorr.rs:194-290), challenges e and weights a supplied.
+        -> (result bool, sides (16,) uint64 = x,y of both affine sums, sides_inf (2,) uint8)."""
+        pk, rr = _u64(pk_xy, 8), _u64(r_xy, 8)
+        ss, aa, ee = _u64(s, 4), _u64(a, 4), _u64(e, 4)
+        n = ss.shape[0]
+        if not (pk.shape[0] == rr.shape[0] == aa.shape[0] == ee.shape[0] == n):
+            raise ValueError("inputs differ in length")
+        pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+        ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)) if r_inf is not None else None
+        res = np.zeros(1, dtype=np.uint8)
+        sides = np.zeros(16, dtype=np.uint64)
+        sinf = np.zeros(2, dtype=np.uint8)
+        _check(self._lib.fec_schnorr_batch_verify_secp256k1(self._h, _ptr(pk), _ptr(pi), _ptr(rr), _ptr(ri), _ptr(ss),
+                                                            _ptr(aa), _ptr(ee), n, _ptr(res), _ptr(sides), _ptr(sinf)),
+               "fec_schnorr_batch_verify_secp256k1")
+        return bool(res[0]), sides, sinf
+
     def field_op(self, curve, op, a, b=None):
         x = _u64(a, 4)
         y = _u64(b, 4) if b is not None else None

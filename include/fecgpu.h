@@ -26,6 +26,15 @@
  *   fec_ecdsa_verify_secp256k1   Ecdsa::<Secp256k1, D>::verify per signature, digest supplied
  *                         (forge-ec-signature/src/ecdsa.rs:213-281; scalar field secp256k1.rs:1953-1969,
  *                         2162-2195, 2270-2297, 2410-2456; FieldElement::to_bytes 138-178)
+ *   fec_batch_compress    out[i] = PointAffine::to_bytes(&points[i]) -> [u8; 33] (secp256k1.rs:875-896,
+ *                         p256.rs:1558-1578, ed25519.rs:1505-1525; the bytes forge-ec-encoding's
+ *                         CompressedPoint::from_affine builds, point.rs:38-67), with each curve's
+ *                         FieldElement::to_bytes (secp256k1.rs:138-178, p256.rs:288-300, ed25519.rs:295-310)
+ *   fec_schnorr_batch_verify_secp256k1   schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/
+ *                         schnorr.rs:194-290): the 3n scalar multiplications in parallel, then the two
+ *                         strictly sequential `+=` folds (268, 281) and the affine comparison (286).
+ *                         The challenges e_i (236-256, a hash) and the random weights a_i (228-233,
+ *                         OsRng) are computed by the caller with the reference's own code
  *   fec_field_op          FieldElement trait ops (core lib.rs:173-241): Add/Sub/Mul/Neg/square
  *   fec_point_op          PointProjective trait ops (core lib.rs:699-748): Add / double / negate
  *
@@ -120,6 +129,18 @@ int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars 
 int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests /* n*32 */, const uint64_t* r /* n*4 */,
                                const uint64_t* s /* n*4 */, const uint64_t* pk_xy /* n*8 */,
                                const uint8_t* pk_inf /* n or NULL */, uint8_t* status /* n */, size_t n);
+/* xy: n*8 limbs (x then y, e.g. from fec_batch_to_affine), inf: n flags or NULL (all finite), out: n*33 bytes */
+int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* out,
+                       size_t n);
+/* *result = 1 if the reference's batch_verify returns true for these inputs, else 0.  pk_xy / r_xy:
+ * AffinePoint x, y raw limbs (n*8), pk_inf / r_inf their infinity flags (may be NULL = all finite);
+ * s, a, e: Scalar::to_raw() limbs (n*4).  sides_xy (16 limbs, may be NULL) receives x, y of
+ * to_affine(s_g) then of to_affine(r_e_p) -- the two points line 286 compares -- and sides_inf (2
+ * bytes, may be NULL) their infinity flags; both stay zero when the call returns false early. */
+int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, const uint8_t* pk_inf,
+                                       const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s,
+                                       const uint64_t* a, const uint64_t* e, size_t n, uint8_t* result,
+                                       uint64_t* sides_xy, uint8_t* sides_inf);
 int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a /* n*4 */,
                  const uint64_t* b /* n*4, may be NULL for unary ops */, uint64_t* out /* n*4 */,
                  size_t n);
@@ -141,6 +162,9 @@ int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1
 int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
                                    const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
                                    void* stream);
+/* d_out must be 4-byte aligned */
+int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf,
+                           uint8_t* d_out, size_t n, void* stream);
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
                             uint8_t* d_inf, size_t n, void* stream);
 

@@ -190,6 +190,55 @@ struct Curve {
   }
 };
 
+// C::multi_scalar_multiply(&points, &scalars) (forge-ec-core/src/lib.rs:934-951): products on the GPU,
+// then the reference's sequential `result += product` fold, also on the GPU.
+template <fec_curve C>
+inline ProjectivePoint<C> multi_scalar_multiply(GpuContext& ctx, const std::vector<ProjectivePoint<C>>& points,
+                                                const std::vector<Scalar<C>>& scalars) {
+  if (points.size() != scalars.size()) throw Error(FEC_E_ARG);
+  ProjectivePoint<C> out;
+  check(fec_multi_scalar_mul(ctx.raw(), C, reinterpret_cast<const uint64_t*>(scalars.data()),
+                             reinterpret_cast<const uint64_t*>(points.data()), out.c.data(), points.size()));
+  return out;
+}
+
+namespace schnorr {
+// forge_ec_signature::schnorr::Signature<Secp256k1> { r: AffinePoint, s: Scalar }
+struct Signature {
+  AffinePoint<FEC_SECP256K1> r;
+  Scalar<FEC_SECP256K1> s;
+};
+// schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290).  The caller hashes:
+// challenges[i] = Scalar::from_bytes_reduced(H(R_i || P_i || m_i)) (236-256) and draws the random
+// weights (228-233) with the reference's own code; everything from line 258 on runs on the GPU.
+inline bool batch_verify(GpuContext& ctx, const std::vector<AffinePoint<FEC_SECP256K1>>& public_keys,
+                         const std::vector<Signature>& signatures,
+                         const std::vector<Scalar<FEC_SECP256K1>>& challenges,
+                         const std::vector<Scalar<FEC_SECP256K1>>& weights) {
+  const size_t n = public_keys.size();
+  if (n != signatures.size() || n != challenges.size() || n != weights.size()) return false;
+  std::vector<uint64_t> pk(n * 8), r(n * 8), s(n * 4);
+  std::vector<uint8_t> pk_inf(n), r_inf(n);
+  for (size_t i = 0; i < n; ++i) {
+    for (int l = 0; l < 4; ++l) {
+      pk[i * 8 + l] = public_keys[i].x_.raw[l];
+      pk[i * 8 + 4 + l] = public_keys[i].y_.raw[l];
+      r[i * 8 + l] = signatures[i].r.x_.raw[l];
+      r[i * 8 + 4 + l] = signatures[i].r.y_.raw[l];
+      s[i * 4 + l] = signatures[i].s.raw[l];
+    }
+    pk_inf[i] = public_keys[i].infinity;
+    r_inf[i] = signatures[i].r.infinity;
+  }
+  uint8_t result = 0;
+  check(fec_schnorr_batch_verify_secp256k1(ctx.raw(), pk.data(), pk_inf.data(), r.data(), r_inf.data(), s.data(),
+                                           reinterpret_cast<const uint64_t*>(weights.data()),
+                                           reinterpret_cast<const uint64_t*>(challenges.data()), n, &result,
+                                           nullptr, nullptr));
+  return result != 0;
+}
+}  // namespace schnorr
+
 using Secp256k1 = Curve<FEC_SECP256K1>;
 using P256 = Curve<FEC_P256>;
 using Ed25519 = Curve<FEC_ED25519>;

@@ -68,6 +68,10 @@ def lib():
         L.fo_secp256k1_ecdsa_verify.restype = ctypes.c_int
         L.fo_batch_secp256k1_ecdsa_verify.argtypes = [p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
         L.fo_batch_secp256k1_ecdsa_verify.restype = None
+        L.fo_secp256k1_schnorr_batch_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, p, p]
+        L.fo_secp256k1_schnorr_batch_verify.restype = ctypes.c_int
+        L.fo_batch_compress.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t]
+        L.fo_batch_compress.restype = None
         _lib = L
     return _lib
 
@@ -201,4 +205,28 @@ def batch_secp256k1_ecdsa_verify(digests, r, s, pk_xy, pk_inf=None, nthreads=1):
     out = np.zeros(n, dtype=np.uint8)
     lib().fo_batch_secp256k1_ecdsa_verify(_ptr(digests), _ptr(r), _ptr(s), _ptr(pk_xy),
                                           _ptr(inf) if inf is not None else None, _ptr(out), n, nthreads)
+    return out
+
+
+def secp256k1_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e):
+    """-> (result, sides (16,) uint64, sides_inf (2,) uint8)."""
+    pk_xy, r_xy, s, a, e = _u64(pk_xy), _u64(r_xy), _u64(s), _u64(a), _u64(e)
+    n = s.size // 4
+    pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+    ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)) if r_inf is not None else None
+    sides = np.zeros(16, dtype=np.uint64)
+    sinf = np.zeros(2, dtype=np.uint8)
+    rc = lib().fo_secp256k1_schnorr_batch_verify(_ptr(pk_xy), _ptr(pi) if pi is not None else None, _ptr(r_xy),
+                                                 _ptr(ri) if ri is not None else None, _ptr(s), _ptr(a), _ptr(e),
+                                                 n, _ptr(sides), _ptr(sinf))
+    return rc, sides, sinf
+
+
+def batch_compress(curve, xy, inf=None):
+    """PointAffine::to_bytes of each (x, y, infinity): (n, 33) uint8."""
+    xy = _u64(xy)
+    n = xy.size // 8
+    fl = np.ascontiguousarray(np.asarray(inf, dtype=np.uint8)) if inf is not None else None
+    out = np.zeros((n, 33), dtype=np.uint8)
+    lib().fo_batch_compress(curve, _ptr(xy), _ptr(fl) if fl is not None else None, _ptr(out), n)
     return out

@@ -1167,6 +1167,76 @@ void fo_batch_secp256k1_ecdsa_verify(const unsigned char* digests, const u64* r,
   for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
 }
 
+/* forge-ec-signature/src/schnorr.rs:194-290  schnorr::batch_verify::<Secp256k1, D>, with the
+ * per-signature challenges e_i = from_bytes_reduced(H(R || P || m)) (236-256) and the random
+ * weights a_i (228-233, OsRng) supplied by the caller as raw scalar limbs.
+ *   - 197-199: n == 0 -> false.
+ *   - 204-225: the two is_on_curve tests are written `!x.unwrap_u8() == 1`; `!` on a u8 is a
+ *     bitwise NOT (254 or 255), never 1, so they can never reject.  The two is_identity tests do.
+ *   - 262-281: s_g += multiply(G, s_i * a_i);  r_e_p += multiply(from_affine(R_i) +
+ *     multiply(from_affine(P_i), e_i), a_i), both folds strictly in index order from identity().
+ *   - 286: to_affine(s_g).ct_eq(to_affine(r_e_p)) with AffinePoint::ct_eq (1292-1296).
+ * sides (optional, 16 limbs): x,y of to_affine(s_g) then of to_affine(r_e_p); sides_inf (optional, 2). */
+int fo_secp256k1_schnorr_batch_verify(const u64* pk_xy, const uint8_t* pk_inf, const u64* r_xy,
+                                      const uint8_t* r_inf, const u64* s, const u64* a, const u64* e, size_t n,
+                                      u64* sides, uint8_t* sides_inf) {
+  if (sides) memset(sides, 0, 16 * sizeof(u64));
+  if (sides_inf) sides_inf[0] = sides_inf[1] = 0;
+  if (n == 0) return 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (pk_inf && pk_inf[i]) return 0;
+    if (r_inf && r_inf[i]) return 0;
+  }
+  jpt g = k_generator();
+  jpt s_g = k_identity(), r_e_p = k_identity();
+  for (size_t i = 0; i < n; ++i) {
+    u64 sa[4];
+    ks_mul(s + 4 * i, a + 4 * i, sa);                          /* impl Mul for Scalar 2410-2456 */
+    jpt t = k_multiply(&g, sa);
+    s_g = k_padd(&s_g, &t);                                    /* AddAssign 1543-1547 */
+    jpt P = {ld(pk_xy + 8 * i), ld(pk_xy + 8 * i + 4), fe_small(1)};   /* from_affine 1365-1373 */
+    jpt ep = k_multiply(&P, e + 4 * i);
+    jpt R = {ld(r_xy + 8 * i), ld(r_xy + 8 * i + 4), fe_small(1)};
+    jpt rp = k_padd(&R, &ep);
+    jpt arp = k_multiply(&rp, a + 4 * i);
+    r_e_p = k_padd(&r_e_p, &arp);
+  }
+  fe x1, y1, x2, y2;
+  int i1 = k_to_affine(&s_g, &x1, &y1), i2 = k_to_affine(&r_e_p, &x2, &y2);
+  if (sides) { st(sides, x1); st(sides + 4, y1); st(sides + 8, x2); st(sides + 12, y2); }
+  if (sides_inf) { sides_inf[0] = (uint8_t)i1; sides_inf[1] = (uint8_t)i2; }
+  return (fe_eq(&x1, &x2) && fe_eq(&y1, &y2)) || (i1 && i2);
+}
+
+/* PointAffine::to_bytes -> [u8; 33], the compressed SEC1-style encoding every curve implements the
+ * same way (secp256k1.rs:875-896, p256.rs:1558-1578, ed25519.rs:1505-1525): 0x00 + zeros for the
+ * identity, else 0x02 | (y.to_bytes()[31] & 1) followed by x.to_bytes().  FieldElement::to_bytes:
+ *   secp256k1 (138-178): mont_reduce (= Mul by raw 1), big-endian;
+ *   P-256 (288-300): the raw limbs, big-endian;
+ *   Ed25519 (295-310): reduce(), LITTLE-endian -- so byte 31 is the most significant byte and the
+ *     "parity" bit the reference takes is bit 248 of y, and x is emitted little-endian.
+ * forge-ec-encoding/src/point.rs:38-67 (CompressedPoint::from_affine) builds the same bytes. */
+static void field_to_bytes(int curve, fe a, unsigned char out[32]) {
+  if (curve == FO_SECP256K1) a = k_mul(a, fe_small(1));
+  else if (curve == FO_ED25519) e_reduce(&a);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) {
+      unsigned char b = (unsigned char)(a.v[i] >> (8 * j));
+      if (curve == FO_ED25519) out[i * 8 + j] = b; else out[31 - (i * 8 + j)] = b;
+    }
+}
+void fo_batch_compress(int curve, const u64* xy, const uint8_t* inf, unsigned char* out, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    unsigned char* o = out + 33 * i;
+    memset(o, 0, 33);
+    if (inf && inf[i]) continue;
+    unsigned char yb[32];
+    field_to_bytes(curve, ld(xy + 8 * i + 4), yb);
+    o[0] = (yb[31] & 1) ? 0x03 : 0x02;
+    field_to_bytes(curve, ld(xy + 8 * i), o + 1);
+  }
+}
+
 void fo_batch_to_affine(int curve, const u64* points, u64* xy, uint8_t* inf, size_t n, int nthreads) {
   job_t j = {3, curve, NULL, NULL, points, xy, inf, 0, 0};
   run_jobs(j, n, nthreads);

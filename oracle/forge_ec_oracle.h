@@ -66,6 +66,13 @@ void fo_batch_secp256k1_ecdsa_verify(const unsigned char* digests, const uint64_
                                      const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* out, size_t n,
                                      int nthreads);
 
+/* schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290) with the challenges
+ * e_i and the random weights a_i supplied; 1 = true, 0 = false.  sides / sides_inf (optional): the
+ * two affine points the reference compares at 286 */
+int fo_secp256k1_schnorr_batch_verify(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* r_xy,
+                                      const uint8_t* r_inf, const uint64_t* s, const uint64_t* a,
+                                      const uint64_t* e, size_t n, uint64_t* sides, uint8_t* sides_inf);
+
 /* ---- batched drivers (nthreads host threads over contiguous shards) ---- */
 void fo_batch_mul(int curve, const uint64_t* scalars, const uint64_t* points, uint64_t* out,
                   size_t n, int nthreads);
@@ -77,6 +84,9 @@ void fo_batch_double_mul(int curve, const uint64_t* u1, const uint64_t* u2, cons
 /* out[i] = to_affine(points[i]) as x,y (8 limbs); inf[i] = 1 when identity */
 void fo_batch_to_affine(int curve, const uint64_t* points, uint64_t* xy, uint8_t* inf, size_t n,
                         int nthreads);
+
+/* out[i] = PointAffine::to_bytes (33 bytes) of the affine point (xy[i], inf[i]) */
+void fo_batch_compress(int curve, const uint64_t* xy, const uint8_t* inf, unsigned char* out, size_t n);
 
 #ifdef __cplusplus
 }

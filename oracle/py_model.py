@@ -832,6 +832,48 @@ def secp256k1_ecdsa_verify(digest, r, s, pk_xy, pk_inf=False):
     return 1 if xr == list(r) else 0
 
 
+def secp256k1_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e):
+    """schnorr.rs:194-290 with challenges e and weights a supplied.  -> (result, sides, sides_inf):
+    sides = x, y of to_affine(s_g) then x, y of to_affine(r_e_p) (what line 286 compares)."""
+    S, F = SecpScalar, Secp
+    n = len(s)
+    zero = [0, 0, 0, 0]
+    if n == 0:
+        return 0, [zero] * 4, [0, 0]
+    for i in range(n):  # 204-225: the is_on_curve tests are `!u8 == 1`, never true; identity tests reject
+        if (pk_inf is not None and pk_inf[i]) or (r_inf is not None and r_inf[i]):
+            return 0, [zero] * 4, [0, 0]
+    g = F.generator()
+    s_g, r_e_p = F.identity(), F.identity()
+    one = [1, 0, 0, 0]
+    for i in range(n):
+        s_g = F.padd(s_g, F.multiply(g, S.mul(list(s[i]), list(a[i]))))
+        ep = F.multiply((list(pk_xy[i][0:4]), list(pk_xy[i][4:8]), one), list(e[i]))
+        rp = F.padd((list(r_xy[i][0:4]), list(r_xy[i][4:8]), one), ep)
+        r_e_p = F.padd(r_e_p, F.multiply(rp, list(a[i])))
+    x1, y1, i1 = F.to_affine(s_g)
+    x2, y2, i2 = F.to_affine(r_e_p)
+    ok = (x1 == x2 and y1 == y2) or (i1 and i2)
+    return (1 if ok else 0), [x1, y1, x2, y2], [int(i1), int(i2)]
+
+
+def compress(curve, x, y, inf=False):
+    """PointAffine::to_bytes (secp256k1.rs:875-896, p256.rs:1558-1578, ed25519.rs:1505-1525)."""
+    if inf:
+        return bytes(33)
+
+    def fb(a):
+        if curve == SECP256K1:
+            a = Secp.mul(a, [1, 0, 0, 0])  # FieldElement::to_bytes = mont_reduce, big-endian (138-178)
+        elif curve == ED25519:
+            a = Ed.reduce(a)               # reduce(), little-endian (295-310)
+        v = sum(int(a[i]) << (64 * i) for i in range(4))
+        return v.to_bytes(32, "little" if curve == ED25519 else "big")
+
+    yb = fb(list(y))
+    return bytes([0x03 if yb[31] & 1 else 0x02]) + fb(list(x))
+
+
 CURVES = {SECP256K1: Secp, P256: P256c, ED25519: Ed}
 
 

@@ -98,6 +98,33 @@ static void batch_api() {
   // ecdsa.rs:254-256: R = u1*G + u2*Q
   auto r = Secp256k1::batch_double_multiply(ctx, ks, ks, ps);
   CHECK(r[7].ct_eq(Secp256k1::multiply(g, ks[7]) + Secp256k1::multiply(ps[7], ks[7])), "double-mul == r1 + r2");
+  // core lib.rs:934-951: multi_scalar_multiply == identity + k0*P0 + k1*P1 + ... folded left to right
+  {
+    std::vector<Secp256k1::PointProjective> p3(ps.begin(), ps.begin() + 3);
+    std::vector<Secp256k1::ScalarT> k3(ks.begin(), ks.begin() + 3);
+    auto msm = multi_scalar_multiply<FEC_SECP256K1>(ctx, p3, k3);
+    auto fold = ((Secp256k1::identity() + out[0]) + out[1]) + out[2];
+    CHECK(msm.ct_eq(fold), "multi_scalar_multiply == sequential += of the products");
+  }
+  // schnorr.rs:194-290: all weights zero -> both folds stay at the identity -> ct_eq true via the
+  // infinity flags; an identity public key rejects (218-220); an empty batch is false (197-199)
+  {
+    std::vector<Secp256k1::PointAffine> pks(4);
+    std::vector<schnorr::Signature> sigs(4);
+    std::vector<Secp256k1::ScalarT> e(4), a0(4), a1(4);
+    for (uint64_t i = 0; i < 4; ++i) {
+      pks[i] = Secp256k1::to_affine(out[i]);
+      sigs[i].r = Secp256k1::to_affine(out[i + 4]);
+      sigs[i].s = ks[i];
+      e[i] = ks[i + 8];
+      a1[i] = ks[i + 12];
+    }
+    CHECK(schnorr::batch_verify(ctx, pks, sigs, e, a0), "batch_verify with zero weights is true (286, inf & inf)");
+    CHECK(!schnorr::batch_verify(ctx, pks, sigs, e, a1), "unrelated points do not verify");
+    pks[2].infinity = true;
+    CHECK(!schnorr::batch_verify(ctx, pks, sigs, e, a0), "identity public key rejects (218-220)");
+    CHECK(!schnorr::batch_verify(ctx, {}, {}, {}, {}), "empty batch is false (197-199)");
+  }
   bool threw = false;
   try { ks.pop_back(); Secp256k1::batch_multiply(ctx, ps, ks); } catch (const Error&) { threw = true; }
   CHECK(threw, "length mismatch -> Error");

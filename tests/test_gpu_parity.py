@@ -400,3 +400,62 @@ def test_device_pointer_path_with_torch(gpu_ctx, oracle):
     got = do.cpu().numpy().view(np.uint64)
     want = oracle.batch_mul(0, k, p, nthreads=8)
     _assert_same(got, want, "secp256k1 batch_mul_dev")
+
+
+def test_schnorr_batch_verify_secp256k1_matches_oracle(gpu_ctx, oracle):
+    """schnorr::batch_verify::<Secp256k1, D> (schnorr.rs:194-290) through the C ABI: the boolean and the
+    two affine sums the reference compares, bit-exact with the oracle, over several batch sizes
+    (ragged workgroups), with the trivially-true case (all weights zero) and the early rejections."""
+    def inputs(n, seed):
+        pk = V.field_elements(2 * n, 0, seed).reshape(n, 8)
+        r = V.field_elements(2 * n, 0, seed + 1).reshape(n, 8)
+        return pk, r, V.scalars(n, 0, seed + 2), V.scalars(n, 0, seed + 3), V.scalars(n, 0, seed + 4)
+
+    for n, seed in ((1, 800), (5, 810), (64, 820), (300, 830)):
+        pk, r, s, a, e = inputs(n, seed)
+        want, w_sides, w_inf = oracle.secp256k1_schnorr_batch_verify(pk, None, r, None, s, a, e)
+        got, sides, sinf = gpu_ctx.schnorr_batch_verify_secp256k1(pk, r, s, a, e)
+        assert got == bool(want)
+        assert np.array_equal(sides, w_sides) and np.array_equal(sinf, w_inf)
+        assert sides.any()
+    pk, r, s, a, e = inputs(70, 840)
+    # scalars with zero weights / zero challenges / zero s mixed in (multiply's early-outs)
+    a[3] = 0
+    e[5] = 0
+    s[7] = 0
+    want, w_sides, w_inf = oracle.secp256k1_schnorr_batch_verify(pk, None, r, None, s, a, e)
+    got, sides, sinf = gpu_ctx.schnorr_batch_verify_secp256k1(pk, r, s, a, e)
+    assert got == bool(want) and np.array_equal(sides, w_sides) and np.array_equal(sinf, w_inf)
+    # all weights zero -> true via (infinity & infinity)
+    a0 = np.zeros_like(a)
+    want, w_sides, w_inf = oracle.secp256k1_schnorr_batch_verify(pk, None, r, None, s, a0, e)
+    got, sides, sinf = gpu_ctx.schnorr_batch_verify_secp256k1(pk, r, s, a0, e)
+    assert want == 1 and got is True and list(sinf) == [1, 1] and not sides.any()
+    # identity inputs reject early; the empty batch is false
+    inf = np.zeros(70, dtype=np.uint8)
+    inf[69] = 1
+    assert gpu_ctx.schnorr_batch_verify_secp256k1(pk, r, s, a0, e, pk_inf=inf)[0] is False
+    assert gpu_ctx.schnorr_batch_verify_secp256k1(pk, r, s, a0, e, r_inf=inf)[0] is False
+    z4, z8 = np.zeros((0, 4), dtype=np.uint64), np.zeros((0, 8), dtype=np.uint64)
+    assert gpu_ctx.schnorr_batch_verify_secp256k1(z8, z8, z4, z4, z4)[0] is False
+
+
+@pytest.mark.parametrize("curve", [0, 1, 2])
+def test_batch_compress_matches_oracle(gpu_ctx, oracle, curve):
+    """PointAffine::to_bytes (compressed, 33 bytes) of affine points: identity flags, ragged sizes whose
+    byte length is not a multiple of 4, non-canonical Ed25519 limbs, and points produced by the GPU's
+    own to_affine of real ladder outputs."""
+    for n, seed in ((1, 950), (3, 951), (255, 952), (258, 953), (1027, 954)):
+        xy = V.field_elements(2 * n, curve, seed + 10 * curve).reshape(n, 8)
+        raw = V.splitmix64(8 * min(n, 64), V.SEED, seed + 100).reshape(-1, 8)   # arbitrary limbs, >= p included
+        xy[:raw.shape[0]] = raw if n > 64 else xy[:raw.shape[0]]
+        inf = (V.splitmix64(n, V.SEED, seed + 200) % np.uint64(7) == 0).astype(np.uint8)
+        want = oracle.batch_compress(curve, xy, inf)
+        got = gpu_ctx.batch_compress(curve, xy, inf)
+        assert np.array_equal(got, want), (curve, n)
+        assert np.array_equal(gpu_ctx.batch_compress(curve, xy), oracle.batch_compress(curve, xy))
+    k, p = V.scalars(200, curve, 960), V.points(200, curve, 961)
+    pts = gpu_ctx.batch_mul(curve, k, p)
+    axy, ainf = gpu_ctx.batch_to_affine(curve, pts)
+    assert np.array_equal(gpu_ctx.batch_compress(curve, axy, ainf), oracle.batch_compress(curve, axy, ainf))
+    assert gpu_ctx.batch_compress(curve, np.zeros((0, 8), dtype=np.uint64)).shape == (0, 33)

@@ -156,3 +156,57 @@ def test_ecdsa_verify_two_restatements_agree(oracle):
     dg = np.full(32, 0xFF, dtype=np.uint8)
     assert M.secp256k1_ecdsa_verify(bytes(dg), r, s, pk) == 2
     assert int(oracle.batch_secp256k1_ecdsa_verify(dg, [r], [s], [pk])[0]) == 2
+
+
+def _schnorr_inputs(n, seed):
+    """Affine public keys / signature points as raw field limbs (any values: the reference's
+    is_on_curve tests in batch_verify can never reject, schnorr.rs:204-216), scalars s, a, e."""
+    pk = V.field_elements(2 * n, 0, seed).reshape(n, 8)
+    r = V.field_elements(2 * n, 0, seed + 1).reshape(n, 8)
+    s, a, e = V.scalars(n, 0, seed + 2), V.scalars(n, 0, seed + 3), V.scalars(n, 0, seed + 4)
+    return pk, r, s, a, e
+
+
+def test_schnorr_batch_verify_two_restatements_agree(oracle):
+    """schnorr::batch_verify (schnorr.rs:194-290): C oracle vs the independent Python model, on the
+    boolean AND on the two affine sums it compares.  The reference's own test of this function never
+    calls it (schnorr.rs:738-768, "TODO"), so its outputs are restatement-derived."""
+    from oracle import py_model as M
+    for n, seed in ((1, 700), (3, 710)):
+        pk, r, s, a, e = _schnorr_inputs(n, seed)
+        res, sides, sinf = oracle.secp256k1_schnorr_batch_verify(pk, None, r, None, s, a, e)
+        w_res, w_sides, w_inf = M.secp256k1_schnorr_batch_verify(
+            [[int(v) for v in row] for row in pk], None, [[int(v) for v in row] for row in r], None,
+            [[int(v) for v in row] for row in s], [[int(v) for v in row] for row in a],
+            [[int(v) for v in row] for row in e])
+        assert res == w_res == 0
+        assert [int(v) for v in sides] == [v for fe in w_sides for v in fe]
+        assert list(sinf) == w_inf == [0, 0]
+    # all weights zero: both folds stay at the identity, AffinePoint::ct_eq is true through (inf & inf)
+    pk, r, s, a, e = _schnorr_inputs(2, 720)
+    a0 = np.zeros_like(a)
+    res, sides, sinf = oracle.secp256k1_schnorr_batch_verify(pk, None, r, None, s, a0, e)
+    w = M.secp256k1_schnorr_batch_verify([[int(v) for v in row] for row in pk], None,
+                                         [[int(v) for v in row] for row in r], None,
+                                         [[int(v) for v in row] for row in s], [[0, 0, 0, 0]] * 2,
+                                         [[int(v) for v in row] for row in e])
+    assert res == w[0] == 1 and list(sinf) == w[2] == [1, 1] and not sides.any()
+    # an identity public key or signature point rejects before any arithmetic; n = 0 is false
+    assert oracle.secp256k1_schnorr_batch_verify(pk, [0, 1], r, None, s, a, e)[0] == 0
+    assert oracle.secp256k1_schnorr_batch_verify(pk, None, r, [1, 0], s, a0, e)[0] == 0
+    assert oracle.secp256k1_schnorr_batch_verify(pk[:0], None, r[:0], None, s[:0], a[:0], e[:0])[0] == 0
+
+
+@pytest.mark.parametrize("curve", [0, 1, 2])
+def test_compress_two_restatements_agree(oracle, curve):
+    """PointAffine::to_bytes: C oracle vs the independent Python model (identity, arbitrary limbs)."""
+    from oracle import py_model as M
+    xy = V.field_elements(60, curve, 970 + curve).reshape(30, 8)
+    xy[:8] = V.splitmix64(64, V.SEED, 975).reshape(8, 8)
+    inf = np.zeros(30, dtype=np.uint8)
+    inf[4] = inf[29] = 1
+    got = oracle.batch_compress(curve, xy, inf)
+    for i in range(30):
+        want = M.compress(curve, [int(v) for v in xy[i, :4]], [int(v) for v in xy[i, 4:]], bool(inf[i]))
+        assert bytes(got[i]) == want, (curve, i)
+    assert not got[4].any() and got[0][0] in (2, 3)
