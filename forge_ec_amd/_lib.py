@@ -20,8 +20,7 @@ ABI_SYMBOLS = [
 ]
 # include/fecgpu_canon.h: the canonical-math mode (NOT reference parity)
 CANON_ABI_SYMBOLS = [
-    "fec_canon_secp256k1_mul_base", "fec_canon_secp256k1_mul_base_dev", "fec_canon_secp256k1_mul",
-    "fec_canon_secp256k1_mul_dev", "fec_canon_secp256k1_field_op",
+    "fec_canon_mul_base", "fec_canon_mul_base_dev", "fec_canon_mul", "fec_canon_mul_dev", "fec_canon_field_op",
 ]
 F_INV = 5
 
@@ -112,11 +111,11 @@ def lib():
     L.fec_ctx_device_info.restype = ci
     L.fec_strerror.argtypes = [ci]
     L.fec_strerror.restype = ctypes.c_char_p
-    L.fec_canon_secp256k1_mul_base.argtypes = [vp, vp, vp, vp, sz]
-    L.fec_canon_secp256k1_mul_base_dev.argtypes = [vp, vp, vp, vp, sz, vp]
-    L.fec_canon_secp256k1_mul.argtypes = [vp, vp, vp, vp, vp, sz]
-    L.fec_canon_secp256k1_mul_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp]
-    L.fec_canon_secp256k1_field_op.argtypes = [vp, ci, vp, vp, vp, sz]
+    L.fec_canon_mul_base.argtypes = [vp, ci, vp, vp, vp, sz]
+    L.fec_canon_mul_base_dev.argtypes = [vp, ci, vp, vp, vp, sz, vp]
+    L.fec_canon_mul.argtypes = [vp, ci, vp, vp, vp, vp, sz]
+    L.fec_canon_mul_dev.argtypes = [vp, ci, vp, vp, vp, vp, sz, vp]
+    L.fec_canon_field_op.argtypes = [vp, ci, ci, vp, vp, vp, sz]
     for n in CANON_ABI_SYMBOLS:
         getattr(L, n).restype = ci
     _lib = L

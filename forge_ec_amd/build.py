@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libfecgpu.so")
 SOURCES = ["fecgpu.hip"]
-DEPS = ["fecgpu.hip", "limbs.hpp", "secp256k1.hpp", "p256.hpp", "ed25519.hpp", "canon_secp256k1.hpp",
+DEPS = ["fecgpu.hip", "limbs.hpp", "secp256k1.hpp", "p256.hpp", "ed25519.hpp", "canon_curves.hpp",
         "canon_kernels.hpp", os.path.join("..", "..", "include", "fecgpu.h"),
         os.path.join("..", "..", "include", "fecgpu_canon.h")]
 

@@ -1,8 +1,8 @@
 """
 Canonical-math mode over include/fecgpu_canon.h -- NOT reference parity.
 
-The real secp256k1 group (standard public keys / ECDH points), for callers who want results other
-libraries agree with; forge-ec's own arithmetic does not produce them.
+The real secp256k1 / P-256 groups (standard public keys / ECDH points), for callers who want results
+other libraries agree with; forge-ec's own arithmetic does not produce them.
 Arrays are numpy uint64 little-endian limbs of the plain integers: scalars (n,4); affine points
 (n,8) = x then y; status (n,) uint8: 0 finite, 1 infinity (xy = 0), 2 input point rejected.
 GPU only, like the rest of the package.
@@ -15,7 +15,9 @@ from .curves import Context, _check, _ptr, _u64
 FINITE, INFINITY, BAD_POINT = 0, 1, 2
 
 
-class CanonSecp256k1:
+class CanonCurve:
+    CURVE = None
+
     def __init__(self, ctx=None, device=0):
         self.ctx = ctx if ctx is not None else Context(device)
         self._lib = self.ctx._lib
@@ -27,8 +29,7 @@ class CanonSecp256k1:
         n = k.shape[0]
         xy = np.zeros((n, 8), dtype=np.uint64)
         st = np.zeros(n, dtype=np.uint8)
-        _check(self._lib.fec_canon_secp256k1_mul_base(self._h, _ptr(k), _ptr(xy), _ptr(st), n),
-               "fec_canon_secp256k1_mul_base")
+        _check(self._lib.fec_canon_mul_base(self._h, self.CURVE, _ptr(k), _ptr(xy), _ptr(st), n), "fec_canon_mul_base")
         return xy, st
 
     def mul(self, scalars, points_xy):
@@ -40,17 +41,16 @@ class CanonSecp256k1:
         n = k.shape[0]
         xy = np.zeros((n, 8), dtype=np.uint64)
         st = np.zeros(n, dtype=np.uint8)
-        _check(self._lib.fec_canon_secp256k1_mul(self._h, _ptr(k), _ptr(p), _ptr(xy), _ptr(st), n),
-               "fec_canon_secp256k1_mul")
+        _check(self._lib.fec_canon_mul(self._h, self.CURVE, _ptr(k), _ptr(p), _ptr(xy), _ptr(st), n), "fec_canon_mul")
         return xy, st
 
     def mul_base_dev(self, d_scalars, d_out_xy, d_status, n, stream=None):
-        _check(self._lib.fec_canon_secp256k1_mul_base_dev(self._h, d_scalars, d_out_xy, d_status, n, stream),
-               "fec_canon_secp256k1_mul_base_dev")
+        _check(self._lib.fec_canon_mul_base_dev(self._h, self.CURVE, d_scalars, d_out_xy, d_status, n, stream),
+               "fec_canon_mul_base_dev")
 
     def mul_dev(self, d_scalars, d_points_xy, d_out_xy, d_status, n, stream=None):
-        _check(self._lib.fec_canon_secp256k1_mul_dev(self._h, d_scalars, d_points_xy, d_out_xy, d_status, n,
-                                                     stream), "fec_canon_secp256k1_mul_dev")
+        _check(self._lib.fec_canon_mul_dev(self._h, self.CURVE, d_scalars, d_points_xy, d_out_xy, d_status, n, stream),
+               "fec_canon_mul_dev")
 
     def field_op(self, op, a, b=None):
         x = _u64(a, 4)
@@ -58,6 +58,17 @@ class CanonSecp256k1:
         if y is not None and y.shape != x.shape:
             raise ValueError("operands differ in shape")
         out = np.empty_like(x)
-        _check(self._lib.fec_canon_secp256k1_field_op(self._h, op, _ptr(x), _ptr(y), _ptr(out), x.shape[0]),
-               "fec_canon_secp256k1_field_op")
+        _check(self._lib.fec_canon_field_op(self._h, self.CURVE, op, _ptr(x), _ptr(y), _ptr(out), x.shape[0]),
+               "fec_canon_field_op")
         return out
+
+
+class CanonSecp256k1(CanonCurve):
+    CURVE = L.SECP256K1
+
+
+class CanonP256(CanonCurve):
+    CURVE = L.P256
+
+
+CANON_CURVES = {"secp256k1": CanonSecp256k1, "p256": CanonP256}

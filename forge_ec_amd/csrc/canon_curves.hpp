@@ -1,0 +1,684 @@
+// canon_curves.hpp -- CANONICAL-MATH MODE: the REAL curves.
+//
+// NOT reference parity.  The reference's curve arithmetic is not a field / not a group (DESIGN.md
+// section 2), so its outputs are not keys any other library accepts.  This header implements
+//   secp256k1   y^2 = x^3 + 7        over p = 2^256 - 2^32 - 977
+//   P-256       y^2 = x^3 - 3x + b   over p = 2^256 - 2^224 + 2^192 + 2^96 - 1
+// for callers who want standard results (key generation, ECDH) at GPU speed: plain canonical
+// field elements (8 x u32, always in [0, p), no Montgomery form), Jacobian coordinates, a 4-bit
+// fixed-base comb for k*G, 4-bit fixed windows for k*P, a batched Montgomery-trick normalisation.
+// It is validated against an independent big-integer model kept with the tests and public
+// standard vectors (SEC2 / BIP-340 multiples of G, the RFC 6979 A.2.5 key pair), never against
+// the reference.
+#pragma once
+#include "p256.hpp"
+#include "secp256k1.hpp"
+
+namespace fecgpu {
+namespace canon {
+
+// a^e for a public constant exponent (8 words, little-endian): square-and-multiply, MSB first
+template <class F>
+FEC_DEV fe pow_const(const fe& a, const u32* e) {
+  fe r = a;
+  int i = 255;
+  while (i > 0 && !((e[i >> 5] >> (i & 31)) & 1u)) --i;  // leading one: r = a
+#pragma unroll 1
+  for (--i; i >= 0; --i) {
+    r = F::sqr(r);
+    if ((e[i >> 5] >> (i & 31)) & 1u) r = F::mul(r, a);
+  }
+  return r;
+}
+
+// ---- F_p, p = 2^256 - 2^32 - 977 (secp256k1) ----------------------------------------------------
+struct FpSecp {
+// add / sub / neg of the reference ARE correct modulo p for canonical operands (secp256k1.rs
+// 353-440, 509-539 restate the textbook conditional-subtract forms); they are reused.
+FEC_SDEV fe add(const fe& a, const fe& b) { return secp::add(a, b); }
+FEC_SDEV fe sub(const fe& a, const fe& b) { return secp::sub(a, b); }
+FEC_SDEV fe neg(const fe& a) { return secp::neg(a); }
+FEC_SDEV fe dbl(const fe& a) { return secp::add(a, a); }
+
+// t (512 bits) mod p for any t.  2^256 = c (mod p), c = 2^32 + 977:  t = lo + hi * c.
+FEC_SDEV fe reduce512_general(const u32 t[16]) {
+  // u = hi * 977  (9 words)
+  u32 u[9];
+  {
+    u32 carry = 0;
+    FEC_UNROLL for (int k = 0; k < 8; ++k) {
+      u64 p = (u64)t[8 + k] * 977u + carry;
+      u[k] = (u32)p;
+      carry = (u32)(p >> 32);
+    }
+    u[8] = carry;
+  }
+  fe lo, ul, hs, v, w;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    lo.w[i] = t[i];
+    ul.w[i] = u[i];
+  }
+  hs.w[0] = 0;  // (hi << 32), low 8 words
+  FEC_UNROLL for (int i = 1; i < 8; ++i) hs.w[i] = t[7 + i];
+  lmask c1 = add256(v, lo, ul);
+  lmask c2 = add256(w, v, hs);
+  // what spilled past 2^256: u[8] + hi[7] + carries  (< 2^34)
+  u64 top = (u64)u[8] + t[15] + word_select(0u, 1u, c1) + word_select(0u, 1u, c2);
+  // fold it once more: w += top * c = top * 977 + (top << 32)
+  u64 f0 = (u64)(u32)top * 977u;                 // top_lo * 977
+  u64 f1 = (u64)(u32)(top >> 32) * 977u;         // top_hi * 977 (top_hi <= 3)
+  // addend words: a0 = lo(f0); a1 = hi(f0) + lo(f1) + top_lo; a2 = carries + top_hi  (all small)
+  u64 a1 = (f0 >> 32) + (u32)f1 + (u32)top;
+  u64 a2 = (a1 >> 32) + (f1 >> 32) + (top >> 32);
+  fe addend = fe_zero();
+  addend.w[0] = (u32)f0;
+  addend.w[1] = (u32)a1;
+  addend.w[2] = (u32)a2;
+  fe r;
+  lmask c3 = add256(r, w, addend);
+  if (__builtin_expect(c3 != 0, 0)) {  // wrapped past 2^256 once more (probability ~2^-190): add c
+    fe r2;
+    lmask t2;
+    FEC_ADDK256(r2, r, t2, FEC_SECP_C);
+    (void)t2;
+    r = fe_select(r, r2, c3);
+  }
+  return secp::csub_p_unlikely(r);
+}
+
+// The same reduction for the common case, 27 VALU instructions.  Column k of  lo + hi * c  is
+//   p_k = l_k + h_k * 977 + h_k * 2^32  =  mad(h_k, 977, {l_k, h_k})          (one v_mad_u64_u32)
+// which fits 64 bits whenever h_k <= 2^32 - 978; the 9-word sum of the columns is one carry
+// chain, and its top word r8 <= h_7 + 978 folds the same way.  Lanes with any h_k >= 2^32 - 4096
+// (about one multiplication in 2^17) take reduce512_general instead.
+FEC_SDEV fe reduce512(const u32 t[16]) {
+  u32 hmax = t[8];
+  FEC_UNROLL for (int k = 9; k < 16; ++k) hmax = hmax > t[k] ? hmax : t[k];
+  if (__builtin_expect(lanes_where(hmax >= 0xFFFFF000u) != 0, 0)) return reduce512_general(t);
+  fe a, b;
+  u32 top;
+  {
+    u64 p[8];
+    FEC_UNROLL for (int k = 0; k < 8; ++k) p[k] = (u64)t[8 + k] * 977u + (((u64)t[8 + k] << 32) | t[k]);
+    FEC_UNROLL for (int k = 0; k < 8; ++k) a.w[k] = (u32)p[k];
+    b.w[0] = 0;
+    FEC_UNROLL for (int k = 1; k < 8; ++k) b.w[k] = (u32)(p[k - 1] >> 32);
+    top = (u32)(p[7] >> 32);
+  }
+  fe r;
+  lmask c = add256(r, a, b);
+  top += word_select(0u, 1u, c);  // <= h_7 + 978: no wrap
+  u64 q = (u64)top * 977u + (((u64)top << 32) | r.w[0]);
+  r.w[0] = (u32)q;
+  fe r2;
+  lmask c2 = add_lohi256(r2, r, 0u, (u32)(q >> 32));
+  if (__builtin_expect(c2 != 0, 0)) {  // wrapped past 2^256 (probability ~2^-190): add c once more
+    fe r3;
+    lmask t2;
+    FEC_ADDK256(r3, r2, t2, FEC_SECP_C);
+    (void)t2;
+    r2 = fe_select(r2, r3, c2);
+  }
+  return secp::csub_p_unlikely(r2);
+}
+
+FEC_SDEV fe mul(const fe& a, const fe& b) {
+  u32 t[16];
+  mul_wide(t, a, b);
+  return reduce512(t);
+}
+FEC_SDEV fe sqr(const fe& a) { return mul(a, a); }
+FEC_SDEV fe mul3(const fe& a) { return add(add(a, a), a); }
+FEC_SDEV fe mul8(const fe& a) { return dbl(dbl(dbl(a))); }
+
+// a^(p-2): the standard addition chain for p = 2^256 - 2^32 - 977 (255 squarings, 15 multiplications)
+FEC_SDEV fe sqr_n(fe a, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) a = sqr(a);
+  return a;
+}
+FEC_SDEV fe inv(const fe& a) {
+  fe x2 = mul(sqr(a), a);
+  fe x3 = mul(sqr(x2), a);
+  fe x6 = mul(sqr_n(x3, 3), x3);
+  fe x9 = mul(sqr_n(x6, 3), x3);
+  fe x11 = mul(sqr_n(x9, 2), x2);
+  fe x22 = mul(sqr_n(x11, 11), x11);
+  fe x44 = mul(sqr_n(x22, 22), x22);
+  fe x88 = mul(sqr_n(x44, 44), x44);
+  fe x176 = mul(sqr_n(x88, 88), x88);
+  fe x220 = mul(sqr_n(x176, 44), x44);
+  fe x223 = mul(sqr_n(x220, 3), x3);
+  // p - 2 = 2^256 - 2^32 - 979: binary = 223 ones, 0, 22 ones, 0000, 1, 0, 11, 0, 1  (1..1 0 1..1 0000101101)
+  fe t = sqr_n(x223, 23);
+  t = mul(t, x22);
+  t = sqr_n(t, 5);
+  t = mul(t, a);
+  t = sqr_n(t, 3);
+  t = mul(t, x2);
+  t = sqr_n(t, 2);
+  t = mul(t, a);
+  return t;
+}
+// x, y < p and y^2 == x^3 + 7
+FEC_SDEV lmask ge_p(const fe& v) {  // v >= p  <=>  v + c carries out of 2^256
+  fe w;
+  lmask ov;
+  FEC_ADDK256(w, v, ov, FEC_SECP_C);
+  return ov;
+}
+};
+
+// ---- F_p, p = 2^256 - 2^224 + 2^192 + 2^96 - 1 (P-256) -----------------------------------------
+// p = {-1, -1, -1, 0, 0, 0, 1, -1} and 2^256 - p = {1, 0, 0, -1, -1, -1, -2, 0} as 32-bit words: every
+// word is a VOP2 inline constant, so adding / subtracting p costs no registers.
+#define FEC_P256_P -1, -1, -1, 0, 0, 0, 1, -1
+#define FEC_P256_NEGP 1, 0, 0, -1, -1, -1, -2, 0
+#define FEC_P256_5P_LOW -5, -1, -1, 4, 0, 0, 5, -5 /* 5p = 4 * 2^256 + this */
+struct FpP256 {
+  // the reference's Add and Neg are the textbook forms and correct modulo p (p256.rs:416-468, 707-729)
+  FEC_SDEV fe add(const fe& a, const fe& b) { return p256::add(a, b); }
+  FEC_SDEV fe neg(const fe& a) { return p256::neg(a); }
+  FEC_SDEV lmask ge_p(const fe& v) {  // v >= p  <=>  v + (2^256 - p) carries
+    fe w;
+    lmask ov;
+    FEC_ADDK256(w, v, ov, FEC_P256_NEGP);
+    return ov;
+  }
+  FEC_SDEV fe csub_p_unlikely(const fe& v) {  // v >= p needs w7 = 0xFFFFFFFF and w6 >= 1: ~2^-32
+    if (__builtin_expect(lanes_where(v.w[7] == 0xFFFFFFFFu && v.w[6] != 0) != 0, 0)) {
+      fe w;
+      lmask ov;
+      FEC_ADDK256(w, v, ov, FEC_P256_NEGP);
+      return fe_select(v, w, ov);
+    }
+    return v;
+  }
+  FEC_SDEV fe sub(const fe& a, const fe& b) {  // a - b, plus p when it borrowed
+    fe d, d2;
+    lmask borrow = sub256(d, a, b);
+    lmask t;
+    FEC_ADDK256(d2, d, t, FEC_P256_P);
+    (void)t;
+    return fe_select(d, d2, borrow);
+  }
+  // t (512 bits) mod p: the NIST fast reduction (FIPS 186-4 D.2.3) on 32-bit words c0..c15,
+  //   r = s1 + 2 s2 + 2 s3 + s4 + s5 - s6 - s7 - s8 - s9,
+  // as 256-bit carry chains: the positive terms plus 5p (so the total cannot go negative), minus
+  // the negative terms; what spilled past 2^256 (t in 0..12, counted by a ninth instruction on
+  // each chain) is folded back with 2^256 = 2^224 - 2^192 - 2^96 + 1 (mod p).
+  FEC_SDEV fe reduce512(const u32 c[16]) {
+    fe s1, s2, s3, s4, s5, s6, s7, s8, s9;
+    FEC_UNROLL for (int i = 0; i < 8; ++i) s1.w[i] = c[i];
+    s2.w[0] = 0; s2.w[1] = 0; s2.w[2] = 0; s2.w[3] = c[11]; s2.w[4] = c[12]; s2.w[5] = c[13]; s2.w[6] = c[14]; s2.w[7] = c[15];
+    s3.w[0] = 0; s3.w[1] = 0; s3.w[2] = 0; s3.w[3] = c[12]; s3.w[4] = c[13]; s3.w[5] = c[14]; s3.w[6] = c[15]; s3.w[7] = 0;
+    s4.w[0] = c[8]; s4.w[1] = c[9]; s4.w[2] = c[10]; s4.w[3] = 0; s4.w[4] = 0; s4.w[5] = 0; s4.w[6] = c[14]; s4.w[7] = c[15];
+    s5.w[0] = c[9]; s5.w[1] = c[10]; s5.w[2] = c[11]; s5.w[3] = c[13]; s5.w[4] = c[14]; s5.w[5] = c[15]; s5.w[6] = c[13]; s5.w[7] = c[8];
+    s6.w[0] = c[11]; s6.w[1] = c[12]; s6.w[2] = c[13]; s6.w[3] = 0; s6.w[4] = 0; s6.w[5] = 0; s6.w[6] = c[8]; s6.w[7] = c[10];
+    s7.w[0] = c[12]; s7.w[1] = c[13]; s7.w[2] = c[14]; s7.w[3] = c[15]; s7.w[4] = 0; s7.w[5] = 0; s7.w[6] = c[9]; s7.w[7] = c[11];
+    s8.w[0] = c[13]; s8.w[1] = c[14]; s8.w[2] = c[15]; s8.w[3] = c[8]; s8.w[4] = c[9]; s8.w[5] = c[10]; s8.w[6] = 0; s8.w[7] = c[12];
+    s9.w[0] = c[14]; s9.w[1] = c[15]; s9.w[2] = 0; s9.w[3] = c[9]; s9.w[4] = c[10]; s9.w[5] = c[11]; s9.w[6] = 0; s9.w[7] = c[13];
+    u32 tp = 0;
+    fe a, b;
+    add256c(a, s2, s3, tp);
+    tp += tp;              // 2 (s2 + s3) = 2 a + 2 carry * 2^256
+    add256c(b, a, a, tp);
+    add256c(b, b, s1, tp);
+    add256c(b, b, s4, tp);
+    add256c(b, b, s5, tp);
+    {
+      lmask ov;
+      FEC_ADDK256(b, b, ov, FEC_P256_5P_LOW);
+      tp += 4u + word_select(0u, 1u, ov);
+    }
+    u32 tn = 0;
+    fe n;
+    add256c(n, s6, s7, tn);
+    add256c(n, n, s8, tn);
+    add256c(n, n, s9, tn);
+    u32 t = tp - tn;
+    fe v;
+    sub256c(v, b, n, t);   // t in 0..12
+    // K(t) = t * (2^256 - p) = {t, 0, 0, -t, -nz, -nz, -t - nz, t - nz},  nz = (t != 0)
+    const u32 nz = t != 0 ? 1u : 0u;
+    fe k;
+    k.w[0] = t; k.w[1] = 0; k.w[2] = 0; k.w[3] = 0u - t; k.w[4] = 0u - nz; k.w[5] = 0u - nz;
+    k.w[6] = 0u - t - nz; k.w[7] = t - nz;
+    fe r;
+    lmask c2 = add256(r, v, k);
+    if (__builtin_expect(c2 != 0, 0)) {  // wrapped once more (probability ~ t / 2^32): add 2^256 - p again
+      fe r2;
+      lmask t2;
+      FEC_ADDK256(r2, r, t2, FEC_P256_NEGP);
+      (void)t2;
+      r = fe_select(r, r2, c2);
+    }
+    return csub_p_unlikely(r);
+  }
+  FEC_SDEV fe mul(const fe& a, const fe& b) {
+    u32 t[16];
+    mul_wide(t, a, b);
+    return reduce512(t);
+  }
+  FEC_SDEV fe sqr(const fe& a) { return mul(a, a); }
+  FEC_SDEV fe inv(const fe& a) {  // a^(p-2)
+    const u32 e[8] = {0xFFFFFFFDu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 1u, 0xFFFFFFFFu};
+    return pow_const<FpP256>(a, e);
+  }
+};
+
+struct jac {
+  fe x, y, z;
+};  // Z == 0 <=> point at infinity
+struct aff {
+  fe x, y;
+};
+
+FEC_DEV jac jac_infinity() {
+  jac p;
+  p.x = fe_small(1);
+  p.y = fe_small(1);
+  p.z = fe_zero();
+  return p;
+}
+FEC_DEV jac jac_select(const jac& a, const jac& b, lmask m) {
+  jac r;
+  r.x = fe_select(a.x, b.x, m);
+  r.y = fe_select(a.y, b.y, m);
+  r.z = fe_select(a.z, b.z, m);
+  return r;
+}
+
+// ---- per-lane global-memory helpers -------------------------------------------------------------
+#ifdef FEC_HOST_EMUL
+FEC_DEV fe ld8(const u32* p) {
+  fe a;
+  for (int i = 0; i < 8; ++i) a.w[i] = p[i];
+  return a;
+}
+FEC_DEV void st8(u32* p, const fe& a) {
+  for (int i = 0; i < 8; ++i) p[i] = a.w[i];
+}
+#else
+FEC_DEV fe ld8(const u32* p) {
+  const uint4* s = reinterpret_cast<const uint4*>(p);
+  uint4 a = s[0], b = s[1];
+  fe r;
+  r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+  r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+  return r;
+}
+FEC_DEV void st8(u32* p, const fe& a) {
+  uint4* d = reinterpret_cast<uint4*>(p);
+  d[0] = make_uint4(a.w[0], a.w[1], a.w[2], a.w[3]);
+  d[1] = make_uint4(a.w[4], a.w[5], a.w[6], a.w[7]);
+}
+#endif
+
+// Windowed variable-base k*P, 4-bit fixed windows, most significant first.  The lane's table of
+// 1P..15P (Jacobian, 32 words per entry: X, Y, Z, pad) lives in its own slice of a global scratch
+// buffer -- written and read only by this lane, one 128-byte line per lookup.
+constexpr int WIN_ENTRY_WORDS = 32, WIN_ENTRIES = 15;
+#ifdef FEC_HOST_EMUL
+FEC_DEV void win_store(u32* slot, const jac& p) {
+  for (int i = 0; i < 8; ++i) {
+    slot[i] = p.x.w[i];
+    slot[8 + i] = p.y.w[i];
+    slot[16 + i] = p.z.w[i];
+  }
+}
+FEC_DEV jac win_load(const u32* slot) {
+  jac p;
+  for (int i = 0; i < 8; ++i) {
+    p.x.w[i] = slot[i];
+    p.y.w[i] = slot[8 + i];
+    p.z.w[i] = slot[16 + i];
+  }
+  return p;
+}
+#else
+FEC_DEV void win_store(u32* slot, const jac& p) {
+  uint4* d = reinterpret_cast<uint4*>(slot);
+  d[0] = make_uint4(p.x.w[0], p.x.w[1], p.x.w[2], p.x.w[3]);
+  d[1] = make_uint4(p.x.w[4], p.x.w[5], p.x.w[6], p.x.w[7]);
+  d[2] = make_uint4(p.y.w[0], p.y.w[1], p.y.w[2], p.y.w[3]);
+  d[3] = make_uint4(p.y.w[4], p.y.w[5], p.y.w[6], p.y.w[7]);
+  d[4] = make_uint4(p.z.w[0], p.z.w[1], p.z.w[2], p.z.w[3]);
+  d[5] = make_uint4(p.z.w[4], p.z.w[5], p.z.w[6], p.z.w[7]);
+}
+FEC_DEV jac win_load(const u32* slot) {
+  const uint4* s = reinterpret_cast<const uint4*>(slot);
+  uint4 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5];
+  jac p;
+  p.x.w[0] = a.x; p.x.w[1] = a.y; p.x.w[2] = a.z; p.x.w[3] = a.w;
+  p.x.w[4] = b.x; p.x.w[5] = b.y; p.x.w[6] = b.z; p.x.w[7] = b.w;
+  p.y.w[0] = c.x; p.y.w[1] = c.y; p.y.w[2] = c.z; p.y.w[3] = c.w;
+  p.y.w[4] = d.x; p.y.w[5] = d.y; p.y.w[6] = d.z; p.y.w[7] = d.w;
+  p.z.w[0] = e.x; p.z.w[1] = e.y; p.z.w[2] = e.z; p.z.w[3] = e.w;
+  p.z.w[4] = f.x; p.z.w[5] = f.y; p.z.w[6] = f.z; p.z.w[7] = f.w;
+  return p;
+}
+#endif
+
+// ---- batched normalisation (Montgomery's trick) ------------------------------------------------
+// The scalar-multiplication kernels leave Jacobian results in memory -- X, Y in the caller's
+// out_xy slots (16 words per element), Z in a side buffer (8 words per element); one lane then
+// normalises NORM_GROUP of them with a single inversion:  c_j = z_0 ... z_j,  u = 1 / c_last,
+// walking back  1/z_j = u * c_{j-1},  u *= z_j.   (270 + 3 (G-1)) / G + 5 multiplications per
+// element instead of 275.  Elements with Z = 0 (infinity) or a rejected input take z = 1 in the
+// chain and are written as zeros.
+constexpr int NORM_GROUP = 8;
+// status values shared with the kernels / the ABI (fec_canon_status)
+constexpr unsigned char ST_FINITE = 0, ST_INFINITY = 1, ST_BAD_POINT = 2;
+
+// Comb table for k*G with 4-bit digits: entry (i, j), j = 1..15, is the AFFINE point j * 16^i * G.
+// 64 windows x 15 entries x 16 words, entry stride COMB_STRIDE words (odd, spreads LDS banks).
+constexpr int COMB_WINDOWS = 64, COMB_ENTRIES = 15, COMB_STRIDE = 17;
+constexpr int COMB_WORDS = COMB_WINDOWS * COMB_ENTRIES * COMB_STRIDE;
+
+// ---- short Weierstrass curve y^2 = x^3 + a x + b with a in {0, -3}, Jacobian coordinates --------
+// P supplies: F (the field), A_IS_ZERO, b(), generator().
+template <class P>
+struct wei {
+  using F = typename P::F;
+  FEC_SDEV fe add(const fe& a, const fe& b) { return F::add(a, b); }
+  FEC_SDEV fe sub(const fe& a, const fe& b) { return F::sub(a, b); }
+  FEC_SDEV fe neg(const fe& a) { return F::neg(a); }
+  FEC_SDEV fe dbl(const fe& a) { return F::add(a, a); }
+  FEC_SDEV fe mul(const fe& a, const fe& b) { return F::mul(a, b); }
+  FEC_SDEV fe sqr(const fe& a) { return F::sqr(a); }
+  FEC_SDEV fe inv(const fe& a) { return F::inv(a); }
+  FEC_SDEV fe mul3(const fe& a) { return add(add(a, a), a); }
+  FEC_SDEV fe mul8(const fe& a) { return dbl(dbl(dbl(a))); }
+  FEC_SDEV lmask ge_p(const fe& a) { return F::ge_p(a); }
+  FEC_SDEV aff generator() { return P::generator(); }
+
+// Doubling.  a = 0 (dbl-2009-l): 2M + 5S; a = -3 (dbl-2001-b): 3M + 5S.  Infinity (Z = 0) doubles
+// to Z3 = 0; Y = 0 cannot occur on these curves (odd prime order).
+FEC_SDEV jac jdouble(const jac& p) {
+  jac r;
+  if (P::A_IS_ZERO) {
+    fe A = sqr(p.x), B = sqr(p.y), C = sqr(B);
+    fe t = sqr(add(p.x, B));
+    fe D = dbl(sub(sub(t, A), C));
+    fe E = mul3(A);
+    fe Fq = sqr(E);
+    r.x = sub(Fq, dbl(D));
+    r.y = sub(mul(E, sub(D, r.x)), mul8(C));
+    r.z = dbl(mul(p.y, p.z));
+  } else {
+    fe delta = sqr(p.z), gamma = sqr(p.y);
+    fe beta = mul(p.x, gamma);
+    fe alpha = mul3(mul(sub(p.x, delta), add(p.x, delta)));
+    r.x = sub(sqr(alpha), mul8(beta));
+    r.z = sub(sub(sqr(add(p.y, p.z)), gamma), delta);
+    r.y = sub(mul(alpha, sub(dbl(dbl(beta)), r.x)), mul8(sqr(gamma)));
+  }
+  return r;
+}
+
+// madd-2007-bl: Jacobian + affine, 7M + 4S, with the exceptional cases (P infinite; P == +-Q)
+// behind wave-uniform branches.  `skip` lanes return p unchanged (a zero comb digit).
+FEC_SDEV jac jadd_affine(const jac& p, const aff& q, lmask skip) {
+  fe z1z1 = sqr(p.z);
+  fe u2 = mul(q.x, z1z1);
+  fe s2 = mul(mul(q.y, p.z), z1z1);
+  fe h = sub(u2, p.x);
+  fe hh = sqr(h);
+  fe i = dbl(dbl(hh));
+  fe j = mul(h, i);
+  fe rr = dbl(sub(s2, p.y));
+  fe v = mul(p.x, i);
+  jac o;
+  o.x = sub(sub(sqr(rr), j), dbl(v));
+  o.y = sub(mul(rr, sub(v, o.x)), dbl(mul(p.y, j)));
+  o.z = sub(sub(sqr(add(p.z, h)), z1z1), hh);
+  lmask pinf = fe_is_zero(p.z);
+  lmask hzero = fe_is_zero(h) & ~pinf;
+  if (__builtin_expect((pinf | hzero) != 0, 0)) {
+    jac qa;
+    qa.x = q.x;
+    qa.y = q.y;
+    qa.z = fe_small(1);
+    o = jac_select(o, qa, pinf);
+    if (hzero != 0) {  // same x: either P == Q (double) or P == -Q (infinity)
+      lmask same = hzero & fe_is_zero(rr);
+      jac d = jdouble(qa);
+      o = jac_select(o, jac_infinity(), hzero & ~same);
+      o = jac_select(o, d, same);
+    }
+  }
+  return jac_select(o, p, skip);
+}
+
+// general Jacobian + Jacobian (add-2007-bl), 11M + 5S; used only while building tables
+FEC_SDEV jac jadd(const jac& p, const jac& q) {
+  fe z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+  fe u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+  fe s1 = mul(mul(p.y, q.z), z2z2), s2 = mul(mul(q.y, p.z), z1z1);
+  fe h = sub(u2, u1);
+  fe i = sqr(dbl(h));
+  fe j = mul(h, i);
+  fe rr = dbl(sub(s2, s1));
+  fe v = mul(u1, i);
+  jac o;
+  o.x = sub(sub(sqr(rr), j), dbl(v));
+  o.y = sub(mul(rr, sub(v, o.x)), dbl(mul(s1, j)));
+  o.z = mul(sub(sub(sqr(add(p.z, q.z)), z1z1), z2z2), h);
+  lmask pinf = fe_is_zero(p.z), qinf = fe_is_zero(q.z);
+  lmask hzero = fe_is_zero(h) & ~pinf & ~qinf;
+  lmask same = hzero & fe_is_zero(rr);
+  jac d = jdouble(p);
+  o = jac_select(o, jac_infinity(), hzero & ~same);
+  o = jac_select(o, d, same);
+  o = jac_select(o, q, pinf);
+  o = jac_select(o, p, qinf & ~pinf);
+  return o;
+}
+
+// Jacobian + Jacobian for the windowed ladder: q is a table entry (never infinite); `skip` lanes
+// keep p (zero digit).  P infinite / P == +-Q are fixed up behind a wave-uniform branch.
+FEC_SDEV jac jadd_window(const jac& p, const jac& q, lmask skip) {
+  fe z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+  fe u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+  fe s1 = mul(mul(p.y, q.z), z2z2), s2 = mul(mul(q.y, p.z), z1z1);
+  fe h = sub(u2, u1);
+  fe i = sqr(dbl(h));
+  fe j = mul(h, i);
+  fe rr = dbl(sub(s2, s1));
+  fe v = mul(u1, i);
+  jac o;
+  o.x = sub(sub(sqr(rr), j), dbl(v));
+  o.y = sub(mul(rr, sub(v, o.x)), dbl(mul(s1, j)));
+  o.z = mul(sub(sub(sqr(add(p.z, q.z)), z1z1), z2z2), h);
+  lmask pinf = fe_is_zero(p.z) & ~skip;
+  lmask hzero = fe_is_zero(h) & ~pinf & ~skip;
+  if (__builtin_expect((pinf | hzero) != 0, 0)) {
+    o = jac_select(o, q, pinf);
+    if (hzero != 0) {
+      lmask same = hzero & fe_is_zero(rr);
+      jac d = jdouble(q);
+      o = jac_select(o, jac_infinity(), hzero & ~same);
+      o = jac_select(o, d, same);
+    }
+  }
+  return jac_select(o, p, skip);
+}
+
+// x, y < p and y^2 == x^3 + a x + b
+FEC_SDEV lmask on_curve(const aff& q) {
+  lmask xlt = ~ge_p(q.x), ylt = ~ge_p(q.y);
+  fe x2 = sqr(q.x);
+  if (!P::A_IS_ZERO) x2 = sub(x2, fe_small(3));
+  fe rhs = add(mul(x2, q.x), P::b());
+  return uniform_mask(xlt & ylt & fe_eq(sqr(q.y), rhs));
+}
+
+FEC_SDEV jac mul_window(const aff& base, const u32* kw, u32* table /* this lane's 15 x 32 words */) {
+  jac t;
+  t.x = base.x;
+  t.y = base.y;
+  t.z = fe_small(1);
+  win_store(table, t);
+  t = jdouble(t);
+  win_store(table + WIN_ENTRY_WORDS, t);
+#pragma unroll 1
+  for (int j = 3; j <= WIN_ENTRIES; ++j) {
+    t = jadd_affine(t, base, 0);
+    win_store(table + (j - 1) * WIN_ENTRY_WORDS, t);
+  }
+  jac acc = jac_infinity();
+#pragma unroll 1
+  for (int w = 63; w >= 0; --w) {
+    u32 digit = (kw[(w >> 3) * KSTRIDE] >> ((w & 7) * 4)) & 15u;
+    jac q = win_load(table + ((digit == 0 ? 1u : digit) - 1) * WIN_ENTRY_WORDS);
+#pragma unroll 1
+    for (int d = 0; d < 4; ++d) acc = jdouble(acc);
+    acc = jadd_window(acc, q, lanes_where(digit == 0));
+  }
+  return acc;
+}
+
+// This lane's group: elements first, first + stride, ... (NORM_GROUP of them, those < n).
+// status[i] on entry: ST_BAD_POINT for rejected inputs, anything else is recomputed here.
+FEC_SDEV void normalize_group(u32* xy, const u32* zbuf, unsigned char* status, size_t first, size_t stride,
+                             size_t n) {
+  fe c[NORM_GROUP];
+  fe run = fe_small(1);
+  FEC_UNROLL for (int j = 0; j < NORM_GROUP; ++j) {
+    const size_t i = first + (size_t)j * stride;
+    fe z = fe_small(1);
+    if (i < n && status[i] != ST_BAD_POINT) z = ld8(zbuf + i * 8);
+    z = fe_select(z, fe_small(1), fe_is_zero(z));
+    run = j == 0 ? z : mul(run, z);
+    c[j] = run;
+  }
+  fe u = inv(run);
+#pragma unroll 1
+  for (int j = NORM_GROUP - 1; j >= 0; --j) {
+    const size_t i = first + (size_t)j * stride;
+    const bool live = i < n;
+    fe z = fe_small(1);
+    bool bad = false;
+    if (live) {
+      bad = status[i] == ST_BAD_POINT;
+      if (!bad) z = ld8(zbuf + i * 8);
+    }
+    const lmask zero = fe_is_zero(z);
+    z = fe_select(z, fe_small(1), zero);
+    fe prev = fe_small(1);
+    FEC_UNROLL for (int t = 0; t < NORM_GROUP - 1; ++t) prev = fe_select(prev, c[t], lanes_where(t == j - 1));
+    fe zi = mul(u, prev);  // 1 / z_j
+    u = mul(u, z);
+    if (live) {
+      fe x = ld8(xy + i * 16), y = ld8(xy + i * 16 + 8);
+      fe zi2 = sqr(zi);
+      x = mul(x, zi2);
+      y = mul(mul(y, zi2), zi);
+      const lmask wipe = zero | lanes_where(bad);
+      x = fe_select(x, fe_zero(), wipe);
+      y = fe_select(y, fe_zero(), wipe);
+      st8(xy + i * 16, x);
+      st8(xy + i * 16 + 8, y);
+      status[i] = bad ? ST_BAD_POINT : (lane_of(zero) ? ST_INFINITY : ST_FINITE);
+    }
+  }
+}
+
+FEC_SDEV aff comb_entry(const u32* tab, int window, u32 digit /* 1..15 */) {
+  const u32* e = tab + (window * COMB_ENTRIES + (int)digit - 1) * COMB_STRIDE;
+  aff q;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    q.x.w[i] = e[i];
+    q.y.w[i] = e[8 + i];
+  }
+  return q;
+}
+
+// Jacobian -> affine.  inv(0) = 0, so the point at infinity comes out as (0, 0) with the mask set.
+FEC_SDEV lmask to_affine(const jac& p, aff& a) {
+  fe zi = inv(p.z);
+  fe zi2 = sqr(zi);
+  a.x = mul(p.x, zi2);
+  a.y = mul(mul(p.y, zi2), zi);
+  return fe_is_zero(p.z);
+}
+
+// the 15 entries of one comb window: j * base for j = 1..15, base = 16^window * G (affine)
+FEC_SDEV void comb_fill_window(u32* table, int window, const aff& base) {
+  jac acc;
+  acc.x = base.x;
+  acc.y = base.y;
+  acc.z = fe_small(1);
+#pragma unroll 1
+  for (int j = 1; j <= COMB_ENTRIES; ++j) {
+    aff e = base;
+    if (j > 1) {
+      acc = jadd_affine(acc, base, 0);  // j == 2 goes through the P == Q branch
+      to_affine(acc, e);
+    }
+    u32* dst = table + (size_t)(window * COMB_ENTRIES + j - 1) * COMB_STRIDE;
+    FEC_UNROLL for (int w = 0; w < 8; ++w) {
+      dst[w] = e.x.w[w];
+      dst[8 + w] = e.y.w[w];
+    }
+    dst[16] = 0;
+  }
+}
+
+// k*G: one mixed addition per non-zero 4-bit digit of k (64 digits), no doublings.
+// kw: the lane's scalar in LDS (word j at kw[j * KSTRIDE]); any 256-bit k is accepted (k*G with k
+// taken modulo the group order, as the group law gives).
+FEC_SDEV jac mul_base_comb(const u32* tab, const u32* kw) {
+  jac acc = jac_infinity();
+#pragma unroll 1
+  for (int w = 0; w < COMB_WINDOWS; ++w) {
+    u32 digit = (kw[(w >> 3) * KSTRIDE] >> ((w & 7) * 4)) & 15u;
+    lmask skip = lanes_where(digit == 0);
+    aff q = comb_entry(tab, w, digit == 0 ? 1u : digit);
+    acc = jadd_affine(acc, q, skip);
+  }
+  return acc;
+}
+};  // struct wei
+
+struct SecpParams {
+  using F = FpSecp;
+  static constexpr bool A_IS_ZERO = true;
+  FEC_SDEV fe b() { return fe_small(7); }
+  FEC_SDEV aff generator() {  // SEC 2, section 2.4.1
+    aff g;
+    const u32 gx[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu, 0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
+    const u32 gy[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u, 0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      g.x.w[i] = gx[i];
+      g.y.w[i] = gy[i];
+    }
+    return g;
+  }
+};
+struct P256Params {
+  using F = FpP256;
+  static constexpr bool A_IS_ZERO = false;  // a = -3
+  FEC_SDEV fe b() {  // FIPS 186-4 D.1.2.3
+    fe r;
+    const u32 w[8] = {0x27D2604Bu, 0x3BCE3C3Eu, 0xCC53B0F6u, 0x651D06B0u, 0x769886BCu, 0xB3EBBD55u, 0xAA3A93E7u, 0x5AC635D8u};
+    FEC_UNROLL for (int i = 0; i < 8; ++i) r.w[i] = w[i];
+    return r;
+  }
+  FEC_SDEV aff generator() {
+    aff g;
+    const u32 gx[8] = {0xD898C296u, 0xF4A13945u, 0x2DEB33A0u, 0x77037D81u, 0x63A440F2u, 0xF8BCE6E5u, 0xE12C4247u, 0x6B17D1F2u};
+    const u32 gy[8] = {0x37BF51F5u, 0xCBB64068u, 0x6B315ECEu, 0x2BCE3357u, 0x7C0F9E16u, 0x8EE7EB4Au, 0xFE1A7F9Bu, 0x4FE342E2u};
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      g.x.w[i] = gx[i];
+      g.y.w[i] = gy[i];
+    }
+    return g;
+  }
+};
+
+}  // namespace canon
+using csecp = canon::wei<canon::SecpParams>;
+using cp256 = canon::wei<canon::P256Params>;
+}  // namespace fecgpu

@@ -1,64 +1,66 @@
-// canon_kernels.hpp -- kernels of the CANONICAL-MATH MODE (secp256k1), included by fecgpu.hip.
+// canon_kernels.hpp -- kernels of the CANONICAL-MATH MODE (secp256k1, P-256), included by fecgpu.hip.
 //
-// NOT reference parity (see canon_secp256k1.hpp).  Same mapping as the parity kernels: one scalar
+// NOT reference parity (see canon_curves.hpp).  Same mapping as the parity kernels: one scalar
 // per lane, 256-thread workgroups, coalesced 16-byte HBM<->LDS staging of word-major columns.
 #pragma once
-#include "canon_secp256k1.hpp"
+#include "canon_curves.hpp"
 
 namespace fecgpu {
 
-enum { CANON_FINITE = csecp::ST_FINITE, CANON_INFINITY = csecp::ST_INFINITY, CANON_BAD_POINT = csecp::ST_BAD_POINT };
+enum { CANON_FINITE = canon::ST_FINITE, CANON_INFINITY = canon::ST_INFINITY, CANON_BAD_POINT = canon::ST_BAD_POINT };
 
 // table[(i * 15 + j - 1) * COMB_STRIDE ...] = affine j * 16^i * G, i = 0..63, j = 1..15.
 // One wavefront, once per context: lane 0 walks the 16^i * G chain (252 doublings), then lane i
 // derives its 15 multiples by repeated addition and normalises each.
-__global__ __launch_bounds__(64) void k_csecp_build_comb(u32* __restrict__ table) {
+template <class W>
+__global__ __launch_bounds__(64) void k_canon_build_comb(u32* __restrict__ table) {
   __shared__ u32 lds_b[24 * 64];
   const int lane = threadIdx.x;
   if (lane == 0) {
-    csecp::aff g = csecp::generator();
-    csecp::jac b;
+    canon::aff g = W::generator();
+    canon::jac b;
     b.x = g.x;
     b.y = g.y;
     b.z = fe_small(1);
 #pragma unroll 1
-    for (int i = 0; i < csecp::COMB_WINDOWS; ++i) {
+    for (int i = 0; i < canon::COMB_WINDOWS; ++i) {
       store_fe(lds_b + i, 64, b.x);
       store_fe(lds_b + 8 * 64 + i, 64, b.y);
       store_fe(lds_b + 16 * 64 + i, 64, b.z);
 #pragma unroll 1
-      for (int d = 0; d < 4; ++d) b = csecp::jdouble(b);
+      for (int d = 0; d < 4; ++d) b = W::jdouble(b);
     }
   }
   __syncthreads();
-  csecp::jac acc;
+  canon::jac acc;
   acc.x = load_fe(lds_b + lane, 64);
   acc.y = load_fe(lds_b + 8 * 64 + lane, 64);
   acc.z = load_fe(lds_b + 16 * 64 + lane, 64);
-  csecp::aff base;
-  csecp::to_affine(acc, base);
-  csecp::comb_fill_window(table, lane, base);
+  canon::aff base;
+  W::to_affine(acc, base);
+  W::comb_fill_window(table, lane, base);
 }
 
 // Phase 1 of key generation: Jacobian scalars[i] * G by the comb; X, Y go to out_xy[i], Z to zbuf[i].
-__global__ __launch_bounds__(TPB) void k_csecp_mul_base(const u32* __restrict__ scalars,
+template <class W>
+__global__ __launch_bounds__(TPB) void k_canon_mul_base(const u32* __restrict__ scalars,
                                                         const u32* __restrict__ table,
                                                         u32* __restrict__ out_xy, u32* __restrict__ zbuf,
                                                         unsigned char* __restrict__ status, size_t n) {
   __shared__ u32 lds_k[8 * TPB];
-  __shared__ u32 lds_t[csecp::COMB_WORDS];
+  __shared__ u32 lds_t[canon::COMB_WORDS];
   const int valid = block_valid(n);
   const size_t first = (size_t)blockIdx.x * TPB;
   stage_in<8>(lds_k, scalars + first * 8, valid);
-  for (int v = threadIdx.x; v < csecp::COMB_WORDS; v += TPB) lds_t[v] = table[v];
+  for (int v = threadIdx.x; v < canon::COMB_WORDS; v += TPB) lds_t[v] = table[v];
   __syncthreads();
   const int e = threadIdx.x;
   if (e < valid) {
-    csecp::jac r = csecp::mul_base_comb(lds_t, lds_k + e);
+    canon::jac r = W::mul_base_comb(lds_t, lds_k + e);
     const size_t i = first + e;
-    csecp::st8(out_xy + i * 16, r.x);
-    csecp::st8(out_xy + i * 16 + 8, r.y);
-    csecp::st8(zbuf + i * 8, r.z);
+    canon::st8(out_xy + i * 16, r.x);
+    canon::st8(out_xy + i * 16 + 8, r.y);
+    canon::st8(zbuf + i * 8, r.z);
     status[i] = CANON_FINITE;
   }
 }
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(TPB) void k_csecp_mul_base(const u32* __restrict__ 
 // Phase 1 of ECDH: Jacobian scalars[i] * points_xy[i] by the windowed ladder.  `scratch` holds one
 // 15-entry window table per element (WIN_ENTRIES * WIN_ENTRY_WORDS words each), private to the lane
 // that builds it.  Rejected input points get status CANON_BAD_POINT (phase 2 zeroes them).
-__global__ __launch_bounds__(TPB, 2) void k_csecp_mul(const u32* __restrict__ scalars,
+template <class W>
+__global__ __launch_bounds__(TPB, 2) void k_canon_mul(const u32* __restrict__ scalars,
                                                    const u32* __restrict__ points_xy,
                                                    u32* __restrict__ scratch, u32* __restrict__ out_xy,
                                                    u32* __restrict__ zbuf, unsigned char* __restrict__ status,
@@ -80,31 +83,33 @@ __global__ __launch_bounds__(TPB, 2) void k_csecp_mul(const u32* __restrict__ sc
   __syncthreads();
   const int e = threadIdx.x;
   if (e < valid) {
-    csecp::aff base;
+    canon::aff base;
     base.x = load_fe(lds_p + e, TPB);
     base.y = load_fe(lds_p + 8 * TPB + e, TPB);
-    const lmask ok = csecp::on_curve(base);
+    const lmask ok = W::on_curve(base);
     // a bad point still runs the ladder (on garbage; the arithmetic is total) and is zeroed in phase 2
     const size_t i = first + e;
-    u32* table = scratch + i * (size_t)(csecp::WIN_ENTRIES * csecp::WIN_ENTRY_WORDS);
-    csecp::jac r = csecp::mul_window(base, lds_k + e, table);
-    csecp::st8(out_xy + i * 16, r.x);
-    csecp::st8(out_xy + i * 16 + 8, r.y);
-    csecp::st8(zbuf + i * 8, r.z);
+    u32* table = scratch + i * (size_t)(canon::WIN_ENTRIES * canon::WIN_ENTRY_WORDS);
+    canon::jac r = W::mul_window(base, lds_k + e, table);
+    canon::st8(out_xy + i * 16, r.x);
+    canon::st8(out_xy + i * 16 + 8, r.y);
+    canon::st8(zbuf + i * 8, r.z);
     status[i] = lane_of(ok) ? CANON_FINITE : CANON_BAD_POINT;
   }
 }
 
 // Phase 2: Jacobian -> affine in place, one inversion per NORM_GROUP elements per lane.
-__global__ __launch_bounds__(TPB, 2) void k_csecp_normalize(u32* __restrict__ xy, const u32* __restrict__ zbuf,
+template <class W>
+__global__ __launch_bounds__(TPB, 2) void k_canon_normalize(u32* __restrict__ xy, const u32* __restrict__ zbuf,
                                                          unsigned char* __restrict__ status, size_t n,
                                                          size_t stride) {
   const size_t g = (size_t)blockIdx.x * TPB + threadIdx.x;
-  if (g < stride) csecp::normalize_group(xy, zbuf, status, g, stride, n);
+  if (g < stride) W::normalize_group(xy, zbuf, status, g, stride, n);
 }
 
 // canonical field ops for tests and callers: op = fec_field_opcode, plus FEC_F_NEG + 1 = inverse
-__global__ __launch_bounds__(TPB) void k_csecp_field_op(int op, const u32* __restrict__ a,
+template <class W>
+__global__ __launch_bounds__(TPB) void k_canon_field_op(int op, const u32* __restrict__ a,
                                                         const u32* __restrict__ b, u32* __restrict__ out,
                                                         size_t n) {
   __shared__ u32 lds_a[8 * TPB];
@@ -120,12 +125,12 @@ __global__ __launch_bounds__(TPB) void k_csecp_field_op(int op, const u32* __res
     fe y = b ? load_fe(lds_b + e, TPB) : fe_zero();
     fe r;
     switch (op) {
-      case FEC_F_ADD: r = csecp::add(x, y); break;
-      case FEC_F_SUB: r = csecp::sub(x, y); break;
-      case FEC_F_MUL: r = csecp::mul(x, y); break;
-      case FEC_F_SQR: r = csecp::sqr(x); break;
-      case FEC_F_NEG: r = csecp::neg(x); break;
-      default: r = csecp::inv(x); break;
+      case FEC_F_ADD: r = W::add(x, y); break;
+      case FEC_F_SUB: r = W::sub(x, y); break;
+      case FEC_F_MUL: r = W::mul(x, y); break;
+      case FEC_F_SQR: r = W::sqr(x); break;
+      case FEC_F_NEG: r = W::neg(x); break;
+      default: r = W::inv(x); break;
     }
     store_fe(lds_a + e, TPB, r);
   }

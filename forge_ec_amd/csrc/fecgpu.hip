@@ -738,8 +738,8 @@ struct fec_ctx {
   bool ed_table_valid = false;
   u64 h_gen_ed[16] = {0};                       // host copy of the Ed25519 generator (table cache key)
   // canonical-math mode: comb table of affine multiples of G, per-element window-table scratch
-  u32* d_csecp_comb = nullptr;
-  bool csecp_comb_ready = false;
+  u32* d_canon_comb[2] = {nullptr, nullptr};   // per curve: secp256k1, P-256
+  bool canon_comb_ready[2] = {false, false};
   void* d_win_scratch = nullptr;
   size_t win_scratch_cap = 0;
   void* d_zbuf = nullptr;  // Jacobian Z of the batch between the ladder and the batched normalisation
@@ -1007,21 +1007,24 @@ int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, siz
 }
 
 // ---- canonical-math mode -------------------------------------------------------------------
-int ensure_csecp_comb(fec_ctx* ctx, hipStream_t s) {
-  if (ctx->csecp_comb_ready) return FEC_OK;
-  if (!ctx->d_csecp_comb &&
-      hipMalloc(&ctx->d_csecp_comb, (size_t)csecp::COMB_WORDS * sizeof(u32)) != hipSuccess) {
+inline bool canon_curve_ok(int c) { return c == FEC_SECP256K1 || c == FEC_P256; }
+
+int ensure_canon_comb(fec_ctx* ctx, int curve, hipStream_t s) {
+  if (ctx->canon_comb_ready[curve]) return FEC_OK;
+  if (!ctx->d_canon_comb[curve] &&
+      hipMalloc(&ctx->d_canon_comb[curve], (size_t)canon::COMB_WORDS * sizeof(u32)) != hipSuccess) {
     (void)hipGetLastError();
     return FEC_E_OOM;
   }
-  hipLaunchKernelGGL(k_csecp_build_comb, dim3(1), dim3(64), 0, s, ctx->d_csecp_comb);
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_build_comb<csecp>), dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
+  else hipLaunchKernelGGL((k_canon_build_comb<cp256>), dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
   if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
   // the table is read by kernels on either pipeline stream: finish it before anyone can race
   if (hipStreamSynchronize(s) != hipSuccess) {
     (void)hipGetLastError();
     return FEC_E_LAUNCH;
   }
-  ctx->csecp_comb_ready = true;
+  ctx->canon_comb_ready[curve] = true;
   return FEC_OK;
 }
 
@@ -1040,40 +1043,50 @@ int ensure_owned(void** buf, size_t* cap, size_t need) {
   return FEC_OK;
 }
 
-int launch_csecp_normalize(fec_ctx* ctx, u64* dxy, unsigned char* dst, size_t n, hipStream_t s) {
-  const size_t lanes = (n + csecp::NORM_GROUP - 1) / csecp::NORM_GROUP;
+int launch_canon_normalize(fec_ctx* ctx, int curve, u64* dxy, unsigned char* dst, size_t n, hipStream_t s) {
+  const size_t lanes = (n + canon::NORM_GROUP - 1) / canon::NORM_GROUP;
   const size_t stride = (lanes + 63) / 64 * 64;
-  hipLaunchKernelGGL(k_csecp_normalize, dim3(grid_for(stride)), dim3(TPB), 0, s, reinterpret_cast<u32*>(dxy),
-                     reinterpret_cast<const u32*>(ctx->d_zbuf), dst, n, stride);
+  u32* xy = reinterpret_cast<u32*>(dxy);
+  const u32* z = reinterpret_cast<const u32*>(ctx->d_zbuf);
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_normalize<csecp>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
+  else hipLaunchKernelGGL((k_canon_normalize<cp256>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
   return hipGetLastError() == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
 }
 
-int launch_csecp_mul_base(fec_ctx* ctx, const u64* ds, u64* dxy, unsigned char* dst, size_t n, void* stream) {
+int launch_canon_mul_base(fec_ctx* ctx, int curve, const u64* ds, u64* dxy, unsigned char* dst, size_t n,
+                          void* stream) {
   if (n == 0) return FEC_OK;
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-  int rc = ensure_csecp_comb(ctx, s);
+  int rc = ensure_canon_comb(ctx, curve, s);
   if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
   if (rc != FEC_OK) return rc;
-  Launch L(ctx, stream, "k_csecp_mul_base+k_csecp_normalize");
-  hipLaunchKernelGGL(k_csecp_mul_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(ds),
-                     ctx->d_csecp_comb, reinterpret_cast<u32*>(dxy), reinterpret_cast<u32*>(ctx->d_zbuf), dst, n);
-  rc = launch_csecp_normalize(ctx, dxy, dst, n, L.s);
+  Launch L(ctx, stream, "k_canon_mul_base+k_canon_normalize");
+  const u32* k = reinterpret_cast<const u32*>(ds);
+  u32* xy = reinterpret_cast<u32*>(dxy);
+  u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul_base<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
+  else hipLaunchKernelGGL((k_canon_mul_base<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
+  rc = launch_canon_normalize(ctx, curve, dxy, dst, n, L.s);
   int rc2 = L.done();
   return rc != FEC_OK ? rc : rc2;
 }
 
-int launch_csecp_mul(fec_ctx* ctx, const u64* ds, const u64* dp, u64* dxy, unsigned char* dst, size_t n,
+int launch_canon_mul(fec_ctx* ctx, int curve, const u64* ds, const u64* dp, u64* dxy, unsigned char* dst, size_t n,
                      void* stream) {
   if (n == 0) return FEC_OK;
   int rc = ensure_owned(&ctx->d_win_scratch, &ctx->win_scratch_cap,
-                        n * (size_t)(csecp::WIN_ENTRIES * csecp::WIN_ENTRY_WORDS) * sizeof(u32));
+                        n * (size_t)(canon::WIN_ENTRIES * canon::WIN_ENTRY_WORDS) * sizeof(u32));
   if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
   if (rc != FEC_OK) return rc;
-  Launch L(ctx, stream, "k_csecp_mul+k_csecp_normalize");
-  hipLaunchKernelGGL(k_csecp_mul, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(ds),
-                     reinterpret_cast<const u32*>(dp), reinterpret_cast<u32*>(ctx->d_win_scratch),
-                     reinterpret_cast<u32*>(dxy), reinterpret_cast<u32*>(ctx->d_zbuf), dst, n);
-  rc = launch_csecp_normalize(ctx, dxy, dst, n, L.s);
+  Launch L(ctx, stream, "k_canon_mul+k_canon_normalize");
+  const u32* k = reinterpret_cast<const u32*>(ds);
+  const u32* p = reinterpret_cast<const u32*>(dp);
+  u32* scratch = reinterpret_cast<u32*>(ctx->d_win_scratch);
+  u32* xy = reinterpret_cast<u32*>(dxy);
+  u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
+  else hipLaunchKernelGGL((k_canon_mul<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
+  rc = launch_canon_normalize(ctx, curve, dxy, dst, n, L.s);
   int rc2 = L.done();
   return rc != FEC_OK ? rc : rc2;
 }
@@ -1192,7 +1205,8 @@ void fec_ctx_destroy(fec_ctx* ctx) {
   for (int i = 0; i < 3; ++i)
     if (ctx->d_gen[i]) (void)hipFree(ctx->d_gen[i]);
   if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
-  if (ctx->d_csecp_comb) (void)hipFree(ctx->d_csecp_comb);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->d_canon_comb[i]) (void)hipFree(ctx->d_canon_comb[i]);
   if (ctx->d_win_scratch) (void)hipFree(ctx->d_win_scratch);
   if (ctx->d_zbuf) (void)hipFree(ctx->d_zbuf);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1564,51 +1578,56 @@ int fec_ctx_device_info(fec_ctx* ctx, char* name, size_t name_len, int* compute_
 }
 
 // ---- canonical-math mode (include/fecgpu_canon.h): NOT reference parity ----------------------
-int fec_canon_secp256k1_mul_base_dev(fec_ctx* ctx, const uint64_t* d_scalars, uint64_t* d_out_xy,
-                                     uint8_t* d_status, size_t n, void* stream) {
+int fec_canon_mul_base_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, uint64_t* d_out_xy,
+                           uint8_t* d_status, size_t n, void* stream) {
   if (!ctx || (n && (!d_scalars || !d_out_xy || !d_status))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (!aligned16(d_scalars) || !aligned16(d_out_xy)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  return launch_csecp_mul_base(ctx, d_scalars, d_out_xy, d_status, n, stream);
+  return launch_canon_mul_base(ctx, curve, d_scalars, d_out_xy, d_status, n, stream);
 }
 
-int fec_canon_secp256k1_mul_base(fec_ctx* ctx, const uint64_t* scalars, uint64_t* out_xy, uint8_t* status,
-                                 size_t n) {
+int fec_canon_mul_base(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, uint64_t* out_xy, uint8_t* status,
+                       size_t n) {
   if (!ctx || (n && (!scalars || !out_xy || !status))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (n == 0) return FEC_OK;
   const void* const in[3] = {scalars, nullptr, nullptr};
   const size_t in_bytes[3] = {n * 32, 0, 0};
   void* const out[2] = {out_xy, status};
   const size_t out_bytes[2] = {n * 64, n};
   return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void*, void*, void* o, void* st) {
-    return launch_csecp_mul_base(ctx, (const u64*)a, (u64*)o, (unsigned char*)st, n, nullptr);
+    return launch_canon_mul_base(ctx, curve, (const u64*)a, (u64*)o, (unsigned char*)st, n, nullptr);
   });
 }
 
-int fec_canon_secp256k1_mul_dev(fec_ctx* ctx, const uint64_t* d_scalars, const uint64_t* d_points_xy,
-                                uint64_t* d_out_xy, uint8_t* d_status, size_t n, void* stream) {
+int fec_canon_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, const uint64_t* d_points_xy,
+                      uint64_t* d_out_xy, uint8_t* d_status, size_t n, void* stream) {
   if (!ctx || (n && (!d_scalars || !d_points_xy || !d_out_xy || !d_status))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (!aligned16(d_scalars) || !aligned16(d_points_xy) || !aligned16(d_out_xy)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  return launch_csecp_mul(ctx, d_scalars, d_points_xy, d_out_xy, d_status, n, stream);
+  return launch_canon_mul(ctx, curve, d_scalars, d_points_xy, d_out_xy, d_status, n, stream);
 }
 
-int fec_canon_secp256k1_mul(fec_ctx* ctx, const uint64_t* scalars, const uint64_t* points_xy, uint64_t* out_xy,
-                            uint8_t* status, size_t n) {
+int fec_canon_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points_xy,
+                  uint64_t* out_xy, uint8_t* status, size_t n) {
   if (!ctx || (n && (!scalars || !points_xy || !out_xy || !status))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (n == 0) return FEC_OK;
   const void* const in[3] = {scalars, points_xy, nullptr};
   const size_t in_bytes[3] = {n * 32, n * 64, 0};
   void* const out[2] = {out_xy, status};
   const size_t out_bytes[2] = {n * 64, n};
   return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void* b, void*, void* o, void* st) {
-    return launch_csecp_mul(ctx, (const u64*)a, (const u64*)b, (u64*)o, (unsigned char*)st, n, nullptr);
+    return launch_canon_mul(ctx, curve, (const u64*)a, (const u64*)b, (u64*)o, (unsigned char*)st, n, nullptr);
   });
 }
 
-int fec_canon_secp256k1_field_op(fec_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
-                                 size_t n) {
+int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
+                       size_t n) {
   if (!ctx || op < FEC_F_ADD || op > FEC_F_INV || (n && (!a || !out))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   const bool binary = op == FEC_F_ADD || op == FEC_F_SUB || op == FEC_F_MUL;
   if (binary && n && !b) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
@@ -1617,9 +1636,9 @@ int fec_canon_secp256k1_field_op(fec_ctx* ctx, int op, const uint64_t* a, const 
   void* const outs[2] = {out, nullptr};
   const size_t out_bytes[2] = {n * 32, 0};
   return host_oneshot(ctx, in, in_bytes, outs, out_bytes, [&](void* x, void* y, void*, void* o, void*) {
-    Launch L(ctx, nullptr, "k_csecp_field_op");
-    hipLaunchKernelGGL(k_csecp_field_op, dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y,
-                       (u32*)o, n);
+    Launch L(ctx, nullptr, "k_canon_field_op");
+    if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_field_op<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
+    else hipLaunchKernelGGL((k_canon_field_op<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
     return L.done();
   });
 }

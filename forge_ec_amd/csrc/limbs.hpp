@@ -98,6 +98,10 @@ FEC_DEV lmask sub256(fe& r, const fe& a, const fe& b) {
   }
   return bo ? ~0ull : 0ull;
 }
+// r = a + b mod 2^256, top += carry-out;  r = a - b mod 2^256, top -= borrow-out
+FEC_DEV void add256c(fe& r, const fe& a, const fe& b, u32& top) { top += add256(r, a, b) ? 1u : 0u; }
+FEC_DEV void sub256c(fe& r, const fe& a, const fe& b, u32& top) { top -= sub256(r, a, b) ? 1u : 0u; }
+#define FEC_SDEV static inline
 FEC_DEV fe fe_k8(u32 k0, u32 k1, u32 k2, u32 k3, u32 k4, u32 k5, u32 k6, u32 k7) {
   fe k;
   k.w[0] = k0; k.w[1] = k1; k.w[2] = k2; k.w[3] = k3; k.w[4] = k4; k.w[5] = k5; k.w[6] = k6; k.w[7] = k7;
@@ -167,6 +171,41 @@ FEC_DEV lmask sub256(fe& r, const fe& a, const fe& b) {
   r = x;
   return c;
 }
+// r = a + b mod 2^256 and top += carry-out, the carry absorbed by a ninth chain instruction
+FEC_DEV void add256c(fe& r, const fe& a, const fe& b, u32& top) {
+  fe x = a;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %9\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %10, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, %2, %11, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, %3, %12, vcc\n\t"
+      "v_addc_co_u32_e32 %4, vcc, %4, %13, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, %5, %14, vcc\n\t"
+      "v_addc_co_u32_e32 %6, vcc, %6, %15, vcc\n\t"
+      "v_addc_co_u32_e32 %7, vcc, %7, %16, vcc\n\t"
+      "v_addc_co_u32_e32 %8, vcc, 0, %8, vcc"
+      : FEC_RW8(x), "+v"(top)
+      : FEC_V8(b)
+      : "vcc");
+  r = x;
+}
+// r = a - b mod 2^256 and top -= borrow-out
+FEC_DEV void sub256c(fe& r, const fe& a, const fe& b, u32& top) {
+  fe x = a;
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %9\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %1, %10, vcc\n\t"
+      "v_subb_co_u32_e32 %2, vcc, %2, %11, vcc\n\t"
+      "v_subb_co_u32_e32 %3, vcc, %3, %12, vcc\n\t"
+      "v_subb_co_u32_e32 %4, vcc, %4, %13, vcc\n\t"
+      "v_subb_co_u32_e32 %5, vcc, %5, %14, vcc\n\t"
+      "v_subb_co_u32_e32 %6, vcc, %6, %15, vcc\n\t"
+      "v_subb_co_u32_e32 %7, vcc, %7, %16, vcc\n\t"
+      "v_subbrev_co_u32_e32 %8, vcc, 0, %8, vcc"
+      : FEC_RW8(x), "+v"(top)
+      : FEC_V8(b)
+      : "vcc");
+  r = x;
+}
+#define FEC_SDEV __device__ __forceinline__ static
 // r = a + K, K = {k0..k7} compile-time words riding in the VOP2 src0 slot (no registers).  k0 may
 // be any 32-bit literal; k1..k7 must be inline constants (-16..64): a literal plus the VCC
 // carry-in would be two constant-bus reads.  c receives the carry-out mask.

@@ -16,16 +16,20 @@ from oracle import canon_model as M
 
 pytestmark = pytest.mark.gpu
 
-SCALARS = [0, 1, 2, 3, 15, 16, 17, 2**32 - 1, 2**64, 2**128 - 1, 2**255, M.N - 1, M.N, M.N + 1, M.N + 16,
-           2**256 - 1, 2 * M.N % 2**256, 0x1111111111111111111111111111111111111111111111111111111111111111,
-           0xF0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0,
-           0xC9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721]
 
 
-@pytest.fixture(scope="module")
-def canon(gpu_ctx):
-    from forge_ec_amd.canon import CanonSecp256k1
-    return CanonSecp256k1(gpu_ctx)
+def scalars_of(C):
+    return [0, 1, 2, 3, 15, 16, 17, 2**32 - 1, 2**64, 2**128 - 1, 2**255, C.N - 1, C.N, C.N + 1, C.N + 16,
+            2**256 - 1, 2 * C.N % 2**256, 0x1111111111111111111111111111111111111111111111111111111111111111,
+            0xF0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0,
+            0xC9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721]
+
+
+@pytest.fixture(scope="module", params=["secp256k1", "p256"])
+def canon(request, gpu_ctx):
+    """(device wrapper, big-integer model) of one curve"""
+    from forge_ec_amd.canon import CANON_CURVES
+    return CANON_CURVES[request.param](gpu_ctx), M.CURVES[request.param]
 
 
 def _arr(vals):
@@ -37,64 +41,72 @@ def _pts(xy, st):
 
 
 def test_field_ops_match_the_model(canon):
+    canon, C = canon
     from forge_ec_amd import _lib as L
     rng = random.Random(1)
-    edge = [0, 1, 2, 977, 2**32 + 977, 2**255, M.P - 1, M.P - 2, M.P - 977, M.P - 2**32, 2**224 - 1, M.P - 2**224]
-    a = [x for x in edge for _ in edge] + [rng.randrange(M.P) for _ in range(4000)]
-    b = [y for _ in edge for y in edge] + [rng.randrange(M.P) for _ in range(4000)]
+    edge = sorted({v % C.P for v in [0, 1, 2, 977, 2**32 + 977, 2**255, C.P - 1, C.P - 2, C.P - 977, C.P - 2**32, 2**224 - 1, C.P - 2**224, 2**96, C.P - 2**96, 2**192, 2**256 - C.P]})
+    a = [x for x in edge for _ in edge] + [rng.randrange(C.P) for _ in range(4000)]
+    b = [y for _ in edge for y in edge] + [rng.randrange(C.P) for _ in range(4000)]
     A, B = _arr(a), _arr(b)
     for name, op in (("add", L.F_ADD), ("sub", L.F_SUB), ("mul", L.F_MUL), ("sqr", L.F_SQR), ("neg", L.F_NEG),
                      ("inv", L.F_INV)):
         out = canon.field_op(op, A, B if name in ("add", "sub", "mul") else None)
         for i in range(len(a)):
-            assert M.unlimbs(out[i]) == M.field_op(name, a[i], b[i]), (name, hex(a[i]), hex(b[i]))
+            assert M.unlimbs(out[i]) == C.field_op(name, a[i], b[i]), (name, hex(a[i]), hex(b[i]))
 
 
-def test_published_multiples_of_g(canon):
-    ks = sorted(M.KNOWN_MULTIPLES)
+def test_published_points(canon):
+    canon, C = canon
+    ks = sorted(C.KNOWN_MULTIPLES)
     xy, st = canon.mul_base(_arr(ks))
     assert not st.any()
-    assert _pts(xy, st) == [M.KNOWN_MULTIPLES[k] for k in ks]
-    g = np.array([M.xy_limbs(M.G)] * len(ks), dtype=np.uint64)
+    assert _pts(xy, st) == [C.KNOWN_MULTIPLES[k] for k in ks]
+    g = np.array([M.xy_limbs(C.G)] * len(ks), dtype=np.uint64)
     xy2, st2 = canon.mul(_arr(ks), g)
     assert np.array_equal(xy, xy2) and not st2.any()
 
 
 def test_mul_base_matches_the_model(canon):
+    canon, C = canon
+    SCALARS = scalars_of(C)
     rng = random.Random(2)
     ks = SCALARS + [rng.randrange(2**256) for _ in range(700)]  # ragged: 720 = 2 workgroups + tail
     xy, st = canon.mul_base(_arr(ks))
     got = _pts(xy, st)
     for i, k in enumerate(ks):
-        assert got[i] == M.mul(k % M.N, M.G), hex(k)
+        assert got[i] == C.mul(k % C.N, C.G), hex(k)
         if st[i] == 1:
             assert not xy[i].any()
-    assert st[0] == 1 and st[SCALARS.index(M.N)] == 1
+    assert st[0] == 1 and st[SCALARS.index(C.N)] == 1
 
 
 def test_mul_variable_base_matches_the_model(canon):
+    canon, C = canon
+    SCALARS = scalars_of(C)
     rng = random.Random(3)
     ks = SCALARS + [rng.randrange(2**256) for _ in range(280)]
-    base = [M.mul(rng.randrange(1, M.N), M.G) for _ in range(20)]
+    base = [C.mul(rng.randrange(1, C.N), C.G) for _ in range(20)]
     pts = [base[i % 20] for i in range(len(ks))]
     xy, st = canon.mul(_arr(ks), np.array([M.xy_limbs(p) for p in pts], dtype=np.uint64))
     got = _pts(xy, st)
     for i, k in enumerate(ks):
         assert st[i] in (0, 1)
-        assert got[i] == M.mul(k % M.N, pts[i]), (hex(k), pts[i])
+        assert got[i] == C.mul(k % C.N, pts[i]), (hex(k), pts[i])
 
 
 def test_bad_points_are_rejected(canon):
-    x, y = M.G
-    bad = [(x, (y + 1) % M.P), (M.P, y), (0, 0), (x, M.P), (2**256 - 1, 2**256 - 1)]
-    good = M.mul(5, M.G)
+    canon, C = canon
+    x, y = C.G
+    bad = [(x, (y + 1) % C.P), (C.P, y), (0, 0), (x, C.P), (2**256 - 1, 2**256 - 1)]
+    good = C.mul(5, C.G)
     pts = np.array([M.limbs(p[0]) + M.limbs(p[1]) for p in bad] + [M.xy_limbs(good)], dtype=np.uint64)
     xy, st = canon.mul(_arr([7] * len(pts)), pts)
     assert list(st[:-1]) == [2] * len(bad) and not xy[:-1].any()
-    assert st[-1] == 0 and _pts(xy[-1:], st[-1:])[0] == M.mul(35, M.G)
+    assert st[-1] == 0 and _pts(xy[-1:], st[-1:])[0] == C.mul(35, C.G)
 
 
 def test_empty_and_argument_errors(canon):
+    canon, C = canon
     import forge_ec_amd as F
     xy, st = canon.mul_base(np.zeros((0, 4), dtype=np.uint64))
     assert xy.shape == (0, 8) and st.shape == (0,)
@@ -105,6 +117,7 @@ def test_empty_and_argument_errors(canon):
 
 
 def test_full_size_comb_equals_window_and_ecdh_is_symmetric(canon):
+    canon, C = canon
     """2^20 elements, device-resident: k*G by comb == k*G by the windowed ladder on G; a*(b*G) == b*(a*G);
     a seeded sample against the model."""
     import torch
@@ -123,7 +136,7 @@ def test_full_size_comb_equals_window_and_ecdh_is_symmetric(canon):
     torch.cuda.synchronize()
     assert int(sA.sum()) == 0 and int(sB.sum()) == 0
     # comb vs window on the generator
-    g = torch.from_numpy(np.tile(np.array(M.xy_limbs(M.G), dtype=np.uint64), (n, 1)).view(np.int64)).cuda()
+    g = torch.from_numpy(np.tile(np.array(M.xy_limbs(C.G), dtype=np.uint64), (n, 1)).view(np.int64)).cuda()
     A2 = torch.empty_like(A)
     s2 = torch.empty_like(sA)
     canon.mul_dev(da.data_ptr(), g.data_ptr(), A2.data_ptr(), s2.data_ptr(), n, st_)
@@ -143,6 +156,6 @@ def test_full_size_comb_equals_window_and_ecdh_is_symmetric(canon):
     Sh = S1.cpu().numpy().view(np.uint64)
     for i in idx:
         ka, kb = M.unlimbs(a[i]), M.unlimbs(b[i])
-        pa = M.mul(ka % M.N, M.G)
+        pa = C.mul(ka % C.N, C.G)
         assert (M.unlimbs(Ah[i, :4]), M.unlimbs(Ah[i, 4:])) == pa
-        assert (M.unlimbs(Sh[i, :4]), M.unlimbs(Sh[i, 4:])) == M.mul(kb % M.N, pa)
+        assert (M.unlimbs(Sh[i, :4]), M.unlimbs(Sh[i, 4:])) == C.mul(kb % C.N, pa)

@@ -2,7 +2,7 @@
 HIP events inside the library for secp256k1 key generation (k*G, comb) and ECDH (k*P, windowed),
 inputs resident in HBM.  One JSON line per workload.
 
-    python tools/canon_perf.py [log2_n] [reps]
+    python tools/canon_perf.py [log2_n] [reps] [curve,...]
 """
 import json
 import os
@@ -16,7 +16,7 @@ import torch  # noqa: E402
 
 import forge_ec_amd as F  # noqa: E402
 from forge_ec_amd import synth  # noqa: E402
-from forge_ec_amd.canon import CanonSecp256k1  # noqa: E402
+from forge_ec_amd.canon import CANON_CURVES  # noqa: E402
 
 # field multiplications per unit (each = 64 MAD32 for the 512-bit product + 8 for the fold)
 MULS = {"keygen": 64 * 11 + 274, "ecdh": 7 + 13 * 11 + 64 * (4 * 7 + 16) + 274 + 5}
@@ -26,9 +26,9 @@ MAD_PER_MUL = 72
 def main():
     logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    curves = sys.argv[3].split(",") if len(sys.argv) > 3 else list(CANON_CURVES)
     n = 1 << logn
     ctx = F.Context(0)
-    c = CanonSecp256k1(ctx)
     ctx.set_timing(True)
     st = torch.cuda.current_stream().cuda_stream
     k = torch.from_numpy(synth.scalars(n, 0, 41).view(np.int64)).cuda()
@@ -36,22 +36,23 @@ def main():
     pub = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     out = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     status = torch.empty(n, dtype=torch.uint8, device="cuda")
-    for name in ("keygen", "ecdh"):
-        best = None
-        for _ in range(reps + 1):
-            if name == "keygen":
-                c.mul_base_dev(k.data_ptr(), pub.data_ptr(), status.data_ptr(), n, st)
-            else:
-                c.mul_dev(k2.data_ptr(), pub.data_ptr(), out.data_ptr(), status.data_ptr(), n, st)
-            ms, kern = ctx.last_kernel_ms()
-            best = ms if best is None or ms < best else best
-        torch.cuda.synchronize()
-        assert int(status.sum()) == 0
-        rate = n / (best * 1e-3)
-        print(json.dumps({"workload": "secp256k1-canon-" + name, "mode": "canonical math, NOT reference parity",
-                          "n": n, "kernel": kern, "ms": round(best, 4), "M_per_s": round(rate / 1e6, 3),
-                          "field_muls_per_unit": MULS[name],
-                          "TMAD32_per_s": round(rate * MULS[name] * MAD_PER_MUL / 1e12, 3)}), flush=True)
+    for cname in curves:
+        c = CANON_CURVES[cname](ctx)
+        for name in ("keygen", "ecdh"):
+            best = None
+            for _ in range(reps + 1):
+                if name == "keygen":
+                    c.mul_base_dev(k.data_ptr(), pub.data_ptr(), status.data_ptr(), n, st)
+                else:
+                    c.mul_dev(k2.data_ptr(), pub.data_ptr(), out.data_ptr(), status.data_ptr(), n, st)
+                ms, kern = ctx.last_kernel_ms()
+                best = ms if best is None or ms < best else best
+            torch.cuda.synchronize()
+            assert int(status.sum()) == 0
+            rate = n / (best * 1e-3)
+            print(json.dumps({"workload": "%s-canon-%s" % (cname, name), "mode": "canonical math, NOT reference parity",
+                              "n": n, "kernel": kern, "ms": round(best, 4), "M_per_s": round(rate / 1e6, 3)}),
+                  flush=True)
 
 
 main()

@@ -73,77 +73,115 @@ extern "C" int he_secp_scalar_op(int op, const uint64_t* a, const uint64_t* b, u
   return 0;
 }
 
-// ---- canonical-math mode (canon_secp256k1.hpp): checked against oracle/canon_model.py ----
-#include "../forge_ec_amd/csrc/canon_secp256k1.hpp"
-// op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 inv
-extern "C" int he_canon_field_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+// ---- canonical-math mode (canon_curves.hpp): checked against oracle/canon_model.py ----
+// curve: 0 = secp256k1, 1 = P-256
+#include "../forge_ec_amd/csrc/canon_curves.hpp"
+#define CANON_DISPATCH(curve, CALL) ((curve) == 0 ? CALL(csecp) : CALL(cp256))
+
+template <class W>
+static int t_field_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
   fe x = ld(a), y = b ? ld(b) : fe_zero(), r;
-  r = op == 0 ? csecp::add(x, y) : op == 1 ? csecp::sub(x, y) : op == 2 ? csecp::mul(x, y)
-    : op == 3 ? csecp::sqr(x) : op == 4 ? csecp::neg(x) : csecp::inv(x);
+  r = op == 0 ? W::add(x, y) : op == 1 ? W::sub(x, y) : op == 2 ? W::mul(x, y)
+    : op == 3 ? W::sqr(x) : op == 4 ? W::neg(x) : W::inv(x);
   st(out, r);
   return 0;
 }
-static u32* canon_comb_table() {
+// op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 inv
+extern "C" int he_canon_field_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+#define CALL(W) t_field_op<W>(op, a, b, out)
+  return CANON_DISPATCH(curve, CALL);
+#undef CALL
+}
+template <class W>
+static u32* t_comb_table() {
   static u32* tab = nullptr;
   if (!tab) {
-    tab = new u32[csecp::COMB_WORDS];
-    csecp::aff g = csecp::generator();
-    csecp::jac b; b.x = g.x; b.y = g.y; b.z = fe_small(1);
-    for (int i = 0; i < csecp::COMB_WINDOWS; ++i) {
-      csecp::aff base;
-      csecp::to_affine(b, base);
-      csecp::comb_fill_window(tab, i, base);
-      for (int d = 0; d < 4; ++d) b = csecp::jdouble(b);
+    tab = new u32[canon::COMB_WORDS];
+    canon::aff g = W::generator();
+    canon::jac b; b.x = g.x; b.y = g.y; b.z = fe_small(1);
+    for (int i = 0; i < canon::COMB_WINDOWS; ++i) {
+      canon::aff base;
+      W::to_affine(b, base);
+      W::comb_fill_window(tab, i, base);
+      for (int d = 0; d < 4; ++d) b = W::jdouble(b);
     }
   }
   return tab;
 }
-extern "C" const u32* he_canon_comb_table() { return canon_comb_table(); }
+extern "C" const u32* he_canon_comb_table(int curve) {
+#define CALL(W) t_comb_table<W>()
+  return CANON_DISPATCH(curve, CALL);
+#undef CALL
+}
 static void canon_kw(u32* kw, const uint64_t* scalar) {
   for (int i = 0; i < 4; ++i) { kw[(2*i) * KSTRIDE] = (u32)scalar[i]; kw[(2*i+1) * KSTRIDE] = (u32)(scalar[i] >> 32); }
 }
-// returns status: 0 finite, 1 infinity
-extern "C" int he_canon_mul_base(const uint64_t* scalar, uint64_t* xy) {
+template <class W>
+static int t_mul_base(const uint64_t* scalar, uint64_t* xy) {
   static thread_local u32 kw[8 * KSTRIDE];
   canon_kw(kw, scalar);
-  csecp::jac r = csecp::mul_base_comb(canon_comb_table(), kw);
-  csecp::aff a;
-  lmask inf = csecp::to_affine(r, a);
+  canon::jac r = W::mul_base_comb(t_comb_table<W>(), kw);
+  canon::aff a;
+  lmask inf = W::to_affine(r, a);
   st(xy, a.x); st(xy + 4, a.y);
   return inf ? 1 : 0;
 }
-// returns status: 0 finite, 1 infinity, 2 bad point
-extern "C" int he_canon_mul(const uint64_t* scalar, const uint64_t* pxy, uint64_t* xy) {
+// returns status: 0 finite, 1 infinity
+extern "C" int he_canon_mul_base(int curve, const uint64_t* scalar, uint64_t* xy) {
+#define CALL(W) t_mul_base<W>(scalar, xy)
+  return CANON_DISPATCH(curve, CALL);
+#undef CALL
+}
+template <class W>
+static int t_mul(const uint64_t* scalar, const uint64_t* pxy, uint64_t* xy) {
   static thread_local u32 kw[8 * KSTRIDE];
-  static thread_local u32 table[csecp::WIN_ENTRIES * csecp::WIN_ENTRY_WORDS];
+  static thread_local u32 table[canon::WIN_ENTRIES * canon::WIN_ENTRY_WORDS];
   canon_kw(kw, scalar);
-  csecp::aff base; base.x = ld(pxy); base.y = ld(pxy + 4);
-  lmask ok = csecp::on_curve(base);
-  csecp::jac r = csecp::mul_window(base, kw, table);
-  csecp::aff a;
-  lmask inf = csecp::to_affine(r, a);
+  canon::aff base; base.x = ld(pxy); base.y = ld(pxy + 4);
+  lmask ok = W::on_curve(base);
+  canon::jac r = W::mul_window(base, kw, table);
+  canon::aff a;
+  lmask inf = W::to_affine(r, a);
   if (!ok) { a.x = fe_zero(); a.y = fe_zero(); }
   st(xy, a.x); st(xy + 4, a.y);
   return !ok ? 2 : inf ? 1 : 0;
 }
-// Jacobian ops for exceptional-case tests: op 0 = jdouble, 1 = jadd (general), 2 = jadd_affine(p, q.xy), 3 = jadd_window
-extern "C" int he_canon_point_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* out_xy) {
-  csecp::jac a; a.x = ld(p); a.y = ld(p + 4); a.z = ld(p + 8);
-  csecp::jac b; if (q) { b.x = ld(q); b.y = ld(q + 4); b.z = ld(q + 8); }
-  csecp::jac r;
-  if (op == 0) r = csecp::jdouble(a);
-  else if (op == 1) r = csecp::jadd(a, b);
-  else if (op == 2) { csecp::aff qa; qa.x = b.x; qa.y = b.y; r = csecp::jadd_affine(a, qa, 0); }
-  else r = csecp::jadd_window(a, b, 0);
-  csecp::aff o;
-  lmask inf = csecp::to_affine(r, o);
+// returns status: 0 finite, 1 infinity, 2 bad point
+extern "C" int he_canon_mul(int curve, const uint64_t* scalar, const uint64_t* pxy, uint64_t* xy) {
+#define CALL(W) t_mul<W>(scalar, pxy, xy)
+  return CANON_DISPATCH(curve, CALL);
+#undef CALL
+}
+template <class W>
+static int t_point_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* out_xy) {
+  canon::jac a; a.x = ld(p); a.y = ld(p + 4); a.z = ld(p + 8);
+  canon::jac b; if (q) { b.x = ld(q); b.y = ld(q + 4); b.z = ld(q + 8); }
+  canon::jac r;
+  if (op == 0) r = W::jdouble(a);
+  else if (op == 1) r = W::jadd(a, b);
+  else if (op == 2) { canon::aff qa; qa.x = b.x; qa.y = b.y; r = W::jadd_affine(a, qa, 0); }
+  else r = W::jadd_window(a, b, 0);
+  canon::aff o;
+  lmask inf = W::to_affine(r, o);
   st(out_xy, o.x); st(out_xy + 4, o.y);
   return inf ? 1 : 0;
 }
-// the batched normalisation exactly as k_csecp_normalize drives it
-extern "C" int he_canon_normalize(uint32_t* xy, const uint32_t* zbuf, unsigned char* status, size_t n) {
-  const size_t lanes = (n + csecp::NORM_GROUP - 1) / csecp::NORM_GROUP;
+// Jacobian ops for exceptional-case tests: op 0 = jdouble, 1 = jadd (general), 2 = jadd_affine(p, q.xy), 3 = jadd_window
+extern "C" int he_canon_point_op(int curve, int op, const uint64_t* p, const uint64_t* q, uint64_t* out_xy) {
+#define CALL(W) t_point_op<W>(op, p, q, out_xy)
+  return CANON_DISPATCH(curve, CALL);
+#undef CALL
+}
+template <class W>
+static int t_normalize(uint32_t* xy, const uint32_t* zbuf, unsigned char* status, size_t n) {
+  const size_t lanes = (n + canon::NORM_GROUP - 1) / canon::NORM_GROUP;
   const size_t stride = (lanes + 63) / 64 * 64;
-  for (size_t g = 0; g < stride; ++g) csecp::normalize_group(xy, zbuf, status, g, stride, n);
+  for (size_t g = 0; g < stride; ++g) W::normalize_group(xy, zbuf, status, g, stride, n);
   return 0;
+}
+// the batched normalisation exactly as k_canon_normalize drives it
+extern "C" int he_canon_normalize(int curve, uint32_t* xy, const uint32_t* zbuf, unsigned char* status, size_t n) {
+#define CALL(W) t_normalize<W>(xy, zbuf, status, n)
+  return CANON_DISPATCH(curve, CALL);
+#undef CALL
 }

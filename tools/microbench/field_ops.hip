@@ -7,7 +7,7 @@
 #include "secp256k1.hpp"
 #include "p256.hpp"
 #include "ed25519.hpp"
-#include "canon_secp256k1.hpp"
+#include "canon_curves.hpp"
 using namespace fecgpu;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 constexpr int ITERS = 2000;
