@@ -1,7 +1,7 @@
 """
 Canonical-math mode over include/fecgpu_canon.h -- NOT reference parity.
 
-The real secp256k1 / P-256 groups (standard public keys / ECDH points), for callers who want results
+The real secp256k1 / P-256 / Ed25519 groups (standard public keys / ECDH points), for callers who want results
 other libraries agree with; forge-ec's own arithmetic does not produce them.
 Arrays are numpy uint64 little-endian limbs of the plain integers: scalars (n,4); affine points
 (n,8) = x then y; status (n,) uint8: 0 finite, 1 infinity (xy = 0), 2 input point rejected.
@@ -71,4 +71,9 @@ class CanonP256(CanonCurve):
     CURVE = L.P256
 
 
-CANON_CURVES = {"secp256k1": CanonSecp256k1, "p256": CanonP256}
+class CanonEd25519(CanonCurve):
+    """Ed25519 (RFC 8032): affine (x, y) of k*B / k*P; there is no point at infinity, status is 0 or 2."""
+    CURVE = L.ED25519
+
+
+CANON_CURVES = {"secp256k1": CanonSecp256k1, "p256": CanonP256, "ed25519": CanonEd25519}

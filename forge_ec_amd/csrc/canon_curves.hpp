@@ -11,6 +11,7 @@
 // standard vectors (SEC2 / BIP-340 multiples of G, the RFC 6979 A.2.5 key pair), never against
 // the reference.
 #pragma once
+#include "ed25519.hpp"
 #include "p256.hpp"
 #include "secp256k1.hpp"
 
@@ -376,6 +377,58 @@ constexpr unsigned char ST_FINITE = 0, ST_INFINITY = 1, ST_BAD_POINT = 2;
 constexpr int COMB_WINDOWS = 64, COMB_ENTRIES = 15, COMB_STRIDE = 17;
 constexpr int COMB_WORDS = COMB_WINDOWS * COMB_ENTRIES * COMB_STRIDE;
 
+// This lane's group: elements first, first + stride, ... (NORM_GROUP of them, those < n).
+// status[i] on entry: ST_BAD_POINT for rejected inputs, anything else is recomputed here.
+template <class F, bool JACOBIAN>
+FEC_DEV void normalize_group_t(u32* xy, const u32* zbuf, unsigned char* status, size_t first, size_t stride,
+                             size_t n) {
+  fe c[NORM_GROUP];
+  fe run = fe_small(1);
+  FEC_UNROLL for (int j = 0; j < NORM_GROUP; ++j) {
+    const size_t i = first + (size_t)j * stride;
+    fe z = fe_small(1);
+    if (i < n && status[i] != ST_BAD_POINT) z = ld8(zbuf + i * 8);
+    z = fe_select(z, fe_small(1), fe_is_zero(z));
+    run = j == 0 ? z : F::mul(run, z);
+    c[j] = run;
+  }
+  fe u = F::inv(run);
+#pragma unroll 1
+  for (int j = NORM_GROUP - 1; j >= 0; --j) {
+    const size_t i = first + (size_t)j * stride;
+    const bool live = i < n;
+    fe z = fe_small(1);
+    bool bad = false;
+    if (live) {
+      bad = status[i] == ST_BAD_POINT;
+      if (!bad) z = ld8(zbuf + i * 8);
+    }
+    const lmask zero = fe_is_zero(z);
+    z = fe_select(z, fe_small(1), zero);
+    fe prev = fe_small(1);
+    FEC_UNROLL for (int t = 0; t < NORM_GROUP - 1; ++t) prev = fe_select(prev, c[t], lanes_where(t == j - 1));
+    fe zi = F::mul(u, prev);  // 1 / z_j
+    u = F::mul(u, z);
+    if (live) {
+      fe x = ld8(xy + i * 16), y = ld8(xy + i * 16 + 8);
+      if (JACOBIAN) {  // x = X / Z^2, y = Y / Z^3
+        fe zi2 = F::sqr(zi);
+        x = F::mul(x, zi2);
+        y = F::mul(F::mul(y, zi2), zi);
+      } else {         // x = X / Z, y = Y / Z
+        x = F::mul(x, zi);
+        y = F::mul(y, zi);
+      }
+      const lmask wipe = zero | lanes_where(bad);
+      x = fe_select(x, fe_zero(), wipe);
+      y = fe_select(y, fe_zero(), wipe);
+      st8(xy + i * 16, x);
+      st8(xy + i * 16 + 8, y);
+      status[i] = bad ? ST_BAD_POINT : (lane_of(zero) ? ST_INFINITY : ST_FINITE);
+    }
+  }
+}
+
 // ---- short Weierstrass curve y^2 = x^3 + a x + b with a in {0, -3}, Jacobian coordinates --------
 // P supplies: F (the field), A_IS_ZERO, b(), generator().
 template <class P>
@@ -539,50 +592,9 @@ FEC_SDEV jac mul_window(const aff& base, const u32* kw, u32* table /* this lane'
   return acc;
 }
 
-// This lane's group: elements first, first + stride, ... (NORM_GROUP of them, those < n).
-// status[i] on entry: ST_BAD_POINT for rejected inputs, anything else is recomputed here.
 FEC_SDEV void normalize_group(u32* xy, const u32* zbuf, unsigned char* status, size_t first, size_t stride,
-                             size_t n) {
-  fe c[NORM_GROUP];
-  fe run = fe_small(1);
-  FEC_UNROLL for (int j = 0; j < NORM_GROUP; ++j) {
-    const size_t i = first + (size_t)j * stride;
-    fe z = fe_small(1);
-    if (i < n && status[i] != ST_BAD_POINT) z = ld8(zbuf + i * 8);
-    z = fe_select(z, fe_small(1), fe_is_zero(z));
-    run = j == 0 ? z : mul(run, z);
-    c[j] = run;
-  }
-  fe u = inv(run);
-#pragma unroll 1
-  for (int j = NORM_GROUP - 1; j >= 0; --j) {
-    const size_t i = first + (size_t)j * stride;
-    const bool live = i < n;
-    fe z = fe_small(1);
-    bool bad = false;
-    if (live) {
-      bad = status[i] == ST_BAD_POINT;
-      if (!bad) z = ld8(zbuf + i * 8);
-    }
-    const lmask zero = fe_is_zero(z);
-    z = fe_select(z, fe_small(1), zero);
-    fe prev = fe_small(1);
-    FEC_UNROLL for (int t = 0; t < NORM_GROUP - 1; ++t) prev = fe_select(prev, c[t], lanes_where(t == j - 1));
-    fe zi = mul(u, prev);  // 1 / z_j
-    u = mul(u, z);
-    if (live) {
-      fe x = ld8(xy + i * 16), y = ld8(xy + i * 16 + 8);
-      fe zi2 = sqr(zi);
-      x = mul(x, zi2);
-      y = mul(mul(y, zi2), zi);
-      const lmask wipe = zero | lanes_where(bad);
-      x = fe_select(x, fe_zero(), wipe);
-      y = fe_select(y, fe_zero(), wipe);
-      st8(xy + i * 16, x);
-      st8(xy + i * 16 + 8, y);
-      status[i] = bad ? ST_BAD_POINT : (lane_of(zero) ? ST_INFINITY : ST_FINITE);
-    }
-  }
+                               size_t n) {
+  normalize_group_t<F, true>(xy, zbuf, status, first, stride, n);
 }
 
 FEC_SDEV aff comb_entry(const u32* tab, int window, u32 digit /* 1..15 */) {
@@ -678,7 +690,347 @@ struct P256Params {
   }
 };
 
+// ================================================================================================
+// Ed25519:  -x^2 + y^2 = 1 + d x^2 y^2  over p = 2^255 - 19  (RFC 8032), extended coordinates
+// ================================================================================================
+struct FpEd {
+  // the reference's Add / Sub / Neg are the textbook forms and correct modulo p (ed25519.rs:458-520, 547-570)
+  FEC_SDEV fe add(const fe& a, const fe& b) { return ed::add(a, b); }
+  FEC_SDEV fe sub(const fe& a, const fe& b) { return ed::sub(a, b); }
+  FEC_SDEV fe neg(const fe& a) { return ed::neg(a); }
+  FEC_SDEV lmask ge_p(const fe& v) {  // v >= p  <=>  v + 19 reaches 2^255
+    fe u;
+    lmask c = add_word256(u, v, 19u);
+    return c | lanes_where((u.w[7] >> 31) != 0);
+  }
+  // t (512 bits) mod p.  2^256 = 38: column k of lo + 38 hi is one v_mad_u64_u32, the nine columns
+  // one carry chain; what is left above bit 255 (the chain's top word and bit 255 itself) folds
+  // with 2^255 = 19 in a second chain.  ed::reduce (the reference's canonical reduce, correct for
+  // any 256-bit value) finishes the rare lanes that end up >= p.
+  FEC_SDEV fe reduce512(const u32 t[16]) {
+    fe a, b;
+    u32 top;
+    {
+      u64 q[8];
+      FEC_UNROLL for (int k = 0; k < 8; ++k) q[k] = (u64)t[8 + k] * 38u + t[k];
+      FEC_UNROLL for (int k = 0; k < 8; ++k) a.w[k] = (u32)q[k];
+      b.w[0] = 0;
+      FEC_UNROLL for (int k = 1; k < 8; ++k) b.w[k] = (u32)(q[k - 1] >> 32);
+      top = (u32)(q[7] >> 32);  // <= 38
+    }
+    fe r;
+    lmask c = add256(r, a, b);
+    top += word_select(0u, 1u, c);
+    // value = r + top * 2^256 = (r mod 2^255) + 19 * (2 top + bit255(r))
+    const u32 fold = 19u * (2u * top + (r.w[7] >> 31));
+    r.w[7] &= 0x7FFFFFFFu;
+    fe v;
+    add_word256(v, r, fold);  // < 2^255 + 1520: no carry out
+    u32 ones = v.w[1] & v.w[2] & v.w[3] & v.w[4] & v.w[5] & v.w[6] & (v.w[7] | 0x80000000u);
+    if (__builtin_expect(lanes_where(ones == 0xFFFFFFFFu || (v.w[7] >> 31) != 0) != 0, 0)) v = ed::reduce(v);
+    return v;
+  }
+  FEC_SDEV fe mul(const fe& a, const fe& b) {
+    u32 t[16];
+    mul_wide(t, a, b);
+    return reduce512(t);
+  }
+  FEC_SDEV fe sqr(const fe& a) { return mul(a, a); }
+  FEC_SDEV fe sqr_n(fe a, int n) {
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) a = sqr(a);
+    return a;
+  }
+  FEC_SDEV fe inv(const fe& z) {  // z^(2^255 - 21): the usual 254 S + 11 M chain
+    fe z2 = sqr(z);
+    fe z9 = mul(sqr_n(z2, 2), z);
+    fe z11 = mul(z9, z2);
+    fe z2_5_0 = mul(sqr(z11), z9);
+    fe z2_10_0 = mul(sqr_n(z2_5_0, 5), z2_5_0);
+    fe z2_20_0 = mul(sqr_n(z2_10_0, 10), z2_10_0);
+    fe z2_40_0 = mul(sqr_n(z2_20_0, 20), z2_20_0);
+    fe z2_50_0 = mul(sqr_n(z2_40_0, 10), z2_10_0);
+    fe z2_100_0 = mul(sqr_n(z2_50_0, 50), z2_50_0);
+    fe z2_200_0 = mul(sqr_n(z2_100_0, 100), z2_100_0);
+    fe z2_250_0 = mul(sqr_n(z2_200_0, 50), z2_50_0);
+    return mul(sqr_n(z2_250_0, 5), z11);
+  }
+};
+
+struct ext {
+  fe x, y, z, t;
+};  // x = X/Z, y = Y/Z, T = XY/Z
+struct niels {
+  fe ypx, ymx, t2d;
+};  // affine: y + x, y - x, 2 d x y
+struct pniels {
+  fe ypx, ymx, z, t2d;
+};  // projective: Y + X, Y - X, Z, 2 d T
+
+// Signed 4-bit comb for k*B: window w holds j * 16^w * B for j = 1..8 as affine Niels points (24
+// words, stride 25 against LDS bank conflicts); one extra entry, 2^256 * B, absorbs the carry of the
+// signed recoding so that any 256-bit scalar is accepted.
+constexpr int ED_COMB_ENTRIES = 8, ED_COMB_STRIDE = 25;
+constexpr int ED_COMB_WORDS = (COMB_WINDOWS * ED_COMB_ENTRIES + 1) * ED_COMB_STRIDE;
+// Variable base: 1P..8P as projective Niels points, 32 words = one 128-byte line each
+constexpr int ED_WIN_ENTRIES = 8;
+
+struct edw {
+  using F = FpEd;
+  FEC_SDEV fe add(const fe& a, const fe& b) { return F::add(a, b); }
+  FEC_SDEV fe sub(const fe& a, const fe& b) { return F::sub(a, b); }
+  FEC_SDEV fe neg(const fe& a) { return F::neg(a); }
+  FEC_SDEV fe mul(const fe& a, const fe& b) { return F::mul(a, b); }
+  FEC_SDEV fe sqr(const fe& a) { return F::sqr(a); }
+  FEC_SDEV fe inv(const fe& a) { return F::inv(a); }
+  FEC_SDEV fe fe_words(u32 w0, u32 w1, u32 w2, u32 w3, u32 w4, u32 w5, u32 w6, u32 w7) {
+    fe r;
+    r.w[0] = w0; r.w[1] = w1; r.w[2] = w2; r.w[3] = w3; r.w[4] = w4; r.w[5] = w5; r.w[6] = w6; r.w[7] = w7;
+    return r;
+  }
+  FEC_SDEV fe d() {  // -121665 / 121666
+    return fe_words(0x135978A3u, 0x75EB4DCAu, 0x4141D8ABu, 0x00700A4Du, 0x7779E898u, 0x8CC74079u, 0x2B6FFE73u, 0x52036CEEu);
+  }
+  FEC_SDEV fe d2() {
+    return fe_words(0x26B2F159u, 0xEBD69B94u, 0x8283B156u, 0x00E0149Au, 0xEEF3D130u, 0x198E80F2u, 0x56DFFCE7u, 0x2406D9DCu);
+  }
+  FEC_SDEV aff generator() {  // RFC 8032 section 5.1: y = 4/5, x even
+    aff g;
+    g.x = fe_words(0x8F25D51Au, 0xC9562D60u, 0x9525A7B2u, 0x692CC760u, 0xFDD6DC5Cu, 0xC0A4E231u, 0xCD6E53FEu, 0x216936D3u);
+    g.y = fe_words(0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u);
+    return g;
+  }
+  FEC_SDEV ext identity() {
+    ext p;
+    p.x = fe_zero();
+    p.y = fe_small(1);
+    p.z = fe_small(1);
+    p.t = fe_zero();
+    return p;
+  }
+  FEC_SDEV ext from_affine(const aff& a) {
+    ext p;
+    p.x = a.x;
+    p.y = a.y;
+    p.z = fe_small(1);
+    p.t = mul(a.x, a.y);
+    return p;
+  }
+  FEC_SDEV pniels to_pniels(const ext& p) {
+    pniels q;
+    q.ypx = add(p.y, p.x);
+    q.ymx = sub(p.y, p.x);
+    q.z = p.z;
+    q.t2d = mul(p.t, d2());
+    return q;
+  }
+  // x, y < p and -x^2 + y^2 == 1 + d x^2 y^2
+  FEC_SDEV lmask on_curve(const aff& q) {
+    lmask xlt = ~F::ge_p(q.x), ylt = ~F::ge_p(q.y);
+    fe xx = sqr(q.x), yy = sqr(q.y);
+    fe lhs = sub(yy, xx);
+    fe rhs = add(fe_small(1), mul(d(), mul(xx, yy)));
+    return uniform_mask(xlt & ylt & fe_eq(lhs, rhs));
+  }
+  // Doubling (dbl-2008-hwcd).  WITH_T = false skips T3 (the next operation is another doubling).
+  template <bool WITH_T>
+  FEC_SDEV ext dbl(const ext& p) {
+    fe xx = sqr(p.x), yy = sqr(p.y);
+    fe zz = sqr(p.z);
+    fe b2 = add(zz, zz);
+    fe aa = sqr(add(p.x, p.y));
+    fe ys = add(yy, xx);      // completed Y
+    fe zd = sub(yy, xx);      // completed Z
+    fe xc = sub(aa, ys);      // completed X
+    fe tc = sub(b2, zd);      // completed T
+    ext r;
+    r.x = mul(xc, tc);
+    r.y = mul(ys, zd);
+    r.z = mul(zd, tc);
+    r.t = WITH_T ? mul(xc, ys) : fe_zero();
+    return r;
+  }
+  // p +- q, q an affine Niels point (madd-2008-hwcd-3, 7M).  `negate` lanes subtract; `skip` lanes keep p.
+  FEC_SDEV ext add_niels(const ext& p, const niels& q, lmask negate, lmask skip) {
+    fe qp = fe_select(q.ypx, q.ymx, negate), qm = fe_select(q.ymx, q.ypx, negate);
+    fe a = mul(add(p.y, p.x), qp);
+    fe b = mul(sub(p.y, p.x), qm);
+    fe c = mul(q.t2d, p.t);
+    fe dd = add(p.z, p.z);
+    fe zs = add(dd, c), zm = sub(dd, c);
+    fe zc = fe_select(zs, zm, negate);  // completed Z = D + C  (D - C when subtracting)
+    fe tc = fe_select(zm, zs, negate);  // completed T = D - C
+    fe xc = sub(a, b), yc = add(a, b);
+    ext r;
+    r.x = mul(xc, tc);
+    r.y = mul(yc, zc);
+    r.z = mul(zc, tc);
+    r.t = mul(xc, yc);
+    if (skip != 0) {
+      r.x = fe_select(r.x, p.x, skip);
+      r.y = fe_select(r.y, p.y, skip);
+      r.z = fe_select(r.z, p.z, skip);
+      r.t = fe_select(r.t, p.t, skip);
+    }
+    return r;
+  }
+  // p +- q, q a projective Niels point (add-2008-hwcd-3, 8M)
+  FEC_SDEV ext add_pniels(const ext& p, const pniels& q, lmask negate, lmask skip) {
+    fe qp = fe_select(q.ypx, q.ymx, negate), qm = fe_select(q.ymx, q.ypx, negate);
+    fe a = mul(add(p.y, p.x), qp);
+    fe b = mul(sub(p.y, p.x), qm);
+    fe c = mul(q.t2d, p.t);
+    fe zz = mul(p.z, q.z);
+    fe dd = add(zz, zz);
+    fe zs = add(dd, c), zm = sub(dd, c);
+    fe zc = fe_select(zs, zm, negate);
+    fe tc = fe_select(zm, zs, negate);
+    fe xc = sub(a, b), yc = add(a, b);
+    ext r;
+    r.x = mul(xc, tc);
+    r.y = mul(yc, zc);
+    r.z = mul(zc, tc);
+    r.t = mul(xc, yc);
+    if (skip != 0) {
+      r.x = fe_select(r.x, p.x, skip);
+      r.y = fe_select(r.y, p.y, skip);
+      r.z = fe_select(r.z, p.z, skip);
+      r.t = fe_select(r.t, p.t, skip);
+    }
+    return r;
+  }
+  FEC_SDEV aff to_affine(const ext& p) {
+    fe zi = inv(p.z);
+    aff a;
+    a.x = mul(p.x, zi);
+    a.y = mul(p.y, zi);
+    return a;
+  }
+  FEC_SDEV void normalize_group(u32* xy, const u32* zbuf, unsigned char* status, size_t first, size_t stride,
+                                 size_t n) {
+    normalize_group_t<F, false>(xy, zbuf, status, first, stride, n);
+  }
+
+  // ---- fixed base ----
+  FEC_SDEV void comb_store(u32* table, int index, const aff& a) {
+    u32* dst = table + (size_t)index * ED_COMB_STRIDE;
+    fe ypx = add(a.y, a.x), ymx = sub(a.y, a.x), t2d = mul(mul(a.x, a.y), d2());
+    FEC_UNROLL for (int w = 0; w < 8; ++w) {
+      dst[w] = ypx.w[w];
+      dst[8 + w] = ymx.w[w];
+      dst[16 + w] = t2d.w[w];
+    }
+    dst[24] = 0;
+  }
+  // the 8 entries of one window: j * base for j = 1..8 (base = 16^window * B, affine)
+  FEC_SDEV void comb_fill_window(u32* table, int window, const aff& base) {
+    const pniels bq = to_pniels(from_affine(base));
+    ext acc = from_affine(base);
+#pragma unroll 1
+    for (int j = 1; j <= ED_COMB_ENTRIES; ++j) {
+      aff e = base;
+      if (j > 1) {
+        acc = add_pniels(acc, bq, 0, 0);
+        e = to_affine(acc);
+      }
+      comb_store(table, window * ED_COMB_ENTRIES + j - 1, e);
+    }
+  }
+  FEC_SDEV niels comb_entry(const u32* tab, int index) {
+    const u32* e = tab + (size_t)index * ED_COMB_STRIDE;
+    niels q;
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      q.ypx.w[i] = e[i];
+      q.ymx.w[i] = e[8 + i];
+      q.t2d.w[i] = e[16 + i];
+    }
+    return q;
+  }
+  // k*B for any 256-bit k: signed digits d_w in -8..8 with k = sum d_w 16^w + carry * 2^256
+  FEC_SDEV ext mul_base_comb(const u32* tab, const u32* kw) {
+    ext acc = identity();
+    u32 carry = 0;
+#pragma unroll 1
+    for (int w = 0; w < COMB_WINDOWS; ++w) {
+      u32 v = ((kw[(w >> 3) * KSTRIDE] >> ((w & 7) * 4)) & 15u) + carry;  // 0..16
+      carry = v > 8u ? 1u : 0u;
+      const u32 mag = carry ? 16u - v : v;                                // 0..8
+      niels q = comb_entry(tab, w * ED_COMB_ENTRIES + (int)(mag == 0 ? 1u : mag) - 1);
+      acc = add_niels(acc, q, lanes_where(carry != 0 && mag != 0), lanes_where(mag == 0));
+    }
+    niels top = comb_entry(tab, COMB_WINDOWS * ED_COMB_ENTRIES);
+    return add_niels(acc, top, 0, lanes_where(carry == 0));
+  }
+
+  // ---- variable base: signed 4-bit windows, MSB first; the lane's 1P..8P live in its scratch slice ----
+  FEC_SDEV void pn_store(u32* slot, const pniels& q) {
+    st8(slot, q.ypx);
+    st8(slot + 8, q.ymx);
+    st8(slot + 16, q.z);
+    st8(slot + 24, q.t2d);
+  }
+  FEC_SDEV pniels pn_load(const u32* slot) {
+    pniels q;
+    q.ypx = ld8(slot);
+    q.ymx = ld8(slot + 8);
+    q.z = ld8(slot + 16);
+    q.t2d = ld8(slot + 24);
+    return q;
+  }
+  FEC_SDEV ext mul_window(const aff& base, const u32* kw, u32* table /* this lane's 8 x 32 words */) {
+    ext t = from_affine(base);
+    const pniels b1 = to_pniels(t);
+    pn_store(table, b1);
+#pragma unroll 1
+    for (int j = 2; j <= ED_WIN_ENTRIES; ++j) {
+      t = add_pniels(t, b1, 0, 0);
+      pn_store(table + (j - 1) * 32, to_pniels(t));
+    }
+    // signed recoding needs the carry from below: digits are produced LSB first, consumed MSB first,
+    // so recode into a 64 x 5-bit word array first (sign bit 4 + magnitude 0..8)
+    u32 dig[8];  // 8 digits per word, 4 bits magnitude... magnitude needs 0..8 -> 4 bits; signs kept apart
+    u32 sgn[2];
+    sgn[0] = sgn[1] = 0;
+    u32 carry = 0;
+    FEC_UNROLL for (int wd = 0; wd < 8; ++wd) {
+      const u32 word = kw[wd * KSTRIDE];
+      u32 packed = 0;
+      FEC_UNROLL for (int nb = 0; nb < 8; ++nb) {
+        u32 v = ((word >> (4 * nb)) & 15u) + carry;
+        carry = v > 8u ? 1u : 0u;
+        const u32 mag = carry ? 16u - v : v;  // 0..8; 8 only without carry... (v = 8) -> fits 4 bits
+        packed |= mag << (4 * nb);
+        sgn[wd >> 2] |= carry << ((wd & 3) * 8 + nb);
+      }
+      dig[wd] = packed;
+    }
+    // acc = carry * P (the 2^256 term, doubled 256 times by the loop below)
+    ext acc = identity();
+    {
+      pniels q = pn_load(table);
+      acc = add_pniels(acc, q, 0, lanes_where(carry == 0));
+    }
+#pragma unroll 1
+    for (int w = 63; w >= 0; --w) {
+      u32 mag = 0, neg = 0;
+      FEC_UNROLL for (int wd = 0; wd < 8; ++wd) {   // select the digit word without dynamic register indexing
+        if (wd == (w >> 3)) {
+          mag = (dig[wd] >> ((w & 7) * 4)) & 15u;
+          neg = (sgn[wd >> 2] >> ((wd & 3) * 8 + (w & 7))) & 1u;
+        }
+      }
+      pniels q = pn_load(table + ((mag == 0 ? 1u : mag) - 1) * 32);
+#pragma unroll 1
+      for (int dd = 0; dd < 3; ++dd) acc = dbl<false>(acc);
+      acc = dbl<true>(acc);
+      acc = add_pniels(acc, q, lanes_where(neg != 0), lanes_where(mag == 0));
+    }
+    return acc;
+  }
+};
+
 }  // namespace canon
 using csecp = canon::wei<canon::SecpParams>;
 using cp256 = canon::wei<canon::P256Params>;
+using ced = canon::edw;
 }  // namespace fecgpu

@@ -138,4 +138,85 @@ __global__ __launch_bounds__(TPB) void k_canon_field_op(int op, const u32* __res
   stage_out<8>(out + first * 8, lds_a, valid);
 }
 
+// ---- Ed25519 (extended coordinates, signed comb) ------------------------------------------------
+// table: 64 windows x 8 affine Niels multiples of 16^w * B, plus 2^256 * B (ED_COMB_WORDS words).
+__global__ __launch_bounds__(64) void k_ced_build_comb(u32* __restrict__ table) {
+  __shared__ u32 lds_b[32 * 65];
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    canon::ext b = ced::from_affine(ced::generator());
+#pragma unroll 1
+    for (int i = 0; i <= canon::COMB_WINDOWS; ++i) {
+      store_fe(lds_b + i, 65, b.x);
+      store_fe(lds_b + 8 * 65 + i, 65, b.y);
+      store_fe(lds_b + 16 * 65 + i, 65, b.z);
+#pragma unroll 1
+      for (int d = 0; d < 4; ++d) b = ced::dbl<true>(b);
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {  // pass 1: lane 0 alone stores the 2^256 * B entry
+    const int idx = pass == 0 ? lane : canon::COMB_WINDOWS;
+    if (pass == 1 && lane != 0) break;
+    canon::ext acc;
+    acc.x = load_fe(lds_b + idx, 65);
+    acc.y = load_fe(lds_b + 8 * 65 + idx, 65);
+    acc.z = load_fe(lds_b + 16 * 65 + idx, 65);
+    acc.t = fe_zero();
+    canon::aff base = ced::to_affine(acc);
+    if (pass == 0) ced::comb_fill_window(table, lane, base);
+    else ced::comb_store(table, canon::COMB_WINDOWS * canon::ED_COMB_ENTRIES, base);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_ced_mul_base(const u32* __restrict__ scalars, const u32* __restrict__ table,
+                                                      u32* __restrict__ out_xy, u32* __restrict__ zbuf,
+                                                      unsigned char* __restrict__ status, size_t n) {
+  __shared__ u32 lds_k[8 * TPB];
+  __shared__ u32 lds_t[canon::ED_COMB_WORDS];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_k, scalars + first * 8, valid);
+  for (int v = threadIdx.x; v < canon::ED_COMB_WORDS; v += TPB) lds_t[v] = table[v];
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    canon::ext r = ced::mul_base_comb(lds_t, lds_k + e);
+    const size_t i = first + e;
+    canon::st8(out_xy + i * 16, r.x);
+    canon::st8(out_xy + i * 16 + 8, r.y);
+    canon::st8(zbuf + i * 8, r.z);
+    status[i] = CANON_FINITE;
+  }
+}
+
+// `scratch`: ED_WIN_ENTRIES * 32 words per element
+__global__ __launch_bounds__(TPB, 2) void k_ced_mul(const u32* __restrict__ scalars, const u32* __restrict__ points_xy,
+                                                    u32* __restrict__ scratch, u32* __restrict__ out_xy,
+                                                    u32* __restrict__ zbuf, unsigned char* __restrict__ status,
+                                                    size_t n) {
+  __shared__ u32 lds_k[8 * TPB];
+  __shared__ u32 lds_p[16 * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_k, scalars + first * 8, valid);
+  stage_in<16>(lds_p, points_xy + first * 16, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    canon::aff base;
+    base.x = load_fe(lds_p + e, TPB);
+    base.y = load_fe(lds_p + 8 * TPB + e, TPB);
+    const lmask ok = ced::on_curve(base);
+    const size_t i = first + e;
+    u32* table = scratch + i * (size_t)(canon::ED_WIN_ENTRIES * 32);
+    canon::ext r = ced::mul_window(base, lds_k + e, table);
+    canon::st8(out_xy + i * 16, r.x);
+    canon::st8(out_xy + i * 16 + 8, r.y);
+    canon::st8(zbuf + i * 8, r.z);
+    status[i] = lane_of(ok) ? CANON_FINITE : CANON_BAD_POINT;
+  }
+}
+
 }  // namespace fecgpu

@@ -738,8 +738,8 @@ struct fec_ctx {
   bool ed_table_valid = false;
   u64 h_gen_ed[16] = {0};                       // host copy of the Ed25519 generator (table cache key)
   // canonical-math mode: comb table of affine multiples of G, per-element window-table scratch
-  u32* d_canon_comb[2] = {nullptr, nullptr};   // per curve: secp256k1, P-256
-  bool canon_comb_ready[2] = {false, false};
+  u32* d_canon_comb[3] = {nullptr, nullptr, nullptr};   // per curve
+  bool canon_comb_ready[3] = {false, false, false};
   void* d_win_scratch = nullptr;
   size_t win_scratch_cap = 0;
   void* d_zbuf = nullptr;  // Jacobian Z of the batch between the ladder and the batched normalisation
@@ -1007,17 +1007,19 @@ int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, siz
 }
 
 // ---- canonical-math mode -------------------------------------------------------------------
-inline bool canon_curve_ok(int c) { return c == FEC_SECP256K1 || c == FEC_P256; }
+inline bool canon_curve_ok(int c) { return curve_ok(c); }
 
 int ensure_canon_comb(fec_ctx* ctx, int curve, hipStream_t s) {
   if (ctx->canon_comb_ready[curve]) return FEC_OK;
   if (!ctx->d_canon_comb[curve] &&
-      hipMalloc(&ctx->d_canon_comb[curve], (size_t)canon::COMB_WORDS * sizeof(u32)) != hipSuccess) {
+      hipMalloc(&ctx->d_canon_comb[curve],
+                (size_t)(curve == FEC_ED25519 ? canon::ED_COMB_WORDS : canon::COMB_WORDS) * sizeof(u32)) != hipSuccess) {
     (void)hipGetLastError();
     return FEC_E_OOM;
   }
   if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_build_comb<csecp>), dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
-  else hipLaunchKernelGGL((k_canon_build_comb<cp256>), dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_build_comb<cp256>), dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
+  else hipLaunchKernelGGL(k_ced_build_comb, dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
   if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
   // the table is read by kernels on either pipeline stream: finish it before anyone can race
   if (hipStreamSynchronize(s) != hipSuccess) {
@@ -1049,7 +1051,8 @@ int launch_canon_normalize(fec_ctx* ctx, int curve, u64* dxy, unsigned char* dst
   u32* xy = reinterpret_cast<u32*>(dxy);
   const u32* z = reinterpret_cast<const u32*>(ctx->d_zbuf);
   if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_normalize<csecp>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
-  else hipLaunchKernelGGL((k_canon_normalize<cp256>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_normalize<cp256>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
+  else hipLaunchKernelGGL((k_canon_normalize<ced>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
   return hipGetLastError() == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
 }
 
@@ -1065,7 +1068,8 @@ int launch_canon_mul_base(fec_ctx* ctx, int curve, const u64* ds, u64* dxy, unsi
   u32* xy = reinterpret_cast<u32*>(dxy);
   u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
   if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul_base<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
-  else hipLaunchKernelGGL((k_canon_mul_base<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_mul_base<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
+  else hipLaunchKernelGGL(k_ced_mul_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
   rc = launch_canon_normalize(ctx, curve, dxy, dst, n, L.s);
   int rc2 = L.done();
   return rc != FEC_OK ? rc : rc2;
@@ -1085,7 +1089,8 @@ int launch_canon_mul(fec_ctx* ctx, int curve, const u64* ds, const u64* dp, u64*
   u32* xy = reinterpret_cast<u32*>(dxy);
   u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
   if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
-  else hipLaunchKernelGGL((k_canon_mul<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_mul<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
+  else hipLaunchKernelGGL(k_ced_mul, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
   rc = launch_canon_normalize(ctx, curve, dxy, dst, n, L.s);
   int rc2 = L.done();
   return rc != FEC_OK ? rc : rc2;
@@ -1205,7 +1210,7 @@ void fec_ctx_destroy(fec_ctx* ctx) {
   for (int i = 0; i < 3; ++i)
     if (ctx->d_gen[i]) (void)hipFree(ctx->d_gen[i]);
   if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 3; ++i)
     if (ctx->d_canon_comb[i]) (void)hipFree(ctx->d_canon_comb[i]);
   if (ctx->d_win_scratch) (void)hipFree(ctx->d_win_scratch);
   if (ctx->d_zbuf) (void)hipFree(ctx->d_zbuf);
@@ -1638,7 +1643,8 @@ int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a,
   return host_oneshot(ctx, in, in_bytes, outs, out_bytes, [&](void* x, void* y, void*, void* o, void*) {
     Launch L(ctx, nullptr, "k_canon_field_op");
     if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_field_op<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
-    else hipLaunchKernelGGL((k_canon_field_op<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
+    else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_field_op<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
+    else hipLaunchKernelGGL((k_canon_field_op<ced>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
     return L.done();
   });
 }

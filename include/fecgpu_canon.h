@@ -4,13 +4,13 @@
  * *** NOT REFERENCE PARITY. ***  Everything in fecgpu.h reproduces forge-ec's CPU arithmetic bit
  * for bit, and that arithmetic is not the secp256k1 group: its outputs are
  * not public keys any other library would accept.  The entry points below compute the REAL curves
- * -- secp256k1 (y^2 = x^3 + 7, SEC 2) and NIST P-256 (FIPS 186-4) -- for callers that want
+ * -- secp256k1 (SEC 2), NIST P-256 (FIPS 186-4) and Ed25519 (RFC 8032) -- for callers that want
  * standard results at GPU speed.  They replace the same loops as fec_batch_mul_fixed /
  * fec_batch_mul + fec_batch_to_affine (key generation forge-ec-examples/src/ecdh.rs:27-49,
  * forge-ec-signature/src/ecdsa.rs:111-112; ECDH ecdh.rs:51-70), but their results differ from the
  * reference's by design; they are validated against an independent big-integer model
  * (oracle/canon_model.py) and public standard vectors (SEC2 / BIP-340 multiples of G, the RFC 6979
- * A.2.5 P-256 key pair), never against the reference.  A maintainer adopts them only together with a fix of the reference's
+ * A.2.5 P-256 key pair, the RFC 8032 section 7.1 Ed25519 key pairs), never against the reference.  A maintainer adopts them only together with a fix of the reference's
  * field arithmetic.
  *
  * Layout: scalars and coordinates are uint64_t[4] little-endian limbs holding the plain integer
@@ -37,10 +37,12 @@ typedef enum { FEC_CANON_FINITE = 0, FEC_CANON_INFINITY = 1, FEC_CANON_BAD_POINT
 /* field opcode for fec_canon_field_op beyond fec_field_opcode: modular inverse (0 -> 0) */
 #define FEC_F_INV 5
 
-/* curve: FEC_SECP256K1 or FEC_P256 (FEC_ED25519 -> FEC_E_UNSUPPORTED in this mode for now) */
+/* curve: FEC_SECP256K1, FEC_P256 (affine Weierstrass x, y; Jacobian inside) or FEC_ED25519 (RFC 8032
+ * twisted Edwards x, y; extended coordinates inside; no point at infinity: status is 0 or 2) */
 
 /* out_xy[i] = scalars[i] * G, affine.  Fixed-base 4-bit comb (64 mixed additions, no doublings)
- * from a 61 KiB table of affine multiples of G built on the device at first use and kept in LDS. */
+ * from a table of affine multiples of G built on the device at first use and kept in LDS (61 KiB;
+ * Ed25519: signed digits, 50 KiB of affine Niels points). */
 int fec_canon_mul_base(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars /* n*4 */, uint64_t* out_xy /* n*8 */,
                        uint8_t* status /* n */, size_t n);
 int fec_canon_mul_base_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, uint64_t* d_out_xy,

@@ -104,6 +104,73 @@ P256 = Weierstrass(
              0x7903FE1008B8BC99A41AE9E95628BC64F2F1B20C2D7E9F5177A3C294D4462299),
     })
 
+
+
+class TwistedEdwards:
+    """-x^2 + y^2 = 1 + d x^2 y^2 over p (RFC 8032 section 5.1); complete affine addition law."""
+
+    def __init__(self, name, p, d, gx, gy, order):
+        self.name, self.P, self.D, self.N = name, p, d, order
+        self.G = (gx, gy)
+        self.IDENTITY = (0, 1)
+
+    def on_curve(self, pt):
+        x, y = pt
+        P = self.P
+        return 0 <= x < P and 0 <= y < P and (-x * x + y * y - 1 - self.D * x * x * y * y) % P == 0
+
+    def neg(self, pt):
+        return ((-pt[0]) % self.P, pt[1])
+
+    def add(self, p1, p2):
+        P, d = self.P, self.D
+        x1, y1 = p1
+        x2, y2 = p2
+        k = d * x1 * x2 * y1 * y2 % P
+        x3 = (x1 * y2 + x2 * y1) * pow(1 + k, -1, P) % P
+        y3 = (y1 * y2 + x1 * x2) * pow(1 - k, -1, P) % P
+        return (x3, y3)
+
+    def mul(self, k, pt):
+        acc = self.IDENTITY
+        while k:
+            if k & 1:
+                acc = self.add(acc, pt)
+            pt = self.add(pt, pt)
+            k >>= 1
+        return acc
+
+    def field_op(self, op, a, b=0):
+        return Weierstrass.field_op(self, op, a, b)
+
+    def encode(self, pt):
+        """RFC 8032 section 5.1.2: 32 bytes, y little-endian with the sign of x in the top bit."""
+        x, y = pt
+        return (y | ((x & 1) << 255)).to_bytes(32, "little")
+
+    def secret_scalar(self, seed32):
+        """RFC 8032 section 5.1.5: the clamped lower half of SHA-512(seed)."""
+        import hashlib
+        h = bytearray(hashlib.sha512(seed32).digest()[:32])
+        h[0] &= 248
+        h[31] &= 127
+        h[31] |= 64
+        return int.from_bytes(bytes(h), "little")
+
+
+_EDP = 2**255 - 19
+ED25519 = TwistedEdwards(
+    "ed25519", _EDP, (-121665 * pow(121666, -1, _EDP)) % _EDP,
+    0x216936D3CD6E53FEC0A4E231FDD6DC5C692CC7609525A7B2C9562D608F25D51A,
+    0x6666666666666666666666666666666666666666666666666666666666666658,
+    2**252 + 27742317777372353535851937790883648493)
+# RFC 8032 section 7.1, TEST 1 (the vector test_forge_ec/src/bin/test_standard_vectors.rs quotes): secret seed -> public key
+ED25519_RFC8032_TEST1 = (bytes.fromhex("9d61b19deffd5a60ba844af492ec2cc44449c5697b326919703bac031cae7f60"),
+                         bytes.fromhex("d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a"))
+# TEST 2
+ED25519_RFC8032_TEST2 = (bytes.fromhex("4ccd089b28ff96da9db6c346ec114e0f5b8a319f35aba624da8cf6ed4fb8a6fb"),
+                         bytes.fromhex("3d4017c3e843895a92b70aa74d1b7ebc9c982ccf2ec4968cc0cd55f12af4660c"))
+
 CURVES = {"secp256k1": SECP256K1, "p256": P256}
 
 

@@ -247,3 +247,120 @@ def test_batched_normalisation(emu, curve, n):
         x = sum(int(xy[i, w]) << (32 * w) for w in range(8))
         y = sum(int(xy[i, 8 + w]) << (32 * w) for w in range(8))
         assert (x, y) == ((0, 0) if pt is M.INF else pt), i
+
+
+# ---------------------------------------------------------------------------------------------
+# Ed25519 (curve id 2): extended coordinates, signed comb, signed windows
+# ---------------------------------------------------------------------------------------------
+E = M.ED25519
+
+
+def _ext(pt, z):
+    x, y = pt
+    P = E.P
+    return np.array(M.limbs(x * z % P) + M.limbs(y * z % P) + M.limbs(z % P) + M.limbs(x * y % P * z % P), dtype=np.uint64)
+
+
+def test_ed25519_model_is_pinned_by_rfc8032():
+    assert E.on_curve(E.G) and E.mul(E.N, E.G) == E.IDENTITY
+    for seed, pk in (M.ED25519_RFC8032_TEST1, M.ED25519_RFC8032_TEST2):
+        assert E.encode(E.mul(E.secret_scalar(seed), E.G)) == pk
+
+
+def test_ed25519_field_ops(emu):
+    rng = random.Random(0xED)
+    P = E.P
+    edge = sorted({v % P for v in [0, 1, 2, 18, 19, 20, 37, 38, 39, 2**32, 2**64 - 1, 2**128, 2**254, 2**255 - 20,
+                                   P - 1, P - 2, P - 19, P - 38, (P - 1) // 2, (P + 1) // 2, 2**255 - 2**224,
+                                   2**224 - 1, P - 2**32]})
+    pairs = [(a, b) for a in edge for b in edge] + [(rng.randrange(P), rng.randrange(P)) for _ in range(3000)]
+    out = np.zeros(4, dtype=np.uint64)
+    for a, b in pairs:
+        aa, bb = _arr(a), _arr(b)
+        for name, op in OPS.items():
+            if name == "inv" and rng.random() > 0.03 and a not in edge[:6]:
+                continue
+            emu.he_canon_field_op(2, op, _p(aa), _p(bb), _p(out))
+            assert M.unlimbs(out) == E.field_op(name, a, b), (name, hex(a), hex(b))
+
+
+def test_ed25519_point_ops(emu):
+    """complete formulas: doubling, +- through both Niels forms, with the identity, P + P, P - P,
+    and points of small order; T stays consistent (T Z == X Y)"""
+    rng = random.Random(11)
+    out = np.zeros(8, dtype=np.uint64)
+    order4 = None
+    # a point of order 4: (sqrt(-1), 0)
+    i = pow(2, (E.P - 1) // 4, E.P)
+    if E.on_curve((i, 0)):
+        order4 = (i, 0)
+    special = [E.IDENTITY, (0, E.P - 1)] + ([order4] if order4 else [])
+    pts = [E.mul(rng.randrange(1, E.N), E.G) for _ in range(8)] + special
+    for p1 in pts:
+        z1 = rng.randrange(1, E.P)
+        assert emu.he_ced_point_op(0, _p(_ext(p1, z1)), None, _p(out)) == 0
+        assert _pt_of(out, False) == E.add(p1, p1)
+        for p2 in [rng.choice(pts), p1, E.neg(p1), E.IDENTITY] + special:
+            z2 = rng.randrange(1, E.P)
+            for op, want in ((1, E.add(p1, p2)), (2, E.add(p1, E.neg(p2))), (3, E.add(p1, p2)), (4, E.add(p1, E.neg(p2)))):
+                assert emu.he_ced_point_op(op, _p(_ext(p1, z1)), _p(_ext(p2, z2)), _p(out)) == 0
+                assert _pt_of(out, False) == want, (op, p1, p2)
+
+
+ED_SCALARS = [0, 1, 2, 7, 8, 9, 15, 16, 17, 0x88, 0x89, 0x8888888888888888, 2**32 - 1, 2**64, 2**128 - 1, 2**252, 2**255 - 1,
+              2**255, 2**256 - 1, E.N - 1, E.N, E.N + 1, 8 * E.N % 2**256,
+              0x8888888888888888888888888888888888888888888888888888888888888888,
+              0x9999999999999999999999999999999999999999999999999999999999999999,
+              0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF8,
+              0x7777777777777777777777777777777777777777777777777777777777777778]
+
+
+def test_ed25519_mul_base_signed_comb(emu):
+    rng = random.Random(12)
+    out = np.zeros(8, dtype=np.uint64)
+    for k in ED_SCALARS + [rng.randrange(2**256) for _ in range(150)]:
+        emu.he_ced_mul_base(_p(_arr(k)), _p(out))
+        assert _pt_of(out, False) == E.mul(k, E.G), hex(k)
+    for seed, pk in (M.ED25519_RFC8032_TEST1, M.ED25519_RFC8032_TEST2):   # RFC 8032 key pairs through the device code
+        emu.he_ced_mul_base(_p(_arr(E.secret_scalar(seed))), _p(out))
+        assert E.encode(_pt_of(out, False)) == pk
+
+
+def test_ed25519_mul_window_variable_base(emu):
+    rng = random.Random(13)
+    out = np.zeros(8, dtype=np.uint64)
+    for t in range(60):
+        pt = E.mul(rng.randrange(1, E.N), E.G)
+        k = ED_SCALARS[t % len(ED_SCALARS)] if t < 30 else rng.randrange(2**256)
+        pin = np.array(M.limbs(pt[0]) + M.limbs(pt[1]), dtype=np.uint64)
+        assert emu.he_ced_mul(_p(_arr(k)), _p(pin), _p(out)) == 0
+        assert _pt_of(out, False) == E.mul(k, pt), (hex(k), pt)
+    # rejected inputs
+    x, y = E.G
+    for bad in [(x, (y + 1) % E.P), (E.P, 1), (0, E.P + 1), (x + E.P, y), (2**256 - 1, 2**256 - 1)]:
+        pin = np.array(M.limbs(bad[0]) + M.limbs(bad[1]), dtype=np.uint64)
+        out[:] = 1
+        assert emu.he_ced_mul(_p(_arr(5)), _p(pin), _p(out)) == 2 and not out.any()
+
+
+@pytest.mark.parametrize("n", [1, 9, 515])
+def test_ed25519_batched_normalisation(emu, n):
+    rng = random.Random(n)
+    xy = np.zeros((n, 16), dtype=np.uint32)
+    zb = np.zeros((n, 8), dtype=np.uint32)
+    st = np.zeros(n, dtype=np.uint8)
+    want = []
+    for i in range(n):
+        pt = E.mul(rng.randrange(1, 1000), E.G)
+        z = rng.randrange(1, E.P)
+        X, Y = pt[0] * z % E.P, pt[1] * z % E.P
+        for wd in range(8):
+            xy[i, wd] = (X >> (32 * wd)) & 0xFFFFFFFF
+            xy[i, 8 + wd] = (Y >> (32 * wd)) & 0xFFFFFFFF
+            zb[i, wd] = (z >> (32 * wd)) & 0xFFFFFFFF
+        want.append(pt)
+    emu.he_ced_normalize(_p(xy), _p(zb), _p(st), ctypes.c_size_t(n))
+    for i in range(n):
+        x = sum(int(xy[i, w]) << (32 * w) for w in range(8))
+        y = sum(int(xy[i, 8 + w]) << (32 * w) for w in range(8))
+        assert (x, y) == want[i] and st[i] == 0

@@ -159,3 +159,107 @@ def test_full_size_comb_equals_window_and_ecdh_is_symmetric(canon):
         pa = C.mul(ka % C.N, C.G)
         assert (M.unlimbs(Ah[i, :4]), M.unlimbs(Ah[i, 4:])) == pa
         assert (M.unlimbs(Sh[i, :4]), M.unlimbs(Sh[i, 4:])) == C.mul(kb % C.N, pa)
+
+
+# ---------------------------------------------------------------------------------------------
+# Ed25519
+# ---------------------------------------------------------------------------------------------
+E = M.ED25519
+
+
+@pytest.fixture(scope="module")
+def ced(gpu_ctx):
+    from forge_ec_amd.canon import CanonEd25519
+    return CanonEd25519(gpu_ctx)
+
+
+def _epts(xy):
+    return [(M.unlimbs(xy[i, :4]), M.unlimbs(xy[i, 4:])) for i in range(xy.shape[0])]
+
+
+def test_ed25519_field_ops(ced):
+    from forge_ec_amd import _lib as L
+    rng = random.Random(21)
+    P = E.P
+    edge = sorted({v % P for v in [0, 1, 2, 18, 19, 20, 38, 2**254, 2**255 - 20, P - 1, P - 2, P - 19, (P - 1) // 2, 2**224 - 1]})
+    a = [x for x in edge for _ in edge] + [rng.randrange(P) for _ in range(3000)]
+    b = [y for _ in edge for y in edge] + [rng.randrange(P) for _ in range(3000)]
+    A, B = _arr(a), _arr(b)
+    for name, op in (("add", L.F_ADD), ("sub", L.F_SUB), ("mul", L.F_MUL), ("sqr", L.F_SQR), ("neg", L.F_NEG),
+                     ("inv", L.F_INV)):
+        out = ced.field_op(op, A, B if name in ("add", "sub", "mul") else None)
+        for i in range(len(a)):
+            assert M.unlimbs(out[i]) == E.field_op(name, a[i], b[i]), (name, hex(a[i]), hex(b[i]))
+
+
+def test_ed25519_rfc8032_key_pairs(ced):
+    seeds = [M.ED25519_RFC8032_TEST1, M.ED25519_RFC8032_TEST2]
+    xy, st = ced.mul_base(_arr([E.secret_scalar(s) for s, _ in seeds]))
+    assert not st.any()
+    assert [E.encode(p) for p in _epts(xy)] == [pk for _, pk in seeds]
+
+
+def test_ed25519_mul_base_and_variable_base_match_the_model(ced):
+    rng = random.Random(22)
+    special = [0, 1, 2, 7, 8, 9, 16, 0x88, 0x89, 2**252, 2**255 - 1, 2**255, 2**256 - 1, E.N - 1, E.N, E.N + 1,
+               0x8888888888888888888888888888888888888888888888888888888888888888,
+               0x9999999999999999999999999999999999999999999999999999999999999999,
+               0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF8]
+    ks = special + [rng.randrange(2**256) for _ in range(500)]
+    xy, st = ced.mul_base(_arr(ks))
+    assert not st.any()
+    got = _epts(xy)
+    for i, k in enumerate(ks):
+        assert got[i] == E.mul(k, E.G), hex(k)
+    ks = special + [rng.randrange(2**256) for _ in range(150)]
+    base = [E.mul(rng.randrange(1, E.N), E.G) for _ in range(10)] + [E.IDENTITY, (0, E.P - 1)]
+    pts = [base[i % len(base)] for i in range(len(ks))]
+    xy, st = ced.mul(_arr(ks), np.array([M.limbs(p[0]) + M.limbs(p[1]) for p in pts], dtype=np.uint64))
+    assert not st.any()
+    got = _epts(xy)
+    for i, k in enumerate(ks):
+        assert got[i] == E.mul(k, pts[i]), (hex(k), pts[i])
+
+
+def test_ed25519_bad_points(ced):
+    x, y = E.G
+    bad = [(x, (y + 1) % E.P), (E.P, 1), (0, E.P + 1), (2**256 - 1, 2**256 - 1)]
+    pts = np.array([M.limbs(p[0]) + M.limbs(p[1]) for p in bad] + [M.limbs(x) + M.limbs(y)], dtype=np.uint64)
+    xy, st = ced.mul(_arr([7] * len(pts)), pts)
+    assert list(st) == [2] * len(bad) + [0] and not xy[:-1].any()
+    assert _epts(xy[-1:])[0] == E.mul(7, E.G)
+
+
+def test_ed25519_full_size_comb_equals_window_and_dh_is_symmetric(ced):
+    import torch
+    n = 1 << 20
+    a = V.scalars(n, 2, 3101)
+    b = V.scalars(n, 2, 3102)
+    st_ = torch.cuda.current_stream().cuda_stream
+    da = torch.from_numpy(a.view(np.int64)).cuda()
+    db = torch.from_numpy(b.view(np.int64)).cuda()
+    A = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    B = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    s1 = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s2 = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ced.mul_base_dev(da.data_ptr(), A.data_ptr(), s1.data_ptr(), n, st_)
+    ced.mul_base_dev(db.data_ptr(), B.data_ptr(), s2.data_ptr(), n, st_)
+    g = torch.from_numpy(np.tile(np.array(M.limbs(E.G[0]) + M.limbs(E.G[1]), dtype=np.uint64), (n, 1)).view(np.int64)).cuda()
+    A2 = torch.empty_like(A)
+    ced.mul_dev(da.data_ptr(), g.data_ptr(), A2.data_ptr(), s1.data_ptr(), n, st_)
+    torch.cuda.synchronize()
+    assert torch.equal(A, A2) and int(s1.sum()) == 0 and int(s2.sum()) == 0
+    S1 = torch.empty_like(A)
+    S2 = torch.empty_like(A)
+    ced.mul_dev(da.data_ptr(), B.data_ptr(), S1.data_ptr(), s1.data_ptr(), n, st_)
+    ced.mul_dev(db.data_ptr(), A.data_ptr(), S2.data_ptr(), s2.data_ptr(), n, st_)
+    torch.cuda.synchronize()
+    assert torch.equal(S1, S2) and int(s1.sum()) == 0 and int(s2.sum()) == 0
+    rng = np.random.default_rng(6)
+    idx = np.unique(np.concatenate([np.arange(4), np.arange(n - 4, n), rng.integers(0, n, size=100)]))
+    Ah = A.cpu().numpy().view(np.uint64)
+    Sh = S1.cpu().numpy().view(np.uint64)
+    for i in idx:
+        pa = E.mul(M.unlimbs(a[i]), E.G)
+        assert (M.unlimbs(Ah[i, :4]), M.unlimbs(Ah[i, 4:])) == pa
+        assert (M.unlimbs(Sh[i, :4]), M.unlimbs(Sh[i, 4:])) == E.mul(M.unlimbs(b[i]), pa)

@@ -89,6 +89,7 @@ static int t_field_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* ou
 // op: 0 add, 1 sub, 2 mul, 3 sqr, 4 neg, 5 inv
 extern "C" int he_canon_field_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
 #define CALL(W) t_field_op<W>(op, a, b, out)
+  if (curve == 2) return CALL(ced);
   return CANON_DISPATCH(curve, CALL);
 #undef CALL
 }
@@ -184,4 +185,65 @@ extern "C" int he_canon_normalize(int curve, uint32_t* xy, const uint32_t* zbuf,
 #define CALL(W) t_normalize<W>(xy, zbuf, status, n)
   return CANON_DISPATCH(curve, CALL);
 #undef CALL
+}
+
+// ---- canonical Ed25519 (curve id 2) ----
+static u32* ed_comb_table() {
+  static u32* tab = nullptr;
+  if (!tab) {
+    tab = new u32[canon::ED_COMB_WORDS];
+    canon::ext b = ced::from_affine(ced::generator());
+    for (int i = 0; i <= canon::COMB_WINDOWS; ++i) {
+      canon::aff base = ced::to_affine(b);
+      if (i < canon::COMB_WINDOWS) ced::comb_fill_window(tab, i, base);
+      else ced::comb_store(tab, canon::COMB_WINDOWS * canon::ED_COMB_ENTRIES, base);
+      for (int d = 0; d < 4; ++d) b = ced::dbl<true>(b);
+    }
+  }
+  return tab;
+}
+extern "C" int he_ced_mul_base(const uint64_t* scalar, uint64_t* xy) {
+  static thread_local u32 kw[8 * KSTRIDE];
+  canon_kw(kw, scalar);
+  canon::aff a = ced::to_affine(ced::mul_base_comb(ed_comb_table(), kw));
+  st(xy, a.x); st(xy + 4, a.y);
+  return 0;
+}
+extern "C" int he_ced_mul(const uint64_t* scalar, const uint64_t* pxy, uint64_t* xy) {
+  static thread_local u32 kw[8 * KSTRIDE];
+  static thread_local u32 table[canon::ED_WIN_ENTRIES * 32];
+  canon_kw(kw, scalar);
+  canon::aff base; base.x = ld(pxy); base.y = ld(pxy + 4);
+  lmask ok = ced::on_curve(base);
+  canon::aff a = ced::to_affine(ced::mul_window(base, kw, table));
+  if (!ok) { a.x = fe_zero(); a.y = fe_zero(); }
+  st(xy, a.x); st(xy + 4, a.y);
+  return ok ? 0 : 2;
+}
+// op 0: double, 1: p + q (q through projective Niels), 2: p - q, 3: p + q with q affine Niels, 4: p - q affine Niels
+extern "C" int he_ced_point_op(int op, const uint64_t* p, const uint64_t* q, uint64_t* out_xy) {
+  canon::ext a; a.x = ld(p); a.y = ld(p + 4); a.z = ld(p + 8); a.t = ld(p + 12);
+  canon::ext r;
+  if (op == 0) r = ced::dbl<true>(a);
+  else {
+    canon::ext b; b.x = ld(q); b.y = ld(q + 4); b.z = ld(q + 8); b.t = ld(q + 12);
+    if (op <= 2) r = ced::add_pniels(a, ced::to_pniels(b), op == 2 ? ~0ull : 0, 0);
+    else {
+      canon::aff ba = ced::to_affine(b);
+      canon::niels nq; nq.ypx = ced::add(ba.y, ba.x); nq.ymx = ced::sub(ba.y, ba.x);
+      nq.t2d = ced::mul(ced::mul(ba.x, ba.y), ced::d2());
+      r = ced::add_niels(a, nq, op == 4 ? ~0ull : 0, 0);
+    }
+  }
+  canon::aff o = ced::to_affine(r);
+  // also check T: T * Z == X * Y
+  fe lhs = ced::mul(r.t, r.z), rhs = ced::mul(r.x, r.y);
+  st(out_xy, o.x); st(out_xy + 4, o.y);
+  return fe_eq(lhs, rhs) ? 0 : 9;
+}
+extern "C" int he_ced_normalize(uint32_t* xy, const uint32_t* zbuf, unsigned char* status, size_t n) {
+  const size_t lanes = (n + canon::NORM_GROUP - 1) / canon::NORM_GROUP;
+  const size_t stride = (lanes + 63) / 64 * 64;
+  for (size_t g = 0; g < stride; ++g) ced::normalize_group(xy, zbuf, status, g, stride, n);
+  return 0;
 }
