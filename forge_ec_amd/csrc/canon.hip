@@ -1,0 +1,176 @@
+// canon.hip -- the CANONICAL-MATH MODE translation unit of libfecgpu.so (include/fecgpu_canon.h):
+// kernels (canon_kernels.hpp), launch helpers and extern "C" entry points.  NOT reference parity.
+#include <hip/hip_runtime.h>
+
+#include "../../include/fecgpu.h"
+#include "../../include/fecgpu_canon.h"
+#include "host_ctx.hpp"
+#include "canon_kernels.hpp"
+
+using namespace fecgpu;
+using namespace fecgpu::host;
+
+namespace {
+
+// ---- canonical-math mode -------------------------------------------------------------------
+inline bool canon_curve_ok(int c) { return curve_ok(c); }
+
+int ensure_canon_comb(fec_ctx* ctx, int curve, hipStream_t s) {
+  if (ctx->canon_comb_ready[curve]) return FEC_OK;
+  if (!ctx->d_canon_comb[curve] &&
+      hipMalloc(&ctx->d_canon_comb[curve],
+                (size_t)(curve == FEC_ED25519 ? canon::ED_COMB_WORDS : canon::COMB_WORDS) * sizeof(u32)) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_OOM;
+  }
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_build_comb<csecp>), dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_build_comb<cp256>), dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
+  else hipLaunchKernelGGL(k_ced_build_comb, dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
+  if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
+  // the table is read by kernels on either pipeline stream: finish it before anyone can race
+  if (hipStreamSynchronize(s) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  ctx->canon_comb_ready[curve] = true;
+  return FEC_OK;
+}
+
+// grow-only device buffer owned by the ctx (kernels of earlier calls may still use the old one)
+int ensure_owned(void** buf, size_t* cap, size_t need) {
+  if (*cap >= need) return FEC_OK;
+  if (hipDeviceSynchronize() != hipSuccess) return FEC_E_LAUNCH;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr;
+  *cap = 0;
+  if (hipMalloc(buf, need) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_OOM;
+  }
+  *cap = need;
+  return FEC_OK;
+}
+
+int launch_canon_normalize(fec_ctx* ctx, int curve, u64* dxy, unsigned char* dst, size_t n, hipStream_t s) {
+  const size_t lanes = (n + canon::NORM_GROUP - 1) / canon::NORM_GROUP;
+  const size_t stride = (lanes + 63) / 64 * 64;
+  u32* xy = reinterpret_cast<u32*>(dxy);
+  const u32* z = reinterpret_cast<const u32*>(ctx->d_zbuf);
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_normalize<csecp>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_normalize<cp256>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
+  else hipLaunchKernelGGL((k_canon_normalize<ced>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
+  return hipGetLastError() == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
+}
+
+int launch_canon_mul_base(fec_ctx* ctx, int curve, const u64* ds, u64* dxy, unsigned char* dst, size_t n,
+                          void* stream) {
+  if (n == 0) return FEC_OK;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  int rc = ensure_canon_comb(ctx, curve, s);
+  if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
+  if (rc != FEC_OK) return rc;
+  Launch L(ctx, stream, "k_canon_mul_base+k_canon_normalize");
+  const u32* k = reinterpret_cast<const u32*>(ds);
+  u32* xy = reinterpret_cast<u32*>(dxy);
+  u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul_base<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_mul_base<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
+  else hipLaunchKernelGGL(k_ced_mul_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
+  rc = launch_canon_normalize(ctx, curve, dxy, dst, n, L.s);
+  int rc2 = L.done();
+  return rc != FEC_OK ? rc : rc2;
+}
+
+int launch_canon_mul(fec_ctx* ctx, int curve, const u64* ds, const u64* dp, u64* dxy, unsigned char* dst, size_t n,
+                     void* stream) {
+  if (n == 0) return FEC_OK;
+  int rc = ensure_owned(&ctx->d_win_scratch, &ctx->win_scratch_cap,
+                        n * (size_t)(canon::WIN_ENTRIES * canon::WIN_ENTRY_WORDS) * sizeof(u32));
+  if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
+  if (rc != FEC_OK) return rc;
+  Launch L(ctx, stream, "k_canon_mul+k_canon_normalize");
+  const u32* k = reinterpret_cast<const u32*>(ds);
+  const u32* p = reinterpret_cast<const u32*>(dp);
+  u32* scratch = reinterpret_cast<u32*>(ctx->d_win_scratch);
+  u32* xy = reinterpret_cast<u32*>(dxy);
+  u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_mul<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
+  else hipLaunchKernelGGL(k_ced_mul, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
+  rc = launch_canon_normalize(ctx, curve, dxy, dst, n, L.s);
+  int rc2 = L.done();
+  return rc != FEC_OK ? rc : rc2;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- canonical-math mode (include/fecgpu_canon.h): NOT reference parity ----------------------
+int fec_canon_mul_base_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, uint64_t* d_out_xy,
+                           uint8_t* d_status, size_t n, void* stream) {
+  if (!ctx || (n && (!d_scalars || !d_out_xy || !d_status))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
+  if (!aligned16(d_scalars) || !aligned16(d_out_xy)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_canon_mul_base(ctx, curve, d_scalars, d_out_xy, d_status, n, stream);
+}
+
+int fec_canon_mul_base(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, uint64_t* out_xy, uint8_t* status,
+                       size_t n) {
+  if (!ctx || (n && (!scalars || !out_xy || !status))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const void* const in[3] = {scalars, nullptr, nullptr};
+  const size_t in_bytes[3] = {n * 32, 0, 0};
+  void* const out[2] = {out_xy, status};
+  const size_t out_bytes[2] = {n * 64, n};
+  return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void*, void*, void* o, void* st) {
+    return launch_canon_mul_base(ctx, curve, (const u64*)a, (u64*)o, (unsigned char*)st, n, nullptr);
+  });
+}
+
+int fec_canon_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, const uint64_t* d_points_xy,
+                      uint64_t* d_out_xy, uint8_t* d_status, size_t n, void* stream) {
+  if (!ctx || (n && (!d_scalars || !d_points_xy || !d_out_xy || !d_status))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
+  if (!aligned16(d_scalars) || !aligned16(d_points_xy) || !aligned16(d_out_xy)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_canon_mul(ctx, curve, d_scalars, d_points_xy, d_out_xy, d_status, n, stream);
+}
+
+int fec_canon_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points_xy,
+                  uint64_t* out_xy, uint8_t* status, size_t n) {
+  if (!ctx || (n && (!scalars || !points_xy || !out_xy || !status))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const void* const in[3] = {scalars, points_xy, nullptr};
+  const size_t in_bytes[3] = {n * 32, n * 64, 0};
+  void* const out[2] = {out_xy, status};
+  const size_t out_bytes[2] = {n * 64, n};
+  return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void* b, void*, void* o, void* st) {
+    return launch_canon_mul(ctx, curve, (const u64*)a, (const u64*)b, (u64*)o, (unsigned char*)st, n, nullptr);
+  });
+}
+
+int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
+                       size_t n) {
+  if (!ctx || op < FEC_F_ADD || op > FEC_F_INV || (n && (!a || !out))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
+  const bool binary = op == FEC_F_ADD || op == FEC_F_SUB || op == FEC_F_MUL;
+  if (binary && n && !b) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const void* const in[3] = {a, binary ? b : nullptr, nullptr};
+  const size_t in_bytes[3] = {n * 32, n * 32, 0};
+  void* const outs[2] = {out, nullptr};
+  const size_t out_bytes[2] = {n * 32, 0};
+  return host_oneshot(ctx, in, in_bytes, outs, out_bytes, [&](void* x, void* y, void*, void* o, void*) {
+    Launch L(ctx, nullptr, "k_canon_field_op");
+    if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_field_op<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
+    else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_field_op<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
+    else hipLaunchKernelGGL((k_canon_field_op<ced>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
+    return L.done();
+  });
+}
+
+}  // extern "C"

@@ -14,14 +14,13 @@
 #include <new>
 
 #include "../../include/fecgpu.h"
-#include "../../include/fecgpu_canon.h"
 #include "ed25519.hpp"
 #include "p256.hpp"
 #include "secp256k1.hpp"
+#include "host_ctx.hpp"
 
 namespace fecgpu {
 
-constexpr int TPB = 256;  // threads per workgroup = 4 wavefronts, one per SIMD
 
 // ------------------------------------------------------------------------------------------
 // curve adaptors: a uniform static interface over the three curve headers
@@ -149,50 +148,6 @@ struct Ed {
   static constexpr bool BYTES_BIG_ENDIAN = false;
 };
 
-// ------------------------------------------------------------------------------------------
-// HBM <-> LDS staging: coalesced 16-byte accesses, word-major (transposed) LDS image
-//   word w of the workgroup's element e lives at lds[w * TPB + e]
-// ------------------------------------------------------------------------------------------
-template <int W>
-FEC_DEV void stage_in(u32* lds, const u32* g, int valid) {
-  for (int v = threadIdx.x; v < TPB * W / 4; v += TPB) {
-    int e = (v * 4) / W, w = (v * 4) % W;
-    if (e < valid) {
-      uint4 x = *reinterpret_cast<const uint4*>(g + (size_t)v * 4);
-      lds[(w + 0) * TPB + e] = x.x;
-      lds[(w + 1) * TPB + e] = x.y;
-      lds[(w + 2) * TPB + e] = x.z;
-      lds[(w + 3) * TPB + e] = x.w;
-    }
-  }
-}
-template <int W>
-FEC_DEV void stage_out(u32* g, const u32* lds, int valid) {
-  for (int v = threadIdx.x; v < TPB * W / 4; v += TPB) {
-    int e = (v * 4) / W, w = (v * 4) % W;
-    if (e < valid) {
-      uint4 x;
-      x.x = lds[(w + 0) * TPB + e];
-      x.y = lds[(w + 1) * TPB + e];
-      x.z = lds[(w + 2) * TPB + e];
-      x.w = lds[(w + 3) * TPB + e];
-      *reinterpret_cast<uint4*>(g + (size_t)v * 4) = x;
-    }
-  }
-}
-FEC_DEV fe load_fe(const u32* l, int stride) {
-  fe a;
-  FEC_UNROLL for (int i = 0; i < 8; ++i) a.w[i] = l[i * stride];
-  return a;
-}
-FEC_DEV void store_fe(u32* l, int stride, const fe& a) {
-  FEC_UNROLL for (int i = 0; i < 8; ++i) l[i * stride] = a.w[i];
-}
-FEC_DEV int block_valid(size_t n) {
-  size_t first = (size_t)blockIdx.x * TPB;
-  size_t left = n - first;
-  return left < (size_t)TPB ? (int)left : TPB;
-}
 
 // ------------------------------------------------------------------------------------------
 // kernels
@@ -713,39 +668,12 @@ __global__ __launch_bounds__(TPB) void k_peak_mad32(u32* out, u32 seed) {
 
 }  // namespace fecgpu
 
-#include "canon_kernels.hpp"  // canonical-math mode (NOT reference parity)
 
 // ==========================================================================================
 // host side: context + extern "C" ABI
 // ==========================================================================================
 using namespace fecgpu;
-
-struct fec_ctx {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timing = false, timed = false;
-  const char* last_kernel = "";
-  // device staging for the host-pointer entry points: slots 0-3 serve pipeline lane 0 (and the
-  // small one-shot calls), slots 4-7 pipeline lane 1
-  void* d_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  hipStream_t stream2 = nullptr;
-  size_t chunk = (size_t)1 << 18;  // elements per pipeline chunk
-  u64* d_gen[3] = {nullptr, nullptr, nullptr};  // reference generator() per curve, device copy
-  u32* d_ed_table = nullptr;                    // Ed25519 fixed-base addend table (256 x 32 words)
-  u64 ed_table_base[16] = {0};                  // the base point the table was built for
-  bool ed_table_valid = false;
-  u64 h_gen_ed[16] = {0};                       // host copy of the Ed25519 generator (table cache key)
-  // canonical-math mode: comb table of affine multiples of G, per-element window-table scratch
-  u32* d_canon_comb[3] = {nullptr, nullptr, nullptr};   // per curve
-  bool canon_comb_ready[3] = {false, false, false};
-  void* d_win_scratch = nullptr;
-  size_t win_scratch_cap = 0;
-  void* d_zbuf = nullptr;  // Jacobian Z of the batch between the ladder and the batched normalisation
-  size_t zbuf_cap = 0;
-  hipDeviceProp_t prop;
-};
+using namespace fecgpu::host;
 
 namespace {
 
@@ -769,43 +697,6 @@ const u64 GEN_ED[16] = {0x1A1462FAFB9683F2ULL, 0xD2E8A68B8B30C404ULL, 0xA0C0F3A1
                         0, 0, 0, 0};  // T is filled in on the device
 const u64 FE_ONE[4] = {1, 0, 0, 0};
 
-inline bool curve_ok(int c) { return c == FEC_SECP256K1 || c == FEC_P256 || c == FEC_ED25519; }
-inline int plimbs(int c) { return c == FEC_ED25519 ? 16 : 12; }
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-int ensure(fec_ctx* ctx, int slot, size_t bytes) {
-  if (ctx->d_cap[slot] >= bytes) return FEC_OK;
-  if (ctx->d_buf[slot]) (void)hipFree(ctx->d_buf[slot]);
-  ctx->d_buf[slot] = nullptr;
-  ctx->d_cap[slot] = 0;
-  size_t cap = bytes + (bytes >> 2) + 4096;
-  if (hipMalloc(&ctx->d_buf[slot], cap) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_OOM;
-  }
-  ctx->d_cap[slot] = cap;
-  return FEC_OK;
-}
-
-struct Launch {
-  fec_ctx* ctx;
-  hipStream_t s;
-  Launch(fec_ctx* c, void* stream, const char* name) : ctx(c), s(stream ? (hipStream_t)stream : c->stream) {
-    ctx->last_kernel = name;
-    ctx->timed = false;
-    if (ctx->timing) (void)hipEventRecord(ctx->ev0, s);
-  }
-  int done() {
-    hipError_t e = hipGetLastError();
-    if (ctx->timing) {
-      (void)hipEventRecord(ctx->ev1, s);
-      ctx->timed = true;
-    }
-    return e == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
-  }
-};
-
-inline unsigned grid_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 
 // Build (or reuse) the Ed25519 addend table for the base at device address d_base.  `host_base`
 // (may be null) is the same point on the host and lets repeated calls with one base skip the build.
@@ -1000,131 +891,6 @@ int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, siz
   int rc = copy_back(nchunks - 1);
   if (rc != FEC_OK) return rc;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream2) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
-  return FEC_OK;
-}
-
-// ---- canonical-math mode -------------------------------------------------------------------
-inline bool canon_curve_ok(int c) { return curve_ok(c); }
-
-int ensure_canon_comb(fec_ctx* ctx, int curve, hipStream_t s) {
-  if (ctx->canon_comb_ready[curve]) return FEC_OK;
-  if (!ctx->d_canon_comb[curve] &&
-      hipMalloc(&ctx->d_canon_comb[curve],
-                (size_t)(curve == FEC_ED25519 ? canon::ED_COMB_WORDS : canon::COMB_WORDS) * sizeof(u32)) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_OOM;
-  }
-  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_build_comb<csecp>), dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
-  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_build_comb<cp256>), dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
-  else hipLaunchKernelGGL(k_ced_build_comb, dim3(1), dim3(64), 0, s, ctx->d_canon_comb[curve]);
-  if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
-  // the table is read by kernels on either pipeline stream: finish it before anyone can race
-  if (hipStreamSynchronize(s) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
-  ctx->canon_comb_ready[curve] = true;
-  return FEC_OK;
-}
-
-// grow-only device buffer owned by the ctx (kernels of earlier calls may still use the old one)
-int ensure_owned(void** buf, size_t* cap, size_t need) {
-  if (*cap >= need) return FEC_OK;
-  if (hipDeviceSynchronize() != hipSuccess) return FEC_E_LAUNCH;
-  if (*buf) (void)hipFree(*buf);
-  *buf = nullptr;
-  *cap = 0;
-  if (hipMalloc(buf, need) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_OOM;
-  }
-  *cap = need;
-  return FEC_OK;
-}
-
-int launch_canon_normalize(fec_ctx* ctx, int curve, u64* dxy, unsigned char* dst, size_t n, hipStream_t s) {
-  const size_t lanes = (n + canon::NORM_GROUP - 1) / canon::NORM_GROUP;
-  const size_t stride = (lanes + 63) / 64 * 64;
-  u32* xy = reinterpret_cast<u32*>(dxy);
-  const u32* z = reinterpret_cast<const u32*>(ctx->d_zbuf);
-  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_normalize<csecp>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
-  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_normalize<cp256>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
-  else hipLaunchKernelGGL((k_canon_normalize<ced>), dim3(grid_for(stride)), dim3(TPB), 0, s, xy, z, dst, n, stride);
-  return hipGetLastError() == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
-}
-
-int launch_canon_mul_base(fec_ctx* ctx, int curve, const u64* ds, u64* dxy, unsigned char* dst, size_t n,
-                          void* stream) {
-  if (n == 0) return FEC_OK;
-  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-  int rc = ensure_canon_comb(ctx, curve, s);
-  if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
-  if (rc != FEC_OK) return rc;
-  Launch L(ctx, stream, "k_canon_mul_base+k_canon_normalize");
-  const u32* k = reinterpret_cast<const u32*>(ds);
-  u32* xy = reinterpret_cast<u32*>(dxy);
-  u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
-  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul_base<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
-  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_mul_base<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
-  else hipLaunchKernelGGL(k_ced_mul_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
-  rc = launch_canon_normalize(ctx, curve, dxy, dst, n, L.s);
-  int rc2 = L.done();
-  return rc != FEC_OK ? rc : rc2;
-}
-
-int launch_canon_mul(fec_ctx* ctx, int curve, const u64* ds, const u64* dp, u64* dxy, unsigned char* dst, size_t n,
-                     void* stream) {
-  if (n == 0) return FEC_OK;
-  int rc = ensure_owned(&ctx->d_win_scratch, &ctx->win_scratch_cap,
-                        n * (size_t)(canon::WIN_ENTRIES * canon::WIN_ENTRY_WORDS) * sizeof(u32));
-  if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
-  if (rc != FEC_OK) return rc;
-  Launch L(ctx, stream, "k_canon_mul+k_canon_normalize");
-  const u32* k = reinterpret_cast<const u32*>(ds);
-  const u32* p = reinterpret_cast<const u32*>(dp);
-  u32* scratch = reinterpret_cast<u32*>(ctx->d_win_scratch);
-  u32* xy = reinterpret_cast<u32*>(dxy);
-  u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
-  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
-  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_mul<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
-  else hipLaunchKernelGGL(k_ced_mul, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
-  rc = launch_canon_normalize(ctx, curve, dxy, dst, n, L.s);
-  int rc2 = L.done();
-  return rc != FEC_OK ? rc : rc2;
-}
-
-// one-shot host-pointer call with up to three inputs and two outputs (not pipelined)
-template <class F>
-int host_oneshot(fec_ctx* ctx, const void* const in[3], const size_t in_bytes[3], void* const out[2],
-                 const size_t out_bytes[2], F body) {
-  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  void* d_in[3] = {nullptr, nullptr, nullptr};
-  void* d_out[2] = {nullptr, nullptr};
-  for (int i = 0; i < 3; ++i) {
-    if (!in[i]) continue;
-    int rc = ensure(ctx, i, in_bytes[i]);
-    if (rc != FEC_OK) return rc;
-    d_in[i] = ctx->d_buf[i];
-    if (hipMemcpyAsync(d_in[i], in[i], in_bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-      return FEC_E_DEVICE;
-  }
-  for (int i = 0; i < 2; ++i) {
-    if (!out[i]) continue;
-    int rc = ensure(ctx, 3 + i, out_bytes[i]);
-    if (rc != FEC_OK) return rc;
-    d_out[i] = ctx->d_buf[3 + i];
-  }
-  int rc = body(d_in[0], d_in[1], d_in[2], d_out[0], d_out[1]);
-  if (rc != FEC_OK) return rc;
-  for (int i = 0; i < 2; ++i) {
-    if (!out[i]) continue;
-    if (hipMemcpyAsync(out[i], d_out[i], out_bytes[i], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-      return FEC_E_DEVICE;
-  }
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
     (void)hipGetLastError();
     return FEC_E_LAUNCH;
   }
@@ -1580,73 +1346,6 @@ int fec_ctx_device_info(fec_ctx* ctx, char* name, size_t name_len, int* compute_
   if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
   if (clock_khz) *clock_khz = ctx->prop.clockRate;
   return FEC_OK;
-}
-
-// ---- canonical-math mode (include/fecgpu_canon.h): NOT reference parity ----------------------
-int fec_canon_mul_base_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, uint64_t* d_out_xy,
-                           uint8_t* d_status, size_t n, void* stream) {
-  if (!ctx || (n && (!d_scalars || !d_out_xy || !d_status))) return FEC_E_ARG;
-  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
-  if (!aligned16(d_scalars) || !aligned16(d_out_xy)) return FEC_E_ARG;
-  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  return launch_canon_mul_base(ctx, curve, d_scalars, d_out_xy, d_status, n, stream);
-}
-
-int fec_canon_mul_base(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, uint64_t* out_xy, uint8_t* status,
-                       size_t n) {
-  if (!ctx || (n && (!scalars || !out_xy || !status))) return FEC_E_ARG;
-  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
-  if (n == 0) return FEC_OK;
-  const void* const in[3] = {scalars, nullptr, nullptr};
-  const size_t in_bytes[3] = {n * 32, 0, 0};
-  void* const out[2] = {out_xy, status};
-  const size_t out_bytes[2] = {n * 64, n};
-  return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void*, void*, void* o, void* st) {
-    return launch_canon_mul_base(ctx, curve, (const u64*)a, (u64*)o, (unsigned char*)st, n, nullptr);
-  });
-}
-
-int fec_canon_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, const uint64_t* d_points_xy,
-                      uint64_t* d_out_xy, uint8_t* d_status, size_t n, void* stream) {
-  if (!ctx || (n && (!d_scalars || !d_points_xy || !d_out_xy || !d_status))) return FEC_E_ARG;
-  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
-  if (!aligned16(d_scalars) || !aligned16(d_points_xy) || !aligned16(d_out_xy)) return FEC_E_ARG;
-  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  return launch_canon_mul(ctx, curve, d_scalars, d_points_xy, d_out_xy, d_status, n, stream);
-}
-
-int fec_canon_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points_xy,
-                  uint64_t* out_xy, uint8_t* status, size_t n) {
-  if (!ctx || (n && (!scalars || !points_xy || !out_xy || !status))) return FEC_E_ARG;
-  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
-  if (n == 0) return FEC_OK;
-  const void* const in[3] = {scalars, points_xy, nullptr};
-  const size_t in_bytes[3] = {n * 32, n * 64, 0};
-  void* const out[2] = {out_xy, status};
-  const size_t out_bytes[2] = {n * 64, n};
-  return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void* b, void*, void* o, void* st) {
-    return launch_canon_mul(ctx, curve, (const u64*)a, (const u64*)b, (u64*)o, (unsigned char*)st, n, nullptr);
-  });
-}
-
-int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
-                       size_t n) {
-  if (!ctx || op < FEC_F_ADD || op > FEC_F_INV || (n && (!a || !out))) return FEC_E_ARG;
-  if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
-  const bool binary = op == FEC_F_ADD || op == FEC_F_SUB || op == FEC_F_MUL;
-  if (binary && n && !b) return FEC_E_ARG;
-  if (n == 0) return FEC_OK;
-  const void* const in[3] = {a, binary ? b : nullptr, nullptr};
-  const size_t in_bytes[3] = {n * 32, n * 32, 0};
-  void* const outs[2] = {out, nullptr};
-  const size_t out_bytes[2] = {n * 32, 0};
-  return host_oneshot(ctx, in, in_bytes, outs, out_bytes, [&](void* x, void* y, void*, void* o, void*) {
-    Launch L(ctx, nullptr, "k_canon_field_op");
-    if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_field_op<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
-    else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_field_op<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
-    else hipLaunchKernelGGL((k_canon_field_op<ced>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
-    return L.done();
-  });
 }
 
 }  // extern "C"

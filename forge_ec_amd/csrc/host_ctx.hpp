@@ -1,0 +1,118 @@
+// host_ctx.hpp -- the fec_ctx object and the host-side helpers shared by the translation units of
+// libfecgpu.so (fecgpu.hip: parity path; canon.hip: canonical-math mode).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/fecgpu.h"
+#include "staging.hpp"
+
+struct fec_ctx {
+  using u32 = fecgpu::u32;
+  using u64 = fecgpu::u64;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing = false, timed = false;
+  const char* last_kernel = "";
+  // device staging for the host-pointer entry points: slots 0-3 serve pipeline lane 0 (and the
+  // small one-shot calls), slots 4-7 pipeline lane 1
+  void* d_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipStream_t stream2 = nullptr;
+  size_t chunk = (size_t)1 << 18;  // elements per pipeline chunk
+  u64* d_gen[3] = {nullptr, nullptr, nullptr};  // reference generator() per curve, device copy
+  u32* d_ed_table = nullptr;                    // Ed25519 fixed-base addend table (256 x 32 words)
+  u64 ed_table_base[16] = {0};                  // the base point the table was built for
+  bool ed_table_valid = false;
+  u64 h_gen_ed[16] = {0};                       // host copy of the Ed25519 generator (table cache key)
+  // canonical-math mode: comb table of affine multiples of G, per-element window-table scratch
+  u32* d_canon_comb[3] = {nullptr, nullptr, nullptr};   // per curve
+  bool canon_comb_ready[3] = {false, false, false};
+  void* d_win_scratch = nullptr;
+  size_t win_scratch_cap = 0;
+  void* d_zbuf = nullptr;  // Jacobian Z of the batch between the ladder and the batched normalisation
+  size_t zbuf_cap = 0;
+  hipDeviceProp_t prop;
+};
+
+namespace fecgpu {
+namespace host {
+
+inline bool curve_ok(int c) { return c == FEC_SECP256K1 || c == FEC_P256 || c == FEC_ED25519; }
+inline int plimbs(int c) { return c == FEC_ED25519 ? 16 : 12; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int ensure(fec_ctx* ctx, int slot, size_t bytes) {
+  if (ctx->d_cap[slot] >= bytes) return FEC_OK;
+  if (ctx->d_buf[slot]) (void)hipFree(ctx->d_buf[slot]);
+  ctx->d_buf[slot] = nullptr;
+  ctx->d_cap[slot] = 0;
+  size_t cap = bytes + (bytes >> 2) + 4096;
+  if (hipMalloc(&ctx->d_buf[slot], cap) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_OOM;
+  }
+  ctx->d_cap[slot] = cap;
+  return FEC_OK;
+}
+
+struct Launch {
+  fec_ctx* ctx;
+  hipStream_t s;
+  Launch(fec_ctx* c, void* stream, const char* name) : ctx(c), s(stream ? (hipStream_t)stream : c->stream) {
+    ctx->last_kernel = name;
+    ctx->timed = false;
+    if (ctx->timing) (void)hipEventRecord(ctx->ev0, s);
+  }
+  int done() {
+    hipError_t e = hipGetLastError();
+    if (ctx->timing) {
+      (void)hipEventRecord(ctx->ev1, s);
+      ctx->timed = true;
+    }
+    return e == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
+  }
+};
+
+inline unsigned grid_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+// one-shot host-pointer call with up to three inputs and two outputs (not pipelined)
+template <class F>
+inline int host_oneshot(fec_ctx* ctx, const void* const in[3], const size_t in_bytes[3], void* const out[2],
+                 const size_t out_bytes[2], F body) {
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  void* d_in[3] = {nullptr, nullptr, nullptr};
+  void* d_out[2] = {nullptr, nullptr};
+  for (int i = 0; i < 3; ++i) {
+    if (!in[i]) continue;
+    int rc = ensure(ctx, i, in_bytes[i]);
+    if (rc != FEC_OK) return rc;
+    d_in[i] = ctx->d_buf[i];
+    if (hipMemcpyAsync(d_in[i], in[i], in_bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (!out[i]) continue;
+    int rc = ensure(ctx, 3 + i, out_bytes[i]);
+    if (rc != FEC_OK) return rc;
+    d_out[i] = ctx->d_buf[3 + i];
+  }
+  int rc = body(d_in[0], d_in[1], d_in[2], d_out[0], d_out[1]);
+  if (rc != FEC_OK) return rc;
+  for (int i = 0; i < 2; ++i) {
+    if (!out[i]) continue;
+    if (hipMemcpyAsync(out[i], d_out[i], out_bytes[i], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  return FEC_OK;
+}
+
+}  // namespace host
+}  // namespace fecgpu
