@@ -44,6 +44,23 @@ class CanonCurve:
         _check(self._lib.fec_canon_mul(self._h, self.CURVE, _ptr(k), _ptr(p), _ptr(xy), _ptr(st), n), "fec_canon_mul")
         return xy, st
 
+    def double_mul(self, u1, u2, points_xy):
+        """(xy, status) with xy[i] = u1[i] * G + u2[i] * points_xy[i]  (signature-verification point)."""
+        a, b = _u64(u1, 4), _u64(u2, 4)
+        p = _u64(points_xy, 8)
+        if not (a.shape[0] == b.shape[0] == p.shape[0]):
+            raise ValueError("inputs differ in length")
+        n = a.shape[0]
+        xy = np.zeros((n, 8), dtype=np.uint64)
+        st = np.zeros(n, dtype=np.uint8)
+        _check(self._lib.fec_canon_double_mul(self._h, self.CURVE, _ptr(a), _ptr(b), _ptr(p), _ptr(xy), _ptr(st), n),
+               "fec_canon_double_mul")
+        return xy, st
+
+    def double_mul_dev(self, d_u1, d_u2, d_points_xy, d_out_xy, d_status, n, stream=None):
+        _check(self._lib.fec_canon_double_mul_dev(self._h, self.CURVE, d_u1, d_u2, d_points_xy, d_out_xy, d_status, n,
+                                                  stream), "fec_canon_double_mul_dev")
+
     def mul_base_dev(self, d_scalars, d_out_xy, d_status, n, stream=None):
         _check(self._lib.fec_canon_mul_base_dev(self._h, self.CURVE, d_scalars, d_out_xy, d_status, n, stream),
                "fec_canon_mul_base_dev")

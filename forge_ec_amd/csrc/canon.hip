@@ -62,41 +62,54 @@ int launch_canon_normalize(fec_ctx* ctx, int curve, u64* dxy, unsigned char* dst
   return hipGetLastError() == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
 }
 
+// phase 1 of k*G (comb).  finish = false leaves the projective result in dxy / zbuf (/ tbuf for
+// Ed25519) for an accumulate pass; finish = true normalises to affine.
 int launch_canon_mul_base(fec_ctx* ctx, int curve, const u64* ds, u64* dxy, unsigned char* dst, size_t n,
-                          void* stream) {
+                          void* stream, bool finish = true) {
   if (n == 0) return FEC_OK;
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int rc = ensure_canon_comb(ctx, curve, s);
   if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
+  if (rc == FEC_OK && !finish && curve == FEC_ED25519) rc = ensure_owned(&ctx->d_tbuf, &ctx->tbuf_cap, n * 32);
   if (rc != FEC_OK) return rc;
-  Launch L(ctx, stream, "k_canon_mul_base+k_canon_normalize");
+  Launch L(ctx, stream, finish ? "k_canon_mul_base+k_canon_normalize" : "k_canon_mul_base");
+  u32* tb = !finish && curve == FEC_ED25519 ? reinterpret_cast<u32*>(ctx->d_tbuf) : nullptr;
   const u32* k = reinterpret_cast<const u32*>(ds);
   u32* xy = reinterpret_cast<u32*>(dxy);
   u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
   if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul_base<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
   else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_mul_base<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
-  else hipLaunchKernelGGL(k_ced_mul_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
-  rc = launch_canon_normalize(ctx, curve, dxy, dst, n, L.s);
+  else hipLaunchKernelGGL(k_ced_mul_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, tb, dst, n);
+  rc = finish ? launch_canon_normalize(ctx, curve, dxy, dst, n, L.s) : FEC_OK;
   int rc2 = L.done();
   return rc != FEC_OK ? rc : rc2;
 }
 
+// k*P by the windowed ladder; accum = true adds it onto the projective point already in dxy / zbuf
 int launch_canon_mul(fec_ctx* ctx, int curve, const u64* ds, const u64* dp, u64* dxy, unsigned char* dst, size_t n,
-                     void* stream) {
+                     void* stream, bool accum = false) {
   if (n == 0) return FEC_OK;
   int rc = ensure_owned(&ctx->d_win_scratch, &ctx->win_scratch_cap,
                         n * (size_t)(canon::WIN_ENTRIES * canon::WIN_ENTRY_WORDS) * sizeof(u32));
   if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
   if (rc != FEC_OK) return rc;
-  Launch L(ctx, stream, "k_canon_mul+k_canon_normalize");
+  Launch L(ctx, stream, accum ? "k_canon_mul<accum>+k_canon_normalize" : "k_canon_mul+k_canon_normalize");
+  const u32* tb = accum && curve == FEC_ED25519 ? reinterpret_cast<const u32*>(ctx->d_tbuf) : nullptr;
   const u32* k = reinterpret_cast<const u32*>(ds);
   const u32* p = reinterpret_cast<const u32*>(dp);
   u32* scratch = reinterpret_cast<u32*>(ctx->d_win_scratch);
   u32* xy = reinterpret_cast<u32*>(dxy);
   u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
-  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
-  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_mul<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
-  else hipLaunchKernelGGL(k_ced_mul, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, p, scratch, xy, z, dst, n);
+  dim3 g(grid_for(n)), b(TPB);
+  if (curve == FEC_SECP256K1) {
+    if (accum) hipLaunchKernelGGL((k_canon_mul<csecp, true>), g, b, 0, L.s, k, p, scratch, xy, z, dst, n);
+    else hipLaunchKernelGGL((k_canon_mul<csecp, false>), g, b, 0, L.s, k, p, scratch, xy, z, dst, n);
+  } else if (curve == FEC_P256) {
+    if (accum) hipLaunchKernelGGL((k_canon_mul<cp256, true>), g, b, 0, L.s, k, p, scratch, xy, z, dst, n);
+    else hipLaunchKernelGGL((k_canon_mul<cp256, false>), g, b, 0, L.s, k, p, scratch, xy, z, dst, n);
+  } else {
+    hipLaunchKernelGGL(k_ced_mul, g, b, 0, L.s, k, p, scratch, xy, z, tb, dst, n);
+  }
   rc = launch_canon_normalize(ctx, curve, dxy, dst, n, L.s);
   int rc2 = L.done();
   return rc != FEC_OK ? rc : rc2;
@@ -150,6 +163,34 @@ int fec_canon_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const 
   const size_t out_bytes[2] = {n * 64, n};
   return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void* b, void*, void* o, void* st) {
     return launch_canon_mul(ctx, curve, (const u64*)a, (const u64*)b, (u64*)o, (unsigned char*)st, n, nullptr);
+  });
+}
+
+int fec_canon_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1, const uint64_t* d_u2,
+                             const uint64_t* d_points_xy, uint64_t* d_out_xy, uint8_t* d_status, size_t n,
+                             void* stream) {
+  if (!ctx || (n && (!d_u1 || !d_u2 || !d_points_xy || !d_out_xy || !d_status))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return FEC_E_ARG;
+  if (!aligned16(d_u1) || !aligned16(d_u2) || !aligned16(d_points_xy) || !aligned16(d_out_xy)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  int rc = launch_canon_mul_base(ctx, curve, d_u1, d_out_xy, d_status, n, stream, false);
+  if (rc != FEC_OK) return rc;
+  return launch_canon_mul(ctx, curve, d_u2, d_points_xy, d_out_xy, d_status, n, stream, true);
+}
+
+int fec_canon_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, const uint64_t* u2,
+                         const uint64_t* points_xy, uint64_t* out_xy, uint8_t* status, size_t n) {
+  if (!ctx || (n && (!u1 || !u2 || !points_xy || !out_xy || !status))) return FEC_E_ARG;
+  if (!canon_curve_ok(curve)) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const void* const in[3] = {u1, u2, points_xy};
+  const size_t in_bytes[3] = {n * 32, n * 32, n * 64};
+  void* const out[2] = {out_xy, status};
+  const size_t out_bytes[2] = {n * 64, n};
+  return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void* b, void* p, void* o, void* st) {
+    int rc = launch_canon_mul_base(ctx, curve, (const u64*)a, (u64*)o, (unsigned char*)st, n, nullptr, false);
+    if (rc != FEC_OK) return rc;
+    return launch_canon_mul(ctx, curve, (const u64*)b, (const u64*)p, (u64*)o, (unsigned char*)st, n, nullptr, true);
   });
 }
 

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(TPB) void k_canon_mul_base(const u32* __restrict__ 
 // Phase 1 of ECDH: Jacobian scalars[i] * points_xy[i] by the windowed ladder.  `scratch` holds one
 // 15-entry window table per element (WIN_ENTRIES * WIN_ENTRY_WORDS words each), private to the lane
 // that builds it.  Rejected input points get status CANON_BAD_POINT (phase 2 zeroes them).
-template <class W>
+// ACCUM: out_xy / zbuf already hold a Jacobian point per element (u1 * G from the comb kernel); the
+// ladder's result is added to it -- u1*G + u2*P, the verification pattern, with G's half free of doublings.
+template <class W, bool ACCUM>
 __global__ __launch_bounds__(TPB, 2) void k_canon_mul(const u32* __restrict__ scalars,
                                                    const u32* __restrict__ points_xy,
                                                    u32* __restrict__ scratch, u32* __restrict__ out_xy,
@@ -91,6 +93,13 @@ __global__ __launch_bounds__(TPB, 2) void k_canon_mul(const u32* __restrict__ sc
     const size_t i = first + e;
     u32* table = scratch + i * (size_t)(canon::WIN_ENTRIES * canon::WIN_ENTRY_WORDS);
     canon::jac r = W::mul_window(base, lds_k + e, table);
+    if (ACCUM) {
+      canon::jac a;
+      a.x = canon::ld8(out_xy + i * 16);
+      a.y = canon::ld8(out_xy + i * 16 + 8);
+      a.z = canon::ld8(zbuf + i * 8);
+      r = W::jadd(a, r);
+    }
     canon::st8(out_xy + i * 16, r.x);
     canon::st8(out_xy + i * 16 + 8, r.y);
     canon::st8(zbuf + i * 8, r.z);
@@ -170,9 +179,11 @@ __global__ __launch_bounds__(64) void k_ced_build_comb(u32* __restrict__ table) 
   }
 }
 
+// tbuf (may be null): also keep T, for a following accumulate pass
 __global__ __launch_bounds__(TPB) void k_ced_mul_base(const u32* __restrict__ scalars, const u32* __restrict__ table,
                                                       u32* __restrict__ out_xy, u32* __restrict__ zbuf,
-                                                      unsigned char* __restrict__ status, size_t n) {
+                                                      u32* __restrict__ tbuf, unsigned char* __restrict__ status,
+                                                      size_t n) {
   __shared__ u32 lds_k[8 * TPB];
   __shared__ u32 lds_t[canon::ED_COMB_WORDS];
   const int valid = block_valid(n);
@@ -187,15 +198,17 @@ __global__ __launch_bounds__(TPB) void k_ced_mul_base(const u32* __restrict__ sc
     canon::st8(out_xy + i * 16, r.x);
     canon::st8(out_xy + i * 16 + 8, r.y);
     canon::st8(zbuf + i * 8, r.z);
+    if (tbuf) canon::st8(tbuf + i * 8, r.t);
     status[i] = CANON_FINITE;
   }
 }
 
 // `scratch`: ED_WIN_ENTRIES * 32 words per element
+// tbuf != null: accumulate onto the extended point already in out_xy / zbuf / tbuf
 __global__ __launch_bounds__(TPB, 2) void k_ced_mul(const u32* __restrict__ scalars, const u32* __restrict__ points_xy,
                                                     u32* __restrict__ scratch, u32* __restrict__ out_xy,
-                                                    u32* __restrict__ zbuf, unsigned char* __restrict__ status,
-                                                    size_t n) {
+                                                    u32* __restrict__ zbuf, const u32* __restrict__ tbuf,
+                                                    unsigned char* __restrict__ status, size_t n) {
   __shared__ u32 lds_k[8 * TPB];
   __shared__ u32 lds_p[16 * TPB];
   const int valid = block_valid(n);
@@ -212,6 +225,14 @@ __global__ __launch_bounds__(TPB, 2) void k_ced_mul(const u32* __restrict__ scal
     const size_t i = first + e;
     u32* table = scratch + i * (size_t)(canon::ED_WIN_ENTRIES * 32);
     canon::ext r = ced::mul_window(base, lds_k + e, table);
+    if (tbuf) {
+      canon::ext a;
+      a.x = canon::ld8(out_xy + i * 16);
+      a.y = canon::ld8(out_xy + i * 16 + 8);
+      a.z = canon::ld8(zbuf + i * 8);
+      a.t = canon::ld8(tbuf + i * 8);
+      r = ced::add_pniels(r, ced::to_pniels(a), 0, 0);
+    }
     canon::st8(out_xy + i * 16, r.x);
     canon::st8(out_xy + i * 16 + 8, r.y);
     canon::st8(zbuf + i * 8, r.z);

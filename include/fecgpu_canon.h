@@ -55,6 +55,15 @@ int fec_canon_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars /* n*4 
 int fec_canon_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, const uint64_t* d_points_xy,
                       uint64_t* d_out_xy, uint8_t* d_status, size_t n, void* stream);
 
+/* out_xy[i] = u1[i] * G + u2[i] * points_xy[i]  (the point computation of ECDSA / Schnorr verification):
+ * the comb supplies u1 * G without doublings, the windowed ladder adds u2 * P onto it. */
+int fec_canon_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1 /* n*4 */, const uint64_t* u2 /* n*4 */,
+                         const uint64_t* points_xy /* n*8 */, uint64_t* out_xy /* n*8 */, uint8_t* status /* n */,
+                         size_t n);
+int fec_canon_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1, const uint64_t* d_u2,
+                             const uint64_t* d_points_xy, uint64_t* d_out_xy, uint8_t* d_status, size_t n,
+                             void* stream);
+
 /* element-wise F_p arithmetic on canonical values (inputs must be < p): op is a fec_field_opcode
  * or FEC_F_INV; b is ignored for unary ops */
 int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a /* n*4 */,

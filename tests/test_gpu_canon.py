@@ -263,3 +263,40 @@ def test_ed25519_full_size_comb_equals_window_and_dh_is_symmetric(ced):
         pa = E.mul(M.unlimbs(a[i]), E.G)
         assert (M.unlimbs(Ah[i, :4]), M.unlimbs(Ah[i, 4:])) == pa
         assert (M.unlimbs(Sh[i, :4]), M.unlimbs(Sh[i, 4:])) == E.mul(M.unlimbs(b[i]), pa)
+
+
+# ---------------------------------------------------------------------------------------------
+# u1*G + u2*P (the verification point), all three curves
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["secp256k1", "p256", "ed25519"])
+def test_double_mul_matches_the_model(gpu_ctx, name):
+    from forge_ec_amd.canon import CANON_CURVES
+    dev = CANON_CURVES[name](gpu_ctx)
+    C = E if name == "ed25519" else M.CURVES[name]
+    rng = random.Random(31)
+    q = rng.randrange(2, C.N)
+    Q = C.mul(q, C.G)
+    inv_q = pow(q, -1, C.N)
+    cases = []          # (u1, u2, P)
+    for _ in range(280):
+        cases.append((rng.randrange(2**256), rng.randrange(2**256), C.mul(rng.randrange(1, C.N), C.G) if rng.random() < 0.1 else Q))
+    u = rng.randrange(1, C.N)
+    cases += [(0, 0, Q), (0, 5, Q), (5, 0, Q), (1, 1, C.G), (u, C.N - u, C.G),             # ..., G + G, u*G - u*G
+              (u * q % C.N, u, Q), (u * q % C.N, C.N - u, Q),                             # equal halves (doubling), opposite halves
+              (C.N, C.N, Q), (2**256 - 1, 2**256 - 1, Q), (7, inv_q, Q)]
+    u1 = _arr([c[0] for c in cases])
+    u2 = _arr([c[1] for c in cases])
+    pts = np.array([M.limbs(c[2][0]) + M.limbs(c[2][1]) for c in cases], dtype=np.uint64)
+    xy, st = dev.double_mul(u1, u2, pts)
+    for i, (a, b, P) in enumerate(cases):
+        want = C.add(C.mul(a, C.G), C.mul(b, P)) if name == "ed25519" else C.add(C.mul(a % C.N, C.G), C.mul(b % C.N, P))
+        if name != "ed25519" and want is M.INF:
+            assert st[i] == 1 and not xy[i].any(), i
+        else:
+            assert st[i] == 0, i
+            assert (M.unlimbs(xy[i, :4]), M.unlimbs(xy[i, 4:])) == want, (i, hex(a), hex(b))
+    # a rejected point keeps status 2 through the accumulate pass
+    bad = pts.copy()
+    bad[3, 4] ^= np.uint64(1)
+    xy, st = dev.double_mul(u1, u2, bad)
+    assert st[3] == 2 and not xy[3].any() and st[4] == 0

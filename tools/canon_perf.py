@@ -38,14 +38,22 @@ def main():
     status = torch.empty(n, dtype=torch.uint8, device="cuda")
     for cname in curves:
         c = CANON_CURVES[cname](ctx)
-        for name in ("keygen", "ecdh"):
+        for name in ("keygen", "ecdh", "double-mul"):
             best = None
             for _ in range(reps + 1):
                 if name == "keygen":
                     c.mul_base_dev(k.data_ptr(), pub.data_ptr(), status.data_ptr(), n, st)
-                else:
+                    ms, kern = ctx.last_kernel_ms()
+                elif name == "ecdh":
                     c.mul_dev(k2.data_ptr(), pub.data_ptr(), out.data_ptr(), status.data_ptr(), n, st)
-                ms, kern = ctx.last_kernel_ms()
+                    ms, kern = ctx.last_kernel_ms()
+                else:  # u1*G + u2*P: two launches; time both with torch events on the same stream
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    c.double_mul_dev(k.data_ptr(), k2.data_ptr(), pub.data_ptr(), out.data_ptr(), status.data_ptr(), n, st)
+                    e1.record()
+                    e1.synchronize()
+                    ms, kern = e0.elapsed_time(e1), "k_canon_mul_base + k_canon_mul<accum> + k_canon_normalize"
                 best = ms if best is None or ms < best else best
             torch.cuda.synchronize()
             assert int(status.sum()) == 0
