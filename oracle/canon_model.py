@@ -184,3 +184,68 @@ def unlimbs(l):
 
 def xy_limbs(pt):
     return [0] * 8 if pt is INF else limbs(pt[0]) + limbs(pt[1])
+
+
+# ---- standard SIGNATURE vectors, reduced to the point equation u1*G + u2*P the GPU evaluates ----
+# Each helper returns (curve, u1, u2, P, check) with check(R) -> bool for the affine result R.
+def ecdsa_p256_rfc6979_sample():
+    """RFC 6979 A.2.5, P-256 + SHA-256, message "sample" (the key of test_standard_vectors.rs's FIPS case;
+    that file's own r/s strings are truncated to 63/62 hex digits, so the RFC's are used)."""
+    import hashlib
+    C = P256
+    d = 0xC9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721
+    r = 0xEFD48B2AACB6A8FD1140DD9CD45E81D69D2C877B56AAF991C34D0EA84EAF3716
+    s = 0xF7CB1C942D657C41D436C7A1B6E29F65F3E900DBB9AFF4064DC4AB2F843ACDA8
+    z = int.from_bytes(hashlib.sha256(b"sample").digest(), "big")
+    w = pow(s, -1, C.N)
+    return C, z * w % C.N, r * w % C.N, C.KNOWN_MULTIPLES[d], lambda R: R is not INF and R[0] % C.N == r
+
+
+def schnorr_bip340_vector0():
+    """BIP-340 test vector 0 (secret key 3, message 0^32): the signature test_standard_vectors.rs quotes."""
+    import hashlib
+    C = SECP256K1
+    pkx = 0xF9308A019258C31049344F85F89D5229B531C845836F99B08601F113BCE036F9
+    sig = bytes.fromhex("E907831F80848D1069A5371B402410364BDF1C5F8307B0084C55F1CE2DCA8215"
+                        "25F66A4A85EA8B71E482A74F382D2CE5EBEEE8FDB2172F477DF4900D310536C0")
+    r, s = int.from_bytes(sig[:32], "big"), int.from_bytes(sig[32:], "big")
+    y2 = (pow(pkx, 3, C.P) + 7) % C.P
+    y = pow(y2, (C.P + 1) // 4, C.P)
+    assert y * y % C.P == y2
+    P = (pkx, y if y % 2 == 0 else C.P - y)      # lift_x
+    t = hashlib.sha256(b"BIP0340/challenge").digest()
+    e = int.from_bytes(hashlib.sha256(t + t + sig[:32] + pkx.to_bytes(32, "big") + bytes(32)).digest(), "big") % C.N
+    return C, s, (C.N - e) % C.N, P, lambda R: R is not INF and R[1] % 2 == 0 and R[0] == r
+
+
+def ed25519_decode(b):
+    """RFC 8032 section 5.1.3"""
+    E = ED25519
+    v = int.from_bytes(b, "little")
+    sign, y = v >> 255, v & ((1 << 255) - 1)
+    p = E.P
+    x2 = (y * y - 1) * pow(E.D * y * y + 1, -1, p) % p
+    x = pow(x2, (p + 3) // 8, p)
+    if (x * x - x2) % p:
+        x = x * pow(2, (p - 1) // 4, p) % p
+    assert (x * x - x2) % p == 0 and y < p
+    if x & 1 != sign:
+        x = p - x
+    return (x, y)
+
+
+def eddsa_rfc8032_test1():
+    """RFC 8032 section 7.1 TEST 1 (empty message): the signature test_standard_vectors.rs quotes.
+    S*B == R + h*A  <=>  S*B + (l - h)*A == R."""
+    import hashlib
+    E = ED25519
+    _, pk = ED25519_RFC8032_TEST1
+    sig = bytes.fromhex("e5564300c360ac729086e2cc806e828a84877f1eb8e5d974d873e06522490155"
+                        "5fb8821590a33bacc61e39701cf9b46bd25bf5f0595bbe24655141438e7a100b")
+    A, Rp, S = ed25519_decode(pk), ed25519_decode(sig[:32]), int.from_bytes(sig[32:], "little")
+    h = int.from_bytes(hashlib.sha512(sig[:32] + pk + b"").digest(), "little") % E.N
+    return E, S, (E.N - h) % E.N, A, lambda R: R == Rp
+
+
+SIGNATURE_VECTORS = {"p256": ecdsa_p256_rfc6979_sample, "secp256k1": schnorr_bip340_vector0,
+                     "ed25519": eddsa_rfc8032_test1}

@@ -364,3 +364,13 @@ def test_ed25519_batched_normalisation(emu, n):
         x = sum(int(xy[i, w]) << (32 * w) for w in range(8))
         y = sum(int(xy[i, 8 + w]) << (32 * w) for w in range(8))
         assert (x, y) == want[i] and st[i] == 0
+
+
+def test_standard_signature_vectors_verify_in_the_model():
+    """RFC 6979 A.2.5 ECDSA (P-256), BIP-340 vector 0, RFC 8032 test 1 -- the last two are the signatures
+    the reference's test_standard_vectors.rs quotes -- reduced to u1*G + u2*P and checked with big integers."""
+    for name, vec in M.SIGNATURE_VECTORS.items():
+        C, u1, u2, P, check = vec()
+        R = C.add(C.mul(u1, C.G), C.mul(u2, P))
+        assert check(R), name
+        assert not check(C.add(C.mul(u1 + 1, C.G), C.mul(u2, P))), name

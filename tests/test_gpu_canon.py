@@ -300,3 +300,19 @@ def test_double_mul_matches_the_model(gpu_ctx, name):
     bad[3, 4] ^= np.uint64(1)
     xy, st = dev.double_mul(u1, u2, bad)
     assert st[3] == 2 and not xy[3].any() and st[4] == 0
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "p256", "ed25519"])
+def test_standard_signature_vectors_verify_on_the_gpu(gpu_ctx, name):
+    """The verification point of a published signature, computed by fec_canon_double_mul: BIP-340 vector 0
+    (secp256k1), RFC 6979 A.2.5 ECDSA (P-256), RFC 8032 test 1 (Ed25519).  Scalar preparation (hash, s^-1
+    mod n) is done here with Python integers; the GPU evaluates u1*G + u2*P."""
+    from forge_ec_amd.canon import CANON_CURVES
+    dev = CANON_CURVES[name](gpu_ctx)
+    C, u1, u2, P, check = M.SIGNATURE_VECTORS[name]()
+    pts = np.array([M.limbs(P[0]) + M.limbs(P[1])] * 2, dtype=np.uint64)
+    xy, st = dev.double_mul(_arr([u1, (u1 + 1) % C.N]), _arr([u2, u2]), pts)
+    assert list(st) == [0, 0]
+    good = (M.unlimbs(xy[0, :4]), M.unlimbs(xy[0, 4:]))
+    forged = (M.unlimbs(xy[1, :4]), M.unlimbs(xy[1, 4:]))
+    assert check(good) and not check(forged)
