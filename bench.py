@@ -154,7 +154,15 @@ def main():
         inputs.append(synth.points(n, cid, 1002 + 3 * rank))
     d_in = [torch.from_numpy(a.view(np.int64)).cuda() for a in inputs]
     d_out = [torch.empty((n, limbs), dtype=torch.int64, device="cuda") for _ in range(2)]
-    stream = torch.cuda.current_stream().cuda_stream
+    # All launches and collectives are ordered on ONE explicit (non-default) torch stream: the library
+    # launches on the stream it is handed (a null handle would mean its own ctx stream, which torch's
+    # collectives know nothing about), RCCL orders its internal stream against torch's current stream
+    # at enqueue, and handle.wait() makes that stream wait for the collective -- so the gather reads a
+    # finished shard and the next kernel cannot overwrite a buffer the gather is still reading.
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     gather = None
     if dist is not None and args.gather == "all":
@@ -213,6 +221,13 @@ def main():
             g.finish()
     ctx.set_timing(False)
     torch.cuda.synchronize()
+    if gather is not None and os.environ.get("FEC_BENCH_CHECK_GATHER") == "1":
+        # rehearsal aid: the gathered block of this rank must equal the shard the kernel just produced
+        step(0, False)
+        full = gather[0].finish()
+        torch.cuda.synchronize()
+        if not torch.equal(full[rank * n:(rank + 1) * n], d_out[0]):
+            raise SystemExit("gathered shard differs from the kernel output")
     kernel_ms = float(np.mean(kms))
     peak_measured = ctx.measure_peak_mad32()
     info = ctx.device_info()
