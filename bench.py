@@ -108,7 +108,7 @@ def cpu_baseline(workload, inputs, gpu_out, target_s):
 def measured_traffic(workload, n):
     """HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMC itself)."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01", "traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01c", "traffic.json")))
         if t["workload"] == workload and t["units_per_launch"] == n:
             return t["hbm_bytes_per_launch"]
     except Exception:
