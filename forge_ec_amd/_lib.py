@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
 # include/fecgpu_canon.h: the canonical-math mode (NOT reference parity)
 CANON_ABI_SYMBOLS = [
     "fec_canon_mul_base", "fec_canon_mul_base_dev", "fec_canon_mul", "fec_canon_mul_dev", "fec_canon_field_op",
-    "fec_canon_double_mul", "fec_canon_double_mul_dev",
+    "fec_canon_double_mul", "fec_canon_double_mul_dev", "fec_canon_ecdsa_verify", "fec_canon_ecdsa_verify_dev",
 ]
 F_INV = 5
 
@@ -119,6 +119,8 @@ def lib():
     L.fec_canon_field_op.argtypes = [vp, ci, ci, vp, vp, vp, sz]
     L.fec_canon_double_mul.argtypes = [vp, ci, vp, vp, vp, vp, vp, sz]
     L.fec_canon_double_mul_dev.argtypes = [vp, ci, vp, vp, vp, vp, vp, sz, vp]
+    L.fec_canon_ecdsa_verify.argtypes = [vp, ci, vp, vp, vp, vp, vp, sz]
+    L.fec_canon_ecdsa_verify_dev.argtypes = [vp, ci, vp, vp, vp, vp, vp, sz, vp]
     for n in CANON_ABI_SYMBOLS:
         getattr(L, n).restype = ci
     _lib = L

@@ -61,6 +61,22 @@ class CanonCurve:
         _check(self._lib.fec_canon_double_mul_dev(self._h, self.CURVE, d_u1, d_u2, d_points_xy, d_out_xy, d_status, n,
                                                   stream), "fec_canon_double_mul_dev")
 
+    def ecdsa_verify(self, z, r, s, pk_xy):
+        """Standard ECDSA verification (secp256k1, P-256): (n,) uint8, 1 = valid.  z = digest as an integer."""
+        zz, rr, ss = _u64(z, 4), _u64(r, 4), _u64(s, 4)
+        pk = _u64(pk_xy, 8)
+        n = zz.shape[0]
+        if not (rr.shape[0] == ss.shape[0] == pk.shape[0] == n):
+            raise ValueError("inputs differ in length")
+        out = np.zeros(n, dtype=np.uint8)
+        _check(self._lib.fec_canon_ecdsa_verify(self._h, self.CURVE, _ptr(zz), _ptr(rr), _ptr(ss), _ptr(pk), _ptr(out), n),
+               "fec_canon_ecdsa_verify")
+        return out
+
+    def ecdsa_verify_dev(self, d_z, d_r, d_s, d_pk_xy, d_result, n, stream=None):
+        _check(self._lib.fec_canon_ecdsa_verify_dev(self._h, self.CURVE, d_z, d_r, d_s, d_pk_xy, d_result, n, stream),
+               "fec_canon_ecdsa_verify_dev")
+
     def mul_base_dev(self, d_scalars, d_out_xy, d_status, n, stream=None):
         _check(self._lib.fec_canon_mul_base_dev(self._h, self.CURVE, d_scalars, d_out_xy, d_status, n, stream),
                "fec_canon_mul_base_dev")

@@ -115,6 +115,39 @@ int launch_canon_mul(fec_ctx* ctx, int curve, const u64* ds, const u64* dp, u64*
   return rc != FEC_OK ? rc : rc2;
 }
 
+// ECDSA verification: scalars -> u1*G + u2*Q -> compare.  d_work: u1, u2 (n*32 each), xy (n*64),
+// point status (n), range flags (n).
+int launch_canon_ecdsa_verify(fec_ctx* ctx, int curve, const u64* dz, const u64* dr, const u64* ds, const u64* dpk,
+                              unsigned char* dres, size_t n, void* stream) {
+  if (n == 0) return FEC_OK;
+  const size_t need = n * (32 + 32 + 64 + 1 + 1) + 64;
+  int rc = ensure_owned(&ctx->d_verify, &ctx->verify_cap, need);
+  if (rc != FEC_OK) return rc;
+  char* base = (char*)ctx->d_verify;
+  u64* u1 = (u64*)base;
+  u64* u2 = (u64*)(base + n * 32);
+  u64* xy = (u64*)(base + n * 64);
+  unsigned char* pst = (unsigned char*)(base + n * 128);
+  unsigned char* ok = pst + n;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  dim3 g(grid_for(n)), b(TPB);
+  if (curve == FEC_SECP256K1)
+    hipLaunchKernelGGL((k_canon_ecdsa_scalars<canon::NSecp>), g, b, 0, s, (const u32*)dz, (const u32*)dr, (const u32*)ds,
+                       (u32*)u1, (u32*)u2, ok, n);
+  else
+    hipLaunchKernelGGL((k_canon_ecdsa_scalars<canon::NP256>), g, b, 0, s, (const u32*)dz, (const u32*)dr, (const u32*)ds,
+                       (u32*)u1, (u32*)u2, ok, n);
+  if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
+  rc = launch_canon_mul_base(ctx, curve, u1, xy, pst, n, stream, false);
+  if (rc == FEC_OK) rc = launch_canon_mul(ctx, curve, u2, dpk, xy, pst, n, stream, true);
+  if (rc != FEC_OK) return rc;
+  if (curve == FEC_SECP256K1)
+    hipLaunchKernelGGL((k_canon_ecdsa_finish<canon::NSecp>), g, b, 0, s, (const u32*)xy, (const u32*)dr, ok, pst, dres, n);
+  else
+    hipLaunchKernelGGL((k_canon_ecdsa_finish<canon::NP256>), g, b, 0, s, (const u32*)xy, (const u32*)dr, ok, pst, dres, n);
+  return hipGetLastError() == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" {
@@ -192,6 +225,44 @@ int fec_canon_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
     if (rc != FEC_OK) return rc;
     return launch_canon_mul(ctx, curve, (const u64*)b, (const u64*)p, (u64*)o, (unsigned char*)st, n, nullptr, true);
   });
+}
+
+int fec_canon_ecdsa_verify_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_z, const uint64_t* d_r,
+                               const uint64_t* d_s, const uint64_t* d_pk_xy, uint8_t* d_result, size_t n,
+                               void* stream) {
+  if (!ctx || (n && (!d_z || !d_r || !d_s || !d_pk_xy || !d_result))) return FEC_E_ARG;
+  if (curve != FEC_SECP256K1 && curve != FEC_P256) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
+  if (!aligned16(d_z) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_pk_xy)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_canon_ecdsa_verify(ctx, curve, d_z, d_r, d_s, d_pk_xy, d_result, n, stream);
+}
+
+int fec_canon_ecdsa_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* z, const uint64_t* r, const uint64_t* s,
+                           const uint64_t* pk_xy, uint8_t* result, size_t n) {
+  if (!ctx || (n && (!z || !r || !s || !pk_xy || !result))) return FEC_E_ARG;
+  if (curve != FEC_SECP256K1 && curve != FEC_P256) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  const void* src[4] = {z, r, s, pk_xy};
+  const size_t bytes[4] = {n * 32, n * 32, n * 32, n * 64};
+  for (int i = 0; i < 4; ++i) {
+    int rc = ensure(ctx, i, bytes[i]);
+    if (rc != FEC_OK) return rc;
+    if (hipMemcpyAsync(ctx->d_buf[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  }
+  int rc = ensure(ctx, 4, n);
+  if (rc != FEC_OK) return rc;
+  rc = launch_canon_ecdsa_verify(ctx, curve, (const u64*)ctx->d_buf[0], (const u64*)ctx->d_buf[1],
+                                 (const u64*)ctx->d_buf[2], (const u64*)ctx->d_buf[3], (unsigned char*)ctx->d_buf[4], n,
+                                 nullptr);
+  if (rc != FEC_OK) return rc;
+  if (hipMemcpyAsync(result, ctx->d_buf[4], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  return FEC_OK;
 }
 
 int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,

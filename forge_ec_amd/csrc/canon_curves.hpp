@@ -1029,6 +1029,95 @@ struct edw {
   }
 };
 
+// ================================================================================================
+// Scalar fields (integers modulo the group order n) for ECDSA verification: Montgomery arithmetic
+// with R = 2^256 for a general odd modulus.  N supplies n(), nm2() (n - 2), N0INV = -n^-1 mod 2^32,
+// r2() = R^2 mod n.
+// ================================================================================================
+template <class N>
+struct Fn {
+  FEC_SDEV lmask ge_n(const fe& a) {
+    fe d;
+    return ~sub256(d, a, N::n());  // no borrow  <=>  a >= n
+  }
+  // t (512 bits, < n * 2^256) * R^-1 mod n
+  FEC_SDEV fe redc(const u32 tin[16]) {
+    const fe nn = N::n();
+    u32 t[16];
+    FEC_UNROLL for (int i = 0; i < 16; ++i) t[i] = tin[i];
+    u32 extra = 0;
+    FEC_UNROLL for (int k = 0; k < 8; ++k) {
+      const u32 m = t[k] * N::N0INV;
+      u64 c = 0;
+      FEC_UNROLL for (int j = 0; j < 8; ++j) {
+        u64 a = (u64)m * nn.w[j] + t[k + j] + c;  // <= (2^32-1)^2 + 2 (2^32-1): fits
+        t[k + j] = (u32)a;
+        c = a >> 32;
+      }
+      u64 a = (u64)t[k + 8] + c + extra;
+      t[k + 8] = (u32)a;
+      extra = (u32)(a >> 32);
+    }
+    fe r, d;
+    FEC_UNROLL for (int i = 0; i < 8; ++i) r.w[i] = t[8 + i];
+    lmask borrow = sub256(d, r, nn);
+    // value = extra * 2^256 + r < 2n: subtract n when extra is set or r >= n
+    return fe_select(r, d, lanes_where(extra != 0) | ~borrow);
+  }
+  FEC_SDEV fe mmul(const fe& a, const fe& b) {
+    u32 t[16];
+    mul_wide(t, a, b);
+    return redc(t);
+  }
+  // s^-1 in Montgomery form (s plain, in [1, n)): (s R)^(n-2) with Montgomery products
+  FEC_SDEV fe inv_mont(const fe& s) {
+    const fe sm = mmul(s, N::r2());
+    const fe e = N::nm2();
+    fe r = sm;
+    int i = 255;  // n - 2 has its top bit set for both curves
+#pragma unroll 1
+    for (--i; i >= 0; --i) {
+      r = mmul(r, r);
+      if ((e.w[i >> 5] >> (i & 31)) & 1u) r = mmul(r, sm);
+    }
+    return r;
+  }
+};
+
+struct NSecp {
+  static constexpr u32 N0INV = 0x5588B13Fu;
+  FEC_SDEV fe n() { return edw::fe_words(0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); }
+  FEC_SDEV fe nm2() { return edw::fe_words(0xD036413Fu, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); }
+  FEC_SDEV fe r2() { return edw::fe_words(0x67D7D140u, 0x896CF214u, 0x0E7CF878u, 0x741496C2u, 0x5BCD07C6u, 0xE697F5E4u, 0x81C69BC5u, 0x9D671CD5u); }
+};
+struct NP256 {
+  static constexpr u32 N0INV = 0xEE00BC4Fu;
+  FEC_SDEV fe n() { return edw::fe_words(0xFC632551u, 0xF3B9CAC2u, 0xA7179E84u, 0xBCE6FAADu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0xFFFFFFFFu); }
+  FEC_SDEV fe nm2() { return edw::fe_words(0xFC63254Fu, 0xF3B9CAC2u, 0xA7179E84u, 0xBCE6FAADu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0xFFFFFFFFu); }
+  FEC_SDEV fe r2() { return edw::fe_words(0xBE79EEA2u, 0x83244C95u, 0x49BD6FA6u, 0x4699799Cu, 0x2B6BEC59u, 0x2845B239u, 0xF3D95620u, 0x66E12D94u); }
+};
+
+// ECDSA verification (FIPS 186-4 section 6.4 / SEC 1 section 4.1.4), the scalar half:
+//   r, s in [1, n-1]; w = s^-1; u1 = z w, u2 = r w  (mod n).   Returns the lanes that pass the range check.
+template <class N>
+FEC_DEV lmask ecdsa_scalars(const fe& z, const fe& r, const fe& s, fe& u1, fe& u2) {
+  using F = Fn<N>;
+  const lmask ok = ~fe_is_zero(r) & ~fe_is_zero(s) & ~F::ge_n(r) & ~F::ge_n(s);
+  const fe wm = F::inv_mont(s);   // s = 0 gives 0: harmless, the lane is rejected anyway
+  u1 = F::mmul(z, wm);            // plain * Montgomery = plain; z >= n is reduced by the product
+  u2 = F::mmul(r, wm);
+  return uniform_mask(ok);
+}
+// ... and the final comparison: x(R) mod n == r  (x < p < 2n)
+template <class N>
+FEC_DEV lmask ecdsa_x_matches(const fe& x, const fe& r) {
+  using F = Fn<N>;
+  fe d;
+  sub256(d, x, N::n());
+  const fe xr = fe_select(x, d, F::ge_n(x));
+  return fe_eq(xr, r);
+}
+
 }  // namespace canon
 using csecp = canon::wei<canon::SecpParams>;
 using cp256 = canon::wei<canon::P256Params>;

@@ -981,6 +981,7 @@ void fec_ctx_destroy(fec_ctx* ctx) {
   if (ctx->d_win_scratch) (void)hipFree(ctx->d_win_scratch);
   if (ctx->d_zbuf) (void)hipFree(ctx->d_zbuf);
   if (ctx->d_tbuf) (void)hipFree(ctx->d_tbuf);
+  if (ctx->d_verify) (void)hipFree(ctx->d_verify);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

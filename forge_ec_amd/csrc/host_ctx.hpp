@@ -35,6 +35,8 @@ struct fec_ctx {
   size_t win_scratch_cap = 0;
   void* d_zbuf = nullptr;  // Jacobian Z of the batch between the ladder and the batched normalisation
   size_t zbuf_cap = 0;
+  void* d_verify = nullptr;  // canonical ECDSA verification work area (u1, u2, R, flags)
+  size_t verify_cap = 0;
   void* d_tbuf = nullptr;  // Ed25519 double-mul: T of the comb result until the accumulate pass
   size_t tbuf_cap = 0;
   hipDeviceProp_t prop;

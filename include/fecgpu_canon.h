@@ -64,6 +64,20 @@ int fec_canon_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1
                              const uint64_t* d_points_xy, uint64_t* d_out_xy, uint8_t* d_status, size_t n,
                              void* stream);
 
+/* Standard ECDSA verification (FIPS 186-4 section 6.4 / SEC 1 section 4.1.4), FEC_SECP256K1 and FEC_P256:
+ * z = the message digest as an integer (for SHA-256 and these curves: the 32 digest bytes read big-endian),
+ * r, s = the signature, pk_xy = the affine public key; all as little-endian 64-bit limbs.
+ * result[i] = 1 iff r, s in [1, n-1], the key is on the curve, R = (z/s) G + (r/s) Q is finite and
+ * x(R) mod n == r.  Everything after the hash runs on the GPU: s^-1 by Fermat in Montgomery form mod n,
+ * u1 G + u2 Q by comb + windowed accumulate, batched normalisation, comparison.  This is the loop
+ * forge-ec-signature/src/ecdsa.rs:313-361 (batch_verify) runs per signature -- for the real curve. */
+int fec_canon_ecdsa_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* z /* n*4 */, const uint64_t* r /* n*4 */,
+                           const uint64_t* s /* n*4 */, const uint64_t* pk_xy /* n*8 */, uint8_t* result /* n */,
+                           size_t n);
+int fec_canon_ecdsa_verify_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_z, const uint64_t* d_r,
+                               const uint64_t* d_s, const uint64_t* d_pk_xy, uint8_t* d_result, size_t n,
+                               void* stream);
+
 /* element-wise F_p arithmetic on canonical values (inputs must be < p): op is a fec_field_opcode
  * or FEC_F_INV; b is ignored for unary ops */
 int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a /* n*4 */,

@@ -374,3 +374,32 @@ def test_standard_signature_vectors_verify_in_the_model():
         R = C.add(C.mul(u1, C.G), C.mul(u2, P))
         assert check(R), name
         assert not check(C.add(C.mul(u1 + 1, C.G), C.mul(u2, P))), name
+
+
+def test_scalar_field_and_ecdsa_scalars(emu, curve):
+    """Montgomery arithmetic modulo the group order and the scalar half of ECDSA verification"""
+    C, cid = curve
+    n, R = C.N, 2**256
+    rng = random.Random(77)
+    out = np.zeros(4, dtype=np.uint64)
+    Rinv = pow(R, -1, n)
+    edge = [0, 1, 2, n - 1, n - 2, 2**255, 2**256 - 1, n, n + 1, (n - 1) // 2]
+    for a, b in [(x, y) for x in edge for y in edge] + [(rng.randrange(R), rng.randrange(n)) for _ in range(500)]:
+        if a * b >= n * R:
+            continue  # REDC's contract: the product is below n * 2^256
+        emu.he_canon_scalar_op(cid, 0, _p(_arr(a)), _p(_arr(b)), _p(out))
+        assert M.unlimbs(out) == a * b * Rinv % n, (hex(a), hex(b))
+    for a in [1, 2, n - 1, n - 2] + [rng.randrange(1, n) for _ in range(12)]:
+        emu.he_canon_scalar_op(cid, 1, _p(_arr(a)), None, _p(out))
+        assert M.unlimbs(out) == pow(a, -1, n) * R % n
+    u1, u2 = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    for _ in range(12):
+        z, r, s = rng.randrange(R), rng.randrange(1, n), rng.randrange(1, n)
+        assert emu.he_canon_ecdsa_scalars(cid, _p(_arr(z)), _p(_arr(r)), _p(_arr(s)), _p(u1), _p(u2)) == 1
+        w = pow(s, -1, n)
+        assert M.unlimbs(u1) == z * w % n and M.unlimbs(u2) == r * w % n
+    for r, s in [(0, 5), (5, 0), (n, 5), (5, n), (2**256 - 1, 5), (5, n + 3)]:
+        assert emu.he_canon_ecdsa_scalars(cid, _p(_arr(7)), _p(_arr(r)), _p(_arr(s)), _p(u1), _p(u2)) == 0
+    for x, r, want in [(5, 5, 1), (n + 5, 5, 1), (n - 1, n - 1, 1), (n, 0, 1), (5, 6, 0), (C.P - 1, (C.P - 1) % n, 1)]:
+        if x < C.P:
+            assert emu.he_canon_ecdsa_x_matches(cid, _p(_arr(x)), _p(_arr(r))) == want

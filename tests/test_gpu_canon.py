@@ -316,3 +316,63 @@ def test_standard_signature_vectors_verify_on_the_gpu(gpu_ctx, name):
     good = (M.unlimbs(xy[0, :4]), M.unlimbs(xy[0, 4:]))
     forged = (M.unlimbs(xy[1, :4]), M.unlimbs(xy[1, 4:]))
     assert check(good) and not check(forged)
+
+
+# ---------------------------------------------------------------------------------------------
+# standard ECDSA verification end to end (everything after the hash on the GPU)
+# ---------------------------------------------------------------------------------------------
+def _ecdsa_sign(C, d, z, k):
+    R = C.mul(k, C.G)
+    r = R[0] % C.N
+    s = pow(k, -1, C.N) * (z + r * d) % C.N
+    return r, s
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "p256"])
+def test_ecdsa_verify_end_to_end(gpu_ctx, name):
+    import hashlib
+    from forge_ec_amd.canon import CANON_CURVES
+    dev = CANON_CURVES[name](gpu_ctx)
+    C = M.CURVES[name]
+    rng = random.Random(41)
+    rows, want = [], []
+    keys = [(d, C.mul(d, C.G)) for d in (rng.randrange(1, C.N) for _ in range(12))]
+    for i in range(300):
+        d, Q = keys[i % len(keys)]
+        z = int.from_bytes(hashlib.sha256(b"message %d" % i).digest(), "big")
+        while True:
+            r, s = _ecdsa_sign(C, d, z, rng.randrange(1, C.N))
+            if r and s:
+                break
+        kind = i % 10
+        ok = 1
+        if kind == 1:
+            z ^= 1 << rng.randrange(256); ok = 0             # another message
+        elif kind == 2:
+            s = (s + 1) % C.N or 1; ok = 0                    # tampered s
+        elif kind == 3:
+            r = (r + 1) % C.N or 1; ok = 0                    # tampered r
+        elif kind == 4:
+            Q = keys[(i + 1) % len(keys)][1]; ok = 0          # another key
+        elif kind == 5:
+            s = C.N - s                                       # the other valid s (ECDSA malleability)
+        elif kind == 6:
+            r, ok = [0, C.N, 2**256 - 1][i % 3], 0            # r out of range
+        elif kind == 7:
+            s, ok = [0, C.N, C.N + 5][i % 3], 0               # s out of range
+        elif kind == 8:
+            Q, ok = (Q[0], (Q[1] + 1) % C.P), 0               # key not on the curve
+        rows.append((z, r, s, Q))
+        want.append(ok)
+    # the published signature
+    if name == "p256":
+        d = 0xC9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721
+        rows.append((int.from_bytes(hashlib.sha256(b"sample").digest(), "big"),
+                     0xEFD48B2AACB6A8FD1140DD9CD45E81D69D2C877B56AAF991C34D0EA84EAF3716,
+                     0xF7CB1C942D657C41D436C7A1B6E29F65F3E900DBB9AFF4064DC4AB2F843ACDA8, C.KNOWN_MULTIPLES[d]))
+        want.append(1)
+    got = dev.ecdsa_verify(_arr([t[0] for t in rows]), _arr([t[1] for t in rows]), _arr([t[2] for t in rows]),
+                           np.array([M.limbs(t[3][0]) + M.limbs(t[3][1]) for t in rows], dtype=np.uint64))
+    assert list(got) == want
+    assert dev.ecdsa_verify(np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64),
+                            np.zeros((0, 8), np.uint64)).shape == (0,)

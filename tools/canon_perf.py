@@ -34,12 +34,13 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     k = torch.from_numpy(synth.scalars(n, 0, 41).view(np.int64)).cuda()
     k2 = torch.from_numpy(synth.scalars(n, 0, 42).view(np.int64)).cuda()
+    k3 = torch.from_numpy(synth.scalars(n, 0, 43).view(np.int64)).cuda()
     pub = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     out = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     status = torch.empty(n, dtype=torch.uint8, device="cuda")
     for cname in curves:
         c = CANON_CURVES[cname](ctx)
-        for name in ("keygen", "ecdh", "double-mul"):
+        for name in ("keygen", "ecdh", "double-mul") + (("ecdsa-verify",) if cname != "ed25519" else ()):
             best = None
             for _ in range(reps + 1):
                 if name == "keygen":
@@ -48,6 +49,12 @@ def main():
                 elif name == "ecdh":
                     c.mul_dev(k2.data_ptr(), pub.data_ptr(), out.data_ptr(), status.data_ptr(), n, st)
                     ms, kern = ctx.last_kernel_ms()
+                elif name == "ecdsa-verify":  # scalars + comb + accumulate + normalise + compare, wall clock
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    c.ecdsa_verify_dev(k.data_ptr(), k2.data_ptr(), k3.data_ptr(), pub.data_ptr(), status.data_ptr(), n, st)
+                    torch.cuda.synchronize()
+                    ms, kern = (time.perf_counter() - t0) * 1e3, "k_canon_ecdsa_scalars + comb + accumulate + normalize + finish"
                 else:  # u1*G + u2*P: three launches on the ctx stream; wall clock around a device sync
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
@@ -56,7 +63,7 @@ def main():
                     ms, kern = (time.perf_counter() - t0) * 1e3, "k_canon_mul_base + k_canon_mul<accum> + k_canon_normalize"
                 best = ms if best is None or ms < best else best
             torch.cuda.synchronize()
-            assert int(status.sum()) == 0
+            assert name == "ecdsa-verify" or int(status.sum()) == 0
             rate = n / (best * 1e-3)
             print(json.dumps({"workload": "%s-canon-%s" % (cname, name), "mode": "canonical math, NOT reference parity",
                               "n": n, "kernel": kern, "ms": round(best, 4), "M_per_s": round(rate / 1e6, 3)}),

@@ -247,3 +247,24 @@ extern "C" int he_ced_normalize(uint32_t* xy, const uint32_t* zbuf, unsigned cha
   for (size_t g = 0; g < stride; ++g) ced::normalize_group(xy, zbuf, status, g, stride, n);
   return 0;
 }
+// ---- scalar fields for canonical ECDSA: curve 0 secp256k1, 1 P-256 ----
+// op 0: mmul(a, b) (a * b * R^-1 mod n); 1: inv_mont(a) (a^-1 * R mod n)
+extern "C" int he_canon_scalar_op(int curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  fe x = ld(a), y = b ? ld(b) : fe_zero(), r;
+  if (curve == 0) r = op == 0 ? canon::Fn<canon::NSecp>::mmul(x, y) : canon::Fn<canon::NSecp>::inv_mont(x);
+  else r = op == 0 ? canon::Fn<canon::NP256>::mmul(x, y) : canon::Fn<canon::NP256>::inv_mont(x);
+  st(out, r);
+  return 0;
+}
+// returns 1 if the range check passes; u1, u2 out
+extern "C" int he_canon_ecdsa_scalars(int curve, const uint64_t* z, const uint64_t* r, const uint64_t* s, uint64_t* u1, uint64_t* u2) {
+  fe a, b;
+  lmask ok = curve == 0 ? canon::ecdsa_scalars<canon::NSecp>(ld(z), ld(r), ld(s), a, b)
+                        : canon::ecdsa_scalars<canon::NP256>(ld(z), ld(r), ld(s), a, b);
+  st(u1, a); st(u2, b);
+  return ok ? 1 : 0;
+}
+extern "C" int he_canon_ecdsa_x_matches(int curve, const uint64_t* x, const uint64_t* r) {
+  lmask m = curve == 0 ? canon::ecdsa_x_matches<canon::NSecp>(ld(x), ld(r)) : canon::ecdsa_x_matches<canon::NP256>(ld(x), ld(r));
+  return m ? 1 : 0;
+}
