@@ -128,7 +128,11 @@ FEC_SDEV fe mul(const fe& a, const fe& b) {
   mul_wide(t, a, b);
   return reduce512(t);
 }
-FEC_SDEV fe sqr(const fe& a) { return mul(a, a); }
+FEC_SDEV fe sqr(const fe& a) {
+  u32 t[16];
+  sqr_wide(t, a);
+  return reduce512(t);
+}
 FEC_SDEV fe mul3(const fe& a) { return add(add(a, a), a); }
 FEC_SDEV fe mul8(const fe& a) { return dbl(dbl(dbl(a))); }
 
@@ -261,7 +265,11 @@ struct FpP256 {
     mul_wide(t, a, b);
     return reduce512(t);
   }
-  FEC_SDEV fe sqr(const fe& a) { return mul(a, a); }
+  FEC_SDEV fe sqr(const fe& a) {
+    u32 t[16];
+    sqr_wide(t, a);
+    return reduce512(t);
+  }
   FEC_SDEV fe inv(const fe& a) {  // a^(p-2)
     const u32 e[8] = {0xFFFFFFFDu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 1u, 0xFFFFFFFFu};
     return pow_const<FpP256>(a, e);
@@ -735,7 +743,11 @@ struct FpEd {
     mul_wide(t, a, b);
     return reduce512(t);
   }
-  FEC_SDEV fe sqr(const fe& a) { return mul(a, a); }
+  FEC_SDEV fe sqr(const fe& a) {
+    u32 t[16];
+    sqr_wide(t, a);
+    return reduce512(t);
+  }
   FEC_SDEV fe sqr_n(fe a, int n) {
 #pragma unroll 1
     for (int i = 0; i < n; ++i) a = sqr(a);
@@ -1069,6 +1081,11 @@ struct Fn {
     mul_wide(t, a, b);
     return redc(t);
   }
+  FEC_SDEV fe msqr(const fe& a) {
+    u32 t[16];
+    sqr_wide(t, a);
+    return redc(t);
+  }
   // s^-1 in Montgomery form (s plain, in [1, n)): (s R)^(n-2) with Montgomery products
   FEC_SDEV fe inv_mont(const fe& s) {
     const fe sm = mmul(s, N::r2());
@@ -1077,7 +1094,7 @@ struct Fn {
     int i = 255;  // n - 2 has its top bit set for both curves
 #pragma unroll 1
     for (--i; i >= 0; --i) {
-      r = mmul(r, r);
+      r = msqr(r);
       if ((e.w[i >> 5] >> (i & 31)) & 1u) r = mmul(r, sm);
     }
     return r;

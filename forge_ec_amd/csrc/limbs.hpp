@@ -606,6 +606,81 @@ FEC_DEV void mul_wide(u32 t[16], const fe& a, const fe& b) {
 #endif
 #endif
 
+// t[0..15] = a^2, exact.  28 cross products a_i a_j (i < j) by product scanning, doubled with
+// v_alignbit, plus the eight squares: 56 + 16 + 8 + 17 instructions against 128 for mul_wide(a, a).
+#ifdef FEC_HOST_EMUL
+FEC_DEV void sqr_wide(u32 t[16], const fe& a) { mul_wide(t, a, a); }
+#else
+// r = a + b + carry-in mask; returns the carry-out mask
+FEC_DEV lmask add256_cin(fe& r, const fe& a, const fe& b, lmask cin) {
+  lmask c;
+  fe x = a;
+  asm("s_mov_b64 vcc, %17\n\t"
+      "v_addc_co_u32_e32 %0, vcc, %0, %9, vcc\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %10, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, %2, %11, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, %3, %12, vcc\n\t"
+      "v_addc_co_u32_e32 %4, vcc, %4, %13, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, %5, %14, vcc\n\t"
+      "v_addc_co_u32_e32 %6, vcc, %6, %15, vcc\n\t"
+      "v_addc_co_u32_e32 %7, vcc, %7, %16, vcc\n\t"
+      "s_mov_b64 %8, vcc"
+      : FEC_RW8(x), "=s"(c)
+      : FEC_V8(b), "s"(cin)
+      : "vcc");
+  r = x;
+  return c;
+}
+FEC_DEV u64 sq64(u32 x) {
+  u64 r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %1, 0" : "=v"(r) : "v"(x) : "vcc");
+  return r;
+}
+FEC_DEV void sqr_wide(u32 t[16], const fe& a) {
+  u32 x[16];
+  x[0] = 0;
+  u64 acc = (u64)a.w[0] * a.w[1];  // column 1: one product
+  u32 ovf = 0;
+  x[1] = (u32)acc;
+  FEC_UNROLL for (int k = 2; k < 14; ++k) {
+    const u64 cin = (acc >> 32) | ((u64)ovf << 32);
+    const int lo = k < 8 ? 0 : k - 7, hi = (k - 1) / 2, n = hi - lo + 1;  // pairs (i, k - i), lo <= i <= hi
+    u32 xs[4], ys[4];
+    FEC_UNROLL for (int i = 0; i < 4; ++i) {
+      xs[i] = i < n ? a.w[lo + i] : 0;
+      ys[i] = i < n ? a.w[k - lo - i] : 0;
+    }
+    switch (n) {
+      case 1: mcol<1>(acc, ovf, cin, xs, ys); break;
+      case 2: mcol<2>(acc, ovf, cin, xs, ys); break;
+      case 3: mcol<3>(acc, ovf, cin, xs, ys); break;
+      default: mcol<4>(acc, ovf, cin, xs, ys); break;
+    }
+    x[k] = (u32)acc;
+  }
+  x[14] = (u32)(acc >> 32);
+  x[15] = ovf;
+  fe y0, y1, d0, d1;
+  y0.w[0] = 0;
+  FEC_UNROLL for (int k = 1; k < 8; ++k) y0.w[k] = __builtin_amdgcn_alignbit(x[k], x[k - 1], 31);
+  FEC_UNROLL for (int k = 8; k < 16; ++k) y1.w[k - 8] = __builtin_amdgcn_alignbit(x[k], x[k - 1], 31);
+  FEC_UNROLL for (int i = 0; i < 4; ++i) {
+    const u64 s0 = sq64(a.w[i]), s1 = sq64(a.w[4 + i]);
+    d0.w[2 * i] = (u32)s0;
+    d0.w[2 * i + 1] = (u32)(s0 >> 32);
+    d1.w[2 * i] = (u32)s1;
+    d1.w[2 * i + 1] = (u32)(s1 >> 32);
+  }
+  fe r0, r1;
+  const lmask c = add256(r0, y0, d0);
+  add256_cin(r1, y1, d1, c);
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    t[i] = r0.w[i];
+    t[8 + i] = r1.w[i];
+  }
+}
+#endif
+
 // t[0..7] = low 256 bits of a * b (columns 0..7 of the same product scanning)
 #ifdef FEC_HOST_EMUL
 FEC_DEV void mul_low256(u32 t[8], const fe& a, const fe& b) {
