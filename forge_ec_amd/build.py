@@ -43,9 +43,11 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, proc in jobs:
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    failed = [(cmd, proc.returncode) for cmd, proc in jobs if proc.wait() != 0]
+    if failed:
+        if os.path.exists(SO):
+            os.remove(SO)  # never leave a library that no longer matches the sources
+        raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
     if jobs or not os.path.exists(SO) or any(os.path.getmtime(o) > os.path.getmtime(SO) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
         if verbose:

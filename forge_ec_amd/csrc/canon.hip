@@ -131,12 +131,15 @@ int launch_canon_ecdsa_verify(fec_ctx* ctx, int curve, const u64* dz, const u64*
   unsigned char* ok = pst + n;
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   dim3 g(grid_for(n)), b(TPB);
+  const size_t lanes = (n + canon::NORM_GROUP - 1) / canon::NORM_GROUP;
+  const size_t stride = (lanes + 63) / 64 * 64;
+  dim3 gs(grid_for(stride));
   if (curve == FEC_SECP256K1)
-    hipLaunchKernelGGL((k_canon_ecdsa_scalars<canon::NSecp>), g, b, 0, s, (const u32*)dz, (const u32*)dr, (const u32*)ds,
-                       (u32*)u1, (u32*)u2, ok, n);
+    hipLaunchKernelGGL((k_canon_ecdsa_scalars<canon::NSecp>), gs, b, 0, s, (const u32*)dz, (const u32*)dr, (const u32*)ds,
+                       (u32*)u1, (u32*)u2, ok, n, stride);
   else
-    hipLaunchKernelGGL((k_canon_ecdsa_scalars<canon::NP256>), g, b, 0, s, (const u32*)dz, (const u32*)dr, (const u32*)ds,
-                       (u32*)u1, (u32*)u2, ok, n);
+    hipLaunchKernelGGL((k_canon_ecdsa_scalars<canon::NP256>), gs, b, 0, s, (const u32*)dz, (const u32*)dr, (const u32*)ds,
+                       (u32*)u1, (u32*)u2, ok, n, stride);
   if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
   rc = launch_canon_mul_base(ctx, curve, u1, xy, pst, n, stream, false);
   if (rc == FEC_OK) rc = launch_canon_mul(ctx, curve, u2, dpk, xy, pst, n, stream, true);

@@ -1086,9 +1086,8 @@ struct Fn {
     sqr_wide(t, a);
     return redc(t);
   }
-  // s^-1 in Montgomery form (s plain, in [1, n)): (s R)^(n-2) with Montgomery products
-  FEC_SDEV fe inv_mont(const fe& s) {
-    const fe sm = mmul(s, N::r2());
+  // (sm)^-1 for sm in Montgomery form, result in Montgomery form: sm^(n-2) with Montgomery products
+  FEC_SDEV fe inv_mm(const fe& sm) {
     const fe e = N::nm2();
     fe r = sm;
     int i = 255;  // n - 2 has its top bit set for both curves
@@ -1099,6 +1098,8 @@ struct Fn {
     }
     return r;
   }
+  // s^-1 in Montgomery form for s plain, in [1, n)
+  FEC_SDEV fe inv_mont(const fe& s) { return inv_mm(mmul(s, N::r2())); }
 };
 
 struct NSecp {
@@ -1124,6 +1125,50 @@ FEC_DEV lmask ecdsa_scalars(const fe& z, const fe& r, const fe& s, fe& u1, fe& u
   u1 = F::mmul(z, wm);            // plain * Montgomery = plain; z >= n is reduced by the product
   u2 = F::mmul(r, wm);
   return uniform_mask(ok);
+}
+// The same for a group of NORM_GROUP signatures per lane with ONE inversion (Montgomery's trick on
+// the s values): elements first, first + stride, ...; rejected (out-of-range) signatures take s = 1
+// in the chain.  ok[i] = 1 where r, s are in [1, n-1].
+template <class N>
+FEC_DEV void ecdsa_scalars_group(const u32* zs, const u32* rs, const u32* ss, u32* u1, u32* u2, unsigned char* ok,
+                                 size_t first, size_t stride, size_t n) {
+  using F = Fn<N>;
+  fe c[NORM_GROUP];
+  fe run = fe_small(1);
+  FEC_UNROLL for (int j = 0; j < NORM_GROUP; ++j) {
+    const size_t i = first + (size_t)j * stride;
+    fe s = fe_small(1);
+    if (i < n) s = ld8(ss + i * 8);
+    const lmask bad = uniform_mask(fe_is_zero(s) | F::ge_n(s));
+    s = fe_select(s, fe_small(1), bad);
+    const fe sm = F::mmul(s, N::r2());
+    run = j == 0 ? sm : F::mmul(run, sm);
+    c[j] = run;
+  }
+  fe u = F::inv_mm(run);
+#pragma unroll 1
+  for (int j = NORM_GROUP - 1; j >= 0; --j) {
+    const size_t i = first + (size_t)j * stride;
+    const bool live = i < n;
+    fe s = fe_small(1), r = fe_small(1), z = fe_zero();
+    if (live) {
+      s = ld8(ss + i * 8);
+      r = ld8(rs + i * 8);
+      z = ld8(zs + i * 8);
+    }
+    const lmask sbad = uniform_mask(fe_is_zero(s) | F::ge_n(s));
+    const lmask good = uniform_mask(~sbad & ~fe_is_zero(r) & ~F::ge_n(r));
+    s = fe_select(s, fe_small(1), sbad);
+    fe prev = F::mmul(fe_small(1), N::r2());  // 1 in Montgomery form (j = 0)
+    FEC_UNROLL for (int t = 0; t < NORM_GROUP - 1; ++t) prev = fe_select(prev, c[t], lanes_where(t == j - 1));
+    const fe wm = F::mmul(u, prev);          // s_j^-1, Montgomery form
+    u = F::mmul(u, F::mmul(s, N::r2()));
+    if (live) {
+      st8(u1 + i * 8, F::mmul(z, wm));       // plain * Montgomery = plain; z >= n is reduced by the product
+      st8(u2 + i * 8, F::mmul(r, wm));
+      ok[i] = lane_of(good) ? 1 : 0;
+    }
+  }
 }
 // ... and the final comparison: x(R) mod n == r  (x < p < 2n)
 template <class N>

@@ -241,33 +241,14 @@ __global__ __launch_bounds__(TPB, 2) void k_ced_mul(const u32* __restrict__ scal
 }
 
 // ---- canonical ECDSA verification (secp256k1, P-256) ---------------------------------------------
-// scalar half: range check, w = s^-1 mod n, u1 = z w, u2 = r w
+// scalar half: range check, w = s^-1 mod n (one inversion per NORM_GROUP signatures per lane), u1 = z w, u2 = r w
 template <class N>
-__global__ __launch_bounds__(TPB) void k_canon_ecdsa_scalars(const u32* __restrict__ zs, const u32* __restrict__ rs,
-                                                             const u32* __restrict__ ss, u32* __restrict__ u1,
-                                                             u32* __restrict__ u2, unsigned char* __restrict__ ok,
-                                                             size_t n) {
-  __shared__ u32 lds_z[8 * TPB];
-  __shared__ u32 lds_r[8 * TPB];
-  __shared__ u32 lds_s[8 * TPB];
-  const int valid = block_valid(n);
-  const size_t first = (size_t)blockIdx.x * TPB;
-  stage_in<8>(lds_z, zs + first * 8, valid);
-  stage_in<8>(lds_r, rs + first * 8, valid);
-  stage_in<8>(lds_s, ss + first * 8, valid);
-  __syncthreads();
-  const int e = threadIdx.x;
-  if (e < valid) {
-    fe a, b;
-    const lmask good = canon::ecdsa_scalars<N>(load_fe(lds_z + e, TPB), load_fe(lds_r + e, TPB),
-                                               load_fe(lds_s + e, TPB), a, b);
-    store_fe(lds_z + e, TPB, a);
-    store_fe(lds_s + e, TPB, b);
-    ok[first + e] = lane_of(good) ? 1 : 0;
-  }
-  __syncthreads();
-  stage_out<8>(u1 + first * 8, lds_z, valid);
-  stage_out<8>(u2 + first * 8, lds_s, valid);
+__global__ __launch_bounds__(TPB, 2) void k_canon_ecdsa_scalars(const u32* __restrict__ zs, const u32* __restrict__ rs,
+                                                                const u32* __restrict__ ss, u32* __restrict__ u1,
+                                                                u32* __restrict__ u2, unsigned char* __restrict__ ok,
+                                                                size_t n, size_t stride) {
+  const size_t g = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (g < stride) canon::ecdsa_scalars_group<N>(zs, rs, ss, u1, u2, ok, g, stride, n);
 }
 
 // final comparison: valid iff the range check passed, the public key was accepted, R is finite and

@@ -403,3 +403,33 @@ def test_scalar_field_and_ecdsa_scalars(emu, curve):
     for x, r, want in [(5, 5, 1), (n + 5, 5, 1), (n - 1, n - 1, 1), (n, 0, 1), (5, 6, 0), (C.P - 1, (C.P - 1) % n, 1)]:
         if x < C.P:
             assert emu.he_canon_ecdsa_x_matches(cid, _p(_arr(x)), _p(_arr(r))) == want
+
+
+@pytest.mark.parametrize("n", [1, 8, 9, 700])
+def test_ecdsa_scalars_grouped_inversion(emu, curve, n):
+    """one inversion per 8 signatures per lane (Montgomery's trick on s), with out-of-range r / s mixed in"""
+    C, cid = curve
+    rng = random.Random(1000 + n)
+    N = C.N
+    Z, Rr, S = [], [], []
+    for i in range(n):
+        z, r, s = rng.randrange(2**256), rng.randrange(1, N), rng.randrange(1, N)
+        k = rng.random()
+        if k < 0.08:
+            s = rng.choice([0, N, N + 7, 2**256 - 1])
+        elif k < 0.16:
+            r = rng.choice([0, N, 2**256 - 1])
+        Z.append(z); Rr.append(r); S.append(s)
+    def w32(vals):
+        return np.array([[(v >> (32 * k)) & 0xFFFFFFFF for k in range(8)] for v in vals], dtype=np.uint32)
+    z, r, s = w32(Z), w32(Rr), w32(S)
+    u1, u2 = np.zeros((n, 8), dtype=np.uint32), np.zeros((n, 8), dtype=np.uint32)
+    ok = np.zeros(n, dtype=np.uint8)
+    emu.he_canon_ecdsa_scalars_batch(cid, _p(z), _p(r), _p(s), _p(u1), _p(u2), _p(ok), ctypes.c_size_t(n))
+    for i in range(n):
+        good = 1 <= Rr[i] < N and 1 <= S[i] < N
+        assert ok[i] == (1 if good else 0), i
+        if good:
+            w = pow(S[i], -1, N)
+            assert sum(int(u1[i, k]) << (32 * k) for k in range(8)) == Z[i] * w % N
+            assert sum(int(u2[i, k]) << (32 * k) for k in range(8)) == Rr[i] * w % N

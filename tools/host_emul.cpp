@@ -268,3 +268,14 @@ extern "C" int he_canon_ecdsa_x_matches(int curve, const uint64_t* x, const uint
   lmask m = curve == 0 ? canon::ecdsa_x_matches<canon::NSecp>(ld(x), ld(r)) : canon::ecdsa_x_matches<canon::NP256>(ld(x), ld(r));
   return m ? 1 : 0;
 }
+// the grouped scalar half exactly as k_canon_ecdsa_scalars drives it
+extern "C" int he_canon_ecdsa_scalars_batch(int curve, const uint32_t* z, const uint32_t* r, const uint32_t* s, uint32_t* u1,
+                                            uint32_t* u2, unsigned char* ok, size_t n) {
+  const size_t lanes = (n + canon::NORM_GROUP - 1) / canon::NORM_GROUP;
+  const size_t stride = (lanes + 63) / 64 * 64;
+  for (size_t g = 0; g < stride; ++g) {
+    if (curve == 0) canon::ecdsa_scalars_group<canon::NSecp>(z, r, s, u1, u2, ok, g, stride, n);
+    else canon::ecdsa_scalars_group<canon::NP256>(z, r, s, u1, u2, ok, g, stride, n);
+  }
+  return 0;
+}
