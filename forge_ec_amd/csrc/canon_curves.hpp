@@ -442,6 +442,7 @@ FEC_DEV void normalize_group_t(u32* xy, const u32* zbuf, unsigned char* status, 
 template <class P>
 struct wei {
   using F = typename P::F;
+  static constexpr bool P_HAS_GLV = P::HAS_GLV;
   FEC_SDEV fe add(const fe& a, const fe& b) { return F::add(a, b); }
   FEC_SDEV fe sub(const fe& a, const fe& b) { return F::sub(a, b); }
   FEC_SDEV fe neg(const fe& a) { return F::neg(a); }
@@ -665,6 +666,7 @@ FEC_SDEV jac mul_base_comb(const u32* tab, const u32* kw) {
 struct SecpParams {
   using F = FpSecp;
   static constexpr bool A_IS_ZERO = true;
+  static constexpr bool HAS_GLV = true;  // phi(x, y) = (beta x, y): glv_secp below
   FEC_SDEV fe b() { return fe_small(7); }
   FEC_SDEV aff generator() {  // SEC 2, section 2.4.1
     aff g;
@@ -680,6 +682,7 @@ struct SecpParams {
 struct P256Params {
   using F = FpP256;
   static constexpr bool A_IS_ZERO = false;  // a = -3
+  static constexpr bool HAS_GLV = false;
   FEC_SDEV fe b() {  // FIPS 186-4 D.1.2.3
     fe r;
     const u32 w[8] = {0x27D2604Bu, 0x3BCE3C3Eu, 0xCC53B0F6u, 0x651D06B0u, 0x769886BCu, 0xB3EBBD55u, 0xAA3A93E7u, 0x5AC635D8u};
@@ -1100,6 +1103,19 @@ struct Fn {
   }
   // s^-1 in Montgomery form for s plain, in [1, n)
   FEC_SDEV fe inv_mont(const fe& s) { return inv_mm(mmul(s, N::r2())); }
+  // a + b, a - b modulo n for a, b in [0, n)
+  FEC_SDEV fe addn(const fe& a, const fe& b) {
+    fe s, d;
+    const lmask carry = add256(s, a, b);
+    const lmask borrow = sub256(d, s, N::n());
+    return fe_select(s, d, carry | ~borrow);
+  }
+  FEC_SDEV fe subn(const fe& a, const fe& b) {
+    fe d, d2;
+    const lmask borrow = sub256(d, a, b);
+    add256(d2, d, N::n());
+    return fe_select(d, d2, borrow);
+  }
 };
 
 struct NSecp {
@@ -1113,6 +1129,105 @@ struct NP256 {
   FEC_SDEV fe n() { return edw::fe_words(0xFC632551u, 0xF3B9CAC2u, 0xA7179E84u, 0xBCE6FAADu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0xFFFFFFFFu); }
   FEC_SDEV fe nm2() { return edw::fe_words(0xFC63254Fu, 0xF3B9CAC2u, 0xA7179E84u, 0xBCE6FAADu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0xFFFFFFFFu); }
   FEC_SDEV fe r2() { return edw::fe_words(0xBE79EEA2u, 0x83244C95u, 0x49BD6FA6u, 0x4699799Cu, 0x2B6BEC59u, 0x2845B239u, 0xF3D95620u, 0x66E12D94u); }
+};
+
+// ================================================================================================
+// GLV for secp256k1 (Gallant-Lambert-Vanstone): phi(x, y) = (beta x, y) = lambda (x, y), so
+//   k P = k1 P + k2 phi(P),  k = k1 + k2 lambda (mod n),  |k1|, |k2| < 2^128,
+// and the windowed ladder needs 33 windows of (4 doublings + 2 additions) instead of 64 of (4 + 1).
+// Decomposition as in Guide to ECC Alg. 3.74 with the precomputed basis (a1, b1), (a2, b2):
+//   c1 = round(b2 k / n) = (k g1 + 2^383) >> 384,  c2 = round(-b1 k / n) = (k g2 + 2^383) >> 384,
+//   k2 = c1 (-b1) + c2 (-b2),  k1 = k - k2 lambda   (mod n),  each then taken with its sign.
+// ================================================================================================
+struct glv_secp {
+  using W = wei<SecpParams>;
+  using F = Fn<NSecp>;
+  FEC_SDEV fe beta() { return edw::fe_words(0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu); }
+  FEC_SDEV fe g1() { return edw::fe_words(0x45DBB031u, 0xE893209Au, 0x71E8CA7Fu, 0x3DAA8A14u, 0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u); }
+  FEC_SDEV fe g2() { return edw::fe_words(0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu, 0x0ABFE4C4u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u); }
+  // (-b1) R, (-b2) R, lambda R modulo n: plain * Montgomery-form constant = plain product mod n
+  FEC_SDEV fe mb1R() { return edw::fe_words(0x0AD9263Cu, 0xC50468D0u, 0xFAA6ED42u, 0x1B1C8205u, 0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu); }
+  FEC_SDEV fe mb2R() { return edw::fe_words(0x6A144696u, 0x0CAC5E50u, 0xF3BA5939u, 0x1E8A8DC5u, 0xBA244FCEu, 0x176CDF65u, 0x8E173580u, 0xC25575EBu); }
+  FEC_SDEV fe lamR() { return edw::fe_words(0xC9926C9Eu, 0xF07DEB3Du, 0x83C6944Cu, 0x2C93E7ADu, 0x52697D91u, 0x73A96606u, 0x8558D639u, 0x53284017u); }
+  FEC_SDEV fe half_n() { return edw::fe_words(0x681B20A0u, 0xDFE92F46u, 0x57A4501Du, 0x5D576E73u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FFFFFFFu); }
+
+  // (k g + 2^383) >> 384: the top four words of the 512-bit product, rounded
+  FEC_SDEV fe mul_shift384(const fe& k, const fe& g) {
+    u32 t[16];
+    mul_wide(t, k, g);
+    fe c = fe_zero();
+    c.w[0] = t[12]; c.w[1] = t[13]; c.w[2] = t[14]; c.w[3] = t[15];
+    fe r;
+    add_word256(r, c, t[11] >> 31);
+    return r;
+  }
+  // any 256-bit k -> |k1|, |k2| and the lanes where each is negative
+  FEC_SDEV void decompose(const fe& kin, fe& k1, lmask& neg1, fe& k2, lmask& neg2) {
+    fe k = kin, d;
+    const lmask borrow = sub256(d, k, NSecp::n());
+    k = fe_select(d, k, borrow);  // k mod n (k < 2^256 < 2n)
+    const fe c1 = mul_shift384(k, g1()), c2 = mul_shift384(k, g2());
+    const fe r2 = F::addn(F::mmul(c1, mb1R()), F::mmul(c2, mb2R()));
+    const fe r1 = F::subn(k, F::mmul(r2, lamR()));
+    const fe h = half_n();
+    fe t;
+    neg1 = uniform_mask(sub256(t, h, r1));  // r1 > n/2
+    neg2 = uniform_mask(sub256(t, h, r2));
+    fe m1, m2;
+    sub256(m1, NSecp::n(), r1);
+    sub256(m2, NSecp::n(), r2);
+    k1 = fe_select(r1, m1, neg1);
+    k2 = fe_select(r2, m2, neg2);
+  }
+  FEC_SDEV jac entry(const u32* table, u32 digit, lmask negate, bool endo) {
+    jac q = win_load(table + ((digit == 0 ? 1u : digit) - 1) * WIN_ENTRY_WORDS);
+    if (endo) q.x = W::mul(q.x, beta());
+    q.y = fe_select(q.y, W::neg(q.y), negate);
+    return q;
+  }
+  // kw: this lane's scalar column in LDS (8 words at stride KSTRIDE); it is overwritten with the low
+  // four words of |k1| (words 0..3) and |k2| (words 4..7).
+  FEC_SDEV jac mul_window(const aff& base, u32* kw, u32* table) {
+    jac t;
+    t.x = base.x;
+    t.y = base.y;
+    t.z = fe_small(1);
+    win_store(table, t);
+    t = W::jdouble(t);
+    win_store(table + WIN_ENTRY_WORDS, t);
+#pragma unroll 1
+    for (int j = 3; j <= WIN_ENTRIES; ++j) {
+      t = W::jadd_affine(t, base, 0);
+      win_store(table + (j - 1) * WIN_ENTRY_WORDS, t);
+    }
+    fe k, k1, k2;
+    FEC_UNROLL for (int i = 0; i < 8; ++i) k.w[i] = kw[i * KSTRIDE];
+    lmask neg1, neg2;
+    decompose(k, k1, neg1, k2, neg2);
+    FEC_UNROLL for (int i = 0; i < 4; ++i) {
+      kw[i * KSTRIDE] = k1.w[i];
+      kw[(4 + i) * KSTRIDE] = k2.w[i];
+    }
+    // window 32: the bits above 2^128 (zero in practice; kept for the proven bound |k_i| < 2^128 + small)
+    jac acc = jac_infinity();
+    {
+      const u32 d1 = k1.w[4] & 15u, d2 = k2.w[4] & 15u;
+      if (__builtin_expect(lanes_where((d1 | d2) != 0) != 0, 0)) {
+        acc = W::jadd_window(acc, entry(table, d1, neg1, false), lanes_where(d1 == 0));
+        acc = W::jadd_window(acc, entry(table, d2, neg2, true), lanes_where(d2 == 0));
+      }
+    }
+#pragma unroll 1
+    for (int w = 31; w >= 0; --w) {
+      const u32 d1 = (kw[(w >> 3) * KSTRIDE] >> ((w & 7) * 4)) & 15u;
+      const u32 d2 = (kw[(4 + (w >> 3)) * KSTRIDE] >> ((w & 7) * 4)) & 15u;
+#pragma unroll 1
+      for (int d = 0; d < 4; ++d) acc = W::jdouble(acc);
+      acc = W::jadd_window(acc, entry(table, d1, neg1, false), lanes_where(d1 == 0));
+      acc = W::jadd_window(acc, entry(table, d2, neg2, true), lanes_where(d2 == 0));
+    }
+    return acc;
+  }
 };
 
 // ECDSA verification (FIPS 186-4 section 6.4 / SEC 1 section 4.1.4), the scalar half:
@@ -1184,4 +1299,5 @@ FEC_DEV lmask ecdsa_x_matches(const fe& x, const fe& r) {
 using csecp = canon::wei<canon::SecpParams>;
 using cp256 = canon::wei<canon::P256Params>;
 using ced = canon::edw;
+using cglv = canon::glv_secp;
 }  // namespace fecgpu

@@ -92,7 +92,9 @@ __global__ __launch_bounds__(TPB, 2) void k_canon_mul(const u32* __restrict__ sc
     // a bad point still runs the ladder (on garbage; the arithmetic is total) and is zeroed in phase 2
     const size_t i = first + e;
     u32* table = scratch + i * (size_t)(canon::WIN_ENTRIES * canon::WIN_ENTRY_WORDS);
-    canon::jac r = W::mul_window(base, lds_k + e, table);
+    canon::jac r;
+    if constexpr (W::P_HAS_GLV) r = cglv::mul_window(base, lds_k + e, table);  // secp256k1: half the doublings
+    else r = W::mul_window(base, lds_k + e, table);
     if (ACCUM) {
       canon::jac a;
       a.x = canon::ld8(out_xy + i * 16);

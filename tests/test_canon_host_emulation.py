@@ -433,3 +433,40 @@ def test_ecdsa_scalars_grouped_inversion(emu, curve, n):
             w = pow(S[i], -1, N)
             assert sum(int(u1[i, k]) << (32 * k) for k in range(8)) == Z[i] * w % N
             assert sum(int(u2[i, k]) << (32 * k) for k in range(8)) == Rr[i] * w % N
+
+
+# ---------------------------------------------------------------------------------------------
+# GLV (secp256k1)
+# ---------------------------------------------------------------------------------------------
+GLV_LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+GLV_BETA = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
+
+
+def test_glv_constants_and_decomposition(emu):
+    S = M.SECP256K1
+    n = S.N
+    assert pow(GLV_LAMBDA, 3, n) == 1 and pow(GLV_BETA, 3, S.P) == 1
+    assert S.mul(GLV_LAMBDA, S.G) == (GLV_BETA * S.G[0] % S.P, S.G[1])     # phi(G) = lambda G
+    rng = random.Random(55)
+    k1, k2 = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    ks = [0, 1, 2, n - 1, n - 2, n, n + 1, 2**256 - 1, GLV_LAMBDA, n - GLV_LAMBDA, 2**128, 2**128 - 1, 2**255,
+          (n - 1) // 2, (n + 1) // 2] + [rng.randrange(2**256) for _ in range(3000)]
+    for k in ks:
+        signs = emu.he_glv_decompose(_p(_arr(k)), _p(k1), _p(k2))
+        a, b = M.unlimbs(k1), M.unlimbs(k2)
+        assert a < 2**129 and b < 2**129, hex(k)
+        sa = -a if signs & 1 else a
+        sb = -b if signs & 2 else b
+        assert (sa + sb * GLV_LAMBDA - k) % n == 0, hex(k)
+
+
+def test_glv_ladder_matches_the_model(emu):
+    S = M.SECP256K1
+    rng = random.Random(56)
+    out = np.zeros(8, dtype=np.uint64)
+    ks = scalars_of(S) + [GLV_LAMBDA, S.N - GLV_LAMBDA, GLV_LAMBDA + 1] + [rng.randrange(2**256) for _ in range(60)]
+    for i, k in enumerate(ks):
+        pt = S.mul(rng.randrange(1, S.N), S.G) if i % 3 else S.G
+        pin = np.array(M.xy_limbs(pt), dtype=np.uint64)
+        st = emu.he_glv_mul(_p(_arr(k)), _p(pin), _p(out))
+        assert _pt_of(out, st == 1) == S.mul(k % S.N, pt), hex(k)

@@ -22,7 +22,12 @@ def scalars_of(C):
     return [0, 1, 2, 3, 15, 16, 17, 2**32 - 1, 2**64, 2**128 - 1, 2**255, C.N - 1, C.N, C.N + 1, C.N + 16,
             2**256 - 1, 2 * C.N % 2**256, 0x1111111111111111111111111111111111111111111111111111111111111111,
             0xF0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0,
-            0xC9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721]
+            0xC9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721,
+            # around the GLV eigenvalue of secp256k1 (k2 = +-1, k1 = 0 / small) and the half-order boundary
+            0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72,
+            0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD73,
+            C.N - 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72, (C.N - 1) // 2, (C.N + 1) // 2,
+            2**128, 2**128 - 1, 2**129]
 
 
 @pytest.fixture(scope="module", params=["secp256k1", "p256"])

@@ -279,3 +279,21 @@ extern "C" int he_canon_ecdsa_scalars_batch(int curve, const uint32_t* z, const 
   }
   return 0;
 }
+// ---- GLV (secp256k1) ----
+extern "C" int he_glv_decompose(const uint64_t* k, uint64_t* k1, uint64_t* k2) {
+  fe a, b; lmask n1, n2;
+  cglv::decompose(ld(k), a, n1, b, n2);
+  st(k1, a); st(k2, b);
+  return (n1 ? 1 : 0) | (n2 ? 2 : 0);
+}
+extern "C" int he_glv_mul(const uint64_t* scalar, const uint64_t* pxy, uint64_t* xy) {
+  static thread_local u32 kw[8 * KSTRIDE];
+  static thread_local u32 table[canon::WIN_ENTRIES * canon::WIN_ENTRY_WORDS];
+  canon_kw(kw, scalar);
+  canon::aff base; base.x = ld(pxy); base.y = ld(pxy + 4);
+  canon::jac r = cglv::mul_window(base, kw, table);
+  canon::aff a;
+  lmask inf = csecp::to_affine(r, a);
+  st(xy, a.x); st(xy + 4, a.y);
+  return inf ? 1 : 0;
+}
