@@ -36,6 +36,26 @@ int ensure_canon_comb(fec_ctx* ctx, int curve, hipStream_t s) {
   return FEC_OK;
 }
 
+int ensure_canon_comb8(fec_ctx* ctx, int curve, hipStream_t s) {
+  if (ctx->canon_comb8_ready[curve]) return FEC_OK;
+  if (!ctx->d_canon_comb8[curve] &&
+      hipMalloc(&ctx->d_canon_comb8[curve],
+                (curve == FEC_ED25519 ? canon::ED_COMB8_WORDS : canon::COMB8_WORDS) * sizeof(u32)) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_OOM;
+  }
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_build_comb8<csecp>), dim3(canon::COMB8_WINDOWS), dim3(TPB), 0, s, ctx->d_canon_comb8[curve]);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_build_comb8<cp256>), dim3(canon::COMB8_WINDOWS), dim3(TPB), 0, s, ctx->d_canon_comb8[curve]);
+  else hipLaunchKernelGGL(k_ced_build_comb8, dim3(canon::COMB8_WINDOWS + 1), dim3(TPB), 0, s, ctx->d_canon_comb8[curve]);
+  if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
+  if (hipStreamSynchronize(s) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  ctx->canon_comb8_ready[curve] = true;
+  return FEC_OK;
+}
+
 // grow-only device buffer owned by the ctx (kernels of earlier calls may still use the old one)
 int ensure_owned(void** buf, size_t* cap, size_t need) {
   if (*cap >= need) return FEC_OK;
@@ -68,7 +88,8 @@ int launch_canon_mul_base(fec_ctx* ctx, int curve, const u64* ds, u64* dxy, unsi
                           void* stream, bool finish = true) {
   if (n == 0) return FEC_OK;
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-  int rc = ensure_canon_comb(ctx, curve, s);
+  const bool comb8 = ctx->canon_use_comb8;
+  int rc = comb8 ? ensure_canon_comb8(ctx, curve, s) : ensure_canon_comb(ctx, curve, s);
   if (rc == FEC_OK) rc = ensure_owned(&ctx->d_zbuf, &ctx->zbuf_cap, n * 32);
   if (rc == FEC_OK && !finish && curve == FEC_ED25519) rc = ensure_owned(&ctx->d_tbuf, &ctx->tbuf_cap, n * 32);
   if (rc != FEC_OK) return rc;
@@ -77,7 +98,10 @@ int launch_canon_mul_base(fec_ctx* ctx, int curve, const u64* ds, u64* dxy, unsi
   const u32* k = reinterpret_cast<const u32*>(ds);
   u32* xy = reinterpret_cast<u32*>(dxy);
   u32* z = reinterpret_cast<u32*>(ctx->d_zbuf);
-  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul_base<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
+  if (comb8 && curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul_base8<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb8[curve], xy, z, dst, n);
+  else if (comb8 && curve == FEC_P256) hipLaunchKernelGGL((k_canon_mul_base8<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb8[curve], xy, z, dst, n);
+  else if (comb8) hipLaunchKernelGGL(k_ced_mul_base8, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb8[curve], xy, z, tb, dst, n);
+  else if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_mul_base<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
   else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_mul_base<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, dst, n);
   else hipLaunchKernelGGL(k_ced_mul_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, k, ctx->d_canon_comb[curve], xy, z, tb, dst, n);
   rc = finish ? launch_canon_normalize(ctx, curve, dxy, dst, n, L.s) : FEC_OK;

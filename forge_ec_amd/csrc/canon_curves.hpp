@@ -384,6 +384,10 @@ constexpr unsigned char ST_FINITE = 0, ST_INFINITY = 1, ST_BAD_POINT = 2;
 // 64 windows x 15 entries x 16 words, entry stride COMB_STRIDE words (odd, spreads LDS banks).
 constexpr int COMB_WINDOWS = 64, COMB_ENTRIES = 15, COMB_STRIDE = 17;
 constexpr int COMB_WORDS = COMB_WINDOWS * COMB_ENTRIES * COMB_STRIDE;
+// 8-bit comb: 32 windows x 255 affine multiples of 256^w * G, 16 words (64 bytes) each, 510 KiB:
+// lives in global memory and stays L2-resident; one 64-byte gather per lane per window.
+constexpr int COMB8_WINDOWS = 32, COMB8_ENTRIES = 255;
+constexpr size_t COMB8_WORDS = (size_t)COMB8_WINDOWS * COMB8_ENTRIES * 16;
 
 // This lane's group: elements first, first + stride, ... (NORM_GROUP of them, those < n).
 // status[i] on entry: ST_BAD_POINT for rejected inputs, anything else is recomputed here.
@@ -647,6 +651,48 @@ FEC_SDEV void comb_fill_window(u32* table, int window, const aff& base) {
   }
 }
 
+// ---- 8-bit comb (table in global memory / L2) ----
+FEC_SDEV aff comb8_entry(const u32* tab, int window, u32 digit /* 1..255 */) {
+  const u32* e = tab + ((size_t)window * COMB8_ENTRIES + digit - 1) * 16;
+  aff q;
+  q.x = ld8(e);
+  q.y = ld8(e + 8);
+  return q;
+}
+FEC_SDEV void comb8_store(u32* tab, int window, u32 digit, const aff& a) {
+  u32* e = tab + ((size_t)window * COMB8_ENTRIES + digit - 1) * 16;
+  st8(e, a.x);
+  st8(e + 8, a.y);
+}
+// j * base for one 8-bit digit j (1..255), base affine: plain double-and-add, MSB first
+FEC_SDEV jac small_multiple(const aff& base, u32 j) {
+  jac acc = jac_infinity();
+#pragma unroll 1
+  for (int b = 7; b >= 0; --b) {
+    acc = jdouble(acc);
+    acc = jadd_affine(acc, base, lanes_where(((j >> b) & 1u) == 0));
+  }
+  return acc;
+}
+// k*G: one mixed addition per non-zero byte of k (32 bytes), no doublings; the next entry's gather is
+// issued before the current addition so its L2 latency hides behind ~11 field multiplications.
+FEC_SDEV jac mul_base_comb8(const u32* tab, const u32* kw) {
+  jac acc = jac_infinity();
+  u32 d = kw[0] & 255u;
+  aff q = comb8_entry(tab, 0, d == 0 ? 1u : d);
+#pragma unroll 1
+  for (int w = 0; w < COMB8_WINDOWS; ++w) {
+    const aff cur = q;
+    const lmask skip = lanes_where(d == 0);
+    if (w + 1 < COMB8_WINDOWS) {
+      d = (kw[((w + 1) >> 2) * KSTRIDE] >> (((w + 1) & 3) * 8)) & 255u;
+      q = comb8_entry(tab, w + 1, d == 0 ? 1u : d);
+    }
+    acc = jadd_affine(acc, cur, skip);
+  }
+  return acc;
+}
+
 // k*G: one mixed addition per non-zero 4-bit digit of k (64 digits), no doublings.
 // kw: the lane's scalar in LDS (word j at kw[j * KSTRIDE]); any 256-bit k is accepted (k*G with k
 // taken modulo the group order, as the group law gives).
@@ -787,6 +833,10 @@ struct pniels {
 // signed recoding so that any 256-bit scalar is accepted.
 constexpr int ED_COMB_ENTRIES = 8, ED_COMB_STRIDE = 25;
 constexpr int ED_COMB_WORDS = (COMB_WINDOWS * ED_COMB_ENTRIES + 1) * ED_COMB_STRIDE;
+// Signed 8-bit comb: 32 windows x 128 affine Niels multiples of 256^w * B (+ 2^256 * B), each padded to
+// 32 words = one 128-byte line; 512 KiB in global memory, L2-resident.
+constexpr int ED_COMB8_ENTRIES = 128;
+constexpr size_t ED_COMB8_WORDS = ((size_t)COMB8_WINDOWS * ED_COMB8_ENTRIES + 1) * 32;
 // Variable base: 1P..8P as projective Niels points, 32 words = one 128-byte line each
 constexpr int ED_WIN_ENTRIES = 8;
 
@@ -975,6 +1025,56 @@ struct edw {
     }
     niels top = comb_entry(tab, COMB_WINDOWS * ED_COMB_ENTRIES);
     return add_niels(acc, top, 0, lanes_where(carry == 0));
+  }
+
+  // ---- fixed base, signed 8-bit comb in global memory ----
+  FEC_SDEV void comb8_store(u32* table, size_t index, const aff& a) {
+    u32* dst = table + index * 32;
+    st8(dst, add(a.y, a.x));
+    st8(dst + 8, sub(a.y, a.x));
+    st8(dst + 16, mul(mul(a.x, a.y), d2()));
+  }
+  FEC_SDEV niels comb8_entry(const u32* tab, size_t index) {
+    const u32* e = tab + index * 32;
+    niels q;
+    q.ypx = ld8(e);
+    q.ymx = ld8(e + 8);
+    q.t2d = ld8(e + 16);
+    return q;
+  }
+  // j * base for j in 1..128: double-and-add over 8 bits
+  FEC_SDEV ext small_multiple(const aff& base, u32 j) {
+    const pniels bq = to_pniels(from_affine(base));
+    ext acc = identity();
+#pragma unroll 1
+    for (int b = 7; b >= 0; --b) {
+      acc = dbl<true>(acc);
+      acc = add_pniels(acc, bq, 0, lanes_where(((j >> b) & 1u) == 0));
+    }
+    return acc;
+  }
+  // k*B for any 256-bit k: signed bytes d_w in -128..128, k = sum d_w 256^w + carry * 2^256
+  FEC_SDEV ext mul_base_comb8(const u32* tab, const u32* kw) {
+    ext acc = identity();
+    u32 v = kw[0] & 255u;
+    u32 carry = v > 128u ? 1u : 0u;
+    u32 mag = carry ? 256u - v : v;
+    niels q = comb8_entry(tab, (size_t)(mag == 0 ? 1u : mag) - 1);
+#pragma unroll 1
+    for (int w = 0; w < COMB8_WINDOWS; ++w) {
+      const niels cur = q;
+      const lmask negate = lanes_where(carry != 0 && mag != 0), skip = lanes_where(mag == 0);
+      if (w + 1 < COMB8_WINDOWS) {
+        v = ((kw[((w + 1) >> 2) * KSTRIDE] >> (((w + 1) & 3) * 8)) & 255u) + carry;  // 0..256
+        carry = v > 128u ? 1u : 0u;
+        mag = carry ? 256u - v : v;
+        q = comb8_entry(tab, (size_t)(w + 1) * ED_COMB8_ENTRIES + (mag == 0 ? 1u : mag) - 1);
+      } else {
+        q = comb8_entry(tab, (size_t)COMB8_WINDOWS * ED_COMB8_ENTRIES);  // 2^256 * B
+      }
+      acc = add_niels(acc, cur, negate, skip);
+    }
+    return add_niels(acc, q, 0, lanes_where(carry == 0));
   }
 
   // ---- variable base: signed 4-bit windows, MSB first; the lane's 1P..8P live in its scratch slice ----

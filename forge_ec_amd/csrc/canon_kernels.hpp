@@ -149,6 +149,60 @@ __global__ __launch_bounds__(TPB) void k_canon_field_op(int op, const u32* __res
   stage_out<8>(out + first * 8, lds_a, valid);
 }
 
+// ---- 8-bit comb in global memory (L2-resident), Weierstrass curves -------------------------------
+// table[(w * 255 + j - 1) * 16 ...] = affine j * 256^w * G.  Block w: thread 0 walks to 256^w * G
+// (8 w doublings), thread j derives j times it by an 8-step double-and-add and normalises.
+template <class W>
+__global__ __launch_bounds__(TPB, 2) void k_canon_build_comb8(u32* __restrict__ table) {
+  __shared__ u32 lds_b[16];
+  const int w = blockIdx.x;
+  const u32 j = threadIdx.x;
+  if (j == 0) {
+    canon::aff g = W::generator();
+    canon::jac b;
+    b.x = g.x;
+    b.y = g.y;
+    b.z = fe_small(1);
+#pragma unroll 1
+    for (int d = 0; d < 8 * w; ++d) b = W::jdouble(b);
+    canon::aff base;
+    W::to_affine(b, base);
+    store_fe(lds_b, 1, base.x);
+    store_fe(lds_b + 8, 1, base.y);
+  }
+  __syncthreads();
+  if (j == 0) return;
+  canon::aff base;
+  base.x = load_fe(lds_b, 1);
+  base.y = load_fe(lds_b + 8, 1);
+  canon::jac acc = W::small_multiple(base, j);
+  canon::aff e;
+  W::to_affine(acc, e);
+  W::comb8_store(table, w, j, e);
+}
+
+// Phase 1 of key generation with the 8-bit comb: 32 gathers + 32 mixed additions per key, no LDS table.
+template <class W>
+__global__ __launch_bounds__(TPB, 2) void k_canon_mul_base8(const u32* __restrict__ scalars,
+                                                            const u32* __restrict__ table,
+                                                            u32* __restrict__ out_xy, u32* __restrict__ zbuf,
+                                                            unsigned char* __restrict__ status, size_t n) {
+  __shared__ u32 lds_k[8 * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_k, scalars + first * 8, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    canon::jac r = W::mul_base_comb8(table, lds_k + e);
+    const size_t i = first + e;
+    canon::st8(out_xy + i * 16, r.x);
+    canon::st8(out_xy + i * 16 + 8, r.y);
+    canon::st8(zbuf + i * 8, r.z);
+    status[i] = CANON_FINITE;
+  }
+}
+
 // ---- Ed25519 (extended coordinates, signed comb) ------------------------------------------------
 // table: 64 windows x 8 affine Niels multiples of 16^w * B, plus 2^256 * B (ED_COMB_WORDS words).
 __global__ __launch_bounds__(64) void k_ced_build_comb(u32* __restrict__ table) {
@@ -196,6 +250,51 @@ __global__ __launch_bounds__(TPB) void k_ced_mul_base(const u32* __restrict__ sc
   const int e = threadIdx.x;
   if (e < valid) {
     canon::ext r = ced::mul_base_comb(lds_t, lds_k + e);
+    const size_t i = first + e;
+    canon::st8(out_xy + i * 16, r.x);
+    canon::st8(out_xy + i * 16 + 8, r.y);
+    canon::st8(zbuf + i * 8, r.z);
+    if (tbuf) canon::st8(tbuf + i * 8, r.t);
+    status[i] = CANON_FINITE;
+  }
+}
+
+// Signed 8-bit comb table for Ed25519: block w < 32 fills j * 256^w * B for j = 1..128, block 32 the
+// single entry 2^256 * B.
+__global__ __launch_bounds__(TPB, 2) void k_ced_build_comb8(u32* __restrict__ table) {
+  __shared__ u32 lds_b[16];
+  const int w = blockIdx.x;
+  const u32 j = threadIdx.x;
+  if (j == 0) {
+    canon::ext b = ced::from_affine(ced::generator());
+#pragma unroll 1
+    for (int d = 0; d < 8 * w; ++d) b = ced::dbl<true>(b);
+    canon::aff base = ced::to_affine(b);
+    store_fe(lds_b, 1, base.x);
+    store_fe(lds_b + 8, 1, base.y);
+  }
+  __syncthreads();
+  const u32 last = w == canon::COMB8_WINDOWS ? 1u : (u32)canon::ED_COMB8_ENTRIES;
+  if (j == 0 || j > last) return;
+  canon::aff base;
+  base.x = load_fe(lds_b, 1);
+  base.y = load_fe(lds_b + 8, 1);
+  canon::aff e = ced::to_affine(ced::small_multiple(base, j));
+  ced::comb8_store(table, (size_t)w * canon::ED_COMB8_ENTRIES + j - 1, e);
+}
+
+__global__ __launch_bounds__(TPB, 2) void k_ced_mul_base8(const u32* __restrict__ scalars, const u32* __restrict__ table,
+                                                          u32* __restrict__ out_xy, u32* __restrict__ zbuf,
+                                                          u32* __restrict__ tbuf, unsigned char* __restrict__ status,
+                                                          size_t n) {
+  __shared__ u32 lds_k[8 * TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  stage_in<8>(lds_k, scalars + first * 8, valid);
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e < valid) {
+    canon::ext r = ced::mul_base_comb8(table, lds_k + e);
     const size_t i = first + e;
     canon::st8(out_xy + i * 16, r.x);
     canon::st8(out_xy + i * 16 + 8, r.y);

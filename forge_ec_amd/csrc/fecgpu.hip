@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -928,6 +929,10 @@ int fec_ctx_create(fec_ctx** out, int device) {
   fec_ctx* ctx = new (std::nothrow) fec_ctx();
   if (!ctx) return FEC_E_OOM;
   ctx->device = device;
+  {
+    const char* e = std::getenv("FEC_CANON_COMB4");
+    ctx->canon_use_comb8 = !(e && e[0] == '1');
+  }
   if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
       std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0 ||
       hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -978,6 +983,8 @@ void fec_ctx_destroy(fec_ctx* ctx) {
   if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
   for (int i = 0; i < 3; ++i)
     if (ctx->d_canon_comb[i]) (void)hipFree(ctx->d_canon_comb[i]);
+  for (int i = 0; i < 3; ++i)
+    if (ctx->d_canon_comb8[i]) (void)hipFree(ctx->d_canon_comb8[i]);
   if (ctx->d_win_scratch) (void)hipFree(ctx->d_win_scratch);
   if (ctx->d_zbuf) (void)hipFree(ctx->d_zbuf);
   if (ctx->d_tbuf) (void)hipFree(ctx->d_tbuf);

@@ -31,6 +31,9 @@ struct fec_ctx {
   // canonical-math mode: comb table of affine multiples of G, per-element window-table scratch
   u32* d_canon_comb[3] = {nullptr, nullptr, nullptr};   // per curve
   bool canon_comb_ready[3] = {false, false, false};
+  u32* d_canon_comb8[3] = {nullptr, nullptr, nullptr};   // 8-bit comb (~512 KiB, L2-resident) per curve
+  bool canon_comb8_ready[3] = {false, false, false};
+  bool canon_use_comb8 = true;                  // FEC_CANON_COMB4=1 selects the 4-bit LDS comb instead
   void* d_win_scratch = nullptr;
   size_t win_scratch_cap = 0;
   void* d_zbuf = nullptr;  // Jacobian Z of the batch between the ladder and the batched normalisation

@@ -40,9 +40,10 @@ typedef enum { FEC_CANON_FINITE = 0, FEC_CANON_INFINITY = 1, FEC_CANON_BAD_POINT
 /* curve: FEC_SECP256K1, FEC_P256 (affine Weierstrass x, y; Jacobian inside) or FEC_ED25519 (RFC 8032
  * twisted Edwards x, y; extended coordinates inside; no point at infinity: status is 0 or 2) */
 
-/* out_xy[i] = scalars[i] * G, affine.  Fixed-base 4-bit comb (64 mixed additions, no doublings)
- * from a table of affine multiples of G built on the device at first use and kept in LDS (61 KiB;
- * Ed25519: signed digits, 50 KiB of affine Niels points). */
+/* out_xy[i] = scalars[i] * G, affine.  Fixed-base 8-bit comb: 32 mixed additions, no doublings, from a
+ * ~512 KiB table of affine multiples of G built on the device at first use and gathered from L2
+ * (Ed25519: signed bytes, affine Niels points).  FEC_CANON_COMB4=1 in the environment at ctx creation
+ * selects a 4-bit comb held in LDS instead (64 additions). */
 int fec_canon_mul_base(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars /* n*4 */, uint64_t* out_xy /* n*8 */,
                        uint8_t* status /* n */, size_t n);
 int fec_canon_mul_base_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, uint64_t* d_out_xy,

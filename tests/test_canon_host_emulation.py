@@ -470,3 +470,33 @@ def test_glv_ladder_matches_the_model(emu):
         pin = np.array(M.xy_limbs(pt), dtype=np.uint64)
         st = emu.he_glv_mul(_p(_arr(k)), _p(pin), _p(out))
         assert _pt_of(out, st == 1) == S.mul(k % S.N, pt), hex(k)
+
+
+def test_mul_base_comb8(emu, curve):
+    """the 8-bit comb (32 windows x 255 entries): zero bytes, 0xFF bytes, the usual edge scalars"""
+    C, cid = curve
+    rng = random.Random(98)
+    out = np.zeros(8, dtype=np.uint64)
+    extra = [0xFF, 0x100, 0xFF00, 0x01000000000000000000000000000000000000000000000000000000000000FF,
+             int.from_bytes(bytes([0xFF, 0] * 16), "big"), int.from_bytes(bytes([0, 0xFF] * 16), "big"),
+             int.from_bytes(bytes(range(1, 33)), "big")]
+    for k in scalars_of(C) + extra + [rng.randrange(2**256) for _ in range(60)]:
+        st = emu.he_canon_mul_base8(cid, _p(_arr(k)), _p(out))
+        assert _pt_of(out, st == 1) == C.mul(k % C.N, C.G), hex(k)
+    for k, pt in C.KNOWN_MULTIPLES.items():
+        emu.he_canon_mul_base8(cid, _p(_arr(k)), _p(out))
+        assert _pt_of(out, False) == pt
+
+
+def test_ed25519_mul_base_signed_comb8(emu):
+    rng = random.Random(14)
+    out = np.zeros(8, dtype=np.uint64)
+    extra = [0x80, 0x81, 0x7F, 0x8080, 0x807F, 0xFF, 0x100, int.from_bytes(bytes([0x80] * 32), "big"),
+             int.from_bytes(bytes([0x81] * 32), "big"), int.from_bytes(bytes([0xFF, 0x7F] * 16), "big"),
+             int.from_bytes(bytes([0x7F, 0x80] * 16), "big")]
+    for k in ED_SCALARS + extra + [rng.randrange(2**256) for _ in range(100)]:
+        emu.he_ced_mul_base8(_p(_arr(k)), _p(out))
+        assert _pt_of(out, False) == E.mul(k, E.G), hex(k)
+    for seed, pk in (M.ED25519_RFC8032_TEST1, M.ED25519_RFC8032_TEST2):
+        emu.he_ced_mul_base8(_p(_arr(E.secret_scalar(seed))), _p(out))
+        assert E.encode(_pt_of(out, False)) == pk

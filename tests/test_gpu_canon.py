@@ -381,3 +381,20 @@ def test_ecdsa_verify_end_to_end(gpu_ctx, name):
     assert list(got) == want
     assert dev.ecdsa_verify(np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64), np.zeros((0, 4), np.uint64),
                             np.zeros((0, 8), np.uint64)).shape == (0,)
+
+
+def test_both_fixed_base_tables_agree(monkeypatch):
+    """key generation through the 4-bit LDS comb (FEC_CANON_COMB4=1) equals the default 8-bit L2 comb"""
+    import forge_ec_amd as F
+    from forge_ec_amd.canon import CANON_CURVES
+    k = V.scalars(3000, 0, 4001)
+    k[:4] = 0
+    k[4, :] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    monkeypatch.setenv("FEC_CANON_COMB4", "1")
+    with F.Context(0) as ctx4:
+        monkeypatch.delenv("FEC_CANON_COMB4")
+        with F.Context(0) as ctx8:
+            for name in ("secp256k1", "p256", "ed25519"):
+                a, sa = CANON_CURVES[name](ctx4).mul_base(k)
+                b, sb = CANON_CURVES[name](ctx8).mul_base(k)
+                assert np.array_equal(a, b) and np.array_equal(sa, sb) and (name == "ed25519" or sa[:4].all())

@@ -297,3 +297,61 @@ extern "C" int he_glv_mul(const uint64_t* scalar, const uint64_t* pxy, uint64_t*
   st(xy, a.x); st(xy + 4, a.y);
   return inf ? 1 : 0;
 }
+// ---- 8-bit comb (table built exactly as k_canon_build_comb8 does) ----
+template <class W>
+static u32* t_comb8_table() {
+  static u32* tab = nullptr;
+  if (!tab) {
+    tab = new u32[canon::COMB8_WORDS];
+    canon::aff g = W::generator();
+    canon::jac b; b.x = g.x; b.y = g.y; b.z = fe_small(1);
+    for (int w = 0; w < canon::COMB8_WINDOWS; ++w) {
+      canon::aff base;
+      W::to_affine(b, base);
+      for (u32 j = 1; j <= (u32)canon::COMB8_ENTRIES; ++j) {
+        canon::aff e;
+        W::to_affine(W::small_multiple(base, j), e);
+        W::comb8_store(tab, w, j, e);
+      }
+      for (int d = 0; d < 8; ++d) b = W::jdouble(b);
+    }
+  }
+  return tab;
+}
+template <class W>
+static int t_mul_base8(const uint64_t* scalar, uint64_t* xy) {
+  static thread_local u32 kw[8 * KSTRIDE];
+  canon_kw(kw, scalar);
+  canon::jac r = W::mul_base_comb8(t_comb8_table<W>(), kw);
+  canon::aff a;
+  lmask inf = W::to_affine(r, a);
+  st(xy, a.x); st(xy + 4, a.y);
+  return inf ? 1 : 0;
+}
+extern "C" int he_canon_mul_base8(int curve, const uint64_t* scalar, uint64_t* xy) {
+#define CALL(W) t_mul_base8<W>(scalar, xy)
+  return CANON_DISPATCH(curve, CALL);
+#undef CALL
+}
+static u32* ed_comb8_table() {
+  static u32* tab = nullptr;
+  if (!tab) {
+    tab = new u32[canon::ED_COMB8_WORDS];
+    canon::ext b = ced::from_affine(ced::generator());
+    for (int w = 0; w <= canon::COMB8_WINDOWS; ++w) {
+      canon::aff base = ced::to_affine(b);
+      const u32 last = w == canon::COMB8_WINDOWS ? 1u : (u32)canon::ED_COMB8_ENTRIES;
+      for (u32 j = 1; j <= last; ++j)
+        ced::comb8_store(tab, (size_t)w * canon::ED_COMB8_ENTRIES + j - 1, ced::to_affine(ced::small_multiple(base, j)));
+      for (int d = 0; d < 8; ++d) b = ced::dbl<true>(b);
+    }
+  }
+  return tab;
+}
+extern "C" int he_ced_mul_base8(const uint64_t* scalar, uint64_t* xy) {
+  static thread_local u32 kw[8 * KSTRIDE];
+  canon_kw(kw, scalar);
+  canon::aff a = ced::to_affine(ced::mul_base_comb8(ed_comb8_table(), kw));
+  st(xy, a.x); st(xy + 4, a.y);
+  return 0;
+}
