@@ -316,7 +316,7 @@ __global__ __launch_bounds__(TPB) void k_ed_fixed_base(const u32* __restrict__ s
 
 // out[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])     (ecdsa.rs:254-256)
 template <class C>
-__global__ __launch_bounds__(TPB) void k_batch_double_mul(const u32* __restrict__ u1,
+__global__ __launch_bounds__(TPB, 2) void k_batch_double_mul(const u32* __restrict__ u1,
                                                           const u32* __restrict__ u2,
                                                           const u32* __restrict__ q,
                                                           const u32* __restrict__ gen,
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(TPB) void k_to_affine(const u32* __restrict__ point
 // range checks, h, s^-1, u1, u2 in the reference's scalar field (its Mul keeps only the low 256
 // bits of the product), u1*G + u2*Q with one ladder instance, to_affine, FieldElement::to_bytes
 // (a Montgomery reduction of x) and the comparison with r.
-__global__ __launch_bounds__(TPB) void k_ecdsa_verify_secp(const u32* __restrict__ digests,
+__global__ __launch_bounds__(TPB, 2) void k_ecdsa_verify_secp(const u32* __restrict__ digests,
                                                            const u32* __restrict__ rs, const u32* __restrict__ ss,
                                                            const u32* __restrict__ pk, const unsigned char* __restrict__ pk_inf,
                                                            const u32* __restrict__ gen, unsigned char* __restrict__ status,
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(TPB) void k_ecdsa_verify_secp(const u32* __restrict
 //   A_i = multiply(G, s_i * a_i)                                           (266-268)
 //   B_i = multiply(from_affine(R_i) + multiply(from_affine(P_i), e_i), a_i) (273-280)
 // One lane per signature; the three ladders share one instance of the ladder code.
-__global__ __launch_bounds__(TPB) void k_schnorr_terms_secp(const u32* __restrict__ pk_xy,
+__global__ __launch_bounds__(TPB, 2) void k_schnorr_terms_secp(const u32* __restrict__ pk_xy,
                                                             const u32* __restrict__ r_xy,
                                                             const u32* __restrict__ ss, const u32* __restrict__ as,
                                                             const u32* __restrict__ es, const u32* __restrict__ gen,

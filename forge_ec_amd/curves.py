@@ -186,6 +186,17 @@ class Context:
         _check(self._lib.fec_batch_double_mul_dev(self._h, curve, d_u1, d_u2, d_q, d_out, n, stream),
                "fec_batch_double_mul_dev")
 
+    def batch_to_affine_dev(self, curve, d_points, d_xy, d_inf, n, stream=None):
+        _check(self._lib.fec_batch_to_affine_dev(self._h, curve, d_points, d_xy, d_inf, n, stream),
+               "fec_batch_to_affine_dev")
+
+    def batch_compress_dev(self, curve, d_xy, d_inf, d_out, n, stream=None):
+        _check(self._lib.fec_batch_compress_dev(self._h, curve, d_xy, d_inf, d_out, n, stream), "fec_batch_compress_dev")
+
+    def ecdsa_verify_secp256k1_dev(self, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream=None):
+        _check(self._lib.fec_ecdsa_verify_secp256k1_dev(self._h, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n,
+                                                        stream), "fec_ecdsa_verify_secp256k1_dev")
+
     def generator(self, curve):
         out = np.empty(L.POINT_LIMBS[curve], dtype=np.uint64)
         _check(self._lib.fec_generator(self._h, curve, _ptr(out)), "fec_generator")

@@ -1,0 +1,80 @@
+"""Kernel timings of the parity-mode rows next to the hot path: to_affine, compressed
+encoding, ECDSA verify (secp256k1), multi_scalar_multiply, Schnorr batch_verify.  Inputs resident in HBM
+for the *_dev entry points; HIP events inside the library.  One JSON line per measurement.
+
+    python tools/next_rows_perf.py [log2_n]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import forge_ec_amd as F  # noqa: E402
+from forge_ec_amd import synth  # noqa: E402
+
+NAMES = {0: "secp256k1", 1: "p256", 2: "ed25519"}
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if a.dtype == np.uint64 else a.dtype)).cuda()
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def main():
+    logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    n = 1 << logn
+    ctx = F.Context(0)
+    ctx.set_timing(True)
+    s = torch.cuda.Stream()
+    torch.cuda.set_stream(s)
+    st = s.cuda_stream
+    for c in (0, 1, 2):
+        pts = dev(synth.points(n, c, 51))
+        xy = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+        inf = torch.empty(n, dtype=torch.uint8, device="cuda")
+        out = torch.empty(n * 33 + 3, dtype=torch.uint8, device="cuda")
+        best = [1e9, 1e9]
+        for _ in range(4):
+            ctx.batch_to_affine_dev(c, pts.data_ptr(), xy.data_ptr(), inf.data_ptr(), n, st)
+            best[0] = min(best[0], ctx.last_kernel_ms()[0])
+            ctx.batch_compress_dev(c, xy.data_ptr(), inf.data_ptr(), out.data_ptr(), n, st)
+            best[1] = min(best[1], ctx.last_kernel_ms()[0])
+        emit(row="to_affine", curve=NAMES[c], n=n, ms=round(best[0], 4), M_per_s=round(n / best[0] / 1e3, 2))
+        emit(row="compress", curve=NAMES[c], n=n, ms=round(best[1], 4), M_per_s=round(n / best[1] / 1e3, 2),
+             GBps=round(n * 98 / best[1] / 1e6, 1))
+    # ECDSA verify (secp256k1), fused kernel
+    dg = dev(np.frombuffer(synth.scalars(n, 0, 61).tobytes(), dtype=np.uint8).copy())
+    r, sg, pk = dev(synth.scalars(n, 0, 62)), dev(synth.scalars(n, 0, 63)), dev(synth.field_elements(2 * n, 0, 64))
+    status = torch.empty(n, dtype=torch.uint8, device="cuda")
+    best = 1e9
+    for _ in range(3):
+        ctx.ecdsa_verify_secp256k1_dev(dg.data_ptr(), r.data_ptr(), sg.data_ptr(), pk.data_ptr(), None,
+                                       status.data_ptr(), n, st)
+        best = min(best, ctx.last_kernel_ms()[0])
+    emit(row="ecdsa_verify (parity)", curve="secp256k1", n=n, ms=round(best, 4), M_per_s=round(n / best / 1e3, 2))
+    # host-pointer rows with a sequential fold: modest sizes
+    m = 1 << 12
+    ctx.set_timing(False)
+    k, p = synth.scalars(m, 0, 71), synth.points(m, 0, 72)
+    t0 = time.perf_counter()
+    ctx.multi_scalar_mul(0, k, p)
+    emit(row="multi_scalar_multiply", curve="secp256k1", n=m, ms=round((time.perf_counter() - t0) * 1e3, 3),
+         note="products in parallel + strictly sequential fold on one lane; host pointers, PCIe included")
+    pkxy, rxy = synth.field_elements(2 * m, 0, 73).reshape(m, 8), synth.field_elements(2 * m, 0, 74).reshape(m, 8)
+    s_, a_, e_ = synth.scalars(m, 0, 75), synth.scalars(m, 0, 76), synth.scalars(m, 0, 77)
+    t0 = time.perf_counter()
+    ctx.schnorr_batch_verify_secp256k1(pkxy, rxy, s_, a_, e_)
+    emit(row="schnorr batch_verify", curve="secp256k1", n=m, ms=round((time.perf_counter() - t0) * 1e3, 3),
+         note="3 ladders per signature in parallel + two sequential folds; host pointers, PCIe included")
+
+
+main()
