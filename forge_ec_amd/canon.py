@@ -96,8 +96,26 @@ class CanonCurve:
         return out
 
 
+def _four(lib_fn, h, a, b, c, d, what):
+    aa, bb, cc, dd = _u64(a, 4), _u64(b, 4), _u64(c, 4), _u64(d, 4)
+    n = aa.shape[0]
+    if not (bb.shape[0] == cc.shape[0] == dd.shape[0] == n):
+        raise ValueError("inputs differ in length")
+    out = np.zeros(n, dtype=np.uint8)
+    _check(lib_fn(h, _ptr(aa), _ptr(bb), _ptr(cc), _ptr(dd), _ptr(out), n), what)
+    return out
+
+
 class CanonSecp256k1(CanonCurve):
     CURVE = L.SECP256K1
+
+    def bip340_verify(self, pk_x, r, s, e):
+        """BIP-340 Schnorr verification; e = int(tagged_hash("BIP0340/challenge", r || pk || m)).  (n,) uint8."""
+        return _four(self._lib.fec_canon_bip340_verify, self._h, pk_x, r, s, e, "fec_canon_bip340_verify")
+
+    def bip340_verify_dev(self, d_pk_x, d_r, d_s, d_e, d_result, n, stream=None):
+        _check(self._lib.fec_canon_bip340_verify_dev(self._h, d_pk_x, d_r, d_s, d_e, d_result, n, stream),
+               "fec_canon_bip340_verify_dev")
 
 
 class CanonP256(CanonCurve):
@@ -107,6 +125,14 @@ class CanonP256(CanonCurve):
 class CanonEd25519(CanonCurve):
     """Ed25519 (RFC 8032): affine (x, y) of k*B / k*P; there is no point at infinity, status is 0 or 2."""
     CURVE = L.ED25519
+
+    def eddsa_verify(self, a_enc, r_enc, s, h):
+        """RFC 8032 verification; encodings as little-endian 256-bit integers, h = SHA-512(R||A||M) mod l."""
+        return _four(self._lib.fec_canon_eddsa_verify, self._h, a_enc, r_enc, s, h, "fec_canon_eddsa_verify")
+
+    def eddsa_verify_dev(self, d_a_enc, d_r_enc, d_s, d_h, d_result, n, stream=None):
+        _check(self._lib.fec_canon_eddsa_verify_dev(self._h, d_a_enc, d_r_enc, d_s, d_h, d_result, n, stream),
+               "fec_canon_eddsa_verify_dev")
 
 
 CANON_CURVES = {"secp256k1": CanonSecp256k1, "p256": CanonP256, "ed25519": CanonEd25519}

@@ -175,6 +175,63 @@ int launch_canon_ecdsa_verify(fec_ctx* ctx, int curve, const u64* dz, const u64*
   return hipGetLastError() == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
 }
 
+// BIP-340 / EdDSA: prepare -> u1*G + u2*P -> final test.  Work area: P xy (n*64), expected R xy (n*64,
+// EdDSA only), u2 (n*32), result xy (n*64), point status (n), flags (n).
+int launch_canon_sig_verify(fec_ctx* ctx, int curve, const u64* d_key, const u64* d_r, const u64* d_s, const u64* d_e,
+                            unsigned char* dres, size_t n, void* stream) {
+  if (n == 0) return FEC_OK;
+  const size_t need = n * (64 + 64 + 32 + 64 + 1 + 1) + 64;
+  int rc = ensure_owned(&ctx->d_verify, &ctx->verify_cap, need);
+  if (rc != FEC_OK) return rc;
+  char* base = (char*)ctx->d_verify;
+  u64* pxy = (u64*)base;
+  u64* rxy = (u64*)(base + n * 64);
+  u64* u2 = (u64*)(base + n * 128);
+  u64* xy = (u64*)(base + n * 160);
+  unsigned char* pst = (unsigned char*)(base + n * 224);
+  unsigned char* ok = pst + n;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  dim3 g(grid_for(n)), b(TPB);
+  if (curve == FEC_SECP256K1)
+    hipLaunchKernelGGL(k_canon_bip340_prepare, g, b, 0, s, (const u32*)d_key, (const u32*)d_r, (const u32*)d_s,
+                       (const u32*)d_e, (u32*)pxy, (u32*)u2, ok, n);
+  else
+    hipLaunchKernelGGL(k_ced_eddsa_prepare, g, b, 0, s, (const u32*)d_key, (const u32*)d_r, (const u32*)d_s,
+                       (const u32*)d_e, (u32*)pxy, (u32*)rxy, (u32*)u2, ok, n);
+  if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
+  rc = launch_canon_mul_base(ctx, curve, d_s, xy, pst, n, stream, false);   // u1 = s
+  if (rc == FEC_OK) rc = launch_canon_mul(ctx, curve, u2, pxy, xy, pst, n, stream, true);
+  if (rc != FEC_OK) return rc;
+  if (curve == FEC_SECP256K1)
+    hipLaunchKernelGGL(k_canon_bip340_finish, g, b, 0, s, (const u32*)xy, (const u32*)d_r, ok, pst, dres, n);
+  else
+    hipLaunchKernelGGL(k_ced_eddsa_finish, g, b, 0, s, (const u32*)xy, (const u32*)rxy, ok, pst, dres, n);
+  return hipGetLastError() == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
+}
+
+// four n*32-byte inputs, one n-byte output, host pointers
+template <class F>
+int host_four_scalars(fec_ctx* ctx, const uint64_t* const in[4], uint8_t* result, size_t n, F body) {
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  for (int i = 0; i < 4; ++i) {
+    int rc = ensure(ctx, i, n * 32);
+    if (rc != FEC_OK) return rc;
+    if (hipMemcpyAsync(ctx->d_buf[i], in[i], n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  }
+  int rc = ensure(ctx, 4, n);
+  if (rc != FEC_OK) return rc;
+  rc = body((const u64*)ctx->d_buf[0], (const u64*)ctx->d_buf[1], (const u64*)ctx->d_buf[2], (const u64*)ctx->d_buf[3],
+            (unsigned char*)ctx->d_buf[4]);
+  if (rc != FEC_OK) return rc;
+  if (hipMemcpyAsync(result, ctx->d_buf[4], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  return FEC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -290,6 +347,42 @@ int fec_canon_ecdsa_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* z, con
     return FEC_E_LAUNCH;
   }
   return FEC_OK;
+}
+
+int fec_canon_bip340_verify_dev(fec_ctx* ctx, const uint64_t* d_pk_x, const uint64_t* d_r, const uint64_t* d_s,
+                                const uint64_t* d_e, uint8_t* d_result, size_t n, void* stream) {
+  if (!ctx || (n && (!d_pk_x || !d_r || !d_s || !d_e || !d_result))) return FEC_E_ARG;
+  if (!aligned16(d_pk_x) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_e)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_canon_sig_verify(ctx, FEC_SECP256K1, d_pk_x, d_r, d_s, d_e, d_result, n, stream);
+}
+
+int fec_canon_bip340_verify(fec_ctx* ctx, const uint64_t* pk_x, const uint64_t* r, const uint64_t* s,
+                            const uint64_t* e, uint8_t* result, size_t n) {
+  if (!ctx || (n && (!pk_x || !r || !s || !e || !result))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const uint64_t* const in[4] = {pk_x, r, s, e};
+  return host_four_scalars(ctx, in, result, n, [&](const u64* a, const u64* b, const u64* c, const u64* d, unsigned char* o) {
+    return launch_canon_sig_verify(ctx, FEC_SECP256K1, a, b, c, d, o, n, nullptr);
+  });
+}
+
+int fec_canon_eddsa_verify_dev(fec_ctx* ctx, const uint64_t* d_a_enc, const uint64_t* d_r_enc, const uint64_t* d_s,
+                               const uint64_t* d_h, uint8_t* d_result, size_t n, void* stream) {
+  if (!ctx || (n && (!d_a_enc || !d_r_enc || !d_s || !d_h || !d_result))) return FEC_E_ARG;
+  if (!aligned16(d_a_enc) || !aligned16(d_r_enc) || !aligned16(d_s) || !aligned16(d_h)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_canon_sig_verify(ctx, FEC_ED25519, d_a_enc, d_r_enc, d_s, d_h, d_result, n, stream);
+}
+
+int fec_canon_eddsa_verify(fec_ctx* ctx, const uint64_t* a_enc, const uint64_t* r_enc, const uint64_t* s,
+                           const uint64_t* h, uint8_t* result, size_t n) {
+  if (!ctx || (n && (!a_enc || !r_enc || !s || !h || !result))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const uint64_t* const in[4] = {a_enc, r_enc, s, h};
+  return host_four_scalars(ctx, in, result, n, [&](const u64* a, const u64* b, const u64* c, const u64* d, unsigned char* o) {
+    return launch_canon_sig_verify(ctx, FEC_ED25519, a, b, c, d, o, n, nullptr);
+  });
 }
 
 int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,

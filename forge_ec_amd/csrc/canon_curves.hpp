@@ -1395,6 +1395,110 @@ FEC_DEV lmask ecdsa_x_matches(const fe& x, const fe& r) {
   return fe_eq(xr, r);
 }
 
+// ================================================================================================
+// Signature verification beyond ECDSA: BIP-340 Schnorr (secp256k1) and EdDSA (Ed25519, RFC 8032)
+// ================================================================================================
+// a^((p+1)/4) for secp256k1: the square root when one exists (p = 3 mod 4); 253 S + 13 M
+FEC_DEV fe secp_sqrt_candidate(const fe& a) {
+  using F = FpSecp;
+  fe x2 = F::mul(F::sqr(a), a);
+  fe x3 = F::mul(F::sqr(x2), a);
+  fe x6 = F::mul(F::sqr_n(x3, 3), x3);
+  fe x9 = F::mul(F::sqr_n(x6, 3), x3);
+  fe x11 = F::mul(F::sqr_n(x9, 2), x2);
+  fe x22 = F::mul(F::sqr_n(x11, 11), x11);
+  fe x44 = F::mul(F::sqr_n(x22, 22), x22);
+  fe x88 = F::mul(F::sqr_n(x44, 44), x44);
+  fe x176 = F::mul(F::sqr_n(x88, 88), x88);
+  fe x220 = F::mul(F::sqr_n(x176, 44), x44);
+  fe x223 = F::mul(F::sqr_n(x220, 3), x3);
+  fe t = F::mul(F::sqr_n(x223, 23), x22);
+  t = F::mul(F::sqr_n(t, 6), x2);
+  return F::sqr_n(t, 2);
+}
+// BIP-340 lift_x: the point with this x and even y; mask = lanes where x < p and x^3 + 7 is a square
+FEC_DEV lmask bip340_lift_x(const fe& x, aff& out) {
+  using F = FpSecp;
+  const lmask in_range = ~F::ge_p(x);
+  const fe c = F::add(F::mul(F::sqr(x), x), fe_small(7));
+  fe y = secp_sqrt_candidate(c);
+  const lmask is_root = fe_eq(F::sqr(y), c);
+  y = fe_select(y, F::neg(y), lanes_where((y.w[0] & 1u) != 0));
+  out.x = x;
+  out.y = y;
+  return uniform_mask(in_range & is_root);
+}
+// BIP-340 verification, the scalar / decoding half:  P = lift_x(pk), u1 = s, u2 = n - e (mod n);
+// ok = pk liftable, r < p, s < n.   The point half is u1 G + u2 P; the final test is bip340_accept.
+FEC_DEV lmask bip340_prepare(const fe& pkx, const fe& r, const fe& s, const fe& e, aff& P, fe& u2) {
+  using Fs = Fn<NSecp>;
+  const lmask lifted = bip340_lift_x(pkx, P);
+  fe d, er = e;
+  const lmask borrow = sub256(d, e, NSecp::n());
+  er = fe_select(d, e, borrow);                        // e mod n (e < 2^256 < 2n)
+  fe neg;
+  sub256(neg, NSecp::n(), er);
+  u2 = fe_select(neg, fe_zero(), fe_is_zero(er));      // n - e, and 0 for e = 0
+  return uniform_mask(lifted & ~FpSecp::ge_p(r) & ~Fs::ge_n(s));
+}
+// R finite, y(R) even, x(R) == r
+FEC_DEV lmask bip340_accept(const fe& x, const fe& y, const fe& r) {
+  return uniform_mask(fe_eq(x, r) & lanes_where((y.w[0] & 1u) == 0));
+}
+
+// z^((p-5)/8) = z^(2^252 - 3) for p = 2^255 - 19 (the usual 251 S + 11 M chain)
+FEC_DEV fe ed_pow22523(const fe& z) {
+  using F = FpEd;
+  fe z2 = F::sqr(z);
+  fe z9 = F::mul(F::sqr_n(z2, 2), z);
+  fe z11 = F::mul(z9, z2);
+  fe z2_5_0 = F::mul(F::sqr(z11), z9);
+  fe z2_10_0 = F::mul(F::sqr_n(z2_5_0, 5), z2_5_0);
+  fe z2_20_0 = F::mul(F::sqr_n(z2_10_0, 10), z2_10_0);
+  fe z2_40_0 = F::mul(F::sqr_n(z2_20_0, 20), z2_20_0);
+  fe z2_50_0 = F::mul(F::sqr_n(z2_40_0, 10), z2_10_0);
+  fe z2_100_0 = F::mul(F::sqr_n(z2_50_0, 50), z2_50_0);
+  fe z2_200_0 = F::mul(F::sqr_n(z2_100_0, 100), z2_100_0);
+  fe z2_250_0 = F::mul(F::sqr_n(z2_200_0, 50), z2_50_0);
+  return F::mul(F::sqr_n(z2_250_0, 2), z);
+}
+// RFC 8032 section 5.1.3: decode a 32-byte point encoding (given as its little-endian 256-bit integer).
+FEC_DEV lmask ed_decode(const fe& enc, aff& out) {
+  using F = FpEd;
+  const fe sqrtm1 = edw::fe_words(0x4A0EA0B0u, 0xC4EE1B27u, 0xAD2FE478u, 0x2F431806u, 0x3DFBD7A7u, 0x2B4D0099u, 0x4FC1DF0Bu, 0x2B832480u);
+  fe y = enc;
+  const u32 sign = enc.w[7] >> 31;
+  y.w[7] &= 0x7FFFFFFFu;
+  const lmask y_ok = ~F::ge_p(y);
+  const fe yy = F::sqr(y);
+  const fe u = F::sub(yy, fe_small(1));
+  const fe v = F::add(F::mul(edw::d(), yy), fe_small(1));
+  const fe v3 = F::mul(F::sqr(v), v);
+  const fe v7 = F::mul(F::sqr(v3), v);
+  fe x = F::mul(F::mul(u, v3), ed_pow22523(F::mul(u, v7)));   // candidate root of u / v
+  const fe vxx = F::mul(v, F::sqr(x));
+  const lmask direct = fe_eq(vxx, u), twisted = fe_eq(vxx, F::neg(u));
+  x = fe_select(x, F::mul(x, sqrtm1), twisted & ~direct);
+  const lmask x_zero = fe_is_zero(x);
+  const lmask bad_sign = x_zero & lanes_where(sign != 0);
+  x = fe_select(x, F::neg(x), lanes_where((x.w[0] & 1u) != sign));
+  out.x = x;
+  out.y = y;
+  return uniform_mask(y_ok & (direct | twisted) & ~bad_sign);
+}
+// EdDSA verification, decoding half: A, R decoded; S < l; u2 = l - h (mod l)
+FEC_DEV lmask eddsa_prepare(const fe& a_enc, const fe& r_enc, const fe& s, const fe& h, aff& A, aff& R, fe& u2) {
+  const fe l = edw::fe_words(0x5CF5D3EDu, 0x5812631Au, 0xA2F79CD6u, 0x14DEF9DEu, 0u, 0u, 0u, 0x10000000u);
+  const lmask a_ok = ed_decode(a_enc, A), r_ok = ed_decode(r_enc, R);
+  fe t;
+  const lmask s_lt = sub256(t, s, l);           // borrow  <=>  S < l
+  const lmask h_lt = sub256(t, h, l);
+  fe neg;
+  sub256(neg, l, h);
+  u2 = fe_select(neg, fe_zero(), fe_is_zero(h));
+  return uniform_mask(a_ok & r_ok & s_lt & h_lt);
+}
+
 }  // namespace canon
 using csecp = canon::wei<canon::SecpParams>;
 using cp256 = canon::wei<canon::P256Params>;

@@ -366,4 +366,66 @@ __global__ __launch_bounds__(TPB) void k_canon_ecdsa_finish(const u32* __restric
   result[i] = (ok[i] != 0 && point_status[i] == CANON_FINITE && same) ? 1 : 0;
 }
 
+// ---- BIP-340 (secp256k1) and EdDSA (Ed25519) verification: decode / scalar half and final test --------
+__global__ __launch_bounds__(TPB, 2) void k_canon_bip340_prepare(const u32* __restrict__ pkx, const u32* __restrict__ rs,
+                                                                 const u32* __restrict__ ss, const u32* __restrict__ es,
+                                                                 u32* __restrict__ pxy, u32* __restrict__ u2,
+                                                                 unsigned char* __restrict__ ok, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  canon::aff P;
+  fe v;
+  const lmask good = canon::bip340_prepare(canon::ld8(pkx + i * 8), canon::ld8(rs + i * 8), canon::ld8(ss + i * 8),
+                                           canon::ld8(es + i * 8), P, v);
+  const bool mine = lane_of(good);
+  if (!mine) {  // keep the ladder on a valid point; the lane is rejected by `ok`
+    canon::aff g = csecp::generator();
+    P = g;
+  }
+  canon::st8(pxy + i * 16, P.x);
+  canon::st8(pxy + i * 16 + 8, P.y);
+  canon::st8(u2 + i * 8, v);
+  ok[i] = mine ? 1 : 0;
+}
+__global__ __launch_bounds__(TPB) void k_canon_bip340_finish(const u32* __restrict__ xy, const u32* __restrict__ rs,
+                                                             const unsigned char* __restrict__ ok,
+                                                             const unsigned char* __restrict__ point_status,
+                                                             unsigned char* __restrict__ result, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const bool acc = lane_of(canon::bip340_accept(canon::ld8(xy + i * 16), canon::ld8(xy + i * 16 + 8), canon::ld8(rs + i * 8)));
+  result[i] = (ok[i] != 0 && point_status[i] == CANON_FINITE && acc) ? 1 : 0;
+}
+__global__ __launch_bounds__(TPB, 2) void k_ced_eddsa_prepare(const u32* __restrict__ a_enc, const u32* __restrict__ r_enc,
+                                                              const u32* __restrict__ ss, const u32* __restrict__ hs,
+                                                              u32* __restrict__ axy, u32* __restrict__ rxy,
+                                                              u32* __restrict__ u2, unsigned char* __restrict__ ok,
+                                                              size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  canon::aff A, R;
+  fe v;
+  const lmask good = canon::eddsa_prepare(canon::ld8(a_enc + i * 8), canon::ld8(r_enc + i * 8), canon::ld8(ss + i * 8),
+                                          canon::ld8(hs + i * 8), A, R, v);
+  const bool mine = lane_of(good);
+  if (!mine) A = ced::generator();
+  canon::st8(axy + i * 16, A.x);
+  canon::st8(axy + i * 16 + 8, A.y);
+  canon::st8(rxy + i * 16, R.x);
+  canon::st8(rxy + i * 16 + 8, R.y);
+  canon::st8(u2 + i * 8, v);
+  ok[i] = mine ? 1 : 0;
+}
+// S B - h A == R, compared as affine points
+__global__ __launch_bounds__(TPB) void k_ced_eddsa_finish(const u32* __restrict__ xy, const u32* __restrict__ rxy,
+                                                          const unsigned char* __restrict__ ok,
+                                                          const unsigned char* __restrict__ point_status,
+                                                          unsigned char* __restrict__ result, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const bool same = lane_of(fe_eq(canon::ld8(xy + i * 16), canon::ld8(rxy + i * 16)) &
+                            fe_eq(canon::ld8(xy + i * 16 + 8), canon::ld8(rxy + i * 16 + 8)));
+  result[i] = (ok[i] != 0 && point_status[i] == CANON_FINITE && same) ? 1 : 0;
+}
+
 }  // namespace fecgpu

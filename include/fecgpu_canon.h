@@ -79,6 +79,27 @@ int fec_canon_ecdsa_verify_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_
                                const uint64_t* d_s, const uint64_t* d_pk_xy, uint8_t* d_result, size_t n,
                                void* stream);
 
+/* BIP-340 Schnorr verification (secp256k1).  pk_x, r: the 32-byte big-endian x-only public key and the
+ * signature's r read as integers; s: the signature's s; e: the challenge
+ * int(tagged_hash("BIP0340/challenge", r || pk || m)) as an integer (reduced modulo n on the device).
+ * result[i] = 1 iff pk lifts to a curve point, r < p, s < n, R = s G - e P is finite with even y and
+ * x(R) == r.  The square root of lift_x, the scalar negation and everything after run on the GPU. */
+int fec_canon_bip340_verify(fec_ctx* ctx, const uint64_t* pk_x /* n*4 */, const uint64_t* r /* n*4 */,
+                            const uint64_t* s /* n*4 */, const uint64_t* e /* n*4 */, uint8_t* result /* n */,
+                            size_t n);
+int fec_canon_bip340_verify_dev(fec_ctx* ctx, const uint64_t* d_pk_x, const uint64_t* d_r, const uint64_t* d_s,
+                                const uint64_t* d_e, uint8_t* d_result, size_t n, void* stream);
+
+/* EdDSA verification (Ed25519, RFC 8032 section 5.1.7).  a_enc, r_enc: the 32-byte encodings of the public
+ * key and of R read as little-endian 256-bit integers (i.e. the bytes copied into four limbs); s: the
+ * signature's S; h: SHA-512(R || A || M) reduced modulo l by the caller.
+ * result[i] = 1 iff both encodings decode (RFC 8032 5.1.3), S < l, h < l and S B - h A == R. */
+int fec_canon_eddsa_verify(fec_ctx* ctx, const uint64_t* a_enc /* n*4 */, const uint64_t* r_enc /* n*4 */,
+                           const uint64_t* s /* n*4 */, const uint64_t* h /* n*4 */, uint8_t* result /* n */,
+                           size_t n);
+int fec_canon_eddsa_verify_dev(fec_ctx* ctx, const uint64_t* d_a_enc, const uint64_t* d_r_enc, const uint64_t* d_s,
+                               const uint64_t* d_h, uint8_t* d_result, size_t n, void* stream);
+
 /* element-wise F_p arithmetic on canonical values (inputs must be < p): op is a fec_field_opcode
  * or FEC_F_INV; b is ignored for unary ops */
 int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a /* n*4 */,

@@ -500,3 +500,78 @@ def test_ed25519_mul_base_signed_comb8(emu):
     for seed, pk in (M.ED25519_RFC8032_TEST1, M.ED25519_RFC8032_TEST2):
         emu.he_ced_mul_base8(_p(_arr(E.secret_scalar(seed))), _p(out))
         assert E.encode(_pt_of(out, False)) == pk
+
+
+def test_bip340_prepare(emu):
+    """lift_x, range checks and u2 = n - e for BIP-340 verification"""
+    S = M.SECP256K1
+    rng = random.Random(340)
+    pxy, u2 = np.zeros(8, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    n_lift = 0
+    xs = [S.G[0], 0, 1, 2, 3, S.P - 1, S.P, S.P + 1, 2**256 - 1] + [rng.randrange(S.P) for _ in range(40)]
+    for x in xs:
+        e = rng.choice([0, 1, S.N - 1, S.N, S.N + 5, rng.randrange(2**256)])
+        ok = emu.he_bip340_prepare(_p(_arr(x)), _p(_arr(5)), _p(_arr(7)), _p(_arr(e)), _p(pxy), _p(u2))
+        c = (pow(x, 3, S.P) + 7) % S.P
+        y = pow(c, (S.P + 1) // 4, S.P)
+        liftable = x < S.P and y * y % S.P == c
+        assert ok == (1 if liftable else 0), hex(x)
+        assert M.unlimbs(u2) == (-e) % S.N
+        if liftable:
+            n_lift += 1
+            y = y if y % 2 == 0 else S.P - y
+            assert (M.unlimbs(pxy[:4]), M.unlimbs(pxy[4:])) == (x, y) and S.on_curve((x, y))
+    assert n_lift > 10
+    g = _arr(S.G[0])
+    assert emu.he_bip340_prepare(_p(g), _p(_arr(S.P)), _p(_arr(7)), _p(_arr(1)), _p(pxy), _p(u2)) == 0      # r >= p
+    assert emu.he_bip340_prepare(_p(g), _p(_arr(5)), _p(_arr(S.N)), _p(_arr(1)), _p(pxy), _p(u2)) == 0      # s >= n
+    assert emu.he_bip340_prepare(_p(g), _p(_arr(S.P - 1)), _p(_arr(S.N - 1)), _p(_arr(1)), _p(pxy), _p(u2)) == 1
+
+
+def test_ed25519_decode_and_eddsa_prepare(emu):
+    rng = random.Random(8032)
+    xy = np.zeros(8, dtype=np.uint64)
+    # every encodable point decodes to itself; sign bit selects x
+    pts = [E.G, E.IDENTITY, (0, E.P - 1)] + [E.mul(rng.randrange(1, E.N), E.G) for _ in range(25)]
+    i = pow(2, (E.P - 1) // 4, E.P)
+    pts += [(i, 0), (E.P - i, 0)]           # order 4: exercises the sqrt(-1) branch? (y = 0 -> u = -1)
+    for pt in pts:
+        enc = int.from_bytes(E.encode(pt), "little")
+        assert emu.he_ed_decode(_p(_arr(enc)), _p(xy)) == 1
+        assert (M.unlimbs(xy[:4]), M.unlimbs(xy[4:])) == pt
+    # rejected encodings: y >= p; x = 0 with the sign bit set; y with no x
+    bad = [E.P, E.P + 1, 2**255 - 1, (1 << 255) | 1, (1 << 255) | (E.P - 1)]
+    y = 2
+    while True:
+        u, v = (y * y - 1) % E.P, (E.D * y * y + 1) % E.P
+        x2 = u * pow(v, -1, E.P) % E.P
+        if pow(x2, (E.P - 1) // 2, E.P) == E.P - 1:
+            bad.append(y)
+            break
+        y += 1
+    for enc in bad:
+        assert emu.he_ed_decode(_p(_arr(enc)), _p(xy)) == 0, hex(enc)
+    # random 256-bit strings: decode result must agree with the model's decoder
+    for _ in range(60):
+        enc = rng.randrange(2**256)
+        try:
+            want = M.ed25519_decode(enc.to_bytes(32, "little"))
+            sign, yy = enc >> 255, enc & (2**255 - 1)
+            if want[0] == 0 and sign:
+                want = None
+        except AssertionError:
+            want = None
+        ok = emu.he_ed_decode(_p(_arr(enc)), _p(xy))
+        assert ok == (1 if want else 0), hex(enc)
+        if want:
+            assert (M.unlimbs(xy[:4]), M.unlimbs(xy[4:])) == want
+    # prepare: S < l, h < l, u2 = l - h
+    axy, rxy, u2 = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    a_enc = int.from_bytes(E.encode(pts[3]), "little")
+    r_enc = int.from_bytes(E.encode(pts[4]), "little")
+    for s, h, want in [(5, 7, 1), (E.N - 1, E.N - 1, 1), (E.N, 7, 0), (5, E.N, 0), (0, 0, 1), (2**256 - 1, 1, 0)]:
+        ok = emu.he_eddsa_prepare(_p(_arr(a_enc)), _p(_arr(r_enc)), _p(_arr(s)), _p(_arr(h)), _p(axy), _p(rxy), _p(u2))
+        assert ok == want, (s, h)
+        if want:
+            assert M.unlimbs(u2) == (-h) % E.N
+            assert (M.unlimbs(axy[:4]), M.unlimbs(axy[4:])) == pts[3] and (M.unlimbs(rxy[:4]), M.unlimbs(rxy[4:])) == pts[4]

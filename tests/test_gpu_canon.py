@@ -398,3 +398,120 @@ def test_both_fixed_base_tables_agree(monkeypatch):
                 a, sa = CANON_CURVES[name](ctx4).mul_base(k)
                 b, sb = CANON_CURVES[name](ctx8).mul_base(k)
                 assert np.array_equal(a, b) and np.array_equal(sa, sb) and (name == "ed25519" or sa[:4].all())
+
+
+# ---------------------------------------------------------------------------------------------
+# BIP-340 and EdDSA verification end to end (hashing here, everything else on the GPU)
+# ---------------------------------------------------------------------------------------------
+def _tagged(tag, msg):
+    import hashlib
+    t = hashlib.sha256(tag).digest()
+    return hashlib.sha256(t + t + msg).digest()
+
+
+def test_bip340_verify_end_to_end(gpu_ctx):
+    from forge_ec_amd.canon import CanonSecp256k1
+    dev = CanonSecp256k1(gpu_ctx)
+    S = M.SECP256K1
+    rng = random.Random(340)
+    rows, want = [], []
+    for i in range(200):
+        d0 = rng.randrange(1, S.N)
+        P = S.mul(d0, S.G)
+        d = d0 if P[1] % 2 == 0 else S.N - d0
+        msg = b"bip340 message %d" % i
+        k0 = rng.randrange(1, S.N)
+        R = S.mul(k0, S.G)
+        k = k0 if R[1] % 2 == 0 else S.N - k0
+        pkx, rx = P[0], R[0]
+        e = int.from_bytes(_tagged(b"BIP0340/challenge", rx.to_bytes(32, "big") + pkx.to_bytes(32, "big") + msg), "big")
+        s = (k + e * d) % S.N
+        ok = 1
+        kind = i % 8
+        if kind == 1:
+            e ^= 1 << rng.randrange(255); ok = 0                  # another message
+        elif kind == 2:
+            s = (s + 1) % S.N; ok = 0
+        elif kind == 3:
+            rx = S.mul(k0 + 1, S.G)[0]; ok = 0                     # another R
+        elif kind == 4:
+            pkx = S.mul(d0 + 1, S.G)[0]; ok = 0                    # another key
+        elif kind == 5:
+            s, ok = S.N + (s % 1000), 0                            # s >= n
+        elif kind == 6:
+            rx, ok = S.P + (rx % 1000), 0                          # r >= p
+        elif kind == 7:
+            x = pkx
+            while True:                                            # an x with no point on the curve
+                x = (x + 1) % S.P
+                c = (pow(x, 3, S.P) + 7) % S.P
+                if pow(c, (S.P - 1) // 2, S.P) != 1:
+                    break
+            pkx, ok = x, 0
+        rows.append((pkx, rx, s, e))
+        want.append(ok)
+    # BIP-340 test vector 0 (the signature test_standard_vectors.rs quotes)
+    sig = bytes.fromhex("E907831F80848D1069A5371B402410364BDF1C5F8307B0084C55F1CE2DCA8215"
+                        "25F66A4A85EA8B71E482A74F382D2CE5EBEEE8FDB2172F477DF4900D310536C0")
+    pkx = 0xF9308A019258C31049344F85F89D5229B531C845836F99B08601F113BCE036F9
+    e = int.from_bytes(_tagged(b"BIP0340/challenge", sig[:32] + pkx.to_bytes(32, "big") + bytes(32)), "big")
+    rows.append((pkx, int.from_bytes(sig[:32], "big"), int.from_bytes(sig[32:], "big"), e))
+    want.append(1)
+    got = dev.bip340_verify(_arr([t[0] for t in rows]), _arr([t[1] for t in rows]), _arr([t[2] for t in rows]),
+                            _arr([t[3] for t in rows]))
+    assert list(got) == want
+
+
+def test_eddsa_verify_end_to_end(gpu_ctx):
+    import hashlib
+    from forge_ec_amd.canon import CanonEd25519
+    dev = CanonEd25519(gpu_ctx)
+    L_ = E.N
+    rng = random.Random(8032)
+    rows, want = [], []
+
+    def sign(seed, msg):
+        hh = hashlib.sha512(seed).digest()
+        a = E.secret_scalar(seed)
+        A = E.encode(E.mul(a, E.G))
+        r = int.from_bytes(hashlib.sha512(hh[32:] + msg).digest(), "little") % L_
+        Renc = E.encode(E.mul(r, E.G))
+        h = int.from_bytes(hashlib.sha512(Renc + A + msg).digest(), "little") % L_
+        return A, Renc, (r + h * a) % L_, h
+
+    for i in range(160):
+        seed = bytes(rng.randrange(256) for _ in range(32))
+        msg = b"eddsa message %d" % i
+        A, Renc, S_, h = sign(seed, msg)
+        ok = 1
+        kind = i % 8
+        if kind == 1:
+            h = (h + 1) % L_; ok = 0                                # another message
+        elif kind == 2:
+            S_ = (S_ + 1) % L_; ok = 0
+        elif kind == 3:
+            A = sign(bytes(32 - len(b"x")) + b"x", msg)[0]; ok = 0  # another key
+        elif kind == 4:
+            S_, ok = S_ + L_, 0                                     # S >= l (malleability check)
+        elif kind == 5:
+            Renc = E.encode(E.mul(rng.randrange(1, L_), E.G)); ok = 0
+        elif kind == 6:
+            Renc, ok = (E.P + 1).to_bytes(32, "little"), 0          # y >= p: undecodable R
+        elif kind == 7:
+            A = bytes([A[0]]) + A[1:31] + bytes([A[31] ^ 0x80])     # flipped sign bit: another (valid) point
+            ok = 0
+        rows.append((int.from_bytes(A, "little"), int.from_bytes(Renc, "little"), S_, h))
+        want.append(ok)
+    # RFC 8032 TEST 1 (the signature test_standard_vectors.rs quotes) and TEST 2
+    for (seed, pk), msg, sighex in (
+            (M.ED25519_RFC8032_TEST1, b"", "e5564300c360ac729086e2cc806e828a84877f1eb8e5d974d873e06522490155"
+                                           "5fb8821590a33bacc61e39701cf9b46bd25bf5f0595bbe24655141438e7a100b"),
+            (M.ED25519_RFC8032_TEST2, bytes([0x72]), "92a009a9f0d4cab8720e820b5f642540a2b27b5416503f8fb3762223ebdb69da"
+                                                     "085ac1e43e15996e458f3613d0f11d8c387b2eaeb4302aeeb00d291612bb0c00")):
+        sig = bytes.fromhex(sighex)
+        h = int.from_bytes(hashlib.sha512(sig[:32] + pk + msg).digest(), "little") % L_
+        rows.append((int.from_bytes(pk, "little"), int.from_bytes(sig[:32], "little"), int.from_bytes(sig[32:], "little"), h))
+        want.append(1)
+    got = dev.eddsa_verify(_arr([t[0] for t in rows]), _arr([t[1] for t in rows]), _arr([t[2] for t in rows]),
+                           _arr([t[3] for t in rows]))
+    assert list(got) == want

@@ -35,12 +35,14 @@ def main():
     k = torch.from_numpy(synth.scalars(n, 0, 41).view(np.int64)).cuda()
     k2 = torch.from_numpy(synth.scalars(n, 0, 42).view(np.int64)).cuda()
     k3 = torch.from_numpy(synth.scalars(n, 0, 43).view(np.int64)).cuda()
+    k4 = torch.from_numpy(synth.scalars(n, 0, 44).view(np.int64)).cuda()
     pub = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     out = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     status = torch.empty(n, dtype=torch.uint8, device="cuda")
     for cname in curves:
         c = CANON_CURVES[cname](ctx)
-        for name in ("keygen", "ecdh", "double-mul") + (("ecdsa-verify",) if cname != "ed25519" else ()):
+        extra = {"secp256k1": ("ecdsa-verify", "bip340-verify"), "p256": ("ecdsa-verify",), "ed25519": ("eddsa-verify",)}[cname]
+        for name in ("keygen", "ecdh", "double-mul") + extra:
             best = None
             for _ in range(reps + 1):
                 if name == "keygen":
@@ -55,6 +57,13 @@ def main():
                     c.ecdsa_verify_dev(k.data_ptr(), k2.data_ptr(), k3.data_ptr(), pub.data_ptr(), status.data_ptr(), n, st)
                     torch.cuda.synchronize()
                     ms, kern = (time.perf_counter() - t0) * 1e3, "k_canon_ecdsa_scalars + comb + accumulate + normalize + finish"
+                elif name in ("bip340-verify", "eddsa-verify"):  # prepare (decode / lift_x) + double-mul + final test
+                    fn = c.bip340_verify_dev if name == "bip340-verify" else c.eddsa_verify_dev
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    fn(k.data_ptr(), k2.data_ptr(), k3.data_ptr(), k4.data_ptr(), status.data_ptr(), n, st)
+                    torch.cuda.synchronize()
+                    ms, kern = (time.perf_counter() - t0) * 1e3, "prepare + comb + accumulate + normalize + finish"
                 else:  # u1*G + u2*P: three launches on the ctx stream; wall clock around a device sync
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
@@ -63,7 +72,7 @@ def main():
                     ms, kern = (time.perf_counter() - t0) * 1e3, "k_canon_mul_base + k_canon_mul<accum> + k_canon_normalize"
                 best = ms if best is None or ms < best else best
             torch.cuda.synchronize()
-            assert name == "ecdsa-verify" or int(status.sum()) == 0
+            assert name.endswith("-verify") or int(status.sum()) == 0
             rate = n / (best * 1e-3)
             print(json.dumps({"workload": "%s-canon-%s" % (cname, name), "mode": "canonical math, NOT reference parity",
                               "n": n, "kernel": kern, "ms": round(best, 4), "M_per_s": round(rate / 1e6, 3)}),

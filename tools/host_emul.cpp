@@ -355,3 +355,24 @@ extern "C" int he_ced_mul_base8(const uint64_t* scalar, uint64_t* xy) {
   st(xy, a.x); st(xy + 4, a.y);
   return 0;
 }
+// ---- BIP-340 / EdDSA verification halves ----
+extern "C" int he_bip340_prepare(const uint64_t* pkx, const uint64_t* r, const uint64_t* s, const uint64_t* e,
+                                 uint64_t* pxy, uint64_t* u2) {
+  canon::aff P; fe v;
+  lmask ok = canon::bip340_prepare(ld(pkx), ld(r), ld(s), ld(e), P, v);
+  st(pxy, P.x); st(pxy + 4, P.y); st(u2, v);
+  return ok ? 1 : 0;
+}
+extern "C" int he_ed_decode(const uint64_t* enc, uint64_t* xy) {
+  canon::aff a;
+  lmask ok = canon::ed_decode(ld(enc), a);
+  st(xy, a.x); st(xy + 4, a.y);
+  return ok ? 1 : 0;
+}
+extern "C" int he_eddsa_prepare(const uint64_t* a, const uint64_t* r, const uint64_t* s, const uint64_t* h,
+                                uint64_t* axy, uint64_t* rxy, uint64_t* u2) {
+  canon::aff A, R; fe v;
+  lmask ok = canon::eddsa_prepare(ld(a), ld(r), ld(s), ld(h), A, R, v);
+  st(axy, A.x); st(axy + 4, A.y); st(rxy, R.x); st(rxy + 4, R.y); st(u2, v);
+  return ok ? 1 : 0;
+}
