@@ -116,6 +116,17 @@ def measured_traffic(workload, n):
     return None
 
 
+def measured_valu_busy(workload, n):
+    """rocprofv3 derived counter VALUBusy (%) of the kernel, from the committed PMC pass."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01c", "traffic.json")))
+        if t["workload"] == workload and t["units_per_launch"] == n:
+            return t.get("valu_busy_pct")
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse()
     import torch
@@ -257,6 +268,7 @@ def main():
                 "kernel": kname, "kernel_ms": kernel_ms,
                 "algorithmic_mad32_per_unit": alg, "units_per_launch": n,
                 "peak_measured": peak_measured / 1e12, "frac_of_measured_peak": achieved / peak_measured,
+                "valu_busy_pct": measured_valu_busy(workload, n),
                 "hbm": {"achieved_GBps": n * hbm_bytes / (kernel_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
                         "algorithmic_bytes_per_unit": hbm_bytes},
             },
