@@ -110,3 +110,15 @@ def test_config5_secp256k1_double_mul_2p20(gpu_ctx, oracle):
     a = gpu_ctx.batch_mul_fixed(curve, u1[lo:lo + 600], g)
     b = gpu_ctx.batch_mul(curve, u2[lo:lo + 600], q[lo:lo + 600])
     assert np.array_equal(gpu_ctx.point_op(curve, 0, a, b), out[lo:lo + 600])
+
+
+@pytest.mark.parametrize("curve", [0, 1, 2])
+def test_whole_batch_is_bit_exact(gpu_ctx, oracle, curve):
+    """Every one of the 2^20 (secp256k1: 2^19) results of a variable-base batch equals the oracle's -- no
+    sampling.  The oracle runs on all granted host cores (about 25 s for secp256k1)."""
+    n = 1 << (19 if curve == 0 else 20)
+    k, p = V.scalars(n, curve, 2101 + curve), V.points(n, curve, 2201 + curve)
+    out = _run_dev(gpu_ctx, "var", curve, [k, p], n)
+    want = oracle.batch_mul(curve, k, p, nthreads=16)
+    bad = np.nonzero((out != want).any(axis=1))[0]
+    assert bad.size == 0, "first mismatching rows: %s" % bad[:5]
