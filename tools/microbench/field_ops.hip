@@ -33,6 +33,11 @@ KERN(k_ed_add, a = ed::add(a, b);)
 KERN(k_ed_sub, a = ed::sub(a, b);)
 KERN(k_csecp_mul, a = csecp::mul(a, b);)
 KERN(k_csecp_sqr, a = csecp::sqr(a);)
+KERN(k_cp256_mul, a = cp256::mul(a, b);)
+KERN(k_cp256_sqr, a = cp256::sqr(a);)
+KERN(k_ced_mul, a = ced::mul(a, b);)
+KERN(k_ced_sqr, a = ced::sqr(a);)
+KERN(k_nsecp_mmul, a = canon::Fn<canon::NSecp>::mmul(a, b);)
 KERN(k_select, a = fe_select(a, b, lanes_where((a.w[0] & 1) != 0)); b.w[0] += a.w[1];)
 __global__ __launch_bounds__(256) void k_mulwide(const u32* in, u32* out) {
   fe a = load(in, 0), b = load(in, 1);
@@ -57,7 +62,7 @@ int main() {
   Case cases[] = {{"mul_wide (512-bit product)", k_mulwide, ITERS}, {"secp mul", k_secp_mul, ITERS}, {"secp mul x2 interleaved", k_secp_mul2, 2.0 * ITERS},
     {"secp sqr", k_secp_sqr, ITERS}, {"secp mul_small", k_secp_mul_small, ITERS}, {"secp add", k_secp_add, ITERS}, {"secp sub", k_secp_sub, ITERS},
     {"p256 mul", k_p256_mul, ITERS}, {"p256 add", k_p256_add, ITERS}, {"p256 sub", k_p256_sub, ITERS},
-    {"ed mul", k_ed_mul, ITERS}, {"ed add", k_ed_add, ITERS}, {"ed sub", k_ed_sub, ITERS}, {"fe_select", k_select, ITERS}, {"canon secp mul", k_csecp_mul, ITERS}, {"canon secp sqr", k_csecp_sqr, ITERS},
+    {"ed mul", k_ed_mul, ITERS}, {"ed add", k_ed_add, ITERS}, {"ed sub", k_ed_sub, ITERS}, {"fe_select", k_select, ITERS}, {"canon secp mul", k_csecp_mul, ITERS}, {"canon secp sqr", k_csecp_sqr, ITERS}, {"canon p256 mul", k_cp256_mul, ITERS}, {"canon p256 sqr", k_cp256_sqr, ITERS}, {"canon ed25519 mul", k_ced_mul, ITERS}, {"canon ed25519 sqr", k_ced_sqr, ITERS}, {"mont mul mod n (secp256k1)", k_nsecp_mmul, ITERS},
     {"secp padd_nodouble", k_secp_padd, ITERS / 10}, {"secp pdouble", k_secp_pdouble, ITERS / 10}};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("%-30s %6s %10s %16s\n", "op", "w/SIMD", "ms", "ns/op per wave");
