@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "fecgpu.h"
+#include "fecgpu_canon.h"
 
 namespace forge_ec {
 
@@ -238,6 +239,49 @@ inline bool batch_verify(GpuContext& ctx, const std::vector<AffinePoint<FEC_SECP
   return result != 0;
 }
 }  // namespace schnorr
+
+// ---- canonical-math mode (include/fecgpu_canon.h): the REAL curves, NOT reference parity -----------
+// Plain-integer limbs; affine points as {x, y}; status 0 finite / 1 infinity / 2 rejected input.
+namespace canon {
+struct Affine {
+  Limbs x{}, y{};
+};
+struct PointResult {
+  std::vector<Affine> points;
+  std::vector<uint8_t> status;
+};
+// out[i] = scalars[i] * G  (key generation)
+template <fec_curve C>
+inline PointResult mul_base(GpuContext& ctx, const std::vector<Limbs>& scalars) {
+  PointResult r{std::vector<Affine>(scalars.size()), std::vector<uint8_t>(scalars.size())};
+  static_assert(sizeof(Affine) == 64 && sizeof(Limbs) == 32, "ABI layout");
+  check(fec_canon_mul_base(ctx.raw(), C, reinterpret_cast<const uint64_t*>(scalars.data()),
+                           reinterpret_cast<uint64_t*>(r.points.data()), r.status.data(), scalars.size()));
+  return r;
+}
+// out[i] = scalars[i] * points[i]  (ECDH; inputs validated)
+template <fec_curve C>
+inline PointResult mul(GpuContext& ctx, const std::vector<Limbs>& scalars, const std::vector<Affine>& points) {
+  if (scalars.size() != points.size()) throw Error(FEC_E_ARG);
+  PointResult r{std::vector<Affine>(scalars.size()), std::vector<uint8_t>(scalars.size())};
+  check(fec_canon_mul(ctx.raw(), C, reinterpret_cast<const uint64_t*>(scalars.data()),
+                      reinterpret_cast<const uint64_t*>(points.data()), reinterpret_cast<uint64_t*>(r.points.data()),
+                      r.status.data(), scalars.size()));
+  return r;
+}
+// valid[i] = standard ECDSA verification of (r[i], s[i]) on digest z[i] under public key q[i]
+template <fec_curve C>
+inline std::vector<uint8_t> ecdsa_verify(GpuContext& ctx, const std::vector<Limbs>& z, const std::vector<Limbs>& r,
+                                         const std::vector<Limbs>& s, const std::vector<Affine>& q) {
+  const size_t n = z.size();
+  if (r.size() != n || s.size() != n || q.size() != n) throw Error(FEC_E_ARG);
+  std::vector<uint8_t> ok(n);
+  check(fec_canon_ecdsa_verify(ctx.raw(), C, reinterpret_cast<const uint64_t*>(z.data()),
+                               reinterpret_cast<const uint64_t*>(r.data()), reinterpret_cast<const uint64_t*>(s.data()),
+                               reinterpret_cast<const uint64_t*>(q.data()), ok.data(), n));
+  return ok;
+}
+}  // namespace canon
 
 using Secp256k1 = Curve<FEC_SECP256K1>;
 using P256 = Curve<FEC_P256>;

@@ -130,8 +130,31 @@ static void batch_api() {
   CHECK(threw, "length mismatch -> Error");
 }
 
+// canonical-math mode through the C++ mirror: published points and a round trip
+static void canonical_mode() {
+  GpuContext ctx(0);
+  // secp256k1: 1*G, 2*G, 3*G (3*G.x is the BIP-340 vector-0 public key)
+  auto r = canon::mul_base<FEC_SECP256K1>(ctx, {Limbs{1, 0, 0, 0}, Limbs{2, 0, 0, 0}, Limbs{3, 0, 0, 0}, Limbs{0, 0, 0, 0}});
+  CHECK(r.status[0] == 0 && r.status[3] == 1, "status: finite / infinity for k = 0");
+  CHECK((r.points[0].x == Limbs{0x59F2815B16F81798ULL, 0x029BFCDB2DCE28D9ULL, 0x55A06295CE870B07ULL, 0x79BE667EF9DCBBACULL}), "1*G = G (SEC 2)");
+  CHECK((r.points[2].x == Limbs{0x8601F113BCE036F9ULL, 0xB531C845836F99B0ULL, 0x49344F85F89D5229ULL, 0xF9308A019258C310ULL}), "3*G.x = BIP-340 vector 0 public key");
+  // ECDH symmetry: a*(b*G) == b*(a*G)
+  std::vector<Limbs> a{Limbs{0x1234567, 7, 9, 0x0FFFFFFF}}, b{Limbs{0x7654321, 5, 3, 0x0EEEEEEE}};
+  auto A = canon::mul_base<FEC_SECP256K1>(ctx, a), B = canon::mul_base<FEC_SECP256K1>(ctx, b);
+  auto s1 = canon::mul<FEC_SECP256K1>(ctx, a, B.points), s2 = canon::mul<FEC_SECP256K1>(ctx, b, A.points);
+  CHECK(s1.status[0] == 0 && s1.points[0].x == s2.points[0].x && s1.points[0].y == s2.points[0].y, "ECDH is symmetric");
+  // an off-curve point is rejected
+  auto bad = B.points;
+  bad[0].y[0] ^= 1;
+  CHECK(canon::mul<FEC_SECP256K1>(ctx, a, bad).status[0] == 2, "off-curve input -> status 2");
+  // Ed25519 base point comes back for k = 1 (RFC 8032: y = 4/5)
+  auto e = canon::mul_base<FEC_ED25519>(ctx, {Limbs{1, 0, 0, 0}});
+  CHECK((e.points[0].y == Limbs{0x6666666666666658ULL, 0x6666666666666666ULL, 0x6666666666666666ULL, 0x6666666666666666ULL}), "Ed25519 B.y = 4/5");
+}
+
 int main() {
   try {
+    canonical_mode();
     secp256k1_field_arithmetic();
     secp256k1_point_arithmetic();
     secp256k1_scalar_multiplication();
