@@ -287,6 +287,12 @@ __global__ __launch_bounds__(64) void k_ed_build_table(const u32* __restrict__ b
 }
 
 // Ed25519 fixed-base: out[i] = multiply(base, scalars[i]) from the LDS addend table.
+// A lane performs one addition per set bit of its scalar, so a wavefront runs for the largest
+// popcount among its 64 lanes.  The workgroup therefore bins its 256 scalars by popcount (counting
+// sort through LDS) and hands each wavefront one quartile -- rotated by workgroup so that no SIMD
+// always gets the heavy quartile: the four wavefronts then run about 123 + 128 + 134 + 150
+// iterations instead of 4 x 148.  Only the lane -> element assignment changes; every element sees
+// exactly the additions the reference performs, in the reference's order.
 __global__ __launch_bounds__(TPB) void k_ed_fixed_base(const u32* __restrict__ scalars,
                                                        const u32* __restrict__ base,
                                                        const u32* __restrict__ table,
@@ -294,8 +300,11 @@ __global__ __launch_bounds__(TPB) void k_ed_fixed_base(const u32* __restrict__ s
   __shared__ u32 lds_k[8 * TPB];
   __shared__ u32 lds_t[256 * ed::ED_TSTRIDE];
   __shared__ u32 lds_o[Ed::PW * TPB];
+  __shared__ int lds_bin[260];
+  __shared__ unsigned short lds_perm[TPB];
   const int valid = block_valid(n);
   const size_t first = (size_t)blockIdx.x * TPB;
+  const int e = threadIdx.x;
   stage_in<8>(lds_k, scalars + first * 8, valid);
   for (int v = threadIdx.x; v < 256 * 32 / 4; v += TPB) {  // 32 KiB table, 16-byte loads (L2-resident)
     uint4 x = *reinterpret_cast<const uint4*>(table + (size_t)v * 4);
@@ -303,12 +312,45 @@ __global__ __launch_bounds__(TPB) void k_ed_fixed_base(const u32* __restrict__ s
     u32* d = lds_t + j * ed::ED_TSTRIDE + w;
     d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
   }
+  for (int v = e; v < 260; v += TPB) lds_bin[v] = 0;
   __syncthreads();
-  const int e = threadIdx.x;
+  // ---- counting sort of the workgroup's elements by popcount ----
+  int pc = 0;
   if (e < valid) {
+    FEC_UNROLL for (int w = 0; w < 8; ++w) pc += __builtin_popcount(lds_k[w * TPB + e]);
+  }
+  atomicAdd(&lds_bin[pc + 1], 1);  // padding lanes count as popcount 0 and sort to the front
+  __syncthreads();
+  if (e < 64) {  // inclusive prefix over the 257 bins by one wavefront: 5 bins per lane, then a wave scan
+    int loc[5], sum = 0;
+    FEC_UNROLL for (int j = 0; j < 5; ++j) {
+      const int idx = e * 5 + j;
+      loc[j] = idx < 258 ? lds_bin[idx] : 0;
+      sum += loc[j];
+    }
+    int run = sum;
+    FEC_UNROLL for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(run, d, 64);
+      if (e >= d) run += up;
+    }
+    int excl = run - sum;
+    FEC_UNROLL for (int j = 0; j < 5; ++j) {
+      const int idx = e * 5 + j;
+      excl += loc[j];
+      if (idx < 258) lds_bin[idx] = excl;  // lds_bin[b + 1] = number of elements with popcount <= b
+    }
+  }
+  __syncthreads();
+  const int pos = atomicAdd(&lds_bin[pc], 1);  // lds_bin[pc] = first slot of this popcount
+  lds_perm[pos] = (unsigned short)e;
+  __syncthreads();
+  // wavefront w of workgroup b takes quartile (w + b) mod 4 of the sorted list
+  const int slot = ((((e >> 6) + (int)blockIdx.x) & 3) << 6) | (e & 63);
+  const int src = lds_perm[slot];
+  if (src < valid) {
     ed::pt b = Ed::load(base, 1);
-    ed::pt r = ed::multiply_fixed(b, lds_t, lds_k + e);
-    Ed::store(lds_o + e, TPB, r);
+    ed::pt r = ed::multiply_fixed(b, lds_t, lds_k + src);
+    Ed::store(lds_o + src, TPB, r);
   }
   __syncthreads();
   stage_out<Ed::PW>(out + first * Ed::PW, lds_o, valid);
