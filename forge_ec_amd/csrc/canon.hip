@@ -209,29 +209,6 @@ int launch_canon_sig_verify(fec_ctx* ctx, int curve, const u64* d_key, const u64
   return hipGetLastError() == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
 }
 
-// four n*32-byte inputs, one n-byte output, host pointers
-template <class F>
-int host_four_scalars(fec_ctx* ctx, const uint64_t* const in[4], uint8_t* result, size_t n, F body) {
-  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  for (int i = 0; i < 4; ++i) {
-    int rc = ensure(ctx, i, n * 32);
-    if (rc != FEC_OK) return rc;
-    if (hipMemcpyAsync(ctx->d_buf[i], in[i], n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-      return FEC_E_DEVICE;
-  }
-  int rc = ensure(ctx, 4, n);
-  if (rc != FEC_OK) return rc;
-  rc = body((const u64*)ctx->d_buf[0], (const u64*)ctx->d_buf[1], (const u64*)ctx->d_buf[2], (const u64*)ctx->d_buf[3],
-            (unsigned char*)ctx->d_buf[4]);
-  if (rc != FEC_OK) return rc;
-  if (hipMemcpyAsync(result, ctx->d_buf[4], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
-  return FEC_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -251,12 +228,12 @@ int fec_canon_mul_base(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, u
   if (!ctx || (n && (!scalars || !out_xy || !status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (n == 0) return FEC_OK;
-  const void* const in[3] = {scalars, nullptr, nullptr};
-  const size_t in_bytes[3] = {n * 32, 0, 0};
+  const void* const in[4] = {scalars, nullptr, nullptr, nullptr};
+  const size_t in_stride[4] = {32, 0, 0, 0};
   void* const out[2] = {out_xy, status};
-  const size_t out_bytes[2] = {n * 64, n};
-  return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void*, void*, void* o, void* st) {
-    return launch_canon_mul_base(ctx, curve, (const u64*)a, (u64*)o, (unsigned char*)st, n, nullptr);
+  const size_t out_stride[2] = {64, 1};
+  return host_chunked(ctx, n, in, in_stride, out, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
+    return launch_canon_mul_base(ctx, curve, (const u64*)d[0], (u64*)o[0], (unsigned char*)o[1], cnt, nullptr);
   });
 }
 
@@ -274,12 +251,12 @@ int fec_canon_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const 
   if (!ctx || (n && (!scalars || !points_xy || !out_xy || !status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (n == 0) return FEC_OK;
-  const void* const in[3] = {scalars, points_xy, nullptr};
-  const size_t in_bytes[3] = {n * 32, n * 64, 0};
+  const void* const in[4] = {scalars, points_xy, nullptr, nullptr};
+  const size_t in_stride[4] = {32, 64, 0, 0};
   void* const out[2] = {out_xy, status};
-  const size_t out_bytes[2] = {n * 64, n};
-  return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void* b, void*, void* o, void* st) {
-    return launch_canon_mul(ctx, curve, (const u64*)a, (const u64*)b, (u64*)o, (unsigned char*)st, n, nullptr);
+  const size_t out_stride[2] = {64, 1};
+  return host_chunked(ctx, n, in, in_stride, out, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
+    return launch_canon_mul(ctx, curve, (const u64*)d[0], (const u64*)d[1], (u64*)o[0], (unsigned char*)o[1], cnt, nullptr);
   });
 }
 
@@ -300,14 +277,15 @@ int fec_canon_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
   if (!ctx || (n && (!u1 || !u2 || !points_xy || !out_xy || !status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
-  const void* const in[3] = {u1, u2, points_xy};
-  const size_t in_bytes[3] = {n * 32, n * 32, n * 64};
+  const void* const in[4] = {u1, u2, points_xy, nullptr};
+  const size_t in_stride[4] = {32, 32, 64, 0};
   void* const out[2] = {out_xy, status};
-  const size_t out_bytes[2] = {n * 64, n};
-  return host_oneshot(ctx, in, in_bytes, out, out_bytes, [&](void* a, void* b, void* p, void* o, void* st) {
-    int rc = launch_canon_mul_base(ctx, curve, (const u64*)a, (u64*)o, (unsigned char*)st, n, nullptr, false);
+  const size_t out_stride[2] = {64, 1};
+  return host_chunked(ctx, n, in, in_stride, out, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
+    int rc = launch_canon_mul_base(ctx, curve, (const u64*)d[0], (u64*)o[0], (unsigned char*)o[1], cnt, nullptr, false);
     if (rc != FEC_OK) return rc;
-    return launch_canon_mul(ctx, curve, (const u64*)b, (const u64*)p, (u64*)o, (unsigned char*)st, n, nullptr, true);
+    return launch_canon_mul(ctx, curve, (const u64*)d[1], (const u64*)d[2], (u64*)o[0], (unsigned char*)o[1], cnt, nullptr,
+                            true);
   });
 }
 
@@ -326,27 +304,14 @@ int fec_canon_ecdsa_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* z, con
   if (!ctx || (n && (!z || !r || !s || !pk_xy || !result))) return FEC_E_ARG;
   if (curve != FEC_SECP256K1 && curve != FEC_P256) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (n == 0) return FEC_OK;
-  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  const void* src[4] = {z, r, s, pk_xy};
-  const size_t bytes[4] = {n * 32, n * 32, n * 32, n * 64};
-  for (int i = 0; i < 4; ++i) {
-    int rc = ensure(ctx, i, bytes[i]);
-    if (rc != FEC_OK) return rc;
-    if (hipMemcpyAsync(ctx->d_buf[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-      return FEC_E_DEVICE;
-  }
-  int rc = ensure(ctx, 4, n);
-  if (rc != FEC_OK) return rc;
-  rc = launch_canon_ecdsa_verify(ctx, curve, (const u64*)ctx->d_buf[0], (const u64*)ctx->d_buf[1],
-                                 (const u64*)ctx->d_buf[2], (const u64*)ctx->d_buf[3], (unsigned char*)ctx->d_buf[4], n,
-                                 nullptr);
-  if (rc != FEC_OK) return rc;
-  if (hipMemcpyAsync(result, ctx->d_buf[4], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
-  return FEC_OK;
+  const void* const in[4] = {z, r, s, pk_xy};
+  const size_t in_stride[4] = {32, 32, 32, 64};
+  void* const out[2] = {result, nullptr};
+  const size_t out_stride[2] = {1, 0};
+  return host_chunked(ctx, n, in, in_stride, out, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
+    return launch_canon_ecdsa_verify(ctx, curve, (const u64*)d[0], (const u64*)d[1], (const u64*)d[2], (const u64*)d[3],
+                                     (unsigned char*)o[0], cnt, nullptr);
+  });
 }
 
 int fec_canon_bip340_verify_dev(fec_ctx* ctx, const uint64_t* d_pk_x, const uint64_t* d_r, const uint64_t* d_s,
@@ -361,9 +326,13 @@ int fec_canon_bip340_verify(fec_ctx* ctx, const uint64_t* pk_x, const uint64_t* 
                             const uint64_t* e, uint8_t* result, size_t n) {
   if (!ctx || (n && (!pk_x || !r || !s || !e || !result))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
-  const uint64_t* const in[4] = {pk_x, r, s, e};
-  return host_four_scalars(ctx, in, result, n, [&](const u64* a, const u64* b, const u64* c, const u64* d, unsigned char* o) {
-    return launch_canon_sig_verify(ctx, FEC_SECP256K1, a, b, c, d, o, n, nullptr);
+  const void* const in[4] = {pk_x, r, s, e};
+  const size_t in_stride[4] = {32, 32, 32, 32};
+  void* const out[2] = {result, nullptr};
+  const size_t out_stride[2] = {1, 0};
+  return host_chunked(ctx, n, in, in_stride, out, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
+    return launch_canon_sig_verify(ctx, FEC_SECP256K1, (const u64*)d[0], (const u64*)d[1], (const u64*)d[2], (const u64*)d[3],
+                                   (unsigned char*)o[0], cnt, nullptr);
   });
 }
 
@@ -379,9 +348,13 @@ int fec_canon_eddsa_verify(fec_ctx* ctx, const uint64_t* a_enc, const uint64_t* 
                            const uint64_t* h, uint8_t* result, size_t n) {
   if (!ctx || (n && (!a_enc || !r_enc || !s || !h || !result))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
-  const uint64_t* const in[4] = {a_enc, r_enc, s, h};
-  return host_four_scalars(ctx, in, result, n, [&](const u64* a, const u64* b, const u64* c, const u64* d, unsigned char* o) {
-    return launch_canon_sig_verify(ctx, FEC_ED25519, a, b, c, d, o, n, nullptr);
+  const void* const in[4] = {a_enc, r_enc, s, h};
+  const size_t in_stride[4] = {32, 32, 32, 32};
+  void* const out[2] = {result, nullptr};
+  const size_t out_stride[2] = {1, 0};
+  return host_chunked(ctx, n, in, in_stride, out, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
+    return launch_canon_sig_verify(ctx, FEC_ED25519, (const u64*)d[0], (const u64*)d[1], (const u64*)d[2], (const u64*)d[3],
+                                   (unsigned char*)o[0], cnt, nullptr);
   });
 }
 
@@ -392,11 +365,13 @@ int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a,
   const bool binary = op == FEC_F_ADD || op == FEC_F_SUB || op == FEC_F_MUL;
   if (binary && n && !b) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
-  const void* const in[3] = {a, binary ? b : nullptr, nullptr};
-  const size_t in_bytes[3] = {n * 32, n * 32, 0};
+  const void* const in[4] = {a, binary ? b : nullptr, nullptr, nullptr};
+  const size_t in_stride[4] = {32, 32, 0, 0};
   void* const outs[2] = {out, nullptr};
-  const size_t out_bytes[2] = {n * 32, 0};
-  return host_oneshot(ctx, in, in_bytes, outs, out_bytes, [&](void* x, void* y, void*, void* o, void*) {
+  const size_t out_stride[2] = {32, 0};
+  return host_chunked(ctx, n, in, in_stride, outs, out_stride, [&](void* const d[4], void* const oo[2], size_t cnt) {
+    const size_t n = cnt;
+    void *x = d[0], *y = d[1], *o = oo[0];
     Launch L(ctx, nullptr, "k_canon_field_op");
     if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_field_op<csecp>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
     else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_field_op<cp256>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);

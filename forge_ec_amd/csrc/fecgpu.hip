@@ -1259,12 +1259,12 @@ int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const 
                        size_t n) {
   if (!ctx || !curve_ok(curve) || (n && (!xy || !out))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
-  const void* const in[3] = {xy, inf, nullptr};
-  const size_t in_bytes[3] = {n * 64, n, 0};
+  const void* const in[4] = {xy, inf, nullptr, nullptr};
+  const size_t in_stride[4] = {64, 1, 0, 0};
   void* const outs[2] = {out, nullptr};
-  const size_t out_bytes[2] = {n * 33, 0};
-  return host_oneshot(ctx, in, in_bytes, outs, out_bytes, [&](void* a, void* f, void*, void* o, void*) {
-    return launch_compress(ctx, curve, (const u64*)a, (const unsigned char*)f, (unsigned char*)o, n, nullptr);
+  const size_t out_stride[2] = {33, 0};
+  return host_chunked(ctx, n, in, in_stride, outs, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
+    return launch_compress(ctx, curve, (const u64*)d[0], (const unsigned char*)d[1], (unsigned char*)o[0], cnt, nullptr);
   });
 }
 

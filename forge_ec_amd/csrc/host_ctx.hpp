@@ -86,37 +86,46 @@ struct Launch {
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 
-// one-shot host-pointer call with up to three inputs and two outputs (not pipelined)
+// Host-pointer call over chunks of ctx->chunk elements with up to four per-element inputs (slots 0-3)
+// and two per-element outputs (slots 4-5): H2D, body(d_in[4], d_out[2], count), D2H per chunk on the
+// ctx stream.  Device staging and any per-element scratch the body allocates stay bounded by one
+// chunk however large n is.  A null input / output pointer is passed through as null.
 template <class F>
-inline int host_oneshot(fec_ctx* ctx, const void* const in[3], const size_t in_bytes[3], void* const out[2],
-                 const size_t out_bytes[2], F body) {
+inline int host_chunked(fec_ctx* ctx, size_t n, const void* const in[4], const size_t in_stride[4], void* const out[2],
+                        const size_t out_stride[2], F body) {
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  void* d_in[3] = {nullptr, nullptr, nullptr};
-  void* d_out[2] = {nullptr, nullptr};
-  for (int i = 0; i < 3; ++i) {
-    if (!in[i]) continue;
-    int rc = ensure(ctx, i, in_bytes[i]);
+  const size_t chunk = ctx->chunk < n ? ctx->chunk : n;
+  for (size_t lo = 0; lo < n; lo += chunk) {
+    const size_t cnt = lo + chunk <= n ? chunk : n - lo;
+    void* d_in[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* d_out[2] = {nullptr, nullptr};
+    for (int i = 0; i < 4; ++i) {
+      if (!in[i]) continue;
+      int rc = ensure(ctx, i, chunk * in_stride[i]);
+      if (rc != FEC_OK) return rc;
+      d_in[i] = ctx->d_buf[i];
+      if (hipMemcpyAsync(d_in[i], (const char*)in[i] + lo * in_stride[i], cnt * in_stride[i], hipMemcpyHostToDevice,
+                         ctx->stream) != hipSuccess)
+        return FEC_E_DEVICE;
+    }
+    for (int i = 0; i < 2; ++i) {
+      if (!out[i]) continue;
+      int rc = ensure(ctx, 4 + i, chunk * out_stride[i]);
+      if (rc != FEC_OK) return rc;
+      d_out[i] = ctx->d_buf[4 + i];
+    }
+    int rc = body(d_in, d_out, cnt);
     if (rc != FEC_OK) return rc;
-    d_in[i] = ctx->d_buf[i];
-    if (hipMemcpyAsync(d_in[i], in[i], in_bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-      return FEC_E_DEVICE;
-  }
-  for (int i = 0; i < 2; ++i) {
-    if (!out[i]) continue;
-    int rc = ensure(ctx, 3 + i, out_bytes[i]);
-    if (rc != FEC_OK) return rc;
-    d_out[i] = ctx->d_buf[3 + i];
-  }
-  int rc = body(d_in[0], d_in[1], d_in[2], d_out[0], d_out[1]);
-  if (rc != FEC_OK) return rc;
-  for (int i = 0; i < 2; ++i) {
-    if (!out[i]) continue;
-    if (hipMemcpyAsync(out[i], d_out[i], out_bytes[i], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-      return FEC_E_DEVICE;
-  }
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
+    for (int i = 0; i < 2; ++i) {
+      if (!out[i]) continue;
+      if (hipMemcpyAsync((char*)out[i] + lo * out_stride[i], d_out[i], cnt * out_stride[i], hipMemcpyDeviceToHost,
+                         ctx->stream) != hipSuccess)
+        return FEC_E_DEVICE;
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return FEC_E_LAUNCH;
+    }
   }
   return FEC_OK;
 }

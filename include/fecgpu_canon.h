@@ -22,6 +22,10 @@
  * modulo n).  These routines are NOT constant-time with respect to the scalar: table lookups are
  * indexed by scalar digits.  Use them for public or batch-verification workloads, or accept the
  * GPU's threat model explicitly.
+ *
+ * The host-pointer entry points stream the batch through the device in chunks of fec_ctx_set_chunk elements
+ * (default 2^18), so device staging and per-element scratch are bounded by one chunk for any n; the *_dev
+ * entry points work on the whole resident batch.
  */
 #ifndef FECGPU_CANON_H
 #define FECGPU_CANON_H

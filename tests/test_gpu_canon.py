@@ -515,3 +515,30 @@ def test_eddsa_verify_end_to_end(gpu_ctx):
     got = dev.eddsa_verify(_arr([t[0] for t in rows]), _arr([t[1] for t in rows]), _arr([t[2] for t in rows]),
                            _arr([t[3] for t in rows]))
     assert list(got) == want
+
+
+def test_host_pointer_calls_are_chunk_invariant(gpu_ctx):
+    """the host-pointer entry points stream the batch in chunks of fec_ctx_set_chunk elements; a 100-element
+    chunk (ragged last chunk, scratch bounded by one chunk) gives the same bytes as one big chunk"""
+    from forge_ec_amd.canon import CANON_CURVES
+    n = 1037
+    k1, k2, k3 = V.scalars(n, 0, 5001), V.scalars(n, 0, 5002), V.scalars(n, 0, 5003)
+    res = {}
+    for chunk in (1 << 18, 100):
+        gpu_ctx.set_chunk(chunk)
+        out = []
+        for name in ("secp256k1", "p256", "ed25519"):
+            c = CANON_CURVES[name](gpu_ctx)
+            pub, st = c.mul_base(k1)
+            out += [pub, st, *c.mul(k2, pub), *c.double_mul(k1, k2, pub)]
+            if name != "ed25519":
+                out.append(c.ecdsa_verify(k1, k2, k3, pub))
+            else:
+                out.append(c.eddsa_verify(k1, k2, k3, k3))
+        out.append(CANON_CURVES["secp256k1"](gpu_ctx).bip340_verify(k1, k2, k3, k1))
+        xy = V.field_elements(2 * n, 1, 5004).reshape(n, 8)
+        out.append(gpu_ctx.batch_compress(1, xy))
+        res[chunk] = out
+    gpu_ctx.set_chunk(1 << 18)
+    for a, b in zip(res[1 << 18], res[100]):
+        assert np.array_equal(a, b)
