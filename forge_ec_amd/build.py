@@ -3,8 +3,11 @@
     python -m forge_ec_amd.build [--force]
 
 hipcc cross-compiles without a GPU.  The translation units are compiled in parallel and linked into
-one shared library.  The .so is git-ignored but travels with gpurun snapshots.
+one shared library.  The .so is git-ignored but travels with gpurun snapshots; whether it is up to
+date is decided by a hash of the sources stored beside it (file times do not survive a copy to
+another machine).
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -13,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(SRC_DIR, "_obj")
 SO = os.path.join(HERE, "libfecgpu.so")
+STAMP = SO + ".sha256"
 SOURCES = ["fecgpu.hip", "canon.hip"]
 HEADERS = ["limbs.hpp", "staging.hpp", "host_ctx.hpp", "secp256k1.hpp", "p256.hpp", "ed25519.hpp",
            "canon_curves.hpp", "canon_kernels.hpp", os.path.join("..", "..", "include", "fecgpu.h"),
@@ -20,39 +24,46 @@ HEADERS = ["limbs.hpp", "staging.hpp", "host_ctx.hpp", "secp256k1.hpp", "p256.hp
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
-def _mtime(rel):
-    return os.path.getmtime(os.path.join(SRC_DIR, rel))
+def source_hash():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for rel in SOURCES + HEADERS:
+        with open(os.path.join(SRC_DIR, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read())
+    return h.hexdigest()
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(_mtime(d) > t for d in deps)
+def up_to_date():
+    try:
+        return os.path.exists(SO) and open(STAMP).read().strip() == source_hash()
+    except OSError:
+        return False
 
 
 def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)
+    for stale in (SO, STAMP):  # never leave a library that no longer matches the sources
+        if os.path.exists(stale):
+            os.remove(stale)
     jobs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-c", os.path.join(SRC_DIR, src), "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            jobs.append((cmd, subprocess.Popen(cmd)))
-    failed = [(cmd, proc.returncode) for cmd, proc in jobs if proc.wait() != 0]
-    if failed:
-        if os.path.exists(SO):
-            os.remove(SO)  # never leave a library that no longer matches the sources
-        raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
-    if jobs or not os.path.exists(SO) or any(os.path.getmtime(o) > os.path.getmtime(SO) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(SRC_DIR, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        jobs.append((cmd, subprocess.Popen(cmd)))
+    failed = [(cmd, proc.returncode) for cmd, proc in jobs if proc.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return SO
 
 
