@@ -23,6 +23,7 @@ CANON_ABI_SYMBOLS = [
     "fec_canon_mul_base", "fec_canon_mul_base_dev", "fec_canon_mul", "fec_canon_mul_dev", "fec_canon_field_op",
     "fec_canon_double_mul", "fec_canon_double_mul_dev", "fec_canon_ecdsa_verify", "fec_canon_ecdsa_verify_dev",
     "fec_canon_bip340_verify", "fec_canon_bip340_verify_dev", "fec_canon_eddsa_verify", "fec_canon_eddsa_verify_dev",
+    "fec_canon_scalar_op",
 ]
 F_INV = 5
 
@@ -122,6 +123,7 @@ def lib():
     L.fec_canon_double_mul_dev.argtypes = [vp, ci, vp, vp, vp, vp, vp, sz, vp]
     L.fec_canon_ecdsa_verify.argtypes = [vp, ci, vp, vp, vp, vp, vp, sz]
     L.fec_canon_ecdsa_verify_dev.argtypes = [vp, ci, vp, vp, vp, vp, vp, sz, vp]
+    L.fec_canon_scalar_op.argtypes = [vp, ci, ci, vp, vp, vp, vp, sz]
     for name in ("fec_canon_bip340_verify", "fec_canon_eddsa_verify"):
         getattr(L, name).argtypes = [vp, vp, vp, vp, vp, vp, sz]
         getattr(L, name + "_dev").argtypes = [vp, vp, vp, vp, vp, vp, sz, vp]

@@ -77,6 +77,38 @@ class CanonCurve:
         _check(self._lib.fec_canon_ecdsa_verify_dev(self._h, self.CURVE, d_z, d_r, d_s, d_pk_xy, d_result, n, stream),
                "fec_canon_ecdsa_verify_dev")
 
+    def scalar_muladd(self, a, b, c):
+        """a * b + c modulo the group order, element-wise, any 256-bit inputs."""
+        aa, bb, cc = _u64(a, 4), _u64(b, 4), _u64(c, 4)
+        if not (aa.shape == bb.shape == cc.shape):
+            raise ValueError("operands differ in shape")
+        out = np.empty_like(aa)
+        _check(self._lib.fec_canon_scalar_op(self._h, self.CURVE, 0, _ptr(aa), _ptr(bb), _ptr(cc), _ptr(out), aa.shape[0]),
+               "fec_canon_scalar_op")
+        return out
+
+    def scalar_inv(self, a):
+        """a^-1 modulo the group order (0 for a = 0)."""
+        aa = _u64(a, 4)
+        out = np.empty_like(aa)
+        _check(self._lib.fec_canon_scalar_op(self._h, self.CURVE, 1, _ptr(aa), None, None, _ptr(out), aa.shape[0]),
+               "fec_canon_scalar_op")
+        return out
+
+    def ecdsa_sign(self, z, d, k):
+        """ECDSA signing with caller-supplied nonces k (e.g. RFC 6979): r = x(k G) mod n, s = k^-1 (z + r d).
+        -> (r, s, ok) with ok[i] = 0 where r or s came out 0 (the caller picks another nonce).  All arithmetic
+        on the GPU: one comb pass and three scalar-field passes."""
+        kk = _u64(k, 4)
+        one = np.zeros_like(kk)
+        one[:, 0] = 1
+        zero = np.zeros_like(kk)
+        xy, st = self.mul_base(kk)
+        r = self.scalar_muladd(xy[:, :4], one, zero)                       # x mod n
+        s = self.scalar_muladd(self.scalar_inv(kk), self.scalar_muladd(r, d, z), zero)
+        ok = ((st == 0) & r.any(axis=1) & s.any(axis=1)).astype(np.uint8)
+        return r, s, ok
+
     def mul_base_dev(self, d_scalars, d_out_xy, d_status, n, stream=None):
         _check(self._lib.fec_canon_mul_base_dev(self._h, self.CURVE, d_scalars, d_out_xy, d_status, n, stream),
                "fec_canon_mul_base_dev")
@@ -129,6 +161,10 @@ class CanonEd25519(CanonCurve):
     def eddsa_verify(self, a_enc, r_enc, s, h):
         """RFC 8032 verification; encodings as little-endian 256-bit integers, h = SHA-512(R||A||M) mod l."""
         return _four(self._lib.fec_canon_eddsa_verify, self._h, a_enc, r_enc, s, h, "fec_canon_eddsa_verify")
+
+    def eddsa_sign_finish(self, h, a, r):
+        """second half of RFC 8032 signing: S = h * a + r (mod l); the first half is R = mul_base(r)."""
+        return self.scalar_muladd(h, a, r)
 
     def eddsa_verify_dev(self, d_a_enc, d_r_enc, d_s, d_h, d_result, n, stream=None):
         _check(self._lib.fec_canon_eddsa_verify_dev(self._h, d_a_enc, d_r_enc, d_s, d_h, d_result, n, stream),

@@ -358,6 +358,26 @@ int fec_canon_eddsa_verify(fec_ctx* ctx, const uint64_t* a_enc, const uint64_t* 
   });
 }
 
+int fec_canon_scalar_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b,
+                        const uint64_t* c, uint64_t* out, size_t n) {
+  if (!ctx || !canon_curve_ok(curve) || op < 0 || op > 1 || (n && (!a || !out))) return FEC_E_ARG;
+  if (op == 0 && n && (!b || !c)) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const void* const in[4] = {a, op == 0 ? b : nullptr, op == 0 ? c : nullptr, nullptr};
+  const size_t in_stride[4] = {32, 32, 32, 0};
+  void* const outs[2] = {out, nullptr};
+  const size_t out_stride[2] = {32, 0};
+  return host_chunked(ctx, n, in, in_stride, outs, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
+    Launch L(ctx, nullptr, "k_canon_scalar_op");
+    dim3 g(grid_for(cnt)), blk(TPB);
+    const u32 *x = (const u32*)d[0], *y = (const u32*)d[1], *z = (const u32*)d[2];
+    if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_canon_scalar_op<canon::NSecp>), g, blk, 0, L.s, op, x, y, z, (u32*)o[0], cnt);
+    else if (curve == FEC_P256) hipLaunchKernelGGL((k_canon_scalar_op<canon::NP256>), g, blk, 0, L.s, op, x, y, z, (u32*)o[0], cnt);
+    else hipLaunchKernelGGL((k_canon_scalar_op<canon::NEd>), g, blk, 0, L.s, op, x, y, z, (u32*)o[0], cnt);
+    return L.done();
+  });
+}
+
 int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
                        size_t n) {
   if (!ctx || op < FEC_F_ADD || op > FEC_F_INV || (n && (!a || !out))) return FEC_E_ARG;

@@ -1193,7 +1193,8 @@ struct Fn {
   FEC_SDEV fe inv_mm(const fe& sm) {
     const fe e = N::nm2();
     fe r = sm;
-    int i = 255;  // n - 2 has its top bit set for both curves
+    int i = 255;
+    while (i > 0 && !((e.w[i >> 5] >> (i & 31)) & 1u)) --i;  // leading one of the exponent: r = sm
 #pragma unroll 1
     for (--i; i >= 0; --i) {
       r = msqr(r);
@@ -1223,6 +1224,12 @@ struct NSecp {
   FEC_SDEV fe n() { return edw::fe_words(0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); }
   FEC_SDEV fe nm2() { return edw::fe_words(0xD036413Fu, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); }
   FEC_SDEV fe r2() { return edw::fe_words(0x67D7D140u, 0x896CF214u, 0x0E7CF878u, 0x741496C2u, 0x5BCD07C6u, 0xE697F5E4u, 0x81C69BC5u, 0x9D671CD5u); }
+};
+struct NEd {  // l = 2^252 + 27742317777372353535851937790883648493, the order of the Ed25519 base point
+  static constexpr u32 N0INV = 0x12547E1Bu;
+  FEC_SDEV fe n() { return edw::fe_words(0x5CF5D3EDu, 0x5812631Au, 0xA2F79CD6u, 0x14DEF9DEu, 0u, 0u, 0u, 0x10000000u); }
+  FEC_SDEV fe nm2() { return edw::fe_words(0x5CF5D3EBu, 0x5812631Au, 0xA2F79CD6u, 0x14DEF9DEu, 0u, 0u, 0u, 0x10000000u); }
+  FEC_SDEV fe r2() { return edw::fe_words(0x449C0F01u, 0xA40611E3u, 0x68859347u, 0xD00E1BA7u, 0x17F5BE65u, 0xCEEC73D2u, 0x7C309A3Du, 0x0399411Bu); }
 };
 struct NP256 {
   static constexpr u32 N0INV = 0xEE00BC4Fu;
@@ -1329,6 +1336,20 @@ struct glv_secp {
     return acc;
   }
 };
+
+// Scalar-field operations for callers (signing, key derivation): any 256-bit inputs, results in [0, n).
+//   op 0: a * b + c (mod n)      op 1: a^-1 (mod n), 0 for a = 0 (mod n)
+template <class N>
+FEC_DEV fe scalar_op(int op, const fe& a, const fe& b, const fe& c) {
+  using F = Fn<N>;
+  const fe am = F::mmul(a, N::r2());            // a R mod n: the product a * R2 is below n * 2^256 for any a
+  if (op == 0) {
+    const fe ab = F::mmul(am, b);               // (a R) b R^-1 = a b mod n, b any 256-bit value
+    const fe cr = F::mmul(F::mmul(c, N::r2()), fe_small(1));  // c mod n
+    return F::addn(ab, cr);
+  }
+  return F::mmul(F::inv_mm(am), fe_small(1));   // (a R)^-1 R, out of Montgomery form
+}
 
 // ECDSA verification (FIPS 186-4 section 6.4 / SEC 1 section 4.1.4), the scalar half:
 //   r, s in [1, n-1]; w = s^-1; u1 = z w, u2 = r w  (mod n).   Returns the lanes that pass the range check.

@@ -428,4 +428,16 @@ __global__ __launch_bounds__(TPB) void k_ced_eddsa_finish(const u32* __restrict_
   result[i] = (ok[i] != 0 && point_status[i] == CANON_FINITE && same) ? 1 : 0;
 }
 
+// scalar-field arithmetic modulo the group order (signing side): op 0 = a*b + c, 1 = a^-1
+template <class N>
+__global__ __launch_bounds__(TPB, 2) void k_canon_scalar_op(int op, const u32* __restrict__ a, const u32* __restrict__ b,
+                                                            const u32* __restrict__ c, u32* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const fe x = canon::ld8(a + i * 8);
+  const fe y = b ? canon::ld8(b + i * 8) : fe_zero();
+  const fe z = c ? canon::ld8(c + i * 8) : fe_zero();
+  canon::st8(out + i * 8, canon::scalar_op<N>(op, x, y, z));
+}
+
 }  // namespace fecgpu

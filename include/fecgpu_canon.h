@@ -104,6 +104,13 @@ int fec_canon_eddsa_verify(fec_ctx* ctx, const uint64_t* a_enc /* n*4 */, const 
 int fec_canon_eddsa_verify_dev(fec_ctx* ctx, const uint64_t* d_a_enc, const uint64_t* d_r_enc, const uint64_t* d_s,
                                const uint64_t* d_h, uint8_t* d_result, size_t n, void* stream);
 
+/* Arithmetic modulo the group order (n for secp256k1 / P-256, l for Ed25519) on any 256-bit inputs, results
+ * in [0, order): op 0: out = a * b + c, op 1: out = a^-1 (0 for a = 0 mod order; b, c ignored).  With
+ * fec_canon_mul_base this is the device side of signing, e.g. ECDSA  r = x(k G) mod n (a * 1 + 0),
+ * s = k^-1 (z + r d);  EdDSA  S = h a + r (mod l).  Nonces and hashes are the caller's. */
+int fec_canon_scalar_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a /* n*4 */,
+                        const uint64_t* b /* n*4 */, const uint64_t* c /* n*4 */, uint64_t* out /* n*4 */, size_t n);
+
 /* element-wise F_p arithmetic on canonical values (inputs must be < p): op is a fec_field_opcode
  * or FEC_F_INV; b is ignored for unary ops */
 int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a /* n*4 */,

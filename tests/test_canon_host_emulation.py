@@ -575,3 +575,22 @@ def test_ed25519_decode_and_eddsa_prepare(emu):
         if want:
             assert M.unlimbs(u2) == (-h) % E.N
             assert (M.unlimbs(axy[:4]), M.unlimbs(axy[4:])) == pts[3] and (M.unlimbs(rxy[:4]), M.unlimbs(rxy[4:])) == pts[4]
+
+
+@pytest.mark.parametrize("name", ["secp256k1", "p256", "ed25519"])
+def test_general_scalar_ops(emu, name):
+    """a*b+c and a^-1 modulo the group order for ANY 256-bit inputs (the signing-side scalar arithmetic)"""
+    cid = {"secp256k1": 0, "p256": 1, "ed25519": 2}[name]
+    n = E.N if name == "ed25519" else M.CURVES[name].N
+    rng = random.Random(4242)
+    out = np.zeros(4, dtype=np.uint64)
+    edge = [0, 1, 2, n - 1, n, n + 1, 2 * n % 2**256, 2**255, 2**256 - 1, 2**252, 15 * n if 15 * n < 2**256 else n - 2]
+    cases = [(a, b, c) for a in edge for b in edge[:6] for c in (0, 1, n - 1, 2**256 - 1)]
+    cases += [(rng.randrange(2**256), rng.randrange(2**256), rng.randrange(2**256)) for _ in range(400)]
+    for a, b, c in cases:
+        emu.he_canon_scalar_general(cid, 0, _p(_arr(a)), _p(_arr(b)), _p(_arr(c)), _p(out))
+        assert M.unlimbs(out) == (a * b + c) % n, (hex(a), hex(b), hex(c))
+    for a in edge + [rng.randrange(2**256) for _ in range(10)]:
+        emu.he_canon_scalar_general(cid, 1, _p(_arr(a)), None, None, _p(out))
+        want = pow(a % n, -1, n) if a % n else 0
+        assert M.unlimbs(out) == want, hex(a)

@@ -542,3 +542,73 @@ def test_host_pointer_calls_are_chunk_invariant(gpu_ctx):
     gpu_ctx.set_chunk(1 << 18)
     for a, b in zip(res[1 << 18], res[100]):
         assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# signing side: scalar-field arithmetic on the GPU, RFC vectors
+# ---------------------------------------------------------------------------------------------
+def test_scalar_ops_and_ecdsa_sign(gpu_ctx):
+    import hashlib
+    from forge_ec_amd.canon import CANON_CURVES
+    rng = random.Random(6979)
+    for name in ("secp256k1", "p256", "ed25519"):
+        dev = CANON_CURVES[name](gpu_ctx)
+        n = E.N if name == "ed25519" else M.CURVES[name].N
+        vals = [0, 1, n - 1, n, n + 1, 2**256 - 1] + [rng.randrange(2**256) for _ in range(300)]
+        a, b, c = vals, vals[::-1], vals[3:] + vals[:3]
+        got = dev.scalar_muladd(_arr(a), _arr(b), _arr(c))
+        assert [M.unlimbs(g) for g in got] == [(x * y + z) % n for x, y, z in zip(a, b, c)]
+        got = dev.scalar_inv(_arr(a))
+        assert [M.unlimbs(g) for g in got] == [pow(x % n, -1, n) if x % n else 0 for x in a]
+    # RFC 6979 A.2.5 (P-256, SHA-256, "sample"): the deterministic nonce k and the signature it yields
+    dev = CANON_CURVES["p256"](gpu_ctx)
+    C = M.P256
+    d = 0xC9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721
+    k = 0xA6E3C57DD01ABE90086538398355DD4C3B17AA873382B0F24D6129493D8AAD60
+    z = int.from_bytes(hashlib.sha256(b"sample").digest(), "big")
+    r, s, ok = dev.ecdsa_sign(_arr([z]), _arr([d]), _arr([k]))
+    assert ok[0] == 1
+    assert M.unlimbs(r[0]) == 0xEFD48B2AACB6A8FD1140DD9CD45E81D69D2C877B56AAF991C34D0EA84EAF3716
+    assert M.unlimbs(s[0]) == 0xF7CB1C942D657C41D436C7A1B6E29F65F3E900DBB9AFF4064DC4AB2F843ACDA8
+    # sign -> verify round trip on the GPU, both curves
+    for name in ("secp256k1", "p256"):
+        dev = CANON_CURVES[name](gpu_ctx)
+        C = M.CURVES[name]
+        m = 500
+        ds = [rng.randrange(1, C.N) for _ in range(m)]
+        ks = [rng.randrange(1, C.N) for _ in range(m)]
+        zs = [rng.randrange(2**256) for _ in range(m)]
+        pub, st = dev.mul_base(_arr(ds))
+        r, s, ok = dev.ecdsa_sign(_arr(zs), _arr(ds), _arr(ks))
+        assert ok.all() and not st.any()
+        assert dev.ecdsa_verify(_arr(zs), r, s, pub).all()
+        zs2 = _arr(zs)
+        zs2[:, 0] ^= np.uint64(1)
+        assert not dev.ecdsa_verify(zs2, r, s, pub).any()
+
+
+def test_eddsa_sign_rfc8032(gpu_ctx):
+    """RFC 8032 TEST 1 and TEST 2 signatures reproduced: R = r B and S = h a + r mod l on the GPU, the two
+    SHA-512 hashes here"""
+    import hashlib
+    from forge_ec_amd.canon import CanonEd25519
+    dev = CanonEd25519(gpu_ctx)
+    for (seed, pk), msg, sighex in (
+            (M.ED25519_RFC8032_TEST1, b"", "e5564300c360ac729086e2cc806e828a84877f1eb8e5d974d873e06522490155"
+                                           "5fb8821590a33bacc61e39701cf9b46bd25bf5f0595bbe24655141438e7a100b"),
+            (M.ED25519_RFC8032_TEST2, bytes([0x72]), "92a009a9f0d4cab8720e820b5f642540a2b27b5416503f8fb3762223ebdb69da"
+                                                     "085ac1e43e15996e458f3613d0f11d8c387b2eaeb4302aeeb00d291612bb0c00")):
+        hh = hashlib.sha512(seed).digest()
+        a = E.secret_scalar(seed)
+        r = int.from_bytes(hashlib.sha512(hh[32:] + msg).digest(), "little")       # 512 bits: reduce on the GPU
+        r_lo, r_hi = r & (2**256 - 1), r >> 256
+        # r mod l = r_hi * (2^256 mod l) + r_lo: two scalar ops on the device
+        two256 = _arr([2**256 % E.N])
+        rl = dev.scalar_muladd(_arr([r_hi]), two256, _arr([r_lo]))
+        xy, st = dev.mul_base(rl)
+        Renc = E.encode((M.unlimbs(xy[0, :4]), M.unlimbs(xy[0, 4:])))
+        h = int.from_bytes(hashlib.sha512(Renc + pk + msg).digest(), "little")
+        hl = dev.scalar_muladd(_arr([h >> 256]), two256, _arr([h & (2**256 - 1)]))
+        S = dev.eddsa_sign_finish(hl, _arr([a]), rl)
+        sig = Renc + M.unlimbs(S[0]).to_bytes(32, "little")
+        assert sig.hex() == sighex

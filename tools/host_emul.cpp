@@ -376,3 +376,12 @@ extern "C" int he_eddsa_prepare(const uint64_t* a, const uint64_t* r, const uint
   st(axy, A.x); st(axy + 4, A.y); st(rxy, R.x); st(rxy + 4, R.y); st(u2, v);
   return ok ? 1 : 0;
 }
+// general scalar-field op: curve 0 secp256k1 (mod n), 1 P-256 (mod n), 2 Ed25519 (mod l); op 0 = a*b+c, 1 = a^-1
+extern "C" int he_canon_scalar_general(int curve, int op, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t* out) {
+  fe x = ld(a), y = b ? ld(b) : fe_zero(), z = c ? ld(c) : fe_zero(), r;
+  if (curve == 0) r = canon::scalar_op<canon::NSecp>(op, x, y, z);
+  else if (curve == 1) r = canon::scalar_op<canon::NP256>(op, x, y, z);
+  else r = canon::scalar_op<canon::NEd>(op, x, y, z);
+  st(out, r);
+  return 0;
+}
