@@ -128,7 +128,13 @@ FEC_DEV fe mul(const fe& a, const fe& b) {
   mul_wide(t, a, b);
   return reduce_wide(t);
 }
-FEC_DEV fe sqr(const fe& a) { return mul(a, a); }  // 772-776
+// square() (772-776) is self * self: the same exact 512-bit product, formed with the 97-instruction
+// squaring (28 doubled cross products + 8 squares) instead of the 128-instruction general product
+FEC_DEV fe sqr(const fe& a) {
+  u32 t[16];
+  sqr_wide(t, a);
+  return reduce_wide(t);
+}
 
 FEC_DEV fe mul_small(const fe& a, u32 k) {  // FieldElement::from(k) * a  (1893-1904)
   u32 t[16];
