@@ -93,12 +93,55 @@ FEC_DEV fe mont_reduce(const u32 t[16]) {
   return csub_p_unlikely(v2);
 }
 
-// Mul (442-507)
-FEC_DEV fe mul(const fe& a, const fe& b) {
+// Mul (442-507), compiler-scheduled form: the host emulation's Mul and the cross-check of the
+// hand-allocated one below
+FEC_DEV fe mul_cxx(const fe& a, const fe& b) {
   u32 t[16];
   mul_wide(t, a, b);
   return mont_reduce(t);
 }
+
+#ifdef FEC_HOST_EMUL
+FEC_DEV fe mul(const fe& a, const fe& b) { return mul_cxx(a, b); }
+#else
+// v -= 2^64 on the lanes of bw: the borrow out of word 1 continued through words 2..7
+FEC_DEV fe borrow_from_word2(const fe& v, lmask bw) {
+  fe x = v;
+  asm("s_mov_b64 vcc, %6\n\t"
+      "v_subbrev_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+      "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_subbrev_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+      "v_subbrev_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+      "v_subbrev_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+      "v_subbrev_co_u32_e32 %5, vcc, 0, %5, vcc"
+      : "+v"(x.w[2]), "+v"(x.w[3]), "+v"(x.w[4]), "+v"(x.w[5]), "+v"(x.w[6]), "+v"(x.w[7])
+      : "s"(bw)
+      : "vcc");
+  return x;
+}
+// reduce (78-102) of a Mul / square result: v >= p needs words 2..7 all ones, so the whole test sits
+// behind one compare of the top word (2^-32 per lane)
+FEC_DEV fe csub_p_top(const fe& v) {
+  if (__builtin_expect(lanes_where(v.w[7] == 0xFFFFFFFFu) != 0, 0)) return csub_p_unlikely(v);
+  return v;
+}
+// Mul (442-507) as ONE hand-allocated asm statement (tools/gen_field_asm.py): the 512-bit product by
+// product scanning with the Montgomery word recurrence of mont_reduce() interleaved, then
+// V = T_hi + M - Q.  Q < 2^33 is subtracted from words 0..1 only; the borrow out of word 1
+// (2^-31 per lane) is exported as a lane mask and continued behind a wave-uniform branch.
+#include "field_asm.inc"
+FEC_DEV fe mul(const fe& a, const fe& b) {
+  fe r;
+  lmask sc, bw;
+  asm(FEC_SECP_MUL_ASM
+      : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
+        "=v"(r.w[7]), "=&s"(sc), "=&s"(bw)
+      : FEC_V8(a), FEC_V8(b), "s"(0xD2253531u), "s"(977u)
+      : FEC_SECP_MUL_CLOBBERS);
+  if (__builtin_expect(bw != 0, 0)) r = borrow_from_word2(r, bw);
+  return csub_p_top(r);
+}
+#endif
 
 // multiply by a raw small constant through the Montgomery Mul (three/eight at 1523, 1533)
 FEC_DEV fe mul_small(const fe& a, u32 k) {
@@ -207,7 +250,7 @@ FEC_DEV lmask fold_general(u32 r[8], u32 m0, u32 m1, lmask cin) {
   return c;
 }
 
-FEC_DEV fe sqr(const fe& a) {
+FEC_DEV fe sqr_cxx(const fe& a) {
   u32 w[16];
   FEC_UNROLL for (int i = 0; i < 4; ++i)  // 643-649: limb squares
       mul64_words(&w[4 * i], a.w[2 * i], a.w[2 * i + 1], a.w[2 * i], a.w[2 * i + 1]);
@@ -261,6 +304,25 @@ FEC_DEV fe sqr(const fe& a) {
   FEC_UNROLL for (int i = 0; i < 8; ++i) o.w[i] = r[i];
   return csub_p_unlikely(o);
 }
+
+#ifdef FEC_HOST_EMUL
+FEC_DEV fe sqr(const fe& a) { return sqr_cxx(a); }
+#else
+// square() as ONE hand-allocated asm statement (tools/gen_field_asm.py) for the path on which no +1
+// ripples past the limb it is added to (each continuation needs a 64-bit limb of all ones).  The
+// lanes where one would are returned as a mask, and such a wavefront recomputes with sqr_cxx().
+FEC_DEV fe sqr(const fe& a) {
+  fe r;
+  lmask tmp, exc;
+  asm(FEC_SECP_SQR_ASM
+      : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
+        "=v"(r.w[7]), "=&s"(tmp), "=&s"(exc)
+      : FEC_V8(a), "s"(977u)
+      : FEC_SECP_SQR_CLOBBERS);
+  if (__builtin_expect(exc != 0, 0)) return sqr_cxx(a);
+  return csub_p_top(r);
+}
+#endif
 
 struct pt {
   fe x, y, z;

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generator of forge_ec_amd/csrc/field_asm.inc: hand-allocated gfx950 assembly for the field
+multiplications of the three curves.
+
+    python tools/gen_field_asm.py            # rewrites forge_ec_amd/csrc/field_asm.inc
+
+Why generated assembly: hipcc's lowering of the same arithmetic spends ~21 % of the ladder's VALU
+instructions on v_mov (profiles/r02_isa_mix_*.md): 64-bit VGPR operands are even-aligned pairs, so
+every column of the product scanning re-assembles its {carry-in, overflow} pair, and the Montgomery
+recurrence re-assembles a pair per word.  Here every temporary lives in a FIXED register block
+(v[VB..255], declared as clobbers), so halves of pairs are addressed directly:
+
+  * column k of the 512-bit product accumulates in its own pair Q_k = v[VB+2k : VB+2k+1]; the finished
+    word T[k] stays where the last v_mad_u64_u32 left it (the pair's low register), the pair's high
+    register is copied once into the carry pair C (1 v_mov per column instead of 2-3), and the
+    overflow word is counted directly in C's high register;
+  * secp256k1: the Montgomery word recurrence (one v_mul_lo_u32 + one v_mad_u64_u32 per word) runs
+    interleaved with the following column, its 33rd bit travels in an SGPR pair as a carry, and the
+    word m_k is parked in the dead high register of Q_k;
+  * the compiler sees one asm statement per field multiplication: 8 outputs, 16 inputs, 2-4 scalars.
+
+The statements are semantically the routines they replace (limbs.hpp mul_wide + the per-curve
+reduction); tests/test_gpu_parity.py and the host emulation (which keeps the portable C++ form)
+pin them against the oracle.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "forge_ec_amd", "csrc", "field_asm.inc")
+
+
+class Block:
+    """One asm statement under construction."""
+
+    def __init__(self):
+        self.lines = []
+
+    def e(self, s):
+        self.lines.append(s)
+
+    def text(self):
+        return "\n".join('      "%s\\n\\t"' % l for l in self.lines[:-1]) + '\n      "%s"' % self.lines[-1]
+
+
+def v(n):
+    return "v%d" % n
+
+
+def vp(n):
+    assert n % 2 == 0, n
+    return "v[%d:%d]" % (n, n + 1)
+
+
+def interleave(main, side):
+    """Spread the instructions of `side` through `main`: one after every main instruction that is
+    not a v_mad (so a mad and the v_addc that consumes its carry stay adjacent)."""
+    out, si = [], 0
+    for i, m in enumerate(main):
+        out.append(m)
+        if si < len(side) and i >= 1 and not m.startswith("v_mad"):
+            out.append(side[si])
+            si += 1
+    out.extend(side[si:])
+    return out
+
+
+def mul_wide_columns(A, B, VB, side_for_column=None, first_col_src=None):
+    """Product scanning of A[0..7] x B[0..7] (operand strings).  Column k accumulates in the pair
+    Q_k = v[VB+2k : VB+2k+1]; C = v[VB+30 : VB+31] is the carry pair {next column's carry-in low,
+    overflow count}.  Returns the instruction list; afterwards T[k] = v(VB+2k) for k <= 14 and
+    T[15] = v(VB+29).  side_for_column(k) -> instructions to interleave into column k."""
+    C = VB + 30
+    ins = ["v_mov_b32_e32 %s, 0" % v(C + 1)]
+    for k in range(15):
+        q = VB + 2 * k
+        lo = max(0, k - 7)
+        prods = [(i, k - i) for i in range(lo, min(k, 7) + 1)]
+        main = []
+        for n, (i, j) in enumerate(prods):
+            if n == 0:
+                src2 = "0" if k == 0 else vp(C)
+                main.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (vp(q), A[i], B[j], src2))
+                # carry-in < 2^32 for column 1 and the top column is bounded by the true product
+                if k >= 2 and k != 14:
+                    main.append("v_addc_co_u32_e64 %s, vcc, 0, 0, vcc" % v(C + 1))
+            else:
+                main.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (vp(q), A[i], B[j], vp(q)))
+                main.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (v(C + 1), v(C + 1)))
+        if k != 14:
+            main.append("v_mov_b32_e32 %s, %s" % (v(C), v(q + 1)))
+        side = side_for_column(k) if side_for_column else []
+        ins.extend(interleave(main, side))
+    return ins
+
+
+# ------------------------------------------------------------------------------------------------
+# secp256k1 Mul (secp256k1.rs:442-507) = csub_p((T_hi + M - Q) mod 2^256), see secp256k1.hpp
+# operands: %0-%7 r, %8 sc (SGPR pair: the recurrence's 33rd bit), %9 bw (SGPR pair: dummy carry
+# sink, then the borrow out of word 1), %10-%17 a, %18-%25 b, %26 N0' (s), %27 977 (s)
+# ------------------------------------------------------------------------------------------------
+def secp_mul(VB):
+    A = ["%%%d" % (10 + i) for i in range(8)]
+    B = ["%%%d" % (18 + i) for i in range(8)]
+    R = ["%%%d" % i for i in range(8)]
+    SC, BW, N0P, C977 = "%8", "%9", "%26", "%27"
+    P, D = VB + 32, VB + 34  # P = {e_lo, 0}; D = m*977 + P
+    T = [VB + 2 * k for k in range(15)] + [VB + 29]
+    M = [VB + 2 * k + 1 for k in range(8)]
+
+    def side(col):
+        k = col - 1  # recurrence step k needs the finished T[k]
+        if k < 0 or k > 7:
+            return []
+        if k == 0:
+            return ["v_mul_lo_u32 %s, %s, %s" % (v(M[0]), v(T[0]), N0P),
+                    "v_mad_u64_u32 %s, %s, %s, %s, 0" % (vp(D), BW, v(M[0]), C977),
+                    "v_add_co_u32_e64 %s, %s, %s, %s" % (v(P), SC, v(D + 1), v(M[0]))]
+        return ["v_sub_u32_e32 %s, %s, %s" % (v(M[k]), v(T[k]), v(P)),
+                "v_mul_lo_u32 %s, %s, %s" % (v(M[k]), v(M[k]), N0P),
+                "v_mad_u64_u32 %s, %s, %s, %s, %s" % (vp(D), BW, v(M[k]), C977, vp(P)),
+                "v_addc_co_u32_e64 %s, %s, %s, %s, %s" % (v(P), SC, v(D + 1), v(M[k]), SC)]
+
+    b = Block()
+    b.e("v_mov_b32_e32 %s, 0" % v(P + 1))
+    for s in mul_wide_columns(A, B, VB, side):
+        b.e(s)
+    # V = T_hi + M - Q (mod 2^256), Q = {P.lo, sc}
+    b.e("v_add_co_u32_e32 %s, vcc, %s, %s" % (R[0], v(T[8]), v(M[0])))
+    for i in range(1, 8):
+        b.e("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (R[i], v(T[8 + i]), v(M[i])))
+    b.e("v_cndmask_b32_e64 %s, 0, 1, %s" % (v(P + 1), SC))
+    b.e("v_sub_co_u32_e32 %s, vcc, %s, %s" % (R[0], R[0], v(P)))
+    b.e("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (R[1], R[1], v(P + 1)))
+    b.e("s_mov_b64 %s, vcc" % BW)
+    return b, list(range(VB, VB + 36))
+
+
+# ------------------------------------------------------------------------------------------------
+# secp256k1 square() (secp256k1.rs:634-713), common path: see secp256k1.hpp sqr_cxx for the literal
+# restatement.  Every data-dependent continuation of the reference (a +1 that ripples past the limb it
+# is added to; the fold's general carry rule) fires only when a 64-bit limb is all ones; the lanes
+# where one would fire are collected in the exception mask %9 and the caller recomputes those
+# wavefronts with sqr_cxx.
+# operands: %0-%7 r, %8 tmp (SGPR pair), %9 exc (SGPR pair), %10-%17 a, %18 977 (s)
+# ------------------------------------------------------------------------------------------------
+def secp_sqr(VB):
+    A = ["%%%d" % (10 + i) for i in range(8)]
+    R = ["%%%d" % i for i in range(8)]
+    TMP, EXC, C977 = "%8", "%9", "%18"
+    # register homes: every 64-bit product gets its own aligned pair
+    nxt = [VB]
+
+    def pair():
+        r = nxt[0]
+        nxt[0] += 2
+        return r
+
+    Z, Y = pair(), pair()  # Z = {x, 0} zero-extension pair; Y = {acc.hi, ovf}
+    b = Block()
+    b.e("v_mov_b32_e32 %s, 0" % v(Z + 1))
+    b.e("s_mov_b64 %s, 0" % EXC)
+
+    def mul64(x0, x1, y0, y1, pa, pb, pc):
+        """p = (x1:x0)*(y1:y0): p0 = lo(pa), p1 = lo(pb), p2 = lo(pc), p3 = hi(pc)."""
+        b.e("v_mad_u64_u32 %s, vcc, %s, %s, 0" % (vp(pa), x0, y0))
+        b.e("v_mov_b32_e32 %s, %s" % (v(Z), v(pa + 1)))
+        b.e("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (vp(pb), x0, y1, vp(Z)))
+        b.e("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (vp(pb), x1, y0, vp(pb)))
+        b.e("v_addc_co_u32_e64 %s, vcc, 0, 0, vcc" % v(Y + 1))
+        b.e("v_mov_b32_e32 %s, %s" % (v(Y), v(pb + 1)))
+        b.e("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (vp(pc), x1, y1, vp(Y)))
+        return [v(pa), v(pb), v(pc), v(pc + 1)]
+
+    W = [None] * 16
+    for i in range(4):  # 643-649: limb squares
+        pa, pb, pc = pair(), pair(), pair()
+        W[4 * i:4 * i + 4] = mul64(A[2 * i], A[2 * i + 1], A[2 * i], A[2 * i + 1], pa, pb, pc)
+    xa, xb, xc = pair(), pair(), pair()  # cross products reuse one set of pairs
+    for i in range(4):  # 652-679: doubled cross terms
+        for j in range(i + 1, 4):
+            p0, p1, p2, p3 = mul64(A[2 * i], A[2 * i + 1], A[2 * j], A[2 * j + 1], xa, xb, xc)
+            # u128 wrapping_mul(2): bit 127 is lost.  Top word first so every source is still intact.
+            b.e("v_alignbit_b32 %s, %s, %s, 31" % (p3, p3, p2))
+            b.e("v_alignbit_b32 %s, %s, %s, 31" % (p2, p2, p1))
+            b.e("v_alignbit_b32 %s, %s, %s, 31" % (p1, p1, p0))
+            b.e("v_lshlrev_b32_e32 %s, 1, %s" % (p0, p0))
+            B = 2 * (i + j)
+            b.e("v_add_co_u32_e32 %s, vcc, %s, %s" % (W[B], W[B], p0))
+            b.e("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (W[B + 1], W[B + 1], p1))
+            b.e("s_mov_b64 %s, vcc" % TMP)
+            b.e("v_add_co_u32_e32 %s, vcc, %s, %s" % (W[B + 2], W[B + 2], p2))
+            b.e("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (W[B + 3], W[B + 3], p3))
+            b.e("s_or_b64 vcc, vcc, %s" % TMP)
+            b.e("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (W[B + 4], W[B + 4]))
+            b.e("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (W[B + 5], W[B + 5]))
+            if B + 6 < 16:
+                b.e("s_or_b64 %s, %s, vcc" % (EXC, EXC))
+    # 681-707: every high limb folded into limb 0 with the low 64 bits of limb * 0x1000003D1
+    F = xa
+    T = xb  # scratch word
+    for i in range(4, 8):
+        h0, h1 = W[2 * i], W[2 * i + 1]
+        b.e("v_mad_u64_u32 %s, vcc, %s, %s, 0" % (vp(F), h0, C977))
+        b.e("v_mul_lo_u32 %s, %s, %s" % (v(T), h1, C977))
+        b.e("v_add3_u32 %s, %s, %s, %s" % (v(T), v(F + 1), v(T), h0))
+        dst = R if i == 7 else W  # the last fold leaves limbs 0..1 in the output operands
+        b.e("v_add_co_u32_e32 %s, vcc, %s, %s" % (dst[0], W[0], v(F)))
+        b.e("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (dst[1], W[1], v(T)))
+        b.e("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (dst[2], W[2]))
+        b.e("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (dst[3], W[3]))
+        b.e("s_or_b64 %s, %s, vcc" % (EXC, EXC))
+    for i in range(4, 8):
+        b.e("v_mov_b32_e32 %s, %s" % (R[i], W[i]))
+    return b, list(range(VB, nxt[0]))
+
+
+def clobbers(regs):
+    return ", ".join('"v%d"' % r for r in regs)
+
+
+HEADER = """// field_asm.inc -- GENERATED by tools/gen_field_asm.py; do not edit.
+// Hand-allocated gfx950 assembly for the field multiplications (one asm statement each).  All
+// temporaries live in the fixed VGPR block named in each statement's clobber list.
+"""
+
+
+def main():
+    parts = [HEADER]
+    blk, regs = secp_mul(220)
+    parts.append("#define FEC_SECP_MUL_ASM \\\n" + blk.text().replace("\n", " \\\n") + "\n")
+    parts.append("#define FEC_SECP_MUL_CLOBBERS \"vcc\", " + clobbers(regs) + "\n")
+    parts.append("// instruction count: %d\n" % len(blk.lines))
+    sq, sregs = secp_sqr(256 - 34)
+    assert sregs[-1] == 255, sregs
+    parts.append("#define FEC_SECP_SQR_ASM \\\n" + sq.text().replace("\n", " \\\n") + "\n")
+    parts.append("#define FEC_SECP_SQR_CLOBBERS \"vcc\", " + clobbers(sregs) + "\n")
+    parts.append("// instruction count: %d\n" % len(sq.lines))
+    with open(OUT, "w") as f:
+        f.write("\n".join(parts))
+    print("wrote %s (secp mul: %d, secp sqr: %d instructions)" % (OUT, len(blk.lines), len(sq.lines)))
+
+
+if __name__ == "__main__":
+    main()

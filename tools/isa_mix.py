@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Static instruction mix of a kernel's hot loop, from hipcc's gfx950 assembly.
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S forge_ec_amd/csrc/fecgpu.hip -o /tmp/fecgpu.s
+    python tools/isa_mix.py /tmp/fecgpu.s <mangled-kernel-substring> [--loop outer|all] [--md]
+
+The hot loop is the largest natural loop of the kernel (the 256-step ladder): the span from the
+target label of a backward branch to that branch.  Blocks the compiler placed outside that span
+(cold continuations: the rare ripple / equal-points / non-canonical paths) are reported separately
+as "outside the loop span".  Classes follow the measured issue costs (profiles/valu_rates*_r01.txt).
+"""
+import collections
+import re
+import sys
+
+CLASSES = [
+    ("v_mad_u64_u32", lambda m: m.startswith("v_mad_u64_u32")),
+    ("v_mul_lo/hi_u32", lambda m: m.startswith("v_mul_lo_u32") or m.startswith("v_mul_hi_u32")),
+    ("v_addc/v_subb (carry in)", lambda m: m.startswith(("v_addc_co", "v_subb_co", "v_subbrev_co"))),
+    ("v_add_co/v_sub_co (carry out)", lambda m: m.startswith(("v_add_co", "v_sub_co", "v_subrev_co"))),
+    ("v_cndmask", lambda m: m.startswith("v_cndmask")),
+    ("v_cmp", lambda m: m.startswith("v_cmp")),
+    ("v_mov", lambda m: m.startswith("v_mov") or m.startswith("v_accvgpr")),
+    ("v_alignbit/shift/logic/other VALU", lambda m: m.startswith("v_")),
+    ("s_nop", lambda m: m.startswith("s_nop")),
+    ("s_waitcnt/s_barrier", lambda m: m.startswith(("s_waitcnt", "s_barrier"))),
+    ("s_branch/s_cbranch", lambda m: m.startswith(("s_branch", "s_cbranch"))),
+    ("other SALU", lambda m: m.startswith("s_")),
+    ("ds_read/ds_write/ds_*", lambda m: m.startswith("ds_")),
+    ("scratch_*", lambda m: m.startswith("scratch_")),
+    ("global/buffer/flat", lambda m: m.startswith(("global_", "buffer_", "flat_"))),
+]
+
+
+def classify(m):
+    for name, pred in CLASSES:
+        if pred(m):
+            return name
+    return "other"
+
+
+def main():
+    path, needle = sys.argv[1], sys.argv[2]
+    md = "--md" in sys.argv
+    lines = open(path).read().split("\n")
+    start = None
+    for i, l in enumerate(lines):
+        if re.match(r"^[A-Za-z_][\w$.]*:", l) and needle in l.split(":")[0]:
+            start = i
+            break
+    if start is None:
+        raise SystemExit("kernel not found: " + needle)
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    body = lines[start:end]
+    label_at, insts = {}, []  # instruction index of each label; (mnemonic, operands)
+    for l in body:
+        s = l.strip()
+        mm = re.match(r"^(\.LBB\d+_\d+):", s)
+        if mm:
+            label_at[mm.group(1)] = len(insts)
+            continue
+        s = s.split(";")[0].strip()
+        if not s or s.startswith((".", "//")) or s.endswith(":"):
+            continue
+        parts = s.split(None, 1)
+        insts.append((parts[0], parts[1] if len(parts) > 1 else ""))
+    loops = []
+    for idx, (m, ops) in enumerate(insts):
+        if m.startswith(("s_cbranch", "s_branch")):
+            t = ops.split()[0].rstrip(",")
+            if t in label_at and label_at[t] <= idx:
+                loops.append((label_at[t], idx, m.startswith("s_cbranch")))
+    if not loops:
+        raise SystemExit("no loop found")
+    # the ladder loop's back edge is a conditional branch; unconditional backward branches are the
+    # returns of out-of-line cold blocks
+    lo, hi, _ = max([r for r in loops if r[2]] or loops, key=lambda r: r[1] - r[0])
+    inner = [r for r in loops if r[:2] != (lo, hi) and r[0] >= lo and r[1] <= hi]
+
+    def mix(rng):
+        c = collections.Counter()
+        for m, _ in rng:
+            c[classify(m)] += 1
+        return c
+
+    inside, outside = mix(insts[lo:hi + 1]), mix(insts[:lo] + insts[hi + 1:])
+    total_in = sum(inside.values())
+    valu = sum(v for k, v in inside.items() if k.startswith("v_"))
+    print("kernel: %s" % body[0].rstrip(":"))
+    print("hot loop span: %d instructions (%d VALU), %d instructions outside the span, %d nested loops inside"
+          % (total_in, valu, sum(outside.values()), len(inner)))
+    sep = " | " if md else "  "
+    if md:
+        print("| class | in loop span | outside |\n|---|---|---|")
+    for name, _ in CLASSES + [("other", None)]:
+        if inside.get(name, 0) or outside.get(name, 0):
+            row = (name, inside.get(name, 0), outside.get(name, 0))
+            print(("| %s | %d | %d |" if md else "%-36s %8d %8d") % row)
+    top = collections.Counter(m for m, _ in insts[lo:hi + 1]).most_common(25)
+    print("top mnemonics in the loop span: " + ", ".join("%s %d" % t for t in top))
+    # Hot path of one iteration: LLVM lays the likely successor out as the fall-through, so walk
+    # from the loop head taking no conditional branch (except the loop's own back edge) and every
+    # unconditional one, until the walk returns to the head.  Forward conditional branches over
+    # a few instructions (if-conversion leftovers) are treated the same way.
+    path, pc, steps = [], lo, 0
+    while steps < 200000:
+        m, ops = insts[pc]
+        path.append(m)
+        steps += 1
+        if pc == hi:
+            break
+        if m.startswith("s_branch"):
+            t = ops.split()[0].rstrip(",")
+            pc = label_at[t]
+            if pc == lo:
+                break
+            continue
+        pc += 1
+    hot = collections.Counter(classify(m) for m in path)
+    hv = sum(v for k, v in hot.items() if k.startswith("v_"))
+    print("hot path of one iteration (fall-through walk): %d instructions, %d VALU" % (len(path), hv))
+    if md:
+        print("| class | hot path, per iteration |\n|---|---|")
+    for name, _ in CLASSES + [("other", None)]:
+        if hot.get(name, 0):
+            print(("| %s | %d |" if md else "%-36s %8d") % (name, hot[name]))
+    print("top mnemonics on the hot path: " + ", ".join("%s %d" % t for t in collections.Counter(path).most_common(25)))
+
+
+if __name__ == "__main__":
+    main()
