@@ -105,26 +105,33 @@ def cpu_baseline(workload, inputs, gpu_out, target_s):
             "parity_sample_bit_exact": ok}
 
 
-def measured_traffic(workload, n):
-    """HBM bytes per launch from the committed PMC passes (bench.py cannot collect PMC itself)."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01c", "traffic.json")))
-        if t["workload"] == workload and t["units_per_launch"] == n:
-            return t["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
-
-
-def measured_valu_busy(workload, n):
-    """rocprofv3 derived counter VALUBusy (%) of the kernel, from the committed PMC pass."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01c", "traffic.json")))
-        if t["workload"] == workload and t["units_per_launch"] == n:
-            return t.get("valu_busy_pct")
-    except Exception:
-        pass
-    return None
+def committed_pmc(workload, n):
+    """HBM bytes per launch and VALUBusy from a committed rocprofv3 PMC pass (bench.py cannot collect
+    PMC itself).  Only a pass taken on THIS build counts: tools/pmc_summarize.py records the library's
+    source hash beside the counters, and a pass whose hash differs from the loaded library's is
+    ignored -- the fields are then null and say why."""
+    import glob
+    from forge_ec_amd import build as fbuild
+    here = fbuild.source_hash()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*", "*", "pmc.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+        except Exception:
+            continue
+        if t.get("workload") != workload or t.get("units_per_launch") != n:
+            continue
+        rel = os.path.relpath(path, ROOT)
+        if t.get("source_hash") != here:
+            stale = stale or rel
+            continue
+        d = t.get("derived", {})
+        return {"traffic": d.get("hbm_bytes_per_launch"),
+                "valu_busy_pct": t.get("counters", {}).get("VALUBusy", {}).get("per_launch"),
+                "source": "%s: committed rocprofv3 PMC pass of this build (source hash %s), not measured by this run"
+                          % (rel, here[:12])}
+    why = ("only a stale PMC pass exists (%s, other source hash)" % stale) if stale else "no committed PMC pass for this workload"
+    return {"traffic": None, "valu_busy_pct": None, "source": why}
 
 
 def main():
@@ -251,8 +258,21 @@ def main():
                  "double": "k_batch_double_mul<%s>"}[kind] % curve
         if workload == "ed25519-fixed":
             kname = "k_ed_fixed_base"
+        if workload == "p256-var":
+            kname = "k_p256_mul_sched"
+        pmc = committed_pmc(workload, n)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is an N = 1 measurement
+            gpu_out = d_out[(min(args.steps, 5) - 1) & 1].cpu().numpy().view(np.uint64)
+            cpu = cpu_baseline(workload, inputs, gpu_out, args.cpu_seconds)
+            if not cpu["parity_sample_bit_exact"]:
+                # a kernel whose output differs from the oracle has no throughput worth reporting
+                print(json.dumps({"error": "GPU output differs from the CPU oracle on the parity sample",
+                                  "workload": workload, "cpu_baseline": cpu}), flush=True)
+                raise SystemExit(3)
         out = {
-            "metric": "%s scalar-muls/sec (batched, bit-exact vs CPU oracle)" % workload,
+            "metric": "%s scalar-muls/sec (batched, %s)" % (
+                workload, "bit-exact vs CPU oracle on the parity sample" if cpu else "parity check not run in this invocation"),
             "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
@@ -264,18 +284,18 @@ def main():
                        "device": info["name"], "compute_units": info["compute_units"]},
             "roofline": {
                 "bound": "int-valu", "achieved": achieved / 1e12, "peak": PEAK_MAD32_FORMULA / 1e12,
-                "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_FORMULA, "traffic": measured_traffic(workload, n),
+                "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_FORMULA, "traffic": pmc["traffic"],
+                "traffic_source": pmc["source"],
                 "kernel": kname, "kernel_ms": kernel_ms,
                 "algorithmic_mad32_per_unit": alg, "units_per_launch": n,
                 "peak_measured": peak_measured / 1e12, "frac_of_measured_peak": achieved / peak_measured,
-                "valu_busy_pct": measured_valu_busy(workload, n),
+                "valu_busy_pct": pmc["valu_busy_pct"],
                 "hbm": {"achieved_GBps": n * hbm_bytes / (kernel_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
                         "algorithmic_bytes_per_unit": hbm_bytes},
             },
         }
-        if not args.no_cpu_baseline:
-            gpu_out = d_out[(min(args.steps, 5) - 1) & 1].cpu().numpy().view(np.uint64)
-            out["cpu_baseline"] = cpu_baseline(workload, inputs, gpu_out, args.cpu_seconds)
+        if cpu:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
     if dist is not None:

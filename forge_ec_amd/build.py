@@ -17,9 +17,9 @@ SRC_DIR = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(SRC_DIR, "_obj")
 SO = os.path.join(HERE, "libfecgpu.so")
 STAMP = SO + ".sha256"
-SOURCES = ["fecgpu.hip", "canon.hip"]
+SOURCES = ["fecgpu.hip", "canon.hip", "kernels_p256.hip"]
 HEADERS = ["limbs.hpp", "staging.hpp", "host_ctx.hpp", "secp256k1.hpp", "p256.hpp", "ed25519.hpp",
-           "canon_curves.hpp", "canon_kernels.hpp", "field_asm.inc", os.path.join("..", "..", "include", "fecgpu.h"),
+           "canon_curves.hpp", "canon_kernels.hpp", "field_asm.inc", "kernels.hpp", os.path.join("..", "..", "include", "fecgpu.h"),
            os.path.join("..", "..", "include", "fecgpu_canon.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
@@ -39,6 +39,15 @@ def up_to_date():
         return False
 
 
+def _tu_hash(src):
+    """Hash of one translation unit: its own source, every shared header and the flags."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for rel in [src] + HEADERS:
+        with open(os.path.join(SRC_DIR, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return SO
@@ -47,17 +56,29 @@ def build(force=False, verbose=False):
     for stale in (SO, STAMP):  # never leave a library that no longer matches the sources
         if os.path.exists(stale):
             os.remove(stale)
-    jobs, objs = [], []
+    jobs, objs, stamps = [], [], []
     for src in SOURCES:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(obj)
+        ostamp, want = obj + ".sha256", _tu_hash(src)
+        try:  # an object whose translation unit did not change is reused (the TUs compile in ~2 min)
+            if not force and os.path.exists(obj) and open(ostamp).read().strip() == want:
+                continue
+        except OSError:
+            pass
+        if os.path.exists(ostamp):
+            os.remove(ostamp)
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(SRC_DIR, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         jobs.append((cmd, subprocess.Popen(cmd)))
+        stamps.append((ostamp, want))
     failed = [(cmd, proc.returncode) for cmd, proc in jobs if proc.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
+    for ostamp, want in stamps:
+        with open(ostamp, "w") as f:
+            f.write(want + "\n")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -216,6 +216,7 @@ extern "C" {
 // ---- canonical-math mode (include/fecgpu_canon.h): NOT reference parity ----------------------
 int fec_canon_mul_base_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, uint64_t* d_out_xy,
                            uint8_t* d_status, size_t n, void* stream) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_scalars || !d_out_xy || !d_status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (!aligned16(d_scalars) || !aligned16(d_out_xy)) return FEC_E_ARG;
@@ -225,6 +226,7 @@ int fec_canon_mul_base_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scal
 
 int fec_canon_mul_base(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, uint64_t* out_xy, uint8_t* status,
                        size_t n) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!scalars || !out_xy || !status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (n == 0) return FEC_OK;
@@ -239,6 +241,7 @@ int fec_canon_mul_base(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, u
 
 int fec_canon_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, const uint64_t* d_points_xy,
                       uint64_t* d_out_xy, uint8_t* d_status, size_t n, void* stream) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_scalars || !d_points_xy || !d_out_xy || !d_status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (!aligned16(d_scalars) || !aligned16(d_points_xy) || !aligned16(d_out_xy)) return FEC_E_ARG;
@@ -248,6 +251,7 @@ int fec_canon_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, 
 
 int fec_canon_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points_xy,
                   uint64_t* out_xy, uint8_t* status, size_t n) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!scalars || !points_xy || !out_xy || !status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (n == 0) return FEC_OK;
@@ -263,6 +267,7 @@ int fec_canon_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const 
 int fec_canon_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1, const uint64_t* d_u2,
                              const uint64_t* d_points_xy, uint64_t* d_out_xy, uint8_t* d_status, size_t n,
                              void* stream) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_u1 || !d_u2 || !d_points_xy || !d_out_xy || !d_status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return FEC_E_ARG;
   if (!aligned16(d_u1) || !aligned16(d_u2) || !aligned16(d_points_xy) || !aligned16(d_out_xy)) return FEC_E_ARG;
@@ -274,6 +279,7 @@ int fec_canon_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1
 
 int fec_canon_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, const uint64_t* u2,
                          const uint64_t* points_xy, uint64_t* out_xy, uint8_t* status, size_t n) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!u1 || !u2 || !points_xy || !out_xy || !status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
@@ -292,6 +298,7 @@ int fec_canon_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
 int fec_canon_ecdsa_verify_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_z, const uint64_t* d_r,
                                const uint64_t* d_s, const uint64_t* d_pk_xy, uint8_t* d_result, size_t n,
                                void* stream) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_z || !d_r || !d_s || !d_pk_xy || !d_result))) return FEC_E_ARG;
   if (curve != FEC_SECP256K1 && curve != FEC_P256) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (!aligned16(d_z) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_pk_xy)) return FEC_E_ARG;
@@ -301,6 +308,7 @@ int fec_canon_ecdsa_verify_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_
 
 int fec_canon_ecdsa_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* z, const uint64_t* r, const uint64_t* s,
                            const uint64_t* pk_xy, uint8_t* result, size_t n) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!z || !r || !s || !pk_xy || !result))) return FEC_E_ARG;
   if (curve != FEC_SECP256K1 && curve != FEC_P256) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (n == 0) return FEC_OK;
@@ -316,6 +324,7 @@ int fec_canon_ecdsa_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* z, con
 
 int fec_canon_bip340_verify_dev(fec_ctx* ctx, const uint64_t* d_pk_x, const uint64_t* d_r, const uint64_t* d_s,
                                 const uint64_t* d_e, uint8_t* d_result, size_t n, void* stream) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_pk_x || !d_r || !d_s || !d_e || !d_result))) return FEC_E_ARG;
   if (!aligned16(d_pk_x) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_e)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -324,6 +333,7 @@ int fec_canon_bip340_verify_dev(fec_ctx* ctx, const uint64_t* d_pk_x, const uint
 
 int fec_canon_bip340_verify(fec_ctx* ctx, const uint64_t* pk_x, const uint64_t* r, const uint64_t* s,
                             const uint64_t* e, uint8_t* result, size_t n) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!pk_x || !r || !s || !e || !result))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   const void* const in[4] = {pk_x, r, s, e};
@@ -338,6 +348,7 @@ int fec_canon_bip340_verify(fec_ctx* ctx, const uint64_t* pk_x, const uint64_t* 
 
 int fec_canon_eddsa_verify_dev(fec_ctx* ctx, const uint64_t* d_a_enc, const uint64_t* d_r_enc, const uint64_t* d_s,
                                const uint64_t* d_h, uint8_t* d_result, size_t n, void* stream) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_a_enc || !d_r_enc || !d_s || !d_h || !d_result))) return FEC_E_ARG;
   if (!aligned16(d_a_enc) || !aligned16(d_r_enc) || !aligned16(d_s) || !aligned16(d_h)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -346,6 +357,7 @@ int fec_canon_eddsa_verify_dev(fec_ctx* ctx, const uint64_t* d_a_enc, const uint
 
 int fec_canon_eddsa_verify(fec_ctx* ctx, const uint64_t* a_enc, const uint64_t* r_enc, const uint64_t* s,
                            const uint64_t* h, uint8_t* result, size_t n) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!a_enc || !r_enc || !s || !h || !result))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   const void* const in[4] = {a_enc, r_enc, s, h};
@@ -360,6 +372,7 @@ int fec_canon_eddsa_verify(fec_ctx* ctx, const uint64_t* a_enc, const uint64_t* 
 
 int fec_canon_scalar_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b,
                         const uint64_t* c, uint64_t* out, size_t n) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || !canon_curve_ok(curve) || op < 0 || op > 1 || (n && (!a || !out))) return FEC_E_ARG;
   if (op == 0 && n && (!b || !c)) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
@@ -380,6 +393,7 @@ int fec_canon_scalar_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a
 
 int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
                        size_t n) {
+  FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || op < FEC_F_ADD || op > FEC_F_INV || (n && (!a || !out))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   const bool binary = op == FEC_F_ADD || op == FEC_F_SUB || op == FEC_F_MUL;

@@ -87,19 +87,50 @@ FEC_DEV fe reduce_wide(const u32 t[16]) {
   return reduce(low2);
 }
 
-// Mul (522-545)
-FEC_DEV fe mul(const fe& a, const fe& b) {
+// Mul (522-545), compiler-scheduled form: the host emulation's Mul, the cross-check of the
+// hand-allocated one below and its fallback for the wavefronts where a small addition carries
+FEC_DEV fe mul_cxx(const fe& a, const fe& b) {
   u32 t[16];
   mul_wide(t, a, b);
   return reduce_wide(t);
 }
-
 // self * self (623-625) with the same exact 512-bit product formed by the cheaper squaring
-FEC_DEV fe sqr_exact(const fe& a) {
+FEC_DEV fe sqr_cxx(const fe& a) {
   u32 t[16];
   sqr_wide(t, a);
   return reduce_wide(t);
 }
+#ifdef FEC_HOST_EMUL
+FEC_DEV fe mul(const fe& a, const fe& b) { return mul_cxx(a, b); }
+FEC_DEV fe sqr_exact(const fe& a) { return sqr_cxx(a); }
+#else
+// Mul / self*self as ONE hand-allocated asm statement each (tools/gen_field_asm.py), for the path on
+// which neither of reduce_wide's small additions (carry*19, then 19 for bit 255) carries out of
+// word 0 and the value stays below p; the other lanes (~2^-21 per product) are returned as a mask
+// and such a wavefront recomputes with the compiler-scheduled routine.
+FEC_DEV fe mul(const fe& a, const fe& b) {
+  fe r;
+  lmask sink, exc;
+  asm(FEC_ED_MUL_ASM
+      : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
+        "=v"(r.w[7]), "=&s"(sink), "=&s"(exc)
+      : FEC_V8(a), FEC_V8(b)
+      : FEC_ED_MUL_CLOBBERS);
+  if (__builtin_expect(exc != 0, 0)) return mul_cxx(a, b);
+  return r;
+}
+FEC_DEV fe sqr_exact(const fe& a) {
+  fe r;
+  lmask sink, exc;
+  asm(FEC_ED_SQR_ASM
+      : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
+        "=v"(r.w[7]), "=&s"(sink), "=&s"(exc)
+      : FEC_V8(a)
+      : FEC_ED_SQR_CLOBBERS);
+  if (__builtin_expect(exc != 0, 0)) return sqr_cxx(a);
+  return r;
+}
+#endif
 
 struct pt {
   fe x, y, z, t;

@@ -13,12 +13,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <system_error>
+#include <thread>
 
 #include "../../include/fecgpu.h"
 #include "ed25519.hpp"
 #include "p256.hpp"
 #include "secp256k1.hpp"
 #include "host_ctx.hpp"
+#include "kernels.hpp"
 
 namespace fecgpu {
 
@@ -175,104 +178,7 @@ __global__ __launch_bounds__(TPB) void k_batch_mul(const u32* __restrict__ scala
   stage_out<C::PW>(out + first * C::PW, lds_p, valid);
 }
 
-// P-256 Curve::multiply (p256.rs:2120-2156) with workgroup-level compaction of the data-dependent
-// addition.  Every step doubles (all lanes), but `if bit == 1 { result = result + *point }` is needed
-// by about half the lanes.  Instead of executing the addition for whole wavefronts under a mask,
-// the lanes that need it publish their doubled point in LDS and are packed into a dense list
-// (ballot + popcount prefix per wavefront, wavefront offsets through LDS); the first `total` lanes
-// of the workgroup -- rotated by step so every SIMD gets its share -- each perform one addition for
-// the owner at their list position and write the sum back into the owner's LDS column.  The same
-// additions on the same operands as the reference, executed by different lanes: ~17 instead of 25
-// field multiplications per step.  Base points stay resident in LDS (loop-invariant).
-//   word w of lane e's base point : lds_pt[w * TPB + e]   doubled point / sum : lds_d[w * TPB + e]
-template <bool FIXED>
-__global__ __launch_bounds__(TPB, 2) void k_p256_mul_compact(const u32* __restrict__ scalars,
-                                                          const u32* __restrict__ points,
-                                                          u32* __restrict__ out, size_t n) {
-  __shared__ u32 lds_k[8 * TPB];
-  __shared__ u32 lds_pt[24 * TPB];
-  __shared__ u32 lds_d[24 * TPB];
-  __shared__ unsigned short lds_owner[TPB];
-  __shared__ int lds_wcnt[TPB / 64];
-  __shared__ int lds_flag;
-  const int valid = block_valid(n);
-  const size_t first = (size_t)blockIdx.x * TPB;
-  const int e = threadIdx.x, lane = e & 63, wave = e >> 6;
-  stage_in<8>(lds_k, scalars + first * 8, valid);
-  if (!FIXED) stage_in<24>(lds_pt, points + first * 24, valid);
-  if (e == 0) lds_flag = 0;
-  __syncthreads();
-  if (FIXED) P256::store(lds_pt + e, TPB, P256::load(points, 1));
-  if (e >= valid) {  // padding lanes take part in every barrier with a zero scalar
-    FEC_UNROLL for (int w = 0; w < 8; ++w) lds_k[w * TPB + e] = 0;
-    P256::store(lds_pt + e, TPB, p256::identity());
-  }
-  const u32* kw = lds_k + e;
-  u32 any = 0;
-  FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kw[i * KSTRIDE];
-  p256::pt result = p256::identity();
-  lmask early;
-  {
-    p256::pt base = P256::load(lds_pt + e, TPB);
-    early = p256::is_identity(base) | lanes_where(any == 0);
-  }
-#pragma unroll 1
-  for (int i = 0; i < 256; ++i) {
-    const int b = 255 - i;
-    const bool bit = ((kw[(b >> 5) * KSTRIDE] >> (b & 31)) & 1u) != 0;
-    bool dbl_flag = false;  // this lane's addition degenerated to self.double() (p256.rs:1951)
-    // One pdouble instance.  Pass 0 doubles `result` and parks the doubled point in this lane's LDS
-    // column, so that no lane carries point state in registers through the addition phase.  Pass 1
-    // (never on random inputs) doubles again for the owners whose addition found the two operands
-    // projectively equal.
-#pragma unroll 1
-    for (int pass = 0;; ++pass) {
-      p256::pt o = p256::pdouble(pass == 0 ? result : P256::load(lds_d + e, TPB));
-      if (pass == 1) {
-        result = p256::pt_select(result, o, lanes_where(dbl_flag));
-        break;
-      }
-      P256::store(lds_d + e, TPB, o);
-      // ---- compaction of the lanes that must add ----
-      const lmask need = lanes_where(bit);
-      const int rank = __builtin_popcountll(need & ((1ull << lane) - 1));
-      if (lane == 0) lds_wcnt[wave] = __builtin_popcountll(need);
-      __syncthreads();
-      int base_off = 0, total = 0;
-      FEC_UNROLL for (int w = 0; w < TPB / 64; ++w) {
-        const int c = lds_wcnt[w];
-        if (w < wave) base_off += c;
-        total += c;
-      }
-      if (bit) lds_owner[base_off + rank] = (unsigned short)e;
-      __syncthreads();
-      // ---- the additions, packed: worker slot t serves owner lds_owner[t] ----
-      const int t = (e + 64 * (i & 3)) & (TPB - 1);  // rotate the working wavefronts step by step
-      int flagged = 0;
-      if (t < total) {
-        const int owner = lds_owner[t];
-        lmask nd;
-        p256::pt s = p256::padd_nodouble(P256::load(lds_d + owner, TPB), P256::load(lds_pt + owner, TPB), nd);
-        if ((nd >> lane) & 1) {  // rare: the owner's addition must be self.double(); leave its d in place
-          lds_owner[t] = (unsigned short)(owner | 0x8000);
-          flagged = 1;
-        } else {
-          P256::store(lds_d + owner, TPB, s);
-        }
-      }
-      const int any_flag = __syncthreads_or(flagged);
-      result = P256::load(lds_d + e, TPB);  // the doubled point, or the sum a worker left here
-      if (!any_flag) break;
-      if (bit && (lds_owner[base_off + rank] & 0x8000)) dbl_flag = true;
-      __syncthreads();
-    }
-  }
-  result = p256::pt_select(result, p256::identity(), early);
-  __syncthreads();
-  P256::store(lds_d + e, TPB, result);
-  __syncthreads();
-  stage_out<24>(out + first * 24, lds_d, valid);
-}
+// P-256 Curve::multiply lives in kernels_p256.hip (workgroup task scheduler).
 
 // table[j] = 2^j * base by the reference's own doubling chain (ed25519.rs:2089): one lane, 255
 // sequential additions; 32 words per entry, dense.  Runs once per base point.
@@ -783,8 +689,7 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
       else hipLaunchKernelGGL((k_batch_mul<Secp, false>), g, b, 0, L.s, s, p, o, n);
       break;
     case FEC_P256:
-      if (fixed) hipLaunchKernelGGL((k_p256_mul_compact<true>), g, b, 0, L.s, s, p, o, n);
-      else hipLaunchKernelGGL((k_p256_mul_compact<false>), g, b, 0, L.s, s, p, o, n);
+      p256_launch_mul(fixed, s, p, o, n, L.s);
       break;
     default:
       if (fixed) hipLaunchKernelGGL((k_batch_mul<Ed, true>), g, b, 0, L.s, s, p, o, n);
@@ -940,6 +845,31 @@ int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, siz
   return FEC_OK;
 }
 
+// Multi-device ctx: contiguous shards [g*n/N, (g+1)*n/N), one host thread per shard worker, each
+// calling the single-device entry point on its child ctx with offset pointers.  Returns the first
+// failure in shard order.
+template <class F>
+int multi_shard(fec_ctx* ctx, size_t n, F call) {
+  const size_t N = ctx->children.size();
+  std::vector<int> rc(N, FEC_OK);
+  std::vector<std::thread> workers;
+  workers.reserve(N);
+  for (size_t g = 0; g < N; ++g) {
+    const size_t lo = n / N * g + (n % N) * g / N, hi = n / N * (g + 1) + (n % N) * (g + 1) / N;
+    if (hi == lo) continue;
+    try {
+      workers.emplace_back([&rc, &call, ctx, g, lo, hi] { rc[g] = call(ctx->children[g], lo, hi - lo); });
+    } catch (const std::system_error&) {
+      rc[g] = FEC_E_COMM;
+    }
+  }
+  for (auto& w : workers) w.join();
+  for (size_t g = 0; g < N; ++g)
+    if (rc[g] != FEC_OK) return rc[g];
+  return FEC_OK;
+}
+inline bool is_multi(const fec_ctx* ctx) { return ctx && !ctx->children.empty(); }
+
 }  // namespace
 
 extern "C" {
@@ -953,7 +883,8 @@ const char* fec_strerror(int status) {
     case FEC_E_DEVICE: return "no usable gfx950 GPU / HIP runtime error (there is no CPU fallback)";
     case FEC_E_OOM: return "out of device memory";
     case FEC_E_LAUNCH: return "kernel launch or execution failed";
-    case FEC_E_UNSUPPORTED: return "operation not supported for this curve";
+    case FEC_E_UNSUPPORTED: return "operation not supported for this curve or for a multi-device ctx";
+    case FEC_E_COMM: return "multi-device ctx: a shard worker could not be started";
     default: return "unknown fecgpu status";
   }
 }
@@ -1014,8 +945,35 @@ int fec_ctx_create(fec_ctx** out, int device) {
   return FEC_OK;
 }
 
+int fec_ctx_create_multi(fec_ctx** out, const int* devices, int n_devices) {
+  if (!out) return FEC_E_ARG;
+  *out = nullptr;
+  if (n_devices < 1 || n_devices > 16) return FEC_E_ARG;
+  fec_ctx* parent = new (std::nothrow) fec_ctx();
+  if (!parent) return FEC_E_OOM;
+  for (int g = 0; g < n_devices; ++g) {
+    fec_ctx* child = nullptr;
+    int rc = fec_ctx_create(&child, devices ? devices[g] : g);
+    if (rc != FEC_OK) {
+      fec_ctx_destroy(parent);
+      return rc;
+    }
+    parent->children.push_back(child);
+  }
+  parent->device = parent->children[0]->device;
+  *out = parent;
+  return FEC_OK;
+}
+
+int fec_ctx_device_count(fec_ctx* ctx) { return !ctx ? 0 : (ctx->children.empty() ? 1 : (int)ctx->children.size()); }
+
 void fec_ctx_destroy(fec_ctx* ctx) {
   if (!ctx) return;
+  if (!ctx->children.empty()) {
+    for (fec_ctx* c : ctx->children) fec_ctx_destroy(c);
+    delete ctx;
+    return;
+  }
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   for (int i = 0; i < 8; ++i)
     if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
@@ -1039,6 +997,7 @@ void fec_ctx_destroy(fec_ctx* ctx) {
 
 int fec_batch_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* ds, const uint64_t* dp, uint64_t* dout,
                       size_t n, void* stream) {
+  if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!ds || !dp || !dout))) return FEC_E_ARG;
   if (!aligned16(ds) || !aligned16(dp) || !aligned16(dout)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1047,6 +1006,7 @@ int fec_batch_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* ds, const u
 
 int fec_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* ds, const uint64_t* dbase,
                             uint64_t* dout, size_t n, void* stream) {
+  if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!ds || !dbase || !dout))) return FEC_E_ARG;
   if (!aligned16(ds) || !aligned16(dbase) || !aligned16(dout)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1060,6 +1020,7 @@ int fec_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* ds, c
 
 int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d1, const uint64_t* d2,
                              const uint64_t* dq, uint64_t* dout, size_t n, void* stream) {
+  if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!d1 || !d2 || !dq || !dout))) return FEC_E_ARG;
   if (!aligned16(d1) || !aligned16(d2) || !aligned16(dq) || !aligned16(dout)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1068,6 +1029,13 @@ int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d1, 
 
 int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points,
                   uint64_t* out, size_t n) {
+  if (is_multi(ctx)) {
+    if (!curve_ok(curve) || (n && (!scalars || !points || !out))) return FEC_E_ARG;
+    const size_t pl = (size_t)plimbs(curve);
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_batch_mul(c, curve, scalars + lo * 4, points + lo * pl, out + lo * pl, cnt);
+    });
+  }
   if (!ctx || !curve_ok(curve) || (n && (!scalars || !points || !out))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   size_t pb = (size_t)plimbs(curve) * 8;
@@ -1079,6 +1047,13 @@ int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const 
 
 int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* base,
                         uint64_t* out, size_t n) {
+  if (is_multi(ctx)) {
+    if (!curve_ok(curve) || !base || (n && (!scalars || !out))) return FEC_E_ARG;
+    const size_t pl = (size_t)plimbs(curve);
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_batch_mul_fixed(c, curve, scalars + lo * 4, base, out + lo * pl, cnt);
+    });
+  }
   if (!ctx || !curve_ok(curve) || !base || (n && (!scalars || !out))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   size_t pb = (size_t)plimbs(curve) * 8;
@@ -1101,6 +1076,13 @@ int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, 
 
 int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, const uint64_t* u2,
                          const uint64_t* q, uint64_t* out, size_t n) {
+  if (is_multi(ctx)) {
+    if (!curve_ok(curve) || (n && (!u1 || !u2 || !q || !out))) return FEC_E_ARG;
+    const size_t pl = (size_t)plimbs(curve);
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_batch_double_mul(c, curve, u1 + lo * 4, u2 + lo * 4, q + lo * pl, out + lo * pl, cnt);
+    });
+  }
   if (!ctx || !curve_ok(curve) || (n && (!u1 || !u2 || !q || !out))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   size_t pb = (size_t)plimbs(curve) * 8;
@@ -1112,6 +1094,7 @@ int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
 
 int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points,
                          uint64_t* out, size_t n) {
+  FEC_FIRST_DEVICE(ctx);
   if (!ctx || !curve_ok(curve) || !out || (n && (!scalars || !points))) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   const size_t pb = (size_t)plimbs(curve) * 8;
@@ -1153,6 +1136,7 @@ int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars,
 int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
                                    const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
                                    void* stream) {
+  if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || (n && (!d_digests || !d_r || !d_s || !d_pk_xy || !d_status))) return FEC_E_ARG;
   if (!aligned16(d_digests) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_pk_xy)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1161,6 +1145,13 @@ int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const
 
 int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
                                const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) {
+  if (is_multi(ctx)) {
+    if (n && (!digests || !r || !s || !pk_xy || !status)) return FEC_E_ARG;
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_ecdsa_verify_secp256k1(c, digests + lo * 32, r + lo * 4, s + lo * 4, pk_xy + lo * 8,
+                                        pk_inf ? pk_inf + lo : nullptr, status + lo, cnt);
+    });
+  }
   if (!ctx || (n && (!digests || !r || !s || !pk_xy || !status))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1193,6 +1184,7 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
                                        const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s,
                                        const uint64_t* a, const uint64_t* e, size_t n, uint8_t* result,
                                        uint64_t* sides_xy, uint8_t* sides_inf) {
+  FEC_FIRST_DEVICE(ctx);
   if (!ctx || !result || (n && (!pk_xy || !r_xy || !s || !a || !e))) return FEC_E_ARG;
   *result = 0;
   if (sides_xy) std::memset(sides_xy, 0, 16 * sizeof(uint64_t));
@@ -1249,6 +1241,7 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
 
 int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf,
                            uint8_t* d_out, size_t n, void* stream) {
+  if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!d_xy || !d_out))) return FEC_E_ARG;
   if (!aligned16(d_xy) || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1257,6 +1250,12 @@ int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, 
 
 int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* out,
                        size_t n) {
+  if (is_multi(ctx)) {
+    if (!curve_ok(curve) || (n && (!xy || !out))) return FEC_E_ARG;
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_batch_compress(c, curve, xy + lo * 8, inf ? inf + lo : nullptr, out + lo * 33, cnt);
+    });
+  }
   if (!ctx || !curve_ok(curve) || (n && (!xy || !out))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   const void* const in[4] = {xy, inf, nullptr, nullptr};
@@ -1270,6 +1269,7 @@ int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const 
 
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
                             uint8_t* d_inf, size_t n, void* stream) {
+  if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!d_points || !d_xy || !d_inf))) return FEC_E_ARG;
   if (!aligned16(d_points) || !aligned16(d_xy)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1278,6 +1278,13 @@ int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_poi
 
 int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points, uint64_t* xy, uint8_t* inf,
                         size_t n) {
+  if (is_multi(ctx)) {
+    if (!curve_ok(curve) || (n && (!points || !xy || !inf))) return FEC_E_ARG;
+    const size_t pl = (size_t)plimbs(curve);
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_batch_to_affine(c, curve, points + lo * pl, xy + lo * 8, inf + lo, cnt);
+    });
+  }
   if (!ctx || !curve_ok(curve) || (n && (!points || !xy || !inf))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1303,6 +1310,12 @@ int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points, u
 
 int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a, const uint64_t* b,
                  uint64_t* out, size_t n) {
+  if (is_multi(ctx)) {
+    if (!curve_ok(curve) || (n && (!a || !out))) return FEC_E_ARG;
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_field_op(c, curve, op, a + lo * 4, b ? b + lo * 4 : nullptr, out + lo * 4, cnt);
+    });
+  }
   if (!ctx || !curve_ok(curve) || op < FEC_F_ADD || op > FEC_F_NEG || (n && (!a || !out))) return FEC_E_ARG;
   bool binary = op == FEC_F_ADD || op == FEC_F_SUB || op == FEC_F_MUL;
   if (binary && n && !b) return FEC_E_ARG;
@@ -1315,6 +1328,13 @@ int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint6
 
 int fec_point_op(fec_ctx* ctx, fec_curve curve, fec_point_opcode op, const uint64_t* p, const uint64_t* q,
                  uint64_t* out, size_t n) {
+  if (is_multi(ctx)) {
+    if (!curve_ok(curve) || (n && (!p || !out))) return FEC_E_ARG;
+    const size_t pl = (size_t)plimbs(curve);
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_point_op(c, curve, op, p + lo * pl, q ? q + lo * pl : nullptr, out + lo * pl, cnt);
+    });
+  }
   if (!ctx || !curve_ok(curve) || op < FEC_P_ADD || op > FEC_P_DOUBLE_TRAIT || (n && (!p || !out)))
     return FEC_E_ARG;
   if (op == FEC_P_DOUBLE_TRAIT && curve != FEC_SECP256K1) return FEC_E_UNSUPPORTED;
@@ -1328,6 +1348,7 @@ int fec_point_op(fec_ctx* ctx, fec_curve curve, fec_point_opcode op, const uint6
 }
 
 int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out) {
+  FEC_FIRST_DEVICE(ctx);
   if (!ctx || !curve_ok(curve) || !out) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   if (hipMemcpy(out, ctx->d_gen[curve], (size_t)plimbs(curve) * 8, hipMemcpyDeviceToHost) != hipSuccess) {
@@ -1338,17 +1359,23 @@ int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out) {
 }
 
 const uint64_t* fec_generator_dev(fec_ctx* ctx, fec_curve curve) {
+  FEC_FIRST_DEVICE(ctx);
   if (!ctx || !curve_ok(curve)) return nullptr;
   return ctx->d_gen[curve];
 }
 
 int fec_ctx_set_chunk(fec_ctx* ctx, size_t elements) {
+  if (is_multi(ctx)) {
+    for (fec_ctx* c : ctx->children) c->chunk = elements ? elements : c->chunk;
+    return elements ? FEC_OK : FEC_E_ARG;
+  }
   if (!ctx || elements == 0) return FEC_E_ARG;
   ctx->chunk = elements;
   return FEC_OK;
 }
 
 int fec_ctx_set_timing(fec_ctx* ctx, int enabled) {
+  FEC_FIRST_DEVICE(ctx);
   if (!ctx) return FEC_E_ARG;
   ctx->timing = enabled != 0;
   ctx->timed = false;
@@ -1356,6 +1383,7 @@ int fec_ctx_set_timing(fec_ctx* ctx, int enabled) {
 }
 
 int fec_ctx_last_kernel_ms(fec_ctx* ctx, float* ms, const char** kernel_name) {
+  FEC_FIRST_DEVICE(ctx);
   if (!ctx || !ms) return FEC_E_ARG;
   if (!ctx->timed) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1368,6 +1396,7 @@ int fec_ctx_last_kernel_ms(fec_ctx* ctx, float* ms, const char** kernel_name) {
 }
 
 int fec_measure_peak_mad32(fec_ctx* ctx, double* mad32_per_sec) {
+  FEC_FIRST_DEVICE(ctx);
   if (!ctx || !mad32_per_sec) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   const int blocks = ctx->prop.multiProcessorCount * 8;  // 8 wavefronts per SIMD
@@ -1390,6 +1419,7 @@ int fec_measure_peak_mad32(fec_ctx* ctx, double* mad32_per_sec) {
 }
 
 int fec_ctx_device_info(fec_ctx* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz) {
+  FEC_FIRST_DEVICE(ctx);
   if (!ctx) return FEC_E_ARG;
   if (name && name_len) {
     std::snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);

@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "../../include/fecgpu.h"
 #include "staging.hpp"
@@ -43,7 +44,15 @@ struct fec_ctx {
   void* d_tbuf = nullptr;  // Ed25519 double-mul: T of the comb result until the accumulate pass
   size_t tbuf_cap = 0;
   hipDeviceProp_t prop;
+  // multi-device ctx (fec_ctx_create_multi): the shard workers; empty for a single-device ctx
+  std::vector<fec_ctx*> children;
 };
+
+// a multi-device ctx runs everything that is not sharded on its first shard worker
+#define FEC_FIRST_DEVICE(ctx)                                      \
+  do {                                                             \
+    if ((ctx) && !(ctx)->children.empty()) (ctx) = (ctx)->children[0]; \
+  } while (0)
 
 namespace fecgpu {
 namespace host {

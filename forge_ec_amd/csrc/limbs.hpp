@@ -29,6 +29,7 @@
 #define FEC_DEV_NOINLINE static __attribute__((noinline))
 #else
 #include <hip/hip_runtime.h>
+#include "field_asm.inc"  // generated asm statements of the field multiplications (tools/gen_field_asm.py)
 #define FEC_DEV __device__ __forceinline__
 #define FEC_DEV_NOINLINE __device__ __attribute__((noinline))
 #endif

@@ -122,19 +122,52 @@ FEC_DEV fe reduce_wide(const u32 c[16]) {
   return csub_p(r);  // reduce() (701)
 }
 
-// Mul (498-534): exact schoolbook product, then reduce_wide_p256.
-FEC_DEV fe mul(const fe& a, const fe& b) {
+// Mul (498-534): exact schoolbook product, then reduce_wide_p256.  Compiler-scheduled form: the host
+// emulation's Mul and the cross-check of the hand-allocated one below.
+FEC_DEV fe mul_cxx(const fe& a, const fe& b) {
   u32 t[16];
   mul_wide(t, a, b);
   return reduce_wide(t);
 }
 // square() (772-776) is self * self: the same exact 512-bit product, formed with the 97-instruction
 // squaring (28 doubled cross products + 8 squares) instead of the 128-instruction general product
-FEC_DEV fe sqr(const fe& a) {
+FEC_DEV fe sqr_cxx(const fe& a) {
   u32 t[16];
   sqr_wide(t, a);
   return reduce_wide(t);
 }
+#ifdef FEC_HOST_EMUL
+FEC_DEV fe mul(const fe& a, const fe& b) { return mul_cxx(a, b); }
+FEC_DEV fe sqr(const fe& a) { return sqr_cxx(a); }
+#else
+// the closing reduce() (701) of a product: r >= p needs a top word of all ones (2^-32 per lane)
+FEC_DEV fe csub_p_top(const fe& v) {
+  if (__builtin_expect(lanes_where(v.w[7] == 0xFFFFFFFFu) != 0, 0)) return csub_p(v);
+  return v;
+}
+// Mul / square() as ONE hand-allocated asm statement each (tools/gen_field_asm.py): product scanning
+// in a fixed register block, then reduce_wide_p256 as 256-bit carry chains with a signed ninth word
+// and r = L - carry*p (677-698) built from the carry word.
+FEC_DEV fe mul(const fe& a, const fe& b) {
+  fe r;
+  asm(FEC_P256_MUL_ASM
+      : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
+        "=v"(r.w[7])
+      : FEC_V8(a), FEC_V8(b)
+      : FEC_P256_MUL_CLOBBERS);
+  return csub_p_top(r);
+}
+FEC_DEV fe sqr(const fe& a) {
+  fe r;
+  lmask sink;
+  asm(FEC_P256_SQR_ASM
+      : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
+        "=v"(r.w[7]), "=&s"(sink)
+      : FEC_V8(a)
+      : FEC_P256_SQR_CLOBBERS);
+  return csub_p_top(r);
+}
+#endif
 
 FEC_DEV fe mul_small(const fe& a, u32 k) {  // FieldElement::from(k) * a  (1893-1904)
   u32 t[16];

@@ -129,7 +129,6 @@ FEC_DEV fe csub_p_top(const fe& v) {
 // product scanning with the Montgomery word recurrence of mont_reduce() interleaved, then
 // V = T_hi + M - Q.  Q < 2^33 is subtracted from words 0..1 only; the borrow out of word 1
 // (2^-31 per lane) is exported as a lane mask and continued behind a wave-uniform branch.
-#include "field_asm.inc"
 FEC_DEV fe mul(const fe& a, const fe& b) {
   fe r;
   lmask sc, bw;

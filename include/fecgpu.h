@@ -72,7 +72,8 @@ typedef enum {
   FEC_E_DEVICE = -2,      /* no such GPU / HIP runtime failure */
   FEC_E_OOM = -3,         /* device or pinned-host allocation failed */
   FEC_E_LAUNCH = -4,      /* kernel launch or execution failed */
-  FEC_E_UNSUPPORTED = -5  /* op not defined for this curve */
+  FEC_E_UNSUPPORTED = -5, /* op not defined for this curve / for a multi-device ctx */
+  FEC_E_COMM = -6         /* multi-device ctx: a shard worker could not be started */
 } fec_status;
 
 typedef enum { FEC_F_ADD = 0, FEC_F_SUB = 1, FEC_F_MUL = 2, FEC_F_SQR = 3, FEC_F_NEG = 4 } fec_field_opcode;
@@ -91,6 +92,22 @@ int fec_point_limbs(fec_curve curve);
 /* device = HIP device ordinal (honours HIP_VISIBLE_DEVICES).  Fails with FEC_E_DEVICE when no
  * gfx950 GPU is usable -- there is no host fallback. */
 int fec_ctx_create(fec_ctx** out, int device);
+/* Multi-device ctx (the callers it serves loop over Curve::multiply per element:
+ * forge-ec-signature/src/ecdsa.rs:313-361, schnorr.rs:268-284).  devices[0..n_devices) are HIP
+ * ordinals, 1 <= n_devices <= 16; an ordinal may appear more than once (several shard workers on
+ * one GPU).  The element-wise host-pointer entry points -- fec_batch_mul, fec_batch_mul_fixed,
+ * fec_batch_double_mul, fec_batch_to_affine, fec_batch_compress, fec_ecdsa_verify_secp256k1,
+ * fec_field_op, fec_point_op -- then split the batch into n_devices contiguous shards
+ * [g*n/N, (g+1)*n/N), run each shard on its device from its own host thread with that device's
+ * chunked copy/compute pipeline, and write results straight into the caller's output array: the
+ * "gather" is the D2H copy of each shard, there is no device-to-device exchange.  Results are
+ * identical to a single-device ctx.  Entry points that are not element-wise (fec_multi_scalar_mul,
+ * fec_schnorr_batch_verify_secp256k1, fec_generator*, the measurement hooks) run on devices[0];
+ * the *_dev entry points take device pointers of ONE device and return FEC_E_UNSUPPORTED.
+ * devices == NULL means ordinals 0..n_devices-1. */
+int fec_ctx_create_multi(fec_ctx** out, const int* devices, int n_devices);
+/* number of shard workers of the ctx (1 for fec_ctx_create) */
+int fec_ctx_device_count(fec_ctx* ctx);
 void fec_ctx_destroy(fec_ctx* ctx);
 
 /* Curve::generator() exactly as the reference builds it (secp256k1.rs:2608-2625 through its own

@@ -210,3 +210,14 @@ def test_compress_two_restatements_agree(oracle, curve):
         want = M.compress(curve, [int(v) for v in xy[i, :4]], [int(v) for v in xy[i, 4:]], bool(inf[i]))
         assert bytes(got[i]) == want, (curve, i)
     assert not got[4].any() and got[0][0] in (2, 3)
+
+
+def test_forcing_vectors(oracle):
+    """Operands that force the rare continuations (P-256 non-canonical values, secp256k1 Mul's borrow
+    out of word 1, Ed25519 reduce_wide's small-addition carries): C oracle vs the Python model's
+    committed expectations (tests/golden/gen_forcing.py)."""
+    fv = _load("forcing_vectors.json")
+    assert len(fv["cases"]) > 1000
+    for e in fv["cases"]:
+        got = [int(v) for v in oracle.field_op(e["curve"], e["op"], e["a"], e["b"])]
+        assert got == e["expect"], (e["family"], e["curve"], e["op"], e["a"], e["b"])

@@ -215,6 +215,211 @@ def secp_sqr(VB):
     return b, list(range(VB, nxt[0]))
 
 
+def sqr_wide_columns(A, VB, sink):
+    """Exact 512-bit square of A[0..7]: the 28 cross products a_i a_j (i < j) by product scanning
+    (column k in the pair X_k = v[VB+2k : VB+2k+1], k = 1..13, carry pair C = v[VB+28 : VB+29]),
+    doubled with v_alignbit, plus the eight squares a_i^2 (pairs S_i = v[VB+30+2i : ...]).
+    Returns (instructions, T) where T[k] names the register of word k of the square.
+    `sink` = an SGPR-pair operand for carries that cannot occur."""
+    C = VB + 28
+    S = [VB + 30 + 2 * i for i in range(8)]
+    ins = ["v_mov_b32_e32 %s, 0" % v(C + 1)]
+    for k in range(1, 14):
+        q = VB + 2 * k
+        lo = max(0, k - 7)
+        prods = [(i, k - i) for i in range(lo, (k - 1) // 2 + 1)]
+        for n, (i, j) in enumerate(prods):
+            if n == 0:
+                src2 = "0" if k == 1 else vp(C)
+                ins.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (vp(q), A[i], A[j], src2))
+                if k >= 4:  # columns 1..3: the carry-in is < 2^32, the first product cannot overflow
+                    ins.append("v_addc_co_u32_e64 %s, vcc, 0, 0, vcc" % v(C + 1))
+            else:
+                ins.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (vp(q), A[i], A[j], vp(q)))
+                ins.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (v(C + 1), v(C + 1)))
+        if k != 13:
+            ins.append("v_mov_b32_e32 %s, %s" % (v(C), v(q + 1)))
+        if k % 2 == 1:  # spread the independent squares through the columns
+            i = (k - 1) // 2
+            ins.append("v_mad_u64_u32 %s, %s, %s, %s, 0" % (vp(S[i]), sink, A[i], A[i]))
+    ins.append("v_mad_u64_u32 %s, %s, %s, %s, 0" % (vp(S[7]), sink, A[7], A[7]))
+    # X[0] = 0, X[k] = v(VB+2k) for 1 <= k <= 13, X[14] = hi of column 13, X[15] = its overflow count
+    X = [None] + [VB + 2 * k for k in range(1, 14)] + [VB + 27, C + 1]
+    # Y = 2X in place, top word first
+    for k in range(15, 1, -1):
+        ins.append("v_alignbit_b32 %s, %s, %s, 31" % (v(X[k]), v(X[k]), v(X[k - 1])))
+    ins.append("v_lshlrev_b32_e32 %s, 1, %s" % (v(X[1]), v(X[1])))
+    # T = Y + D, D[2i] = lo(S_i), D[2i+1] = hi(S_i); T[0] = D[0] (Y[0] = 0), sums in place in X
+    ins.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (v(X[1]), v(X[1]), v(S[0] + 1)))
+    for k in range(2, 16):
+        ins.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (v(X[k]), v(X[k]), v(S[k // 2] + (k & 1))))
+    T = [S[0]] + X[1:]
+    return ins, T
+
+
+# ------------------------------------------------------------------------------------------------
+# P-256 reduce_wide_p256 (p256.rs:544-704) on T[0..15] (register numbers), result into the operands
+# R[0..7].  S = s1 + 2 s2 + 2 s3 + s4 + s5 - s6 - s7 - s8 - s9 as 256-bit chains on the accumulator
+# T[0..7] with a signed ninth word; then r = L - carry*p mod 2^256 (677-698).  The closing reduce()
+# (701) is left to the caller (one compare of the top word).  `free` = 8 dead registers.
+# ------------------------------------------------------------------------------------------------
+def p256_reduce(T, R, free):
+    c = [v(t) for t in T]
+    w = c[:8]
+    U = [v(f) for f in free[:6]]   # s2 + s3, words 3..8
+    top, sx, v3, c3, v6, v7 = [v(f) for f in free[6:12]]
+    ins = []
+    # U = s2 + s3 = (c11+c12, c12+c13, c13+c14, c14+c15, c15, carry) at words 3..8
+    ins.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (U[0], c[11], c[12]))
+    ins.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (U[1], c[12], c[13]))
+    ins.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (U[2], c[13], c[14]))
+    ins.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (U[3], c[14], c[15]))
+    ins.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (U[4], c[15]))
+    ins.append("v_addc_co_u32_e64 %s, vcc, 0, 0, vcc" % U[5])
+    ins.append("v_mov_b32_e32 %s, 0" % top)
+
+    def chain(words, sub):
+        """acc +-= words (list of 8 operand strings or None for a zero word); top +-= carry."""
+        first = True
+        for i in range(8):
+            x = words[i]
+            if first:
+                if x is None:
+                    continue  # leading zero words change nothing
+                ins.append("%s %s, vcc, %s, %s" % ("v_sub_co_u32_e32" if sub else "v_add_co_u32_e32", w[i], w[i], x))
+                first = False
+            elif x is None:
+                ins.append("%s %s, vcc, 0, %s, vcc" % ("v_subbrev_co_u32_e32" if sub else "v_addc_co_u32_e32", w[i], w[i]))
+            else:
+                ins.append("%s %s, vcc, %s, %s, vcc" % ("v_subb_co_u32_e32" if sub else "v_addc_co_u32_e32", w[i], w[i], x))
+        return None
+
+    for rep in range(2):  # 2 (s2 + s3)
+        chain([None, None, None, U[0], U[1], U[2], U[3], U[4]], False)
+        ins.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (top, top, U[5]))
+    Z = None
+    chain([c[8], c[9], c[10], Z, Z, Z, c[14], c[15]], False)  # s4
+    ins.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (top, top))
+    chain([c[9], c[10], c[11], c[13], c[14], c[15], c[13], c[8]], False)  # s5
+    ins.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (top, top))
+    for words in ([c[11], c[12], c[13], Z, Z, Z, c[8], c[10]],       # s6
+                  [c[12], c[13], c[14], c[15], Z, Z, c[9], c[11]],   # s7
+                  [c[13], c[14], c[15], c[8], c[9], c[10], Z, c[12]],  # s8
+                  [c[14], c[15], Z, c[9], c[10], c[11], Z, c[13]]):  # s9
+        chain(words, True)
+        ins.append("v_subbrev_co_u32_e32 %s, vcc, 0, %s, vcc" % (top, top))
+    # r = L + t*(1 - 2^96 - 2^192 + 2^224) mod 2^256, t = top (signed): the words of t*K are
+    # (t, s, s, s - t, c3, c3, c3 - t, t + c6) with s = t >> 31, c3 = (s - t) >> 31, c6 = (c3 - t) >> 31
+    ins.append("v_ashrrev_i32_e32 %s, 31, %s" % (sx, top))
+    ins.append("v_sub_u32_e32 %s, %s, %s" % (v3, sx, top))
+    ins.append("v_ashrrev_i32_e32 %s, 31, %s" % (c3, v3))
+    ins.append("v_sub_u32_e32 %s, %s, %s" % (v6, c3, top))
+    ins.append("v_ashrrev_i32_e32 %s, 31, %s" % (v7, v6))
+    ins.append("v_add_u32_e32 %s, %s, %s" % (v7, v7, top))
+    adds = [top, sx, sx, v3, c3, c3, v6, v7]
+    ins.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (R[0], w[0], adds[0]))
+    for i in range(1, 8):
+        ins.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (R[i], w[i], adds[i]))
+    return ins
+
+
+def p256_mul(VB):
+    """operands: %0-%7 r, %8-%15 a, %16-%23 b"""
+    A = ["%%%d" % (8 + i) for i in range(8)]
+    B = ["%%%d" % (16 + i) for i in range(8)]
+    R = ["%%%d" % i for i in range(8)]
+    b = Block()
+    for s in mul_wide_columns(A, B, VB):
+        b.e(s)
+    T = [VB + 2 * k for k in range(15)] + [VB + 29]
+    free = [VB + 2 * k + 1 for k in range(14)]  # the dead high halves of the column pairs
+    for s in p256_reduce(T, R, free):
+        b.e(s)
+    return b, list(range(VB, VB + 32))
+
+
+def p256_sqr(VB):
+    """operands: %0-%7 r, %8 sink (SGPR pair), %9-%16 a"""
+    A = ["%%%d" % (9 + i) for i in range(8)]
+    R = ["%%%d" % i for i in range(8)]
+    b = Block()
+    ins, T = sqr_wide_columns(A, VB, "%8")
+    for s in ins:
+        b.e(s)
+    S = [VB + 30 + 2 * i for i in range(8)]
+    used = set(T)
+    free = [r for r in range(VB, VB + 46) if r not in used and r not in (VB + 28,)]
+    assert len(free) >= 12, free
+    for s in p256_reduce(T, R, free):
+        b.e(s)
+    return b, list(range(VB, VB + 46))
+
+
+# ------------------------------------------------------------------------------------------------
+# Ed25519 reduce_wide (ed25519.rs:260-289) + reduce (214-247), common path: low + 38*high word by
+# word, the carry word times 19 added to word 0, bit 255 cleared and 19 added for it.  Each of the
+# two small additions carries out of word 0 with probability ~2^-22, and the final value reaches
+# p only with a top word of 0x7FFFFFFF: those lanes are returned in the exception mask and the
+# caller recomputes the wavefront with the compiler-scheduled routine.
+# ------------------------------------------------------------------------------------------------
+def ed_reduce(T, R, sink, exc, tmp):
+    """T: register numbers of the 16 product words; the registers T[0..7]+1 must be free (they
+    are zeroed to zero-extend T[k]) -- true for the column pairs of mul_wide_columns."""
+    ins = []
+    for i in range(8):
+        assert T[i] % 2 == 0
+        ins.append("v_mov_b32_e32 %s, 0" % v(T[i] + 1))
+    for i in range(8):  # D_i = T[8+i]*38 + T[i]  (in place in the pair of T[i])
+        ins.append("v_mad_u64_u32 %s, %s, %s, 38, %s" % (vp(T[i]), sink, v(T[8 + i]), vp(T[i])))
+    lo = [v(T[i]) for i in range(8)]
+    hi = [v(T[i] + 1) for i in range(8)]
+    t = v(tmp)
+    # words 1..7 first: w_i = lo_i + hi_{i-1} + carry; the carry word (<= 38) ends in t
+    ins.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (R[1], lo[1], hi[0]))
+    for i in range(2, 8):
+        ins.append("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (R[i], lo[i], hi[i - 1]))
+    ins.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (t, hi[7]))
+    ins.append("v_mul_u32_u24_e32 %s, 19, %s" % (t, t))
+    ins.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (R[0], lo[0], t))
+    ins.append("s_mov_b64 %s, vcc" % exc)
+    ins.append("v_lshrrev_b32_e32 %s, 31, %s" % (t, R[7]))
+    ins.append("v_and_b32_e32 %s, 0x7fffffff, %s" % (R[7], R[7]))
+    ins.append("v_mul_u32_u24_e32 %s, 19, %s" % (t, t))
+    ins.append("v_add_co_u32_e32 %s, vcc, %s, %s" % (R[0], R[0], t))
+    ins.append("s_or_b64 %s, %s, vcc" % (exc, exc))
+    ins.append("v_cmp_eq_u32_e32 vcc, 0x7fffffff, %s" % R[7])
+    ins.append("s_or_b64 %s, %s, vcc" % (exc, exc))
+    return ins
+
+
+def ed_mul(VB):
+    """operands: %0-%7 r, %8 sink, %9 exc, %10-%17 a, %18-%25 b"""
+    A = ["%%%d" % (10 + i) for i in range(8)]
+    B = ["%%%d" % (18 + i) for i in range(8)]
+    R = ["%%%d" % i for i in range(8)]
+    b = Block()
+    for s in mul_wide_columns(A, B, VB):
+        b.e(s)
+    T = [VB + 2 * k for k in range(15)] + [VB + 29]
+    for s in ed_reduce(T, R, "%8", "%9", VB + 31):
+        b.e(s)
+    return b, list(range(VB, VB + 32))
+
+
+def ed_sqr(VB):
+    """operands: %0-%7 r, %8 sink, %9 exc, %10-%17 a"""
+    A = ["%%%d" % (10 + i) for i in range(8)]
+    R = ["%%%d" % i for i in range(8)]
+    b = Block()
+    ins, T = sqr_wide_columns(A, VB, "%8")
+    for s in ins:
+        b.e(s)
+    # T[0] = lo(S_0) and T[k] = lo(X_k), k = 1..7: even registers whose odd partners are dead by now
+    for s in ed_reduce(T, R, "%8", "%9", VB + 28):
+        b.e(s)
+    return b, list(range(VB, VB + 46))
+
+
 def clobbers(regs):
     return ", ".join('"v%d"' % r for r in regs)
 
@@ -222,23 +427,30 @@ def clobbers(regs):
 HEADER = """// field_asm.inc -- GENERATED by tools/gen_field_asm.py; do not edit.
 // Hand-allocated gfx950 assembly for the field multiplications (one asm statement each).  All
 // temporaries live in the fixed VGPR block named in each statement's clobber list.
+#pragma once
 """
 
 
 def main():
     parts = [HEADER]
-    blk, regs = secp_mul(220)
-    parts.append("#define FEC_SECP_MUL_ASM \\\n" + blk.text().replace("\n", " \\\n") + "\n")
-    parts.append("#define FEC_SECP_MUL_CLOBBERS \"vcc\", " + clobbers(regs) + "\n")
-    parts.append("// instruction count: %d\n" % len(blk.lines))
-    sq, sregs = secp_sqr(256 - 34)
-    assert sregs[-1] == 255, sregs
-    parts.append("#define FEC_SECP_SQR_ASM \\\n" + sq.text().replace("\n", " \\\n") + "\n")
-    parts.append("#define FEC_SECP_SQR_CLOBBERS \"vcc\", " + clobbers(sregs) + "\n")
-    parts.append("// instruction count: %d\n" % len(sq.lines))
+    report = []
+
+    def add(name, blk, regs):
+        assert regs[-1] == 255 and regs[0] % 2 == 0, (name, regs[0], regs[-1])
+        parts.append("#define FEC_%s_ASM \\\n" % name + blk.text().replace("\n", " \\\n") + "\n")
+        parts.append("#define FEC_%s_CLOBBERS \"vcc\", " % name + clobbers(regs) + "\n")
+        parts.append("// FEC_%s_ASM: %d instructions, fixed block v[%d:255]\n" % (name, len(blk.lines), regs[0]))
+        report.append("%s %d" % (name, len(blk.lines)))
+
+    add("SECP_MUL", *secp_mul(256 - 36))
+    add("SECP_SQR", *secp_sqr(256 - 34))
+    add("P256_MUL", *p256_mul(256 - 32))
+    add("P256_SQR", *p256_sqr(256 - 46))
+    add("ED_MUL", *ed_mul(256 - 32))
+    add("ED_SQR", *ed_sqr(256 - 46))
     with open(OUT, "w") as f:
         f.write("\n".join(parts))
-    print("wrote %s (secp mul: %d, secp sqr: %d instructions)" % (OUT, len(blk.lines), len(sq.lines)))
+    print("wrote %s (%s)" % (OUT, ", ".join(report)))
 
 
 if __name__ == "__main__":

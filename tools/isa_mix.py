@@ -52,12 +52,14 @@ def main():
         raise SystemExit("kernel not found: " + needle)
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[start:end]
-    label_at, insts = {}, []  # instruction index of each label; (mnemonic, operands)
+    label_at, insts, headers = {}, [], []  # instruction index of each label; (mnemonic, operands)
     for l in body:
         s = l.strip()
         mm = re.match(r"^(\.LBB\d+_\d+):", s)
         if mm:
             label_at[mm.group(1)] = len(insts)
+            if "Loop Header: Depth=1" in s:
+                headers.append(mm.group(1))
             continue
         s = s.split(";")[0].strip()
         if not s or s.startswith((".", "//")) or s.endswith(":"):
@@ -74,7 +76,10 @@ def main():
         raise SystemExit("no loop found")
     # the ladder loop's back edge is a conditional branch; unconditional backward branches are the
     # returns of out-of-line cold blocks
-    lo, hi, _ = max([r for r in loops if r[2]] or loops, key=lambda r: r[1] - r[0])
+    # the ladder loop = the depth-1 loop (LLVM's own "Loop Header: Depth=1" annotation) with the
+    # widest span; its back edges are all branches to that header
+    cands = [r for r in loops if any(label_at[h] == r[0] for h in headers)] or [r for r in loops if r[2]] or loops
+    lo, hi, _ = max(cands, key=lambda r: r[1] - r[0])
     inner = [r for r in loops if r[:2] != (lo, hi) and r[0] >= lo and r[1] <= hi]
 
     def mix(rng):
@@ -98,27 +103,42 @@ def main():
             print(("| %s | %d | %d |" if md else "%-36s %8d %8d") % row)
     top = collections.Counter(m for m, _ in insts[lo:hi + 1]).most_common(25)
     print("top mnemonics in the loop span: " + ", ".join("%s %d" % t for t in top))
-    # Hot path of one iteration: LLVM lays the likely successor out as the fall-through, so walk
-    # from the loop head taking no conditional branch (except the loop's own back edge) and every
-    # unconditional one, until the walk returns to the head.  Forward conditional branches over
-    # a few instructions (if-conversion leftovers) are treated the same way.
-    path, pc, steps = [], lo, 0
-    while steps < 200000:
+    # Hot path of one iteration: walk from the loop head evaluating each conditional branch under
+    # the assumption that every rare-path lane mask is zero (that is what the rare paths are: lane
+    # masks tested with s_cmp_{eq,lg}_u64 mask, 0 or v_cmp + s_cbranch_vcc*), EXEC is non-zero, and
+    # any other condition falls through; unconditional branches are followed.  The walk ends at the
+    # loop's back edge.
+    outer = [h for h in headers if any(h + ":" in l and "Inner" not in l for l in body)]
+    start_pc = max((label_at[h] for h in outer), default=lo) if outer else lo
+    path, pc, steps, scc, first_visit = [], start_pc, 0, None, {}
+    while steps < 400000:
+        if pc in first_visit:  # the cycle closed: one iteration = the walk since the first visit
+            path = path[first_visit[pc]:]
+            break
+        first_visit[pc] = len(path)
         m, ops = insts[pc]
         path.append(m)
         steps += 1
-        if pc == hi:
-            break
-        if m.startswith("s_branch"):
-            t = ops.split()[0].rstrip(",")
-            pc = label_at[t]
-            if pc == lo:
-                break
+        if m in ("s_cmp_eq_u64", "s_cmp_lg_u64") and ops.replace(" ", "").endswith(",0"):
+            scc = 1 if m == "s_cmp_eq_u64" else 0
+        elif m.startswith(("s_cmp", "s_add", "s_sub", "s_and", "s_or", "s_xor", "s_lshl", "s_lshr", "s_bitcmp", "s_andn2", "s_orn2", "s_not")):
+            scc = None  # SCC rewritten by something that is not a rare-mask test
+        taken = False
+        if m == "s_branch":
+            taken = True
+        elif m == "s_cbranch_scc0":
+            taken = scc == 0
+        elif m == "s_cbranch_scc1":
+            taken = scc == 1
+        elif m in ("s_cbranch_vccz", "s_cbranch_execnz"):
+            taken = True
+        if taken:
+            pc = label_at[ops.split()[0].rstrip(",")]
             continue
         pc += 1
     hot = collections.Counter(classify(m) for m in path)
     hv = sum(v for k, v in hot.items() if k.startswith("v_"))
-    print("hot path of one iteration (fall-through walk): %d instructions, %d VALU" % (len(path), hv))
+    print("hot path of one iteration (rare masks = 0): %d instructions, %d VALU" % (len(path), hv))
     if md:
         print("| class | hot path, per iteration |\n|---|---|")
     for name, _ in CLASSES + [("other", None)]:

@@ -19,6 +19,8 @@ import sys
 
 def main():
     src, needle = sys.argv[1], sys.argv[2]
+    workload = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else None
+    units = int(sys.argv[sys.argv.index("--units") + 1]) if "--units" in sys.argv else 1 << 20
     copy_to = sys.argv[sys.argv.index("--copy-to") + 1] if "--copy-to" in sys.argv else None
     counters, meta, durs = {}, {}, []
     for path in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)):
@@ -47,7 +49,11 @@ def main():
         if copy_to:
             os.makedirs(copy_to, exist_ok=True)
             shutil.copy(path, os.path.join(copy_to, "kernel_stats.csv"))
-    out = {"source_dir": src, "code_object": meta, "counters": counters, "kernel_stats": stats,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from forge_ec_amd import build as fbuild
+    # the library sources must be the ones that were profiled: run this right after the passes
+    out = {"workload": workload, "units_per_launch": units, "source_hash": fbuild.source_hash(),
+           "source_dir": src, "code_object": meta, "counters": counters, "kernel_stats": stats,
            "duration_under_pmc_ms": (sum(durs) / len(durs)) if durs else None}
     c = {k: v["per_launch"] for k, v in counters.items()}
     derived = {}
