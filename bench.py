@@ -10,7 +10,8 @@ Default workload (BASELINE.json configs[1], the headline): 2^20 secp256k1 variab
 multiplications per GPU (--workload selects the other BASELINE configurations) on synthetic seeded inputs (forge_ec_amd/synth.py), inputs resident in HBM before the timed
 region.  One "step" = one pass of the hot path over one 2^20 batch.  With N > 1 ranks every rank
 runs its own 2^20 shard (weak scaling, no collective on the compute path) and the result shards
-are all-gathered over RCCL/xGMI on a side stream, overlapped with the next step's kernel.
+are gathered to rank 0 over RCCL/xGMI (--gather rank0, the default; all / none for comparison),
+overlapped with the next step's kernel.
 
 Prints ONE JSON line on rank 0: metric/value (whole-job scalar-muls/s), roofline (integer-VALU:
 algorithmic 32x32 multiply-adds per second against the chip's peak; kernel time from HIP events
@@ -54,8 +55,9 @@ def parse():
     ap.add_argument("--workload", default="secp256k1-var", choices=list(WORKLOADS),
                     help="default = the headline (BASELINE.json configs[1])")
     ap.add_argument("--log2-batch", type=int, default=20, help="scalar-muls per GPU per step = 2^this")
-    ap.add_argument("--gather", default="all", choices=["all", "none"],
-                    help="N>1: all-gather result shards over RCCL (overlapped) or not")
+    ap.add_argument("--gather", default="rank0", choices=["rank0", "all", "none"],
+                    help="N>1: gather the result shards to rank 0 over RCCL (overlapped with the next step), "
+                         "all-gather them to every rank, or leave them in place")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -183,9 +185,10 @@ def main():
     assert stream != 0
 
     gather = None
-    if dist is not None and args.gather == "all":
+    if dist is not None and args.gather != "none":
         from forge_ec_amd.dist import ResultGather
-        gather = [ResultGather(n * world, limbs, torch.device("cuda", local_rank)) for _ in range(2)]
+        gather = [ResultGather(n * world, limbs, torch.device("cuda", local_rank),
+                               dst=0 if args.gather == "rank0" else None) for _ in range(2)]
 
     def step(i, timed):
         buf = i & 1
@@ -244,7 +247,7 @@ def main():
         step(0, False)
         full = gather[0].finish()
         torch.cuda.synchronize()
-        if not torch.equal(full[rank * n:(rank + 1) * n], d_out[0]):
+        if full is not None and not torch.equal(full[rank * n:(rank + 1) * n], d_out[0]):
             raise SystemExit("gathered shard differs from the kernel output")
     kernel_ms = float(np.mean(kms))
     peak_measured = ctx.measure_peak_mad32()

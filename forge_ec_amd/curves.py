@@ -36,14 +36,26 @@ def _check(rc, what=""):
 
 
 class Context:
-    """One fec_ctx: one GPU, one stream.  Use one per process per GPU."""
+    """One fec_ctx.  Context(device) = one GPU, one stream pair (use one per process per GPU).
+    Context(devices=[...]) = the multi-device ctx of fec_ctx_create_multi: the element-wise host-pointer
+    calls shard the batch contiguously over the listed devices (an ordinal may repeat: several shard
+    workers on one GPU) and write straight into the caller's output; the *_dev calls are not available."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
         self._lib = L.lib()
         h = ctypes.c_void_p()
-        _check(self._lib.fec_ctx_create(ctypes.byref(h), int(device)), "fec_ctx_create")
+        if devices is not None:
+            devs = [int(d) for d in devices]
+            arr = (ctypes.c_int * len(devs))(*devs)
+            _check(self._lib.fec_ctx_create_multi(ctypes.byref(h), arr, len(devs)), "fec_ctx_create_multi")
+            self.device = devs[0] if devs else 0
+        else:
+            _check(self._lib.fec_ctx_create(ctypes.byref(h), int(device)), "fec_ctx_create")
+            self.device = int(device)
         self._h = h
-        self.device = int(device)
+
+    def device_count(self):
+        return int(self._lib.fec_ctx_device_count(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -120,7 +132,9 @@ class Context:
         n = d.shape[0]
         if not (rr.shape[0] == ss.shape[0] == pk.shape[0] == n):
             raise ValueError("inputs differ in length")
-        inf = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+        inf = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)).reshape(-1) if pk_inf is not None else None
+        if inf is not None and inf.shape[0] != n:
+            raise ValueError("pk_inf and the signatures differ in length")  # the C side reads n bytes
         out = np.empty(n, dtype=np.uint8)
         _check(self._lib.fec_ecdsa_verify_secp256k1(self._h, _ptr(d), _ptr(rr), _ptr(ss), _ptr(pk), _ptr(inf),
                                                     _ptr(out), n), "fec_ecdsa_verify_secp256k1")
@@ -145,8 +159,11 @@ class Context:
         n = ss.shape[0]
         if not (pk.shape[0] == rr.shape[0] == aa.shape[0] == ee.shape[0] == n):
             raise ValueError("inputs differ in length")
-        pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
-        ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)) if r_inf is not None else None
+        pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)).reshape(-1) if pk_inf is not None else None
+        ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)).reshape(-1) if r_inf is not None else None
+        for flags in (pi, ri):
+            if flags is not None and flags.shape[0] != n:
+                raise ValueError("infinity flags and the signatures differ in length")  # the C side reads n bytes
         res = np.zeros(1, dtype=np.uint8)
         sides = np.zeros(16, dtype=np.uint64)
         sinf = np.zeros(2, dtype=np.uint8)

@@ -44,7 +44,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, curve, q):
+def _worker(rank, world, port, n, curve, q, dst="all"):
     import torch
     import torch.distributed as dist
     from forge_ec_amd.dist import ResultGather, shard_range
@@ -57,22 +57,25 @@ def _worker(rank, world, port, n, curve, q):
         p = V.points(n, curve, 602)
         lo, hi = shard_range(n, rank, world)
         local = c_oracle.batch_mul(curve, k[lo:hi], p[lo:hi])  # stand-in for the rank's GPU shard
-        g = ResultGather(n, V.POINT_LIMBS[curve], torch.device("cpu"))
-        g.start(torch.from_numpy(local.view(np.int64)))
-        full = g.finish().numpy().view(np.uint64)
-        q.put((rank, full.copy()))
+        g = ResultGather(n, V.POINT_LIMBS[curve], torch.device("cpu"), dst=None if dst == "all" else dst)
+        for _ in range(2):  # the object is reused step after step (bench.py double-buffers two of them)
+            g.start(torch.from_numpy(local.view(np.int64)))
+            full = g.finish()
+        q.put((rank, None if full is None else full.numpy().view(np.uint64).copy()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [10, 11])
-def test_two_rank_gloo_gather_reassembles_the_batch(oracle, n):
+@pytest.mark.parametrize("n,dst", [(10, "all"), (11, "all"), (10, 0), (11, 0), (11, 1)])
+def test_two_rank_gloo_gather_reassembles_the_batch(oracle, n, dst):
+    """world_size 2 over gloo: the shard + gather path of bench.py, in both forms -- gather to the
+    consumer rank (the default: only rank `dst` receives the batch) and all-gather."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     curve = 0
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, curve, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, curve, q, dst)) for r in range(2)]
     for pr in procs:
         pr.start()
     results = dict(q.get(timeout=120) for _ in range(2))
@@ -81,4 +84,7 @@ def test_two_rank_gloo_gather_reassembles_the_batch(oracle, n):
         assert pr.exitcode == 0
     want = oracle.batch_mul(curve, V.scalars(n, curve, 601), V.points(n, curve, 602))
     for r in range(2):
-        assert np.array_equal(results[r], want)
+        if dst == "all" or dst == r:
+            assert np.array_equal(results[r], want)
+        else:
+            assert results[r] is None  # a non-consumer rank holds no copy of the batch
