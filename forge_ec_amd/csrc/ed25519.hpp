@@ -183,6 +183,32 @@ FEC_DEV pt padd(const pt& p, const pt& q) {
   return o;
 }
 
+// double() (1828-1832) = self + self: Add with both operands equal.  Its four self-products
+// (y-x)^2, (y+x)^2, t*t, z*z are the same exact 512-bit products as Mul's, formed with the squaring.
+FEC_DEV pt pdbl(const pt& p) {
+  fe a = sqr_exact(sub(p.y, p.x));
+  fe b = sqr_exact(add(p.y, p.x));
+  fe c = mul(sqr_exact(p.t), D_());
+  fe d = sqr_exact(p.z);
+  fe e = sub(b, a);
+  fe f = sub(d, c);
+  fe g = add(d, c);
+  fe h = add(b, a);
+  pt o;
+  o.x = mul(e, f);
+  o.y = mul(g, h);
+  o.t = mul(e, h);
+  o.z = mul(f, g);
+  // Add's early-outs with q = p (1869-1880): "opposite" needs x == -x, i.e. x == 0
+  lmask opposite = fe_eq(p.x, neg(p.x));
+  lmask idp = is_identity(p);
+  if (__builtin_expect((opposite | idp) != 0, 0)) {
+    o = pt_select(o, identity(), opposite);
+    o = pt_select(o, p, idp);
+  }
+  return o;
+}
+
 // pow (410-431): every bit computes result * base and selects it on the bit; base = base.square().
 // invert (603-621): a^(p-2) (for zero the CtOption is none; the value pow returns is 0).
 FEC_DEV fe inv(const fe& a) {

@@ -693,7 +693,7 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
       break;
     default:
       if (fixed) hipLaunchKernelGGL((k_batch_mul<Ed, true>), g, b, 0, L.s, s, p, o, n);
-      else hipLaunchKernelGGL((k_batch_mul<Ed, false>), g, b, 0, L.s, s, p, o, n);
+      else ed_launch_mul(s, p, o, n, L.s);
       break;
   }
   return L.done();

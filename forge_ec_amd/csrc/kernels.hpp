@@ -9,4 +9,8 @@ namespace fecgpu {
 // kernels_p256.hip: P-256 Curve::multiply, workgroup task scheduler.  out[i] = multiply(fixed ? points[0] : points[i], scalars[i])
 void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
 
+// kernels_ed.hip: Ed25519 variable-base Curve::multiply, workgroup task scheduler.  `out` doubles as the
+// running result of every element during the launch.
+void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
+
 }  // namespace fecgpu

@@ -1,0 +1,481 @@
+//! Safe Rust API over `libfecgpu.so` (include/fecgpu.h): batched `Curve::multiply` and the calls next to
+//! it on AMD MI355X, bit-identical to the CPU trait methods of forge-ec-curves.
+//!
+//! All `unsafe` of the integration lives here (`forge-ec-curves` is `#![forbid(unsafe_code)]`).
+//! NOT COMPILED where it was written (no rustc in that image): see README.md; the `extern "C"` block
+//! below is diffed against include/fecgpu.h by tests/test_rust_shim_signatures.py.
+#![deny(missing_docs)]
+
+use core::ffi::{c_char, c_double, c_float, c_int, c_void};
+
+use forge_ec_core::{Curve, Error, Result};
+use forge_ec_curves::{ed25519, p256, secp256k1};
+
+/// Opaque `fec_ctx`.
+#[repr(C)]
+pub struct FecCtx {
+    _private: [u8; 0],
+}
+
+// ---- include/fecgpu.h, symbol for symbol (same order as the header) ----
+#[link(name = "fecgpu")]
+extern "C" {
+    fn fec_point_limbs(curve: c_int) -> c_int;
+    fn fec_ctx_create(out: *mut *mut FecCtx, device: c_int) -> c_int;
+    fn fec_ctx_create_multi(out: *mut *mut FecCtx, devices: *const c_int, n_devices: c_int) -> c_int;
+    fn fec_ctx_device_count(ctx: *mut FecCtx) -> c_int;
+    fn fec_ctx_destroy(ctx: *mut FecCtx);
+    fn fec_generator(ctx: *mut FecCtx, curve: c_int, out: *mut u64) -> c_int;
+    fn fec_generator_dev(ctx: *mut FecCtx, curve: c_int) -> *const u64;
+    fn fec_batch_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_batch_mul_fixed(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, base: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_batch_double_mul(ctx: *mut FecCtx, curve: c_int, u1: *const u64, u2: *const u64, q: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_batch_to_affine(ctx: *mut FecCtx, curve: c_int, points: *const u64, xy: *mut u64, inf: *mut u8, n: usize) -> c_int;
+    fn fec_multi_scalar_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_ecdsa_verify_secp256k1(ctx: *mut FecCtx, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, status: *mut u8, n: usize) -> c_int;
+    fn fec_batch_compress(ctx: *mut FecCtx, curve: c_int, xy: *const u64, inf: *const u8, out: *mut u8, n: usize) -> c_int;
+    fn fec_schnorr_batch_verify_secp256k1(ctx: *mut FecCtx, pk_xy: *const u64, pk_inf: *const u8, r_xy: *const u64, r_inf: *const u8, s: *const u64, a: *const u64, e: *const u64, n: usize, result: *mut u8, sides_xy: *mut u64, sides_inf: *mut u8) -> c_int;
+    fn fec_field_op(ctx: *mut FecCtx, curve: c_int, op: c_int, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_point_op(ctx: *mut FecCtx, curve: c_int, op: c_int, p: *const u64, q: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_batch_mul_dev(ctx: *mut FecCtx, curve: c_int, d_scalars: *const u64, d_points: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
+    fn fec_batch_mul_fixed_dev(ctx: *mut FecCtx, curve: c_int, d_scalars: *const u64, d_base: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
+    fn fec_batch_double_mul_dev(ctx: *mut FecCtx, curve: c_int, d_u1: *const u64, d_u2: *const u64, d_q: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
+    fn fec_ecdsa_verify_secp256k1_dev(ctx: *mut FecCtx, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
+    fn fec_batch_compress_dev(ctx: *mut FecCtx, curve: c_int, d_xy: *const u64, d_inf: *const u8, d_out: *mut u8, n: usize, stream: *mut c_void) -> c_int;
+    fn fec_batch_to_affine_dev(ctx: *mut FecCtx, curve: c_int, d_points: *const u64, d_xy: *mut u64, d_inf: *mut u8, n: usize, stream: *mut c_void) -> c_int;
+    fn fec_ctx_set_chunk(ctx: *mut FecCtx, elements: usize) -> c_int;
+    fn fec_ctx_set_timing(ctx: *mut FecCtx, enabled: c_int) -> c_int;
+    fn fec_ctx_last_kernel_ms(ctx: *mut FecCtx, ms: *mut c_float, kernel_name: *mut *const c_char) -> c_int;
+    fn fec_measure_peak_mad32(ctx: *mut FecCtx, mad32_per_sec: *mut c_double) -> c_int;
+    fn fec_ctx_device_info(ctx: *mut FecCtx, name: *mut c_char, name_len: usize, compute_units: *mut c_int, clock_khz: *mut c_int) -> c_int;
+    fn fec_strerror(status: c_int) -> *const c_char;
+}
+
+/// Maps a non-zero `fec_status` to the reference's error type (`forge-ec-core/src/lib.rs:70-103`).
+fn check(rc: c_int) -> Result<()> {
+    match rc {
+        0 => Ok(()),
+        -1 => Err(Error::ValidationError),       // FEC_E_ARG
+        -5 => Err(Error::UnsupportedOperation),  // FEC_E_UNSUPPORTED
+        _ => Err(Error::GenericError),           // device / memory / launch / comm
+    }
+}
+
+/// Text of a status code (`fec_strerror`).
+pub fn status_text(rc: i32) -> &'static str {
+    // SAFETY: fec_strerror returns a pointer to a static NUL-terminated string for every input.
+    unsafe { core::ffi::CStr::from_ptr(fec_strerror(rc)) }.to_str().unwrap_or("?")
+}
+
+/// One `fec_ctx`: a GPU (or several, see [`GpuContext::new_multi`]).  `Send`, not `Sync`: calls on
+/// one ctx are serialised by its owner, different ctxs are independent.
+pub struct GpuContext {
+    raw: *mut FecCtx,
+}
+// SAFETY: the ctx holds no thread-affine state; every entry point selects its device itself.
+unsafe impl Send for GpuContext {}
+
+impl GpuContext {
+    /// `fec_ctx_create`: one MI355X.  Fails when no gfx950 GPU is usable -- there is no CPU fallback.
+    pub fn new(device: i32) -> Result<Self> {
+        let mut raw = core::ptr::null_mut();
+        // SAFETY: `raw` is a valid out-pointer; on failure the library leaves it null.
+        check(unsafe { fec_ctx_create(&mut raw, device) })?;
+        Ok(Self { raw })
+    }
+
+    /// `fec_ctx_create_multi`: the element-wise batch calls shard contiguously over `devices`
+    /// (e.g. `&[0, 1, 2, 3, 4, 5, 6, 7]` on one 8-GPU node) and write into the caller's buffers.
+    pub fn new_multi(devices: &[i32]) -> Result<Self> {
+        let mut raw = core::ptr::null_mut();
+        // SAFETY: pointer/length pair of a live slice.
+        check(unsafe { fec_ctx_create_multi(&mut raw, devices.as_ptr(), devices.len() as c_int) })?;
+        Ok(Self { raw })
+    }
+
+    /// Number of shard workers (1 for a single-device ctx).
+    pub fn device_count(&self) -> usize {
+        // SAFETY: self.raw is a live ctx.
+        unsafe { fec_ctx_device_count(self.raw) as usize }
+    }
+
+    /// Elements per pipeline chunk of the host-pointer calls (tuning knob; results do not depend on it).
+    pub fn set_chunk(&mut self, elements: usize) -> Result<()> {
+        // SAFETY: self.raw is a live ctx.
+        check(unsafe { fec_ctx_set_chunk(self.raw, elements) })
+    }
+}
+
+impl Drop for GpuContext {
+    fn drop(&mut self) {
+        // SAFETY: created by fec_ctx_create*, destroyed exactly once.
+        unsafe { fec_ctx_destroy(self.raw) }
+    }
+}
+
+/// A curve the backend implements: maps the reference's value types to the ABI's limb arrays
+/// (`to_raw()` layout: little-endian `[u64; 4]` per field element / scalar; a point = X, Y, Z(, T)).
+pub trait GpuCurve: Curve {
+    /// `fec_curve` value.
+    const ID: c_int;
+    /// `u64` limbs per projective point (`fec_point_limbs`).
+    const LIMBS: usize;
+    /// `Scalar::to_raw()`.
+    fn scalar_limbs(s: &Self::Scalar) -> [u64; 4];
+    /// Writes the point's raw coordinates into `out[..LIMBS]`.
+    fn point_limbs(p: &Self::PointProjective, out: &mut [u64]);
+    /// Rebuilds a point from `LIMBS` raw limbs (no validation, like `multiply`'s own return value).
+    fn point_from_limbs(l: &[u64]) -> Self::PointProjective;
+    /// Raw (x, y) and the infinity flag of an affine point.
+    fn affine_limbs(a: &Self::PointAffine) -> ([u64; 8], bool);
+    /// Rebuilds an affine point from raw (x, y) and the infinity flag.
+    fn affine_from_limbs(xy: &[u64], infinity: bool) -> Self::PointAffine;
+}
+
+fn limb4(l: &[u64], i: usize) -> [u64; 4] {
+    [l[4 * i], l[4 * i + 1], l[4 * i + 2], l[4 * i + 3]]
+}
+
+macro_rules! impl_weierstrass {
+    ($curve:ty, $m:ident, $id:expr) => {
+        impl GpuCurve for $curve {
+            const ID: c_int = $id;
+            const LIMBS: usize = 12;
+            fn scalar_limbs(s: &$m::Scalar) -> [u64; 4] {
+                s.to_raw()
+            }
+            fn point_limbs(p: &$m::ProjectivePoint, out: &mut [u64]) {
+                for (i, c) in p.to_raw_coords().iter().enumerate() {
+                    out[4 * i..4 * i + 4].copy_from_slice(c);
+                }
+            }
+            fn point_from_limbs(l: &[u64]) -> $m::ProjectivePoint {
+                $m::ProjectivePoint::from_raw_coords([limb4(l, 0), limb4(l, 1), limb4(l, 2)])
+            }
+            fn affine_limbs(a: &$m::AffinePoint) -> ([u64; 8], bool) {
+                let (c, inf) = a.to_raw_coords();
+                let mut o = [0u64; 8];
+                o[..4].copy_from_slice(&c[0]);
+                o[4..].copy_from_slice(&c[1]);
+                (o, inf)
+            }
+            fn affine_from_limbs(xy: &[u64], infinity: bool) -> $m::AffinePoint {
+                $m::AffinePoint::from_raw_coords([limb4(xy, 0), limb4(xy, 1)], infinity)
+            }
+        }
+    };
+}
+impl_weierstrass!(secp256k1::Secp256k1, secp256k1, 0);
+impl_weierstrass!(p256::P256, p256, 1);
+
+impl GpuCurve for ed25519::Ed25519 {
+    const ID: c_int = 2;
+    const LIMBS: usize = 16;
+    fn scalar_limbs(s: &ed25519::Scalar) -> [u64; 4] {
+        s.to_raw()
+    }
+    fn point_limbs(p: &ed25519::ExtendedPoint, out: &mut [u64]) {
+        for (i, c) in p.to_raw_coords().iter().enumerate() {
+            out[4 * i..4 * i + 4].copy_from_slice(c);
+        }
+    }
+    fn point_from_limbs(l: &[u64]) -> ed25519::ExtendedPoint {
+        ed25519::ExtendedPoint::from_raw_coords([limb4(l, 0), limb4(l, 1), limb4(l, 2), limb4(l, 3)])
+    }
+    fn affine_limbs(a: &ed25519::AffinePoint) -> ([u64; 8], bool) {
+        let (c, inf) = a.to_raw_coords();
+        let mut o = [0u64; 8];
+        o[..4].copy_from_slice(&c[0]);
+        o[4..].copy_from_slice(&c[1]);
+        (o, inf)
+    }
+    fn affine_from_limbs(xy: &[u64], infinity: bool) -> ed25519::AffinePoint {
+        ed25519::AffinePoint::from_raw_coords([limb4(xy, 0), limb4(xy, 1)], infinity)
+    }
+}
+
+fn pack_scalars<C: GpuCurve>(s: &[C::Scalar]) -> Vec<u64> {
+    let mut k = vec![0u64; 4 * s.len()];
+    for (i, x) in s.iter().enumerate() {
+        k[4 * i..4 * i + 4].copy_from_slice(&C::scalar_limbs(x));
+    }
+    k
+}
+
+fn pack_points<C: GpuCurve>(p: &[C::PointProjective]) -> Vec<u64> {
+    let mut v = vec![0u64; C::LIMBS * p.len()];
+    for (i, x) in p.iter().enumerate() {
+        C::point_limbs(x, &mut v[C::LIMBS * i..C::LIMBS * (i + 1)]);
+    }
+    v
+}
+
+fn unpack_points<C: GpuCurve>(v: &[u64]) -> Vec<C::PointProjective> {
+    v.chunks_exact(C::LIMBS).map(C::point_from_limbs).collect()
+}
+
+/// `out[i] = C::multiply(&points[i], &scalars[i])`, bit-identical to the CPU trait method
+/// (`secp256k1.rs:2635-2692`, `p256.rs:2120-2156`, `ed25519.rs:2062-2097`).
+pub fn batch_multiply<C: GpuCurve>(ctx: &mut GpuContext, points: &[C::PointProjective], scalars: &[C::Scalar]) -> Result<Vec<C::PointProjective>> {
+    if points.len() != scalars.len() {
+        return Err(Error::ValidationError);
+    }
+    let (k, p) = (pack_scalars::<C>(scalars), pack_points::<C>(points));
+    let mut out = vec![0u64; C::LIMBS * points.len()];
+    // SAFETY: every pointer covers n elements of the documented layout; nothing is retained after return.
+    check(unsafe { fec_batch_mul(ctx.raw, C::ID, k.as_ptr(), p.as_ptr(), out.as_mut_ptr(), points.len()) })?;
+    Ok(unpack_points::<C>(&out))
+}
+
+/// `out[i] = C::multiply(base, &scalars[i])` -- key generation with `base = C::generator()`.
+pub fn batch_multiply_fixed<C: GpuCurve>(ctx: &mut GpuContext, base: &C::PointProjective, scalars: &[C::Scalar]) -> Result<Vec<C::PointProjective>> {
+    let k = pack_scalars::<C>(scalars);
+    let b = pack_points::<C>(core::slice::from_ref(base));
+    let mut out = vec![0u64; C::LIMBS * scalars.len()];
+    // SAFETY: as above; `b` holds one point.
+    check(unsafe { fec_batch_mul_fixed(ctx.raw, C::ID, k.as_ptr(), b.as_ptr(), out.as_mut_ptr(), scalars.len()) })?;
+    Ok(unpack_points::<C>(&out))
+}
+
+/// `R[i] = C::multiply(&G, &u1[i]) + C::multiply(&q[i], &u2[i])` (`forge-ec-signature/src/ecdsa.rs:254-256`).
+pub fn batch_double_multiply<C: GpuCurve>(ctx: &mut GpuContext, u1: &[C::Scalar], u2: &[C::Scalar], q: &[C::PointProjective]) -> Result<Vec<C::PointProjective>> {
+    if u1.len() != u2.len() || u1.len() != q.len() {
+        return Err(Error::ValidationError);
+    }
+    let (a, b, p) = (pack_scalars::<C>(u1), pack_scalars::<C>(u2), pack_points::<C>(q));
+    let mut out = vec![0u64; C::LIMBS * q.len()];
+    // SAFETY: as above.
+    check(unsafe { fec_batch_double_mul(ctx.raw, C::ID, a.as_ptr(), b.as_ptr(), p.as_ptr(), out.as_mut_ptr(), q.len()) })?;
+    Ok(unpack_points::<C>(&out))
+}
+
+/// `C::to_affine(&points[i])` with the reference's own field inversion (`secp256k1.rs:1342-1363`,
+/// `p256.rs:1835-1857`, `ed25519.rs:1793-1811`).
+pub fn batch_to_affine<C: GpuCurve>(ctx: &mut GpuContext, points: &[C::PointProjective]) -> Result<Vec<C::PointAffine>> {
+    let n = points.len();
+    let p = pack_points::<C>(points);
+    let (mut xy, mut inf) = (vec![0u64; 8 * n], vec![0u8; n]);
+    // SAFETY: as above.
+    check(unsafe { fec_batch_to_affine(ctx.raw, C::ID, p.as_ptr(), xy.as_mut_ptr(), inf.as_mut_ptr(), n) })?;
+    Ok((0..n).map(|i| C::affine_from_limbs(&xy[8 * i..8 * i + 8], inf[i] != 0)).collect())
+}
+
+/// `PointAffine::to_bytes` of every point (33 bytes each; `secp256k1.rs:875-896`, `p256.rs:1558-1578`,
+/// `ed25519.rs:1505-1525`).
+pub fn batch_compress<C: GpuCurve>(ctx: &mut GpuContext, points: &[C::PointAffine]) -> Result<Vec<[u8; 33]>> {
+    let n = points.len();
+    let (mut xy, mut inf) = (vec![0u64; 8 * n], vec![0u8; n]);
+    for (i, a) in points.iter().enumerate() {
+        let (l, f) = C::affine_limbs(a);
+        xy[8 * i..8 * i + 8].copy_from_slice(&l);
+        inf[i] = f as u8;
+    }
+    let mut out = vec![0u8; 33 * n];
+    // SAFETY: as above.
+    check(unsafe { fec_batch_compress(ctx.raw, C::ID, xy.as_ptr(), inf.as_ptr(), out.as_mut_ptr(), n) })?;
+    Ok(out.chunks_exact(33).map(|c| <[u8; 33]>::try_from(c).unwrap()).collect())
+}
+
+/// `C::multi_scalar_multiply(points, scalars)` (`forge-ec-core/src/lib.rs:934-951`): the sum, folded
+/// left to right from the identity exactly as the default method does.
+pub fn multi_scalar_multiply<C: GpuCurve>(ctx: &mut GpuContext, points: &[C::PointProjective], scalars: &[C::Scalar]) -> Result<C::PointProjective> {
+    if points.len() != scalars.len() {
+        return Err(Error::ValidationError);
+    }
+    let (k, p) = (pack_scalars::<C>(scalars), pack_points::<C>(points));
+    let mut out = vec![0u64; C::LIMBS];
+    // SAFETY: as above; `out` holds one point.
+    check(unsafe { fec_multi_scalar_mul(ctx.raw, C::ID, k.as_ptr(), p.as_ptr(), out.as_mut_ptr(), points.len()) })?;
+    Ok(C::point_from_limbs(&out))
+}
+
+/// Outcome of one ECDSA verification as the reference computes it (`ecdsa.rs:213-281`).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum VerifyStatus {
+    /// `verify` returns `false`.
+    Invalid,
+    /// `verify` returns `true`.
+    Valid,
+    /// The reference panics (`CtOption::unwrap` on `None`: digest or affine x >= n as a scalar).
+    ReferencePanics,
+}
+
+/// `Ecdsa::<Secp256k1, D>::verify` per element, everything after the hash on the GPU.
+/// `digests[i] = D::digest(msg_i)` (32 bytes, as the hash emits them).
+pub fn ecdsa_verify_batch_secp256k1(ctx: &mut GpuContext, digests: &[[u8; 32]], r: &[secp256k1::Scalar], s: &[secp256k1::Scalar], public_keys: &[secp256k1::AffinePoint]) -> Result<Vec<VerifyStatus>> {
+    let n = digests.len();
+    if r.len() != n || s.len() != n || public_keys.len() != n {
+        return Err(Error::ValidationError);
+    }
+    type C = secp256k1::Secp256k1;
+    let (rr, ss) = (pack_scalars::<C>(r), pack_scalars::<C>(s));
+    let (mut xy, mut inf) = (vec![0u64; 8 * n], vec![0u8; n]);
+    for (i, a) in public_keys.iter().enumerate() {
+        let (l, f) = C::affine_limbs(a);
+        xy[8 * i..8 * i + 8].copy_from_slice(&l);
+        inf[i] = f as u8;
+    }
+    let mut status = vec![0u8; n];
+    // SAFETY: `digests` is n contiguous 32-byte arrays; the other buffers hold n elements each.
+    check(unsafe { fec_ecdsa_verify_secp256k1(ctx.raw, digests.as_ptr().cast(), rr.as_ptr(), ss.as_ptr(), xy.as_ptr(), inf.as_ptr(), status.as_mut_ptr(), n) })?;
+    Ok(status.iter().map(|&v| match v { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid }).collect())
+}
+
+/// `schnorr::batch_verify::<Secp256k1, D>` from line 258 on (`forge-ec-signature/src/schnorr.rs:194-290`):
+/// the caller hashes (challenges `e`, 236-256) and draws the weights (`a`, 228-233) with the
+/// reference's own code and passes them as scalars.
+pub fn schnorr_batch_verify_secp256k1(ctx: &mut GpuContext, public_keys: &[secp256k1::AffinePoint], sig_r: &[secp256k1::AffinePoint], sig_s: &[secp256k1::Scalar], a: &[secp256k1::Scalar], e: &[secp256k1::Scalar]) -> Result<bool> {
+    let n = public_keys.len();
+    if sig_r.len() != n || sig_s.len() != n || a.len() != n || e.len() != n {
+        return Err(Error::ValidationError);
+    }
+    type C = secp256k1::Secp256k1;
+    let marshal = |pts: &[secp256k1::AffinePoint]| {
+        let (mut xy, mut inf) = (vec![0u64; 8 * n], vec![0u8; n]);
+        for (i, p) in pts.iter().enumerate() {
+            let (l, f) = C::affine_limbs(p);
+            xy[8 * i..8 * i + 8].copy_from_slice(&l);
+            inf[i] = f as u8;
+        }
+        (xy, inf)
+    };
+    let ((pk_xy, pk_inf), (r_xy, r_inf)) = (marshal(public_keys), marshal(sig_r));
+    let (s, aa, ee) = (pack_scalars::<C>(sig_s), pack_scalars::<C>(a), pack_scalars::<C>(e));
+    let mut result = 0u8;
+    // SAFETY: n elements behind every pointer; the two optional outputs are null.
+    check(unsafe { fec_schnorr_batch_verify_secp256k1(ctx.raw, pk_xy.as_ptr(), pk_inf.as_ptr(), r_xy.as_ptr(), r_inf.as_ptr(), s.as_ptr(), aa.as_ptr(), ee.as_ptr(), n, &mut result, core::ptr::null_mut(), core::ptr::null_mut()) })?;
+    Ok(result == 1)
+}
+
+/// `C::generator()` as the library holds it (evaluated on the device with the reference's own
+/// construction) -- a self-check for an integration: must equal the CPU `C::generator()`.
+pub fn generator<C: GpuCurve>(ctx: &mut GpuContext) -> Result<C::PointProjective> {
+    let mut out = vec![0u64; C::LIMBS];
+    // SAFETY: `out` holds fec_point_limbs(curve) limbs.
+    check(unsafe { fec_generator(ctx.raw, C::ID, out.as_mut_ptr()) })?;
+    debug_assert_eq!(unsafe { fec_point_limbs(C::ID) } as usize, C::LIMBS);
+    Ok(C::point_from_limbs(&out))
+}
+
+/// Raw access for callers that keep their batches resident in HBM: the `*_dev` entry points take HIP
+/// device pointers (16-byte aligned) of the ctx's device and a `hipStream_t`; nothing is copied or
+/// synchronised.  Unsafe because the pointers are not checked.
+pub mod dev {
+    use super::*;
+
+    /// `fec_batch_mul_dev`.
+    ///
+    /// # Safety
+    /// Device pointers of the ctx's device covering n elements; `stream` a live `hipStream_t` or null.
+    pub unsafe fn batch_mul(ctx: &mut GpuContext, curve: c_int, d_scalars: *const u64, d_points: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_batch_mul_dev(ctx.raw, curve, d_scalars, d_points, d_out, n, stream))
+    }
+
+    /// `fec_batch_mul_fixed_dev`; pass [`generator_ptr`] as the base to reuse the cached Ed25519 table.
+    ///
+    /// # Safety
+    /// As [`batch_mul`].
+    pub unsafe fn batch_mul_fixed(ctx: &mut GpuContext, curve: c_int, d_scalars: *const u64, d_base: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_batch_mul_fixed_dev(ctx.raw, curve, d_scalars, d_base, d_out, n, stream))
+    }
+
+    /// `fec_batch_double_mul_dev`.
+    ///
+    /// # Safety
+    /// As [`batch_mul`].
+    pub unsafe fn batch_double_mul(ctx: &mut GpuContext, curve: c_int, d_u1: *const u64, d_u2: *const u64, d_q: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_batch_double_mul_dev(ctx.raw, curve, d_u1, d_u2, d_q, d_out, n, stream))
+    }
+
+    /// `fec_batch_to_affine_dev`.
+    ///
+    /// # Safety
+    /// As [`batch_mul`].
+    pub unsafe fn batch_to_affine(ctx: &mut GpuContext, curve: c_int, d_points: *const u64, d_xy: *mut u64, d_inf: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_batch_to_affine_dev(ctx.raw, curve, d_points, d_xy, d_inf, n, stream))
+    }
+
+    /// `fec_batch_compress_dev`.
+    ///
+    /// # Safety
+    /// As [`batch_mul`]; `d_out` 4-byte aligned.
+    pub unsafe fn batch_compress(ctx: &mut GpuContext, curve: c_int, d_xy: *const u64, d_inf: *const u8, d_out: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_batch_compress_dev(ctx.raw, curve, d_xy, d_inf, d_out, n, stream))
+    }
+
+    /// `fec_ecdsa_verify_secp256k1_dev`.
+    ///
+    /// # Safety
+    /// As [`batch_mul`].
+    pub unsafe fn ecdsa_verify_secp256k1(ctx: &mut GpuContext, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_ecdsa_verify_secp256k1_dev(ctx.raw, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream))
+    }
+
+    /// `fec_generator_dev`: device address of the ctx's generator of `curve` (valid for the ctx's lifetime).
+    pub fn generator_ptr(ctx: &mut GpuContext, curve: c_int) -> *const u64 {
+        // SAFETY: self.raw is a live ctx.
+        unsafe { fec_generator_dev(ctx.raw, curve) }
+    }
+}
+
+/// Parity hooks on the trait operators (`forge-ec-core/src/lib.rs:173-241, 699-748`) and the
+/// measurement hooks of the header, for tests and benchmarks of an integration.
+pub mod hooks {
+    use super::*;
+
+    /// `fec_field_op` on raw limbs: op 0 add, 1 sub, 2 mul, 3 square, 4 neg.
+    pub fn field_op(ctx: &mut GpuContext, curve: c_int, op: c_int, a: &[[u64; 4]], b: Option<&[[u64; 4]]>) -> Result<Vec<[u64; 4]>> {
+        let n = a.len();
+        if b.map_or(false, |x| x.len() != n) {
+            return Err(Error::ValidationError);
+        }
+        let mut out = vec![[0u64; 4]; n];
+        // SAFETY: n elements of 4 limbs behind every non-null pointer.
+        check(unsafe { fec_field_op(ctx.raw, curve, op, a.as_ptr().cast(), b.map_or(core::ptr::null(), |x| x.as_ptr().cast()), out.as_mut_ptr().cast(), n) })?;
+        Ok(out)
+    }
+
+    /// `fec_point_op` on raw limbs: op 0 add, 1 double, 2 negate, 3 trait double (secp256k1 only).
+    pub fn point_op(ctx: &mut GpuContext, curve: c_int, op: c_int, limbs: usize, p: &[u64], q: Option<&[u64]>) -> Result<Vec<u64>> {
+        if limbs == 0 || p.len() % limbs != 0 || q.map_or(false, |x| x.len() != p.len()) {
+            return Err(Error::ValidationError);
+        }
+        let mut out = vec![0u64; p.len()];
+        // SAFETY: p.len() / limbs elements behind every non-null pointer.
+        check(unsafe { fec_point_op(ctx.raw, curve, op, p.as_ptr(), q.map_or(core::ptr::null(), |x| x.as_ptr()), out.as_mut_ptr(), p.len() / limbs) })?;
+        Ok(out)
+    }
+
+    /// `fec_ctx_set_timing` + `fec_ctx_last_kernel_ms`: duration of the last kernel launched through the ctx.
+    pub fn last_kernel_ms(ctx: &mut GpuContext) -> Result<f32> {
+        let mut ms = 0f32;
+        let mut name: *const c_char = core::ptr::null();
+        // SAFETY: valid out-pointers.
+        check(unsafe { fec_ctx_last_kernel_ms(ctx.raw, &mut ms, &mut name) })?;
+        Ok(ms)
+    }
+
+    /// `fec_ctx_set_timing`.
+    pub fn set_timing(ctx: &mut GpuContext, enabled: bool) -> Result<()> {
+        // SAFETY: live ctx.
+        check(unsafe { fec_ctx_set_timing(ctx.raw, enabled as c_int) })
+    }
+
+    /// `fec_measure_peak_mad32`: measured 32x32->64 multiply-add peak of the GPU.
+    pub fn measure_peak_mad32(ctx: &mut GpuContext) -> Result<f64> {
+        let mut v = 0f64;
+        // SAFETY: valid out-pointer.
+        check(unsafe { fec_measure_peak_mad32(ctx.raw, &mut v) })?;
+        Ok(v)
+    }
+
+    /// `fec_ctx_device_info`: (name, compute units, clock in kHz).
+    pub fn device_info(ctx: &mut GpuContext) -> Result<(String, i32, i32)> {
+        let mut buf = [0 as c_char; 128];
+        let (mut cus, mut khz) = (0, 0);
+        // SAFETY: buffer and out-pointers are valid; the library NUL-terminates within name_len.
+        check(unsafe { fec_ctx_device_info(ctx.raw, buf.as_mut_ptr(), buf.len(), &mut cus, &mut khz) })?;
+        let name = unsafe { core::ffi::CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned();
+        Ok((name, cus, khz))
+    }
+}
