@@ -685,8 +685,12 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
   Launch L(ctx, stream, fixed ? "k_batch_mul<fixed>" : "k_batch_mul<var>");
   switch (curve) {
     case FEC_SECP256K1:
-      if (fixed) hipLaunchKernelGGL((k_batch_mul<Secp, true>), g, b, 0, L.s, s, p, o, n);
-      else hipLaunchKernelGGL((k_batch_mul<Secp, false>), g, b, 0, L.s, s, p, o, n);
+      if (std::getenv("FEC_SECP_2WAVE")) {  // the round-1 register-resident form (2 waves per SIMD), kept for A/B runs
+        if (fixed) hipLaunchKernelGGL((k_batch_mul<Secp, true>), g, b, 0, L.s, s, p, o, n);
+        else hipLaunchKernelGGL((k_batch_mul<Secp, false>), g, b, 0, L.s, s, p, o, n);
+      } else {
+        secp_launch_mul(fixed, s, p, o, n, L.s);
+      }
       break;
     case FEC_P256:
       p256_launch_mul(fixed, s, p, o, n, L.s);
@@ -699,6 +703,12 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
   return L.done();
 }
 
+// out[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])   (ecdsa.rs:254-256).
+// secp256k1: one fused kernel (two ladders sharing one copy of the ladder code + the addition).
+// P-256 / Ed25519: the two multiplications run through the task-scheduler kernels (P-256: fixed and
+// variable base; Ed25519: the LDS addend-table kernel for u1*G and the scheduler for u2*Q), which skip
+// the additions of clear bits, into per-stream scratch; one point-addition pass combines them.  The
+// fused masked-ladder form of round 1 (38 spilled VGPRs for P-256) is gone.
 int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, const u64* dq, u64* dout,
                       size_t n, void* stream) {
   if (n == 0) return FEC_OK;
@@ -708,11 +718,30 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
   const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
   u32* o = reinterpret_cast<u32*>(dout);
   dim3 g(grid_for(n)), b(TPB);
-  Launch L(ctx, stream, "k_batch_double_mul");
-  switch (curve) {
-    case FEC_SECP256K1: hipLaunchKernelGGL((k_batch_double_mul<Secp>), g, b, 0, L.s, a, b2, q, gen, o, n); break;
-    case FEC_P256: hipLaunchKernelGGL((k_batch_double_mul<P256>), g, b, 0, L.s, a, b2, q, gen, o, n); break;
-    default: hipLaunchKernelGGL((k_batch_double_mul<Ed>), g, b, 0, L.s, a, b2, q, gen, o, n); break;
+  if (curve == FEC_SECP256K1) {
+    Launch L(ctx, stream, "k_batch_double_mul");
+    hipLaunchKernelGGL((k_batch_double_mul<Secp>), g, b, 0, L.s, a, b2, q, gen, o, n);
+    return L.done();
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  const size_t pb = (size_t)plimbs(curve) * 8;
+  char* scratch = static_cast<char*>(scratch_for(ctx, st, 2 * n * pb));
+  if (!scratch) return FEC_E_OOM;
+  u32* ta = reinterpret_cast<u32*>(scratch);
+  u32* tb = reinterpret_cast<u32*>(scratch + n * pb);
+  if (curve == FEC_ED25519) {  // the addend table of G is built (once) before the timed sequence
+    int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
+    if (rc != FEC_OK) return rc;
+  }
+  Launch L(ctx, stream, curve == FEC_P256 ? "k_p256_mul_sched x2 + k_point_op" : "k_ed_fixed_base + k_ed_mul_sched + k_point_op");
+  if (curve == FEC_P256) {
+    p256_launch_mul(true, a, gen, ta, n, L.s);
+    p256_launch_mul(false, b2, q, tb, n, L.s);
+    hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
+  } else {
+    hipLaunchKernelGGL(k_ed_fixed_base, g, b, 0, L.s, a, gen, ctx->d_ed_table, ta, n);
+    ed_launch_mul(b2, q, tb, n, L.s);
+    hipLaunchKernelGGL((k_point_op<Ed>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   }
   return L.done();
 }
@@ -981,6 +1010,8 @@ void fec_ctx_destroy(fec_ctx* ctx) {
   for (int i = 0; i < 3; ++i)
     if (ctx->d_gen[i]) (void)hipFree(ctx->d_gen[i]);
   if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
+  for (auto& e : ctx->stream_scratch)
+    if (e.buf) (void)hipFree(e.buf);
   for (int i = 0; i < 3; ++i)
     if (ctx->d_canon_comb[i]) (void)hipFree(ctx->d_canon_comb[i]);
   for (int i = 0; i < 3; ++i)

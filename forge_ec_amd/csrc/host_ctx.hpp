@@ -46,6 +46,14 @@ struct fec_ctx {
   hipDeviceProp_t prop;
   // multi-device ctx (fec_ctx_create_multi): the shard workers; empty for a single-device ctx
   std::vector<fec_ctx*> children;
+  // per-stream scratch of the composed launches (two ladders + one addition): a buffer is only ever
+  // used by launches on the stream it belongs to, so calls on different streams cannot race on it
+  struct StreamScratch {
+    hipStream_t stream;
+    void* buf;
+    size_t cap;
+  };
+  std::vector<StreamScratch> stream_scratch;
 };
 
 // a multi-device ctx runs everything that is not sharded on its first shard worker
@@ -73,6 +81,32 @@ inline int ensure(fec_ctx* ctx, int slot, size_t bytes) {
   }
   ctx->d_cap[slot] = cap;
   return FEC_OK;
+}
+
+// Device scratch of at least `bytes` dedicated to `stream` (grown on demand; growing waits for that stream).
+inline void* scratch_for(fec_ctx* ctx, hipStream_t stream, size_t bytes) {
+  for (auto& e : ctx->stream_scratch) {
+    if (e.stream != stream) continue;
+    if (e.cap >= bytes) return e.buf;
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(e.buf);
+    e.buf = nullptr;
+    e.cap = 0;
+    if (hipMalloc(&e.buf, bytes + (bytes >> 2)) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    e.cap = bytes + (bytes >> 2);
+    return e.buf;
+  }
+  fec_ctx::StreamScratch e{stream, nullptr, 0};
+  if (hipMalloc(&e.buf, bytes + (bytes >> 2)) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  e.cap = bytes + (bytes >> 2);
+  ctx->stream_scratch.push_back(e);
+  return e.buf;
 }
 
 struct Launch {

@@ -13,4 +13,7 @@ void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out
 // running result of every element during the launch.
 void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
 
+// kernels_secp.hip: secp256k1 Curve::multiply, lane-per-element ladder at three wavefronts per SIMD.
+void secp_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
+
 }  // namespace fecgpu

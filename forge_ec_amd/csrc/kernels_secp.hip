@@ -1,0 +1,99 @@
+// kernels_secp.hip -- the headline kernel: secp256k1 Curve::multiply (secp256k1.rs:2635-2692), one
+// scalar multiplication per lane, at THREE wavefronts per SIMD.
+//
+// The ladder step is s = r0 + r1; d = double(bit ? r1 : r0); (r0, r1) = bit ? (s, d) : (d, s).
+// Held entirely in registers it needs 214-256 VGPRs (2 waves per SIMD).  The measured issue cost of
+// the v_mad_u64_u32 / v_addc pairs that make up most of the kernel drops from 5.3 to 5.0 cycles per
+// instruction with a third wavefront on the SIMD (profiles/valu_latency_r02.txt), so this kernel is
+// built for 168 VGPRs: both ladder points are PARKED in LDS at the top of a step (48 words per lane),
+// the addition consumes its register copies, the doubling's operand is re-read from LDS afterwards,
+// the field multiplications' fixed register block sits at v[132:167] (tools/gen_field_asm.py), and the
+// scalar is read from HBM one word per 32 steps instead of being staged in LDS.  LDS: 48 KiB per
+// workgroup, three workgroups per CU.
+#include <hip/hip_runtime.h>
+
+#include "../../include/fecgpu.h"
+#include "secp256k1.hpp"
+#include "staging.hpp"
+#include "kernels.hpp"
+
+namespace fecgpu {
+
+namespace {
+
+FEC_DEV secp::pt ld3(const u32* l, int stride) {
+  secp::pt p;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    p.x.w[i] = l[i * stride];
+    p.y.w[i] = l[(8 + i) * stride];
+    p.z.w[i] = l[(16 + i) * stride];
+  }
+  return p;
+}
+FEC_DEV void st3(u32* l, int stride, const secp::pt& p) {
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    l[i * stride] = p.x.w[i];
+    l[(8 + i) * stride] = p.y.w[i];
+    l[(16 + i) * stride] = p.z.w[i];
+  }
+}
+
+}  // namespace
+
+template <bool FIXED>
+__global__ __launch_bounds__(TPB, 3) void k_secp_mul(const u32* __restrict__ scalars,
+                                                  const u32* __restrict__ points,
+                                                  u32* __restrict__ out, size_t n) {
+  __shared__ u32 lds[48 * TPB];  // word w of lane e: r0 at lds[w * TPB + e], r1 at lds[(24 + w) * TPB + e]
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  const int e = threadIdx.x;
+  if (!FIXED) stage_in<24>(lds, points + first * 24, valid);
+  __syncthreads();
+  if (e < valid) {
+    const u32* kg = scalars + (first + e) * 8;
+    secp::pt r1 = FIXED ? ld3(points, 1) : ld3(lds + e, TPB);
+    u32 any = 0;
+    FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kg[i];
+    const lmask early = secp::is_identity(r1) | lanes_where(any == 0);
+    secp::pt r0 = secp::identity();
+    u32 kword = 0;
+#pragma unroll 1
+    for (int i = 0; i < 256; ++i) {
+      if ((i & 31) == 0) kword = kg[i >> 5];
+      // bit i of the ladder (2655-2659): byte i/8 of the little-endian bytes, MSB first in the byte
+      const int sh = (((i >> 3) & 3) << 3) + 7 - (i & 7);
+      const lmask bit = lanes_where(((kword >> sh) & 1u) != 0);
+      st3(lds + e, TPB, r0);
+      st3(lds + 24 * TPB + e, TPB, r1);
+      lmask nd;
+      secp::pt s = secp::padd_nodouble(r0, r1, nd);
+      if (__builtin_expect(nd != 0, 0)) {  // Add (1469-1473) returns self.double(): never on random inputs
+        secp::pt d0 = secp::pdouble(ld3(lds + e, TPB));
+        s = secp::pt_select(s, d0, nd);
+      }
+      // only the doubling the reference keeps (2669-2684): double(bit ? r1 : r0), operand re-read from LDS
+      secp::pt din;
+      FEC_UNROLL for (int w = 0; w < 8; ++w) {
+        din.x.w[w] = word_select(lds[w * TPB + e], lds[(24 + w) * TPB + e], bit);
+        din.y.w[w] = word_select(lds[(8 + w) * TPB + e], lds[(32 + w) * TPB + e], bit);
+        din.z.w[w] = word_select(lds[(16 + w) * TPB + e], lds[(40 + w) * TPB + e], bit);
+      }
+      secp::pt d = secp::pdouble(din);
+      r0 = secp::pt_select(d, s, bit);
+      r1 = secp::pt_select(s, d, bit);
+    }
+    r0 = secp::pt_select(r0, secp::identity(), early);
+    st3(lds + e, TPB, r0);
+  }
+  __syncthreads();
+  stage_out<24>(out + first * 24, lds, valid);
+}
+
+void secp_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s) {
+  const unsigned grid = (unsigned)((n + TPB - 1) / TPB);
+  if (fixed) hipLaunchKernelGGL((k_secp_mul<true>), dim3(grid), dim3(TPB), 0, s, scalars, points, out, n);
+  else hipLaunchKernelGGL((k_secp_mul<false>), dim3(grid), dim3(TPB), 0, s, scalars, points, out, n);
+}
+
+}  // namespace fecgpu

@@ -93,6 +93,13 @@ FEC_DEV fe mont_reduce(const u32 t[16]) {
   return csub_p_unlikely(v2);
 }
 
+// multiply by a raw small constant through the Montgomery Mul (three/eight at 1523, 1533)
+FEC_DEV fe mul_small_cxx(const fe& a, u32 k) {
+  u32 t[16];
+  mul_wide_small(t, a, k);
+  return mont_reduce(t);
+}
+
 // Mul (442-507), compiler-scheduled form: the host emulation's Mul and the cross-check of the
 // hand-allocated one below
 FEC_DEV fe mul_cxx(const fe& a, const fe& b) {
@@ -140,14 +147,36 @@ FEC_DEV fe mul(const fe& a, const fe& b) {
   if (__builtin_expect(bw != 0, 0)) r = borrow_from_word2(r, bw);
   return csub_p_top(r);
 }
+// Mul by raw 3 / raw 8 (1523, 1533): the nine-word product a*k and the same recurrence, one asm statement
+template <u32 K>
+FEC_DEV fe mul_small_k(const fe& a) {
+  static_assert(K == 3 || K == 8, "the ladder multiplies by 3 and 8 only");
+  fe r;
+  lmask sc, bw, exc;
+  if (K == 3) {
+    asm(FEC_SECP_MUL3_ASM
+        : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
+          "=v"(r.w[7]), "=&s"(sc), "=&s"(bw), "=&s"(exc)
+        : FEC_V8(a), "s"(0xD2253531u), "s"(977u)
+        : FEC_SECP_MUL3_CLOBBERS);
+  } else {
+    asm(FEC_SECP_MUL8_ASM
+        : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
+          "=v"(r.w[7]), "=&s"(sc), "=&s"(bw), "=&s"(exc)
+        : FEC_V8(a), "s"(0xD2253531u), "s"(977u)
+        : FEC_SECP_MUL8_CLOBBERS);
+  }
+  if (__builtin_expect(exc != 0, 0)) return mul_small_cxx(a, K);  // m0 + t8 carried out of word 0
+  if (__builtin_expect(bw != 0, 0)) r = borrow_from_word2(r, bw);
+  return csub_p_top(r);
+}
+#endif
+#ifdef FEC_HOST_EMUL
+FEC_DEV fe mul_small(const fe& a, u32 k) { return mul_small_cxx(a, k); }
+#else
+FEC_DEV fe mul_small(const fe& a, u32 k) { return k == 3 ? mul_small_k<3>(a) : (k == 8 ? mul_small_k<8>(a) : mul_small_cxx(a, k)); }
 #endif
 
-// multiply by a raw small constant through the Montgomery Mul (three/eight at 1523, 1533)
-FEC_DEV fe mul_small(const fe& a, u32 k) {
-  u32 t[16];
-  mul_wide_small(t, a, k);
-  return mont_reduce(t);
-}
 
 // ---- square() (634-713) ---------------------------------------------------------------------
 // NOT Montgomery and NOT mul(x,x).  Restated on 16 words w[] (the reference's product[0..8]):
@@ -314,8 +343,8 @@ FEC_DEV fe sqr(const fe& a) {
   fe r;
   lmask tmp, exc;
   asm(FEC_SECP_SQR_ASM
-      : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
-        "=v"(r.w[7]), "=&s"(tmp), "=&s"(exc)
+      : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=&v"(r.w[4]), "=&v"(r.w[5]), "=&v"(r.w[6]),
+        "=&v"(r.w[7]), "=&s"(tmp), "=&s"(exc)
       : FEC_V8(a), "s"(977u)
       : FEC_SECP_SQR_CLOBBERS);
   if (__builtin_expect(exc != 0, 0)) return sqr_cxx(a);

@@ -137,6 +137,46 @@ def secp_mul(VB):
 
 
 # ------------------------------------------------------------------------------------------------
+# secp256k1 Mul by a raw small constant (three / eight at secp256k1.rs:1523, 1533): T = a * k has
+# nine words, so V = T_hi + M - Q is M + t8 - Q.  The carry of m0 + t8 (t8 < 8) out of word 0 is an
+# exception lane (2^-29), the borrow of - Q out of word 1 the same rare continuation as in Mul.
+# operands: %0-%7 r, %8 sc, %9 bw (sink, then the borrow mask), %10 exc, %11-%18 a, %19 N0' (s), %20 977 (s)
+# ------------------------------------------------------------------------------------------------
+def secp_mul_small(VB, K):
+    A = ["%%%d" % (11 + i) for i in range(8)]
+    R = ["%%%d" % i for i in range(8)]
+    SC, BW, EXC, N0P, C977 = "%8", "%9", "%10", "%19", "%20"
+    Q = [VB + 2 * i for i in range(8)]      # Q_i = a_i * K + hi(Q_{i-1}): T[i] = lo(Q_i), T[8] = hi(Q_7)
+    C = VB + 16                             # {hi(Q_{i-1}), 0}
+    P, D = VB + 18, VB + 20
+    b = Block()
+    b.e("v_mov_b32_e32 %s, 0" % v(C + 1))
+    b.e("v_mov_b32_e32 %s, 0" % v(P + 1))
+    for i in range(8):
+        b.e("v_mad_u64_u32 %s, %s, %s, %d, %s" % (vp(Q[i]), BW, A[i], K, "0" if i == 0 else vp(C)))
+        if i < 7:
+            b.e("v_mov_b32_e32 %s, %s" % (v(C), v(Q[i] + 1)))
+    T = [v(q) for q in Q]
+    t8 = v(Q[7] + 1)
+    # the Montgomery word recurrence, m_k straight into the output operands
+    b.e("v_mul_lo_u32 %s, %s, %s" % (R[0], T[0], N0P))
+    b.e("v_mad_u64_u32 %s, %s, %s, %s, 0" % (vp(D), BW, R[0], C977))
+    b.e("v_add_co_u32_e64 %s, %s, %s, %s" % (v(P), SC, v(D + 1), R[0]))
+    for k in range(1, 8):
+        b.e("v_sub_u32_e32 %s, %s, %s" % (R[k], T[k], v(P)))
+        b.e("v_mul_lo_u32 %s, %s, %s" % (R[k], R[k], N0P))
+        b.e("v_mad_u64_u32 %s, %s, %s, %s, %s" % (vp(D), BW, R[k], C977, vp(P)))
+        b.e("v_addc_co_u32_e64 %s, %s, %s, %s, %s" % (v(P), SC, v(D + 1), R[k], SC))
+    b.e("v_add_co_u32_e32 %s, vcc, %s, %s" % (R[0], R[0], t8))
+    b.e("s_mov_b64 %s, vcc" % EXC)
+    b.e("v_cndmask_b32_e64 %s, 0, 1, %s" % (v(P + 1), SC))
+    b.e("v_sub_co_u32_e32 %s, vcc, %s, %s" % (R[0], R[0], v(P)))
+    b.e("v_subb_co_u32_e32 %s, vcc, %s, %s, vcc" % (R[1], R[1], v(P + 1)))
+    b.e("s_mov_b64 %s, vcc" % BW)
+    return b, list(range(VB, VB + 22))
+
+
+# ------------------------------------------------------------------------------------------------
 # secp256k1 square() (secp256k1.rs:634-713), common path: see secp256k1.hpp sqr_cxx for the literal
 # restatement.  Every data-dependent continuation of the reference (a +1 that ripples past the limb it
 # is added to; the fold's general carry rule) fires only when a 64-bit limb is all ones; the lanes
@@ -210,8 +250,13 @@ def secp_sqr(VB):
         b.e("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (dst[2], W[2]))
         b.e("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (dst[3], W[3]))
         b.e("s_or_b64 %s, %s, vcc" % (EXC, EXC))
+    # limbs 2..3 (W[4..7]) are final after the cross terms: their last writers target the output
+    # operands directly (those four outputs are early-clobber in the C++ wrapper)
     for i in range(4, 8):
-        b.e("v_mov_b32_e32 %s, %s" % (R[i], W[i]))
+        last = max(n for n, l in enumerate(b.lines) if l.split()[1].rstrip(",") == W[i])
+        assert not any(W[i] in l for l in b.lines[last + 1:]), W[i]
+        parts = b.lines[last].split(" ", 2)
+        b.lines[last] = "%s %s, %s" % (parts[0], R[i], parts[2])
     return b, list(range(VB, nxt[0]))
 
 
@@ -431,19 +476,25 @@ HEADER = """// field_asm.inc -- GENERATED by tools/gen_field_asm.py; do not edit
 """
 
 
+SECP_TOP = 168
+
+
 def main():
     parts = [HEADER]
     report = []
 
     def add(name, blk, regs):
-        assert regs[-1] == 255 and regs[0] % 2 == 0, (name, regs[0], regs[-1])
+        assert regs[-1] in (255, SECP_TOP - 1) and regs[0] % 2 == 0, (name, regs[0], regs[-1])
         parts.append("#define FEC_%s_ASM \\\n" % name + blk.text().replace("\n", " \\\n") + "\n")
         parts.append("#define FEC_%s_CLOBBERS \"vcc\", " % name + clobbers(regs) + "\n")
-        parts.append("// FEC_%s_ASM: %d instructions, fixed block v[%d:255]\n" % (name, len(blk.lines), regs[0]))
+        parts.append("// FEC_%s_ASM: %d instructions, fixed block v[%d:%d]\n" % (name, len(blk.lines), regs[0], regs[-1]))
         report.append("%s %d" % (name, len(blk.lines)))
 
-    add("SECP_MUL", *secp_mul(256 - 36))
-    add("SECP_SQR", *secp_sqr(256 - 34))
+    # the secp256k1 blocks end at v167 so that the ladder kernel fits 168 VGPRs (3 waves per SIMD)
+    add("SECP_MUL", *secp_mul(SECP_TOP - 36))
+    add("SECP_SQR", *secp_sqr(SECP_TOP - 34))
+    add("SECP_MUL3", *secp_mul_small(SECP_TOP - 22, 3))
+    add("SECP_MUL8", *secp_mul_small(SECP_TOP - 22, 8))
     add("P256_MUL", *p256_mul(256 - 32))
     add("P256_SQR", *p256_sqr(256 - 46))
     add("ED_MUL", *ed_mul(256 - 32))

@@ -27,6 +27,8 @@ __device__ fe run_new(const fe& a, const fe& b) {
   if (OP == 4) return ed::mul(a, b);
   if (OP == 5) return ed::sqr_exact(a);
 #endif
+  if (OP == 6) return secp::mul_small(a, 3);
+  if (OP == 7) return secp::mul_small(a, 8);
   return a;
 }
 template <int OP>
@@ -43,6 +45,8 @@ __device__ fe run_old(const fe& a, const fe& b) {
   if (OP == 4) return ed::mul_cxx(a, b);
   if (OP == 5) return ed::sqr_cxx(a);
 #endif
+  if (OP == 6) return secp::mul_small_cxx(a, 3);
+  if (OP == 7) return secp::mul_small_cxx(a, 8);
   return a;
 }
 
@@ -172,7 +176,10 @@ int main() {
   fail |= check<4>("ed mul", a, b);
   fail |= check<5>("ed sqr", a, b);
 #endif
+  fail |= check<6>("secp mul3", a, b);
+  fail |= check<7>("secp mul8", a, b);
   timeit<0>("secp mul", cus);
+  timeit<6>("secp mul3", cus);
 #ifdef HAVE_SECP_SQR
   timeit<1>("secp sqr", cus);
 #endif
