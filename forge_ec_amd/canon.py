@@ -98,7 +98,12 @@ class CanonCurve:
     def ecdsa_sign(self, z, d, k):
         """ECDSA signing with caller-supplied nonces k (e.g. RFC 6979): r = x(k G) mod n, s = k^-1 (z + r d).
         -> (r, s, ok) with ok[i] = 0 where r or s came out 0 (the caller picks another nonce).  All arithmetic
-        on the GPU: one comb pass and three scalar-field passes."""
+        on the GPU: one comb pass and three scalar-field passes.
+
+        NOT FOR PRODUCTION SECRETS: the comb indexes its table by digits of k, skips zero digits and takes
+        wave-level branches on exceptional cases (include/fecgpu_canon.h) -- the nonce and the key are not
+        handled in constant time.  This helper exists to check the arithmetic against RFC 6979 / FIPS
+        vectors (test keys).  The ctx staging that held k and d is zeroed before returning."""
         kk = _u64(k, 4)
         one = np.zeros_like(kk)
         one[:, 0] = 1
@@ -107,6 +112,7 @@ class CanonCurve:
         r = self.scalar_muladd(xy[:, :4], one, zero)                       # x mod n
         s = self.scalar_muladd(self.scalar_inv(kk), self.scalar_muladd(r, d, z), zero)
         ok = ((st == 0) & r.any(axis=1) & s.any(axis=1)).astype(np.uint8)
+        self._lib.fec_ctx_wipe(self._h)
         return r, s, ok
 
     def mul_base_dev(self, d_scalars, d_out_xy, d_status, n, stream=None):
@@ -163,8 +169,11 @@ class CanonEd25519(CanonCurve):
         return _four(self._lib.fec_canon_eddsa_verify, self._h, a_enc, r_enc, s, h, "fec_canon_eddsa_verify")
 
     def eddsa_sign_finish(self, h, a, r):
-        """second half of RFC 8032 signing: S = h * a + r (mod l); the first half is R = mul_base(r)."""
-        return self.scalar_muladd(h, a, r)
+        """second half of RFC 8032 signing: S = h * a + r (mod l); the first half is R = mul_base(r).
+        NOT FOR PRODUCTION SECRETS (see ecdsa_sign): vector-checking only; the ctx staging is zeroed after."""
+        out = self.scalar_muladd(h, a, r)
+        self._lib.fec_ctx_wipe(self._h)
+        return out
 
     def eddsa_verify_dev(self, d_a_enc, d_r_enc, d_s, d_h, d_result, n, stream=None):
         _check(self._lib.fec_canon_eddsa_verify_dev(self._h, d_a_enc, d_r_enc, d_s, d_h, d_result, n, stream),

@@ -650,6 +650,7 @@ const u64 FE_ONE[4] = {1, 0, 0, 0};
 // Build (or reuse) the Ed25519 addend table for the base at device address d_base.  `host_base`
 // (may be null) is the same point on the host and lets repeated calls with one base skip the build.
 int ensure_ed_table(fec_ctx* ctx, const u64* d_base, const u64* host_base, hipStream_t s) {
+  order_after_previous(ctx, s);  // the table is ctx-owned: a (re)build or a reuse on another stream waits for the last user
   if (!ctx->d_ed_table && hipMalloc(&ctx->d_ed_table, 256 * 32 * sizeof(u32)) != hipSuccess) {
     (void)hipGetLastError();
     return FEC_E_OOM;
@@ -1009,9 +1010,11 @@ void fec_ctx_destroy(fec_ctx* ctx) {
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   for (int i = 0; i < 3; ++i)
     if (ctx->d_gen[i]) (void)hipFree(ctx->d_gen[i]);
+  (void)fec_ctx_wipe(ctx);  // nothing a caller passed in outlives the ctx in device memory
   if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
   for (auto& e : ctx->stream_scratch)
     if (e.buf) (void)hipFree(e.buf);
+  if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
   for (int i = 0; i < 3; ++i)
     if (ctx->d_canon_comb[i]) (void)hipFree(ctx->d_canon_comb[i]);
   for (int i = 0; i < 3; ++i)
@@ -1393,6 +1396,35 @@ const uint64_t* fec_generator_dev(fec_ctx* ctx, fec_curve curve) {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx || !curve_ok(curve)) return nullptr;
   return ctx->d_gen[curve];
+}
+
+int fec_ctx_wipe(fec_ctx* ctx) {
+  if (!ctx) return FEC_E_ARG;
+  if (is_multi(ctx)) {
+    int rc = FEC_OK;
+    for (fec_ctx* c : ctx->children) {
+      const int r = fec_ctx_wipe(c);
+      if (rc == FEC_OK) rc = r;
+    }
+    return rc;
+  }
+  if (ctx->device < 0 || !ctx->stream) return FEC_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  (void)hipDeviceSynchronize();
+  bool ok = true;
+  for (int i = 0; i < 8; ++i)
+    if (ctx->d_buf[i]) ok = ok && hipMemset(ctx->d_buf[i], 0, ctx->d_cap[i]) == hipSuccess;
+  for (auto& e : ctx->stream_scratch)
+    if (e.buf) ok = ok && hipMemset(e.buf, 0, e.cap) == hipSuccess;
+  if (ctx->d_win_scratch) ok = ok && hipMemset(ctx->d_win_scratch, 0, ctx->win_scratch_cap) == hipSuccess;
+  if (ctx->d_zbuf) ok = ok && hipMemset(ctx->d_zbuf, 0, ctx->zbuf_cap) == hipSuccess;
+  if (ctx->d_tbuf) ok = ok && hipMemset(ctx->d_tbuf, 0, ctx->tbuf_cap) == hipSuccess;
+  if (ctx->d_verify) ok = ok && hipMemset(ctx->d_verify, 0, ctx->verify_cap) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    return FEC_E_DEVICE;
+  }
+  return FEC_OK;
 }
 
 int fec_ctx_set_chunk(fec_ctx* ctx, size_t elements) {

@@ -54,6 +54,10 @@ struct fec_ctx {
     size_t cap;
   };
   std::vector<StreamScratch> stream_scratch;
+  // ordering of launches that share ctx-owned scratch (Ed25519 addend table, canonical-mode work areas,
+  // staging): a launch on a stream other than the previous launch's stream first waits for that one
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev_order = nullptr;
 };
 
 // a multi-device ctx runs everything that is not sharded on its first shard worker
@@ -109,10 +113,25 @@ inline void* scratch_for(fec_ctx* ctx, hipStream_t stream, size_t bytes) {
   return e.buf;
 }
 
+// Calls on one ctx are serialised by the caller on the HOST, but they may name different streams while
+// sharing ctx-owned device scratch.  Every launch therefore orders itself after the previous launch of
+// the ctx when that one went to a different stream (event record + stream wait: no host blocking).
+inline void order_after_previous(fec_ctx* ctx, hipStream_t s) {
+  if (ctx->last_stream && ctx->last_stream != s) {
+    if (!ctx->ev_order) (void)hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming);
+    if (ctx->ev_order) {
+      (void)hipEventRecord(ctx->ev_order, ctx->last_stream);
+      (void)hipStreamWaitEvent(s, ctx->ev_order, 0);
+    }
+  }
+  ctx->last_stream = s;
+}
+
 struct Launch {
   fec_ctx* ctx;
   hipStream_t s;
   Launch(fec_ctx* c, void* stream, const char* name) : ctx(c), s(stream ? (hipStream_t)stream : c->stream) {
+    order_after_previous(ctx, s);
     ctx->last_kernel = name;
     ctx->timed = false;
     if (ctx->timing) (void)hipEventRecord(ctx->ev0, s);

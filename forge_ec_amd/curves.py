@@ -54,6 +54,10 @@ class Context:
             self.device = int(device)
         self._h = h
 
+    def wipe(self):
+        """fec_ctx_wipe: zero every ctx-owned device buffer that can hold copies of caller data."""
+        _check(self._lib.fec_ctx_wipe(self._h), "fec_ctx_wipe")
+
     def device_count(self):
         return int(self._lib.fec_ctx_device_count(self._h))
 

@@ -167,7 +167,13 @@ int fec_point_op(fec_ctx* ctx, fec_curve curve, fec_point_opcode op, const uint6
 
 /* ---- device-pointer entry points: pointers are HIP device pointers on the ctx's device,
  * 16-byte aligned; the launch is enqueued on `stream` (a hipStream_t; NULL = the ctx's own
- * stream) and NOT synchronised -- the caller orders it like any other stream work. ---- */
+ * stream) and NOT synchronised -- the caller orders it like any other stream work.  Calls on one
+ * ctx are serialised by the caller on the host; they MAY name different streams: some entry points
+ * use ctx-owned device scratch (the Ed25519 addend table, the scratch of the composed P-256 /
+ * Ed25519 double-mul, the canonical-mode work areas), so a launch that goes to another stream than
+ * the ctx's previous launch is ordered after it with an event (no host blocking) -- launches of
+ * one ctx therefore execute in call order whatever streams they name.  Use one ctx per stream for
+ * concurrent streams. ---- */
 int fec_batch_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars,
                       const uint64_t* d_points, uint64_t* d_out, size_t n, void* stream);
 int fec_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars,
@@ -184,6 +190,11 @@ int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, 
                            uint8_t* d_out, size_t n, void* stream);
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
                             uint8_t* d_inf, size_t n, void* stream);
+
+/* Zeroes every device buffer the ctx owns that can hold copies of caller data (host-call staging, the
+ * per-stream scratch of composed launches, the canonical-mode work areas).  Synchronises the device.
+ * fec_ctx_destroy calls it; call it yourself after a batch whose inputs were sensitive. */
+int fec_ctx_wipe(fec_ctx* ctx);
 
 /* Host-pointer batches are processed as a two-lane pipeline of `elements`-sized chunks (default
  * 2^18): copies of one chunk overlap the kernel of the other, and device staging memory is bounded

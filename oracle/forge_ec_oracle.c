@@ -1237,6 +1237,262 @@ void fo_batch_compress(int curve, const u64* xy, const uint8_t* inf, unsigned ch
   }
 }
 
+/* ================================================================================================
+ * Point DECODING (the half round 1 left out).
+ *
+ *  fo_batch_decompress          PointAffine::from_bytes(&[u8; 33]) of each curve:
+ *                               secp256k1.rs:896-976, p256.rs:1580-1639, ed25519.rs:1526-1582
+ *  fo_batch_encode_uncompressed UncompressedPoint::from_affine, forge-ec-encoding/src/point.rs:186-211
+ *  fo_batch_decode_uncompressed UncompressedPoint::to_affine, point.rs:214-281 (generic over the curve:
+ *                               C::Field::from_bytes, Mul, get_a/get_b, then C::PointAffine::new)
+ *
+ * ok[i] = 1 when the reference returns Some(point), 0 for None (xy and inf are then zero).  The
+ * arithmetic is the reference's own, quirks included:
+ *  - secp256k1 FieldElement::sqrt (112-131) raises to the four-limb exponent [0xFF0C, 0xFFFF, 0xFFFE,
+ *    0x3FFF] -- (p+1)/4 written as 16-bit words into 64-bit limbs -- so it returns None for essentially
+ *    every input; the x^3 + 7 it is applied to mixes a non-Montgomery square() and a raw 7 into
+ *    Montgomery-form values; whatever survives is re-checked by is_on_curve (978-1004).
+ *  - P-256: the inherent sqrt (320-339) with its own exponent; no on-curve check at the end.
+ *  - Ed25519 FieldElement::from_bytes (315-357) rejects a value as soon as ANY limb exceeds the same limb
+ *    of p (an early `return` inside the comparison loop), not only values >= p; from_bytes evaluates the
+ *    MONTGOMERY-curve equation x^3 + a x^2 + x with a = 0x7FFFFFDA on what it calls x.
+ * ================================================================================================ */
+static fe k_one(void) { return fe_small(1); }
+/* secp256k1.rs:715-735 trait pow: LSB first, `result *= base` when the bit is set, base = base.square() */
+static fe k_pow(fe a, const u64* e, int limbs) {
+  fe result = k_one(), base = a;
+  for (int w = 0; w < limbs; ++w)
+    for (int j = 0; j < 64; ++j) {
+      if ((e[w] >> j) & 1) result = k_mul(result, base);
+      base = k_sqr(base);
+    }
+  return result;
+}
+static int k_sqrt_inherent(fe a, fe* out) {      /* 112-131 */
+  static const u64 e[4] = {0xFF0C, 0xFFFF, 0xFFFE, 0x3FFF};
+  fe s = k_pow(a, e, 4);
+  fe s2 = k_sqr(s);
+  *out = s;
+  return fe_eq(&s2, &a);
+}
+static fe k_to_montgomery(fe a) {                 /* 219-235 */
+  fe r2 = {{0x000E9F61ULL, 0x07A20000ULL, 0x00000100ULL, 0}};
+  return k_mul(a, r2);
+}
+static int k_from_bytes(const unsigned char b[32], fe* out) {   /* 182-212: big-endian, < p, then to_montgomery */
+  u64 l[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) l[3 - i] |= (u64)b[i * 8 + j] << (56 - j * 8);
+  int valid = k_cmp_p(l) < 0;
+  fe raw = {{l[0], l[1], l[2], l[3]}};
+  fe m = k_to_montgomery(raw);
+  *out = valid ? m : fe_small(0);
+  return valid;
+}
+static int k_affine_new(fe x, fe y) {             /* PointAffine::new 856-869 (= is_on_curve 978-1004) */
+  fe x3 = k_mul(k_sqr(x), x);
+  fe rhs = k_add(x3, k_to_montgomery(fe_small(7)));
+  fe y2 = k_sqr(y);
+  return fe_eq(&y2, &rhs);
+}
+static int k_decompress(const unsigned char* in, fe* x, fe* y, int* inf) {   /* 896-976 */
+  *inf = 0;
+  if (in[0] == 0x00) { *x = fe_small(0); *y = fe_small(0); *inf = 1; return 1; }
+  if (in[0] != 0x02 && in[0] != 0x03) return 0;
+  if (!k_from_bytes(in + 1, x)) return 0;
+  fe xs = k_sqr(*x);
+  fe xc = k_mul(xs, *x);
+  fe y2 = k_add(xc, fe_small(7));               /* `seven` is the RAW 7 here (935) */
+  fe ye;
+  if (!k_sqrt_inherent(y2, &ye)) return 0;
+  fe yo = k_neg(ye);
+  fe red = k_mul(ye, fe_small(1));              /* to_bytes: mont_reduce; byte 31 = least significant */
+  int parity = (int)(red.v[0] & 1);
+  int want_odd = in[0] == 0x03;
+  *y = (want_odd ^ parity) ? yo : ye;
+  return k_affine_new(*x, *y);                  /* is_on_curve */
+}
+
+static int n_from_bytes(const unsigned char b[32], fe* out) {   /* p256.rs:303-317 */
+  u64 l[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) l[i] |= (u64)b[31 - (i * 8 + j)] << (j * 8);
+  fe r = {{l[0], l[1], l[2], l[3]}};
+  *out = r;
+  return n_cmp(l, N_P) < 0;
+}
+static const u64 N_B[4] = {0x3BCE3C3E27D2604BULL, 0x651D06B0CC53B0F6ULL, 0xB3EBBD55769886BCULL, 0x5AC635D8AA3A93E7ULL};
+static fe n_rhs(fe x) {                           /* x^3 - 3x + b as 1536-1543 / 1612-1618 spell it */
+  fe x2 = n_sqr(x);
+  fe x3 = n_mul(x2, x);
+  fe three_x = n_mul(fe_small(3), x);
+  fe b = {{N_B[0], N_B[1], N_B[2], N_B[3]}};
+  return n_add(n_sub(x3, three_x), b);
+}
+static int n_sqrt_inherent(fe a, fe* out) {       /* 320-339 */
+  static const u64 e[4] = {0xC0000000ULL, 0x40000000ULL, 0x4000000000000000ULL, 0x40000000C0000000ULL};
+  fe s = n_pow(a, e);
+  fe s2 = n_sqr(s);
+  *out = s;
+  return fe_eq(&s2, &a);
+}
+static int n_decompress(const unsigned char* in, fe* x, fe* y, int* inf) {   /* 1580-1639 */
+  *inf = 0;
+  if (in[0] == 0x00) { *x = fe_small(0); *y = fe_small(0); *inf = 1; return 1; }
+  if (in[0] != 0x02 && in[0] != 0x03) return 0;
+  if (!n_from_bytes(in + 1, x)) return 0;
+  fe y2 = n_rhs(*x);
+  fe r;
+  if (!n_sqrt_inherent(y2, &r)) return 0;
+  int parity = (int)(r.v[0] & 1);               /* to_bytes (288-300) is the raw limbs, big-endian */
+  if (parity != (in[0] == 0x03)) r = n_neg(r);
+  *y = r;
+  return 1;                                      /* no curve check here (1638) */
+}
+static int n_affine_new(fe x, fe y) {             /* 1535-1552 */
+  fe rhs = n_rhs(x);
+  fe y2 = n_sqr(y);
+  return fe_eq(&y2, &rhs);
+}
+
+static const u64 E_SQRT_M1[4] = {0xC4EE1B274A0EA0B0ULL, 0x2F431806AD2FE478ULL, 0x2B4D00993DFBD7A7ULL, 0x2B8324804FC1DF0BULL};
+static int e_from_bytes(const unsigned char b[32], fe* out) {   /* ed25519.rs:315-357 */
+  u64 l[4];
+  for (int i = 0; i < 4; ++i) {
+    l[i] = 0;
+    for (int j = 0; j < 8; ++j) l[i] |= (u64)b[i * 8 + j] << (8 * j);
+  }
+  int is_less = 0, is_equal = 1;
+  for (int i = 3; i >= 0; --i) {
+    int lt = l[i] < E_P[i], eq = l[i] == E_P[i], gt = l[i] > E_P[i];
+    is_less |= is_equal & lt;
+    is_equal &= eq;
+    if (gt) { *out = fe_small(0); return 0; }   /* 346-348: returns None whatever the higher limbs said */
+  }
+  fe r = {{l[0], l[1], l[2], l[3]}};
+  *out = r;
+  return is_less;
+}
+static int e_sqrt(fe a, fe* out) {                /* 359-402 */
+  static const u64 e1[4] = {0x7FFFFFFFFFFFFFF6ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0x3FFFFFFFFFFFFFFFULL};
+  static const u64 e2[4] = {0x1FFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0x0FFFFFFFFFFFFFFFULL};
+  fe leg = e_pow(a, e1);
+  fe one = fe_small(1), zero = fe_small(0);
+  if (!(fe_eq(&leg, &one) | fe_eq(&leg, &zero))) return 0;
+  fe cand = e_pow(a, e2);
+  fe c2 = e_sqr(cand);
+  int ok1 = fe_eq(&c2, &a);
+  fe sm1 = {{E_SQRT_M1[0], E_SQRT_M1[1], E_SQRT_M1[2], E_SQRT_M1[3]}};
+  fe alt = e_mul(cand, sm1);
+  fe a2 = e_sqr(alt);
+  int ok2 = fe_eq(&a2, &a);
+  *out = ok2 ? alt : cand;
+  return ok1 | ok2;
+}
+static int e_decompress(const unsigned char* in, fe* x, fe* y, int* inf) {   /* 1526-1582 */
+  *inf = 0;
+  if (in[0] == 0x00) { *x = fe_small(0); *y = fe_small(0); *inf = 1; return 1; }
+  if (in[0] != 0x02 && in[0] != 0x03) return 0;
+  if (!e_from_bytes(in + 1, x)) return 0;
+  fe x2 = e_sqr(*x);
+  fe x3 = e_mul(x2, *x);
+  fe a = fe_small(0x7FFFFFDAULL);
+  fe y2 = e_add(e_add(x3, e_mul(a, x2)), *x);
+  fe r;
+  if (!e_sqrt(y2, &r)) return 0;
+  fe red = r;
+  e_reduce(&red);                                /* to_bytes (295-310): reduce(), little-endian: byte 31 is the TOP byte */
+  int parity = (int)((red.v[3] >> 56) & 1);
+  if (parity != (in[0] == 0x03)) r = e_neg(r);
+  *y = r;
+  return 1;
+}
+static int e_affine_new(fe x, fe y) {             /* 1476-1498 */
+  fe x2 = e_sqr(x), y2 = e_sqr(y);
+  fe x2y2 = e_mul(x2, y2);
+  fe d = {{E_D[0], E_D[1], E_D[2], E_D[3]}};
+  fe lhs = e_add(e_neg(x2), y2);
+  fe rhs = e_add(fe_small(1), e_mul(d, x2y2));
+  return fe_eq(&lhs, &rhs);
+}
+
+void fo_batch_decompress(int curve, const unsigned char* in, u64* xy, uint8_t* inf, uint8_t* ok, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    fe x = fe_small(0), y = fe_small(0);
+    int f = 0, v;
+    const unsigned char* b = in + 33 * i;
+    if (curve == FO_SECP256K1) v = k_decompress(b, &x, &y, &f);
+    else if (curve == FO_P256) v = n_decompress(b, &x, &y, &f);
+    else v = e_decompress(b, &x, &y, &f);
+    if (!v) { x = fe_small(0); y = fe_small(0); f = 0; }
+    st(xy + 8 * i, x);
+    st(xy + 8 * i + 4, y);
+    inf[i] = (uint8_t)f;
+    ok[i] = (uint8_t)v;
+  }
+}
+
+/* UncompressedPoint::from_affine (point.rs:186-211): 0x00 + 64 zero bytes for the identity, else
+ * 0x04 || x.to_bytes() || y.to_bytes() */
+void fo_batch_encode_uncompressed(int curve, const u64* xy, const uint8_t* inf, unsigned char* out, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    unsigned char* o = out + 65 * i;
+    memset(o, 0, 65);
+    if (inf && inf[i]) continue;
+    o[0] = 0x04;
+    field_to_bytes(curve, ld(xy + 8 * i), o + 1);
+    field_to_bytes(curve, ld(xy + 8 * i + 4), o + 33);
+  }
+}
+
+/* UncompressedPoint::to_affine (point.rs:214-281), generic over C */
+void fo_batch_decode_uncompressed(int curve, const unsigned char* in, u64* xy, uint8_t* inf, uint8_t* ok, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned char* b = in + 65 * i;
+    fe x = fe_small(0), y = fe_small(0);
+    int f = 0, v = 0;
+    if (b[0] == 0x00) {                          /* 221-226: C::to_affine(&C::identity()) */
+      f = 1;
+      v = 1;
+    } else if (b[0] == 0x04) {
+      int vx, vy, on = 0;
+      if (curve == FO_SECP256K1) {
+        vx = k_from_bytes(b + 1, &x); vy = k_from_bytes(b + 33, &y);
+        if (vx && vy) {
+          fe x3 = k_mul(k_mul(x, x), x), y2 = k_mul(y, y);          /* `x * x`, not square() (251-253) */
+          fe ax = k_mul(fe_small(0), x);                              /* get_a() = zero (2712-2715) */
+          fe rhs = k_add(k_add(x3, ax), fe_small(7));                 /* get_b() = raw 7 (2717-2720) */
+          on = fe_eq(&y2, &rhs) && k_affine_new(x, y);
+        }
+      } else if (curve == FO_P256) {
+        vx = n_from_bytes(b + 1, &x); vy = n_from_bytes(b + 33, &y);
+        if (vx && vy) {
+          fe x3 = n_mul(n_mul(x, x), x), y2 = n_mul(y, y);
+          fe a = {{0xFFFFFFFCULL, 0xFFFFFFFFULL, 0xFFFFFFFEULL, 0xFFFFFFFFULL}};   /* get_a() as written (2177-2180) */
+          fe bb = {{N_B[0], N_B[1], N_B[2], N_B[3]}};
+          fe rhs = n_add(n_add(x3, n_mul(a, x)), bb);
+          on = fe_eq(&y2, &rhs) && n_affine_new(x, y);
+        }
+      } else {
+        vx = e_from_bytes(b + 1, &x); vy = e_from_bytes(b + 33, &y);
+        if (vx && vy) {
+          fe x3 = e_mul(e_mul(x, x), x), y2 = e_mul(y, y);
+          fe a = {{0x7FFFFFFFFFFFFFEDULL, 0x7FFFFFFFFFFFFULL, 0, 0}};             /* get_a() as written (2107-2110) */
+          fe rhs = e_add(e_add(x3, e_mul(a, x)), fe_small(0));                     /* get_b() = zero */
+          on = fe_eq(&y2, &rhs) && e_affine_new(x, y);
+        }
+      }
+      v = vx && vy && on;
+    }
+    if (!v || f) { x = fe_small(0); y = fe_small(0); }
+    if (!v) f = 0;
+    st(xy + 8 * i, x);
+    st(xy + 8 * i + 4, y);
+    inf[i] = (uint8_t)f;
+    ok[i] = (uint8_t)v;
+  }
+}
+
 void fo_batch_to_affine(int curve, const u64* points, u64* xy, uint8_t* inf, size_t n, int nthreads) {
   job_t j = {3, curve, NULL, NULL, points, xy, inf, 0, 0};
   run_jobs(j, n, nthreads);

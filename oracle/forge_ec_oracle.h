@@ -88,6 +88,11 @@ void fo_batch_to_affine(int curve, const uint64_t* points, uint64_t* xy, uint8_t
 /* out[i] = PointAffine::to_bytes (33 bytes) of the affine point (xy[i], inf[i]) */
 void fo_batch_compress(int curve, const uint64_t* xy, const uint8_t* inf, unsigned char* out, size_t n);
 
+/* ---- point decoding (see the block comment in forge_ec_oracle.c): ok[i] = 1 for Some, 0 for None ---- */
+void fo_batch_decompress(int curve, const unsigned char* in33, uint64_t* xy, uint8_t* inf, uint8_t* ok, size_t n);
+void fo_batch_encode_uncompressed(int curve, const uint64_t* xy, const uint8_t* inf, unsigned char* out65, size_t n);
+void fo_batch_decode_uncompressed(int curve, const unsigned char* in65, uint64_t* xy, uint8_t* inf, uint8_t* ok, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

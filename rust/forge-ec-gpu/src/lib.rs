@@ -25,6 +25,7 @@ extern "C" {
     fn fec_ctx_create_multi(out: *mut *mut FecCtx, devices: *const c_int, n_devices: c_int) -> c_int;
     fn fec_ctx_device_count(ctx: *mut FecCtx) -> c_int;
     fn fec_ctx_destroy(ctx: *mut FecCtx);
+    fn fec_ctx_wipe(ctx: *mut FecCtx) -> c_int;
     fn fec_generator(ctx: *mut FecCtx, curve: c_int, out: *mut u64) -> c_int;
     fn fec_generator_dev(ctx: *mut FecCtx, curve: c_int) -> *const u64;
     fn fec_batch_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
@@ -97,6 +98,12 @@ impl GpuContext {
     pub fn device_count(&self) -> usize {
         // SAFETY: self.raw is a live ctx.
         unsafe { fec_ctx_device_count(self.raw) as usize }
+    }
+
+    /// `fec_ctx_wipe`: zero every ctx-owned device buffer that can hold copies of caller data.
+    pub fn wipe(&mut self) -> Result<()> {
+        // SAFETY: self.raw is a live ctx.
+        check(unsafe { fec_ctx_wipe(self.raw) })
     }
 
     /// Elements per pipeline chunk of the host-pointer calls (tuning knob; results do not depend on it).

@@ -292,6 +292,39 @@ def test_ed25519_fixed_base_device_path_reuses_table(gpu_ctx, oracle):
         _assert_same(got, oracle.batch_mul_fixed(2, k, base_host, nthreads=8), "ed25519 fixed-base dev path")
 
 
+def test_dev_calls_on_two_streams_share_ctx_scratch_in_call_order(gpu_ctx, oracle):
+    """*_dev calls of ONE ctx issued back to back on two different streams with no host synchronisation
+    in between: the Ed25519 fixed-base path rebuilds and reads the ctx-owned addend table, the P-256 /
+    Ed25519 double-mul writes per-stream scratch.  The library orders a launch after the ctx's previous
+    launch when the stream changes, so every result must still be the oracle's."""
+    import torch
+    n = 20000
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    k = V.scalars(n, 2, 371)
+    bases = V.points(4, 2, 372)
+    dk = torch.from_numpy(k.view(np.int64)).cuda()
+    dbases = [torch.from_numpy(b.view(np.int64)).cuda() for b in bases]
+    outs = [torch.empty((n, 16), dtype=torch.int64, device="cuda") for _ in bases]
+    torch.cuda.synchronize()
+    for i in range(4):  # four different bases, alternating streams: the table is rebuilt under the previous user
+        st = (s1, s2)[i & 1]
+        gpu_ctx.batch_mul_fixed_dev(2, dk.data_ptr(), dbases[i].data_ptr(), outs[i].data_ptr(), n, st.cuda_stream)
+    # double-mul on both streams at once (per-stream scratch)
+    u1, u2 = V.scalars(n, 1, 373), V.scalars(n, 1, 374)
+    q = V.points(n, 1, 375)
+    du1, du2, dq = (torch.from_numpy(a.view(np.int64)).cuda() for a in (u1, u2, q))
+    dd = [torch.empty((n, 12), dtype=torch.int64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    gpu_ctx.batch_double_mul_dev(1, du1.data_ptr(), du2.data_ptr(), dq.data_ptr(), dd[0].data_ptr(), n, s1.cuda_stream)
+    gpu_ctx.batch_double_mul_dev(1, du2.data_ptr(), du1.data_ptr(), dq.data_ptr(), dd[1].data_ptr(), n, s2.cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(4):
+        _assert_same(outs[i].cpu().numpy().view(np.uint64), oracle.batch_mul_fixed(2, k, bases[i], nthreads=16),
+                     "ed25519 fixed-base, call %d of 4 on alternating streams" % i)
+    _assert_same(dd[0].cpu().numpy().view(np.uint64), oracle.batch_double_mul(1, u1, u2, q, nthreads=16), "p256 double-mul s1")
+    _assert_same(dd[1].cpu().numpy().view(np.uint64), oracle.batch_double_mul(1, u2, u1, q, nthreads=16), "p256 double-mul s2")
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_batch_to_affine_matches_oracle(gpu_ctx, oracle, curve):
     """Curve::to_affine with the reference's own field inversion (next row of SURVEY section 8f)."""

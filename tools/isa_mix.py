@@ -109,33 +109,41 @@ def main():
     # any other condition falls through; unconditional branches are followed.  The walk ends at the
     # loop's back edge.
     outer = [h for h in headers if any(h + ":" in l and "Inner" not in l for l in body)]
-    start_pc = max((label_at[h] for h in outer), default=lo) if outer else lo
-    path, pc, steps, scc, first_visit = [], start_pc, 0, None, {}
-    while steps < 400000:
-        if pc in first_visit:  # the cycle closed: one iteration = the walk since the first visit
-            path = path[first_visit[pc]:]
-            break
-        first_visit[pc] = len(path)
-        m, ops = insts[pc]
-        path.append(m)
-        steps += 1
-        if m in ("s_cmp_eq_u64", "s_cmp_lg_u64") and ops.replace(" ", "").endswith(",0"):
-            scc = 1 if m == "s_cmp_eq_u64" else 0
-        elif m.startswith(("s_cmp", "s_add", "s_sub", "s_and", "s_or", "s_xor", "s_lshl", "s_lshr", "s_bitcmp", "s_andn2", "s_orn2", "s_not")):
-            scc = None  # SCC rewritten by something that is not a rare-mask test
-        taken = False
-        if m == "s_branch":
-            taken = True
-        elif m == "s_cbranch_scc0":
-            taken = scc == 0
-        elif m == "s_cbranch_scc1":
-            taken = scc == 1
-        elif m in ("s_cbranch_vccz", "s_cbranch_execnz"):
-            taken = True
-        if taken:
-            pc = label_at[ops.split()[0].rstrip(",")]
-            continue
-        pc += 1
+
+    def walk(start_pc):
+        path, pc, steps, scc, first_visit = [], start_pc, 0, None, {}
+        while steps < 400000:
+            if pc in first_visit:  # the cycle closed: one iteration = the walk since the first visit
+                return path[first_visit[pc]:]
+            first_visit[pc] = len(path)
+            m, ops = insts[pc]
+            path.append(m)
+            steps += 1
+            if m in ("s_cmp_eq_u64", "s_cmp_lg_u64") and ops.replace(" ", "").endswith(",0"):
+                scc = 1 if m == "s_cmp_eq_u64" else 0
+            elif m.startswith(("s_cmp", "s_add", "s_sub", "s_and", "s_or", "s_xor", "s_lshl", "s_lshr", "s_bitcmp", "s_andn2", "s_orn2", "s_not")):
+                scc = None  # SCC rewritten by something that is not a rare-mask test
+            taken = False
+            if m == "s_branch":
+                taken = True
+            elif m == "s_cbranch_scc0":
+                taken = scc == 0
+            elif m == "s_cbranch_scc1":
+                taken = scc == 1
+            elif m in ("s_cbranch_vccz", "s_cbranch_execnz"):
+                taken = True
+            if m.startswith("s_cbranch") and label_at.get(ops.split()[0].rstrip(",")) == start_pc:
+                taken = True  # the loop's own back edge (its condition is the trip counter)
+            if taken:
+                pc = label_at[ops.split()[0].rstrip(",")]
+                continue
+            pc += 1
+            if pc >= len(insts):
+                return []
+        return path
+
+    # the ladder loop = the depth-1 loop whose iteration is longest
+    path = max((walk(label_at[h]) for h in (outer or headers)), key=len, default=[]) or walk(lo)
     hot = collections.Counter(classify(m) for m in path)
     hv = sum(v for k, v in hot.items() if k.startswith("v_"))
     print("hot path of one iteration (rare masks = 0): %d instructions, %d VALU" % (len(path), hv))
