@@ -227,6 +227,85 @@ FEC_DEV fe inv(const fe& a) {
   return result;
 }
 
+// ---- point decoding ----
+// inherent pow (410-431) with a constant (wave-uniform) exponent: the products of clear bits are
+// computed and discarded by the reference; only the kept ones are formed here
+FEC_DEV fe pow_lsb(const fe& a, const u64 (&e)[4]) {
+  fe result = fe_small(1), base = a;
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+      if ((e[w] >> i) & 1) result = mul(result, base);
+      base = sqr_exact(base);
+    }
+  }
+  return result;
+}
+// FieldElement::from_bytes (315-357) on the little-endian value: the comparison loop returns None as
+// soon as ANY 64-bit limb exceeds the same limb of p (346-348), whatever the higher limbs decided;
+// otherwise valid iff value < p.  p's limbs 1..2 are all ones, so only limb 0 (> 2^64 - 19) and limb 3
+// (> 2^63 - 1) can exceed.
+FEC_DEV lmask value_valid(const fe& v) {
+  lmask gt0 = lanes_where(v.w[1] == 0xFFFFFFFFu && v.w[0] > 0xFFFFFFEDu);
+  lmask gt3 = lanes_where((v.w[7] >> 31) != 0);
+  // value < p  <=>  value + 19 < 2^255 (for values below 2^255)
+  fe t;
+  lmask c;
+  FEC_ADDK256(t, v, c, 19, 0, 0, 0, 0, 0, 0, 0);
+  lmask lt = lanes_where((t.w[7] >> 31) == 0) & ~c;
+  return lt & ~gt0 & ~gt3;
+}
+FEC_DEV fe SQRT_M1_() {  // 132-137
+  fe s;
+  s.w[0] = 0x4A0EA0B0u; s.w[1] = 0xC4EE1B27u; s.w[2] = 0xAD2FE478u; s.w[3] = 0x2F431806u;
+  s.w[4] = 0x3DFBD7A7u; s.w[5] = 0x2B4D0099u; s.w[6] = 0x4FC1DF0Bu; s.w[7] = 0x2B832480u;
+  return s;
+}
+// inherent sqrt (359-402)
+FEC_DEV fe sqrt_inherent(const fe& a, lmask& valid) {
+  const u64 e1[4] = {0x7FFFFFFFFFFFFFF6ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0x3FFFFFFFFFFFFFFFULL};
+  const u64 e2[4] = {0x1FFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0x0FFFFFFFFFFFFFFFULL};
+  fe leg = pow_lsb(a, e1);
+  lmask is_qr = fe_eq(leg, fe_small(1)) | fe_is_zero(leg);
+  fe cand = pow_lsb(a, e2);
+  lmask ok1 = fe_eq(sqr_exact(cand), a);
+  fe alt = mul(cand, SQRT_M1_());
+  lmask ok2 = fe_eq(sqr_exact(alt), a);
+  valid = is_qr & (ok1 | ok2);
+  return fe_select(cand, alt, uniform_mask(ok2));
+}
+// PointAffine::from_bytes (1526-1582) after the prefix tests: the MONTGOMERY-curve equation
+// x^3 + a x^2 + x with a = 0x7FFFFFDA is what the reference evaluates
+FEC_DEV lmask decompress(const fe& xv, lmask want_odd, fe& x, fe& y) {
+  x = xv;
+  lmask valid = value_valid(xv);
+  fe x2 = sqr_exact(x);
+  fe x3 = mul(x2, x);
+  fe y2 = add(add(x3, mul(fe_small(0x7FFFFFDAu), x2)), x);
+  lmask is_sqrt;
+  fe r = sqrt_inherent(y2, is_sqrt);
+  fe red = reduce(r);                                // to_bytes: reduce(), little-endian -> byte 31 is the top byte
+  lmask parity = lanes_where(((red.w[7] >> 24) & 1u) != 0);
+  y = fe_select(r, neg(r), uniform_mask(parity ^ want_odd));
+  return valid & is_sqrt;
+}
+// UncompressedPoint::to_affine (point.rs:214-281) for C = Ed25519, then PointAffine::new (1476-1498)
+FEC_DEV lmask decode_uncompressed(const fe& xv, const fe& yv, fe& x, fe& y) {
+  x = xv;
+  y = yv;
+  lmask v = value_valid(xv) & value_valid(yv);
+  fe a = fe_zero();  // get_a() exactly as written (2107-2110)
+  a.w[0] = 0xFFFFFFEDu; a.w[1] = 0x7FFFFFFFu; a.w[2] = 0xFFFFFFFFu; a.w[3] = 0x0007FFFFu;
+  fe x3 = mul(mul(x, x), x);
+  fe rhs = add(add(x3, mul(a, x)), fe_zero());       // get_b() = zero
+  lmask eq1 = fe_eq(mul(y, y), rhs);
+  fe x2 = sqr_exact(x), y2 = sqr_exact(y);
+  fe lhs = add(neg(x2), y2);
+  fe rh2 = add(fe_small(1), mul(D_(), mul(x2, y2)));
+  return v & eq1 & fe_eq(lhs, rh2);
+}
+
 // to_affine (1793-1811): x = X * Z^-1, y = Y * Z^-1; identity -> (0, 0, infinity).
 FEC_DEV lmask to_affine(const pt& p, fe& x, fe& y) {
   lmask inf = is_identity(p);

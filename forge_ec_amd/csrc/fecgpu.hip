@@ -1301,6 +1301,86 @@ int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const 
   });
 }
 
+// decode entry points: in -> (xy, inf, ok).  The device writes inf and ok into one staging area
+// (inf at [0, cnt), ok at [chunk, chunk + cnt)), so host_chunked's two output slots suffice.
+static int decode_host(fec_ctx* ctx, int op, fec_curve curve, const uint8_t* in, size_t in_stride, uint64_t* xy,
+                       uint8_t* inf, uint8_t* ok, size_t n) {
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  const size_t chunk = ctx->chunk < n ? ctx->chunk : n;
+  for (size_t lo = 0; lo < n; lo += chunk) {
+    const size_t cnt = lo + chunk <= n ? chunk : n - lo;
+    int rc = ensure(ctx, 0, chunk * in_stride);
+    if (rc == FEC_OK) rc = ensure(ctx, 4, chunk * 64);
+    if (rc == FEC_OK) rc = ensure(ctx, 5, chunk * 2);
+    if (rc != FEC_OK) return rc;
+    if (hipMemcpyAsync(ctx->d_buf[0], in + lo * in_stride, cnt * in_stride, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+    unsigned char* flags = (unsigned char*)ctx->d_buf[5];
+    {
+      Launch L(ctx, nullptr, op == 0 ? "k_decompress" : "k_decode_uncompressed");
+      codec_launch(op, curve, ctx->d_buf[0], nullptr, ctx->d_buf[4], flags, flags + chunk, cnt, L.s);
+      rc = L.done();
+      if (rc != FEC_OK) return rc;
+    }
+    if (hipMemcpyAsync(xy + lo * 8, ctx->d_buf[4], cnt * 64, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(inf + lo, flags, cnt, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(ok + lo, flags + chunk, cnt, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return FEC_E_LAUNCH;
+    }
+  }
+  return FEC_OK;
+}
+
+int fec_batch_decompress(fec_ctx* ctx, fec_curve curve, const uint8_t* in, uint64_t* xy, uint8_t* inf, uint8_t* ok,
+                         size_t n) {
+  if (is_multi(ctx)) {
+    if (!curve_ok(curve) || (n && (!in || !xy || !inf || !ok))) return FEC_E_ARG;
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_batch_decompress(c, curve, in + lo * 33, xy + lo * 8, inf + lo, ok + lo, cnt);
+    });
+  }
+  if (!ctx || !curve_ok(curve) || (n && (!in || !xy || !inf || !ok))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  return decode_host(ctx, 0, curve, in, 33, xy, inf, ok, n);
+}
+
+int fec_batch_decode_uncompressed(fec_ctx* ctx, fec_curve curve, const uint8_t* in, uint64_t* xy, uint8_t* inf,
+                                  uint8_t* ok, size_t n) {
+  if (is_multi(ctx)) {
+    if (!curve_ok(curve) || (n && (!in || !xy || !inf || !ok))) return FEC_E_ARG;
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_batch_decode_uncompressed(c, curve, in + lo * 65, xy + lo * 8, inf + lo, ok + lo, cnt);
+    });
+  }
+  if (!ctx || !curve_ok(curve) || (n && (!in || !xy || !inf || !ok))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  return decode_host(ctx, 1, curve, in, 65, xy, inf, ok, n);
+}
+
+int fec_batch_encode_uncompressed(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* out,
+                                  size_t n) {
+  if (is_multi(ctx)) {
+    if (!curve_ok(curve) || (n && (!xy || !out))) return FEC_E_ARG;
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_batch_encode_uncompressed(c, curve, xy + lo * 8, inf ? inf + lo : nullptr, out + lo * 65, cnt);
+    });
+  }
+  if (!ctx || !curve_ok(curve) || (n && (!xy || !out))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  const void* const in[4] = {xy, inf, nullptr, nullptr};
+  const size_t in_stride[4] = {64, 1, 0, 0};
+  void* const outs[2] = {out, nullptr};
+  const size_t out_stride[2] = {65, 0};
+  return host_chunked(ctx, n, in, in_stride, outs, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
+    Launch L(ctx, nullptr, "k_encode_uncompressed");
+    codec_launch(2, curve, d[0], d[1], o[0], nullptr, nullptr, cnt, L.s);
+    return L.done();
+  });
+}
+
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
                             uint8_t* d_inf, size_t n, void* stream) {
   if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device

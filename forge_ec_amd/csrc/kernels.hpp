@@ -16,4 +16,10 @@ void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hi
 // kernels_secp.hip: secp256k1 Curve::multiply, lane-per-element ladder at three wavefronts per SIMD.
 void secp_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
 
+// kernels_codec.hip: op 0 = PointAffine::from_bytes (in: n*33 bytes -> out xy, out2 inf, out3 ok),
+// op 1 = UncompressedPoint::to_affine (in: n*65 bytes -> xy, inf, ok), op 2 = UncompressedPoint::from_affine
+// (in xy, in2 inf or null -> out n*65 bytes)
+void codec_launch(int op, int curve, const void* in, const void* in2, void* out, void* out2, void* out3, size_t n,
+                  hipStream_t s);
+
 }  // namespace fecgpu

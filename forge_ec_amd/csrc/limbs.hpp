@@ -373,7 +373,7 @@ FEC_DEV lmask uniform_mask(lmask m) {
 // this lane's bit of a lane mask.  Goes through word_select so that the mask stays in SGPRs: a
 // 64-bit shift by the lane id would let the compiler move the whole mask computation to the VALU,
 // and the "s" operands of the asm selects above would then be handed VGPRs.
-FEC_DEV bool lane_of(lmask m) { return word_select(0u, 1u, m) != 0; }
+FEC_DEV bool lane_of(lmask m) { return word_select(0u, 1u, uniform_mask(m)) != 0; }
 
 // one level of indirection so that a constant list passed as a single macro (FEC_SECP_C, ...)
 // is expanded before it is split into k0..k7

@@ -272,6 +272,69 @@ FEC_DEV fe inv(const fe& a) {
   return fe_select(result, fe_zero(), fe_is_zero(a));
 }
 
+// ---- point decoding ----
+FEC_DEV fe B_() {  // 28-33
+  fe b;
+  b.w[0] = 0x27D2604Bu; b.w[1] = 0x3BCE3C3Eu; b.w[2] = 0xCC53B0F6u; b.w[3] = 0x651D06B0u;
+  b.w[4] = 0x769886BCu; b.w[5] = 0xB3EBBD55u; b.w[6] = 0xAA3A93E7u; b.w[7] = 0x5AC635D8u;
+  return b;
+}
+// pow (376-393), LSB first, with a constant (wave-uniform) exponent
+FEC_DEV fe pow_lsb(const fe& a, const u64 (&e)[4]) {
+  fe result = fe_small(1), base = a;
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+      if ((e[w] >> i) & 1) result = mul(result, base);
+      base = sqr(base);
+    }
+  }
+  return result;
+}
+// FieldElement::from_bytes (303-317): the value itself, valid iff < p
+FEC_DEV lmask value_lt_p(const fe& v) {
+  fe t;
+  lmask borrow;
+  FEC_SUBK256(t, v, borrow, FEC_P256_P);
+  return borrow;
+}
+// x^3 - 3x + b exactly as PointAffine::new (1536-1543) and from_bytes (1612-1618) spell it
+FEC_DEV fe curve_rhs(const fe& x) {
+  fe x3 = mul(sqr(x), x);
+  fe three_x = mul(fe_small(3), x);
+  return add(sub(x3, three_x), B_());
+}
+// inherent sqrt (320-339) with the reference's own exponent
+FEC_DEV fe sqrt_inherent(const fe& a, lmask& is_sqrt) {
+  const u64 e[4] = {0xC0000000ULL, 0x40000000ULL, 0x4000000000000000ULL, 0x40000000C0000000ULL};
+  fe s = pow_lsb(a, e);
+  is_sqrt = fe_eq(sqr(s), a);
+  return s;
+}
+// PointAffine::from_bytes (1580-1639) after the prefix tests; no curve check at the end (1638)
+FEC_DEV lmask decompress(const fe& xv, lmask want_odd, fe& x, fe& y) {
+  x = xv;
+  lmask valid = value_lt_p(xv);
+  lmask is_sqrt;
+  fe r = sqrt_inherent(curve_rhs(x), is_sqrt);
+  lmask parity = lanes_where((r.w[0] & 1u) != 0);   // to_bytes (288-300) is the raw limbs
+  y = fe_select(r, neg(r), uniform_mask(parity ^ want_odd));
+  return valid & is_sqrt;
+}
+// UncompressedPoint::to_affine (point.rs:214-281) for C = P256, then PointAffine::new (1535-1552)
+FEC_DEV lmask decode_uncompressed(const fe& xv, const fe& yv, fe& x, fe& y) {
+  x = xv;
+  y = yv;
+  lmask v = value_lt_p(xv) & value_lt_p(yv);
+  fe a;  // get_a() exactly as written (2177-2180): 64-bit limbs holding 32-bit patterns
+  a.w[0] = 0xFFFFFFFCu; a.w[1] = 0; a.w[2] = 0xFFFFFFFFu; a.w[3] = 0; a.w[4] = 0xFFFFFFFEu; a.w[5] = 0;
+  a.w[6] = 0xFFFFFFFFu; a.w[7] = 0;
+  fe x3 = mul(mul(x, x), x);
+  fe rhs = add(add(x3, mul(a, x)), B_());
+  return v & fe_eq(mul(y, y), rhs) & fe_eq(sqr(y), curve_rhs(x));
+}
+
 // to_affine (1835-1857)
 FEC_DEV lmask to_affine(const pt& p, fe& x, fe& y) {
   lmask inf = is_identity(p);

@@ -482,6 +482,74 @@ FEC_DEV lmask to_affine(const pt& p, fe& x, fe& y) {
   return inf;
 }
 
+// ---- point decoding: FieldElement::from_bytes / sqrt / PointAffine::{new, from_bytes} ----
+// to_montgomery (219-235): Mul by the reference's R_SQUARED constant
+FEC_DEV fe to_montgomery(const fe& a) {
+  fe r2 = fe_zero();
+  r2.w[0] = 0x000E9F61u; r2.w[2] = 0x07A20000u; r2.w[4] = 0x00000100u;
+  return mul(a, r2);
+}
+// FieldElement::from_bytes (182-212) on the VALUE (big-endian bytes already assembled into limbs):
+// valid iff value < p; Some(to_montgomery(value)), or zero when invalid
+FEC_DEV fe from_value(const fe& v, lmask& valid) {
+  fe t;
+  lmask ov;
+  FEC_ADDK256(t, v, ov, FEC_SECP_C);  // v >= p  <=>  v + c carries out of 2^256
+  valid = ~ov;
+  return fe_select(fe_zero(), to_montgomery(v), uniform_mask(valid));
+}
+// trait pow (715-735): LSB first over 64-bit limbs; `result *= base` on set bits, `base = base.square()`.
+// The exponents are compile-time constants of the reference, so every branch is wave-uniform.
+FEC_DEV fe pow_lsb(const fe& a, const u64 (&e)[4]) {
+  fe result = fe_small(1), base = a;
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+    for (int j = 0; j < 64; ++j) {
+      if ((e[w] >> j) & 1) result = mul(result, base);
+      base = sqr(base);
+    }
+  }
+  return result;
+}
+// inherent FieldElement::sqrt (112-131): the exponent is (p+1)/4 written as FOUR 16-BIT WORDS into
+// 64-bit limbs, so sqrt^2 == self fails for essentially every input; reproduced as is
+FEC_DEV fe sqrt_inherent(const fe& a, lmask& is_sqrt) {
+  const u64 e[4] = {0xFF0CULL, 0xFFFFULL, 0xFFFEULL, 0x3FFFULL};
+  fe s = pow_lsb(a, e);
+  is_sqrt = fe_eq(sqr(s), a);
+  return s;
+}
+// PointAffine::new (856-869) / is_on_curve (978-1004): y.square() == x.square() * x + to_montgomery(7)
+FEC_DEV lmask affine_on_curve(const fe& x, const fe& y) {
+  fe rhs = add(mul(sqr(x), x), to_montgomery(fe_small(7)));
+  return fe_eq(sqr(y), rhs);
+}
+// PointAffine::from_bytes (896-976) after the prefix tests: xv = the 32 x bytes as a value.
+// Returns the lanes that yield Some(point).
+FEC_DEV lmask decompress(const fe& xv, lmask want_odd, fe& x, fe& y) {
+  lmask valid;
+  x = from_value(xv, valid);
+  fe y2 = add(mul(sqr(x), x), fe_small(7));   // the RAW seven (935)
+  lmask is_sqrt;
+  fe ye = sqrt_inherent(y2, is_sqrt);
+  fe yo = neg(ye);
+  fe red = mul(ye, fe_small(1));               // to_bytes: mont_reduce; byte 31 = least significant byte
+  lmask parity = lanes_where((red.w[0] & 1u) != 0);
+  y = fe_select(ye, yo, uniform_mask(want_odd ^ parity));
+  return valid & is_sqrt & affine_on_curve(x, y);
+}
+// forge-ec-encoding UncompressedPoint::to_affine (point.rs:214-281) for C = Secp256k1
+FEC_DEV lmask decode_uncompressed(const fe& xv, const fe& yv, fe& x, fe& y) {
+  lmask vx, vy;
+  x = from_value(xv, vx);
+  y = from_value(yv, vy);
+  fe x3 = mul(mul(x, x), x);                   // `x * x`, not square() (251-252)
+  fe ax = mul(fe_zero(), x);                   // get_a() = zero (2712-2715)
+  fe rhs = add(add(x3, ax), fe_small(7));      // get_b() = raw 7 (2717-2720)
+  return vx & vy & fe_eq(mul(y, y), rhs) & affine_on_curve(x, y);
+}
+
 // Bit i of the ladder (2655-2659): byte i/8 of the little-endian bytes, MSB first in the byte.
 FEC_DEV u32 ladder_bit(const u32* kw, int i) {
   u32 w = kw[(i >> 5) * KSTRIDE];

@@ -155,6 +155,35 @@ class Context:
         _check(self._lib.fec_batch_compress(self._h, curve, _ptr(p), _ptr(fl), _ptr(out), n), "fec_batch_compress")
         return out
 
+    def _decode(self, fn, what, curve, data, width):
+        b = np.ascontiguousarray(np.asarray(data, dtype=np.uint8)).reshape(-1, width)
+        n = b.shape[0]
+        xy = np.zeros((n, 8), dtype=np.uint64)
+        inf, ok = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        _check(fn(self._h, curve, _ptr(b), _ptr(xy), _ptr(inf), _ptr(ok), n), what)
+        return xy, inf, ok
+
+    def batch_decompress(self, curve, data33):
+        """PointAffine::from_bytes of each 33-byte encoding -> (xy (n,8), infinity (n,), ok (n,)); ok = 0 where
+        the reference returns None."""
+        return self._decode(self._lib.fec_batch_decompress, "fec_batch_decompress", curve, data33, 33)
+
+    def batch_decode_uncompressed(self, curve, data65):
+        """forge-ec-encoding UncompressedPoint::to_affine of each 65-byte encoding."""
+        return self._decode(self._lib.fec_batch_decode_uncompressed, "fec_batch_decode_uncompressed", curve, data65, 65)
+
+    def batch_encode_uncompressed(self, curve, xy, inf=None):
+        """UncompressedPoint::from_affine -> (n, 65) uint8."""
+        p = _u64(xy, 8)
+        n = p.shape[0]
+        fl = np.ascontiguousarray(np.asarray(inf, dtype=np.uint8)).reshape(-1) if inf is not None else None
+        if fl is not None and fl.shape[0] != n:
+            raise ValueError("flags and points differ in length")
+        out = np.zeros((n, 65), dtype=np.uint8)
+        _check(self._lib.fec_batch_encode_uncompressed(self._h, curve, _ptr(p), _ptr(fl), _ptr(out), n),
+               "fec_batch_encode_uncompressed")
+        return out
+
     def schnorr_batch_verify_secp256k1(self, pk_xy, r_xy, s, a, e, pk_inf=None, r_inf=None):
         """schnorr::batch_verify::<Secp256k1, D> (schnorr.rs:194-290), challenges e and weights a supplied.
         -> (result bool, sides (16,) uint64 = x,y of both affine sums, sides_inf (2,) uint8)."""

@@ -149,6 +149,24 @@ int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests /* n*32 */, 
 /* xy: n*8 limbs (x then y, e.g. from fec_batch_to_affine), inf: n flags or NULL (all finite), out: n*33 bytes */
 int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* out,
                        size_t n);
+/* ---- point decoding, and the uncompressed (65-byte) form both ways ----
+ * ok[i] = 1 where the reference returns Some(point), 0 where it returns None (xy[i] and inf[i] are then
+ * zero); inf[i] = 1 for the identity.  Everything is the reference's own arithmetic, including the
+ * parts that make most inputs decode to None:
+ *   fec_batch_decompress          PointAffine::from_bytes(&[u8; 33]) -- secp256k1.rs:896-976 (its
+ *                                 FieldElement::sqrt raises to (p+1)/4 written as 16-bit words, 112-131),
+ *                                 p256.rs:1580-1639, ed25519.rs:1526-1582 (evaluates the Montgomery-curve
+ *                                 equation; FieldElement::from_bytes rejects any limb above p's, 315-357)
+ *   fec_batch_encode_uncompressed UncompressedPoint::from_affine, forge-ec-encoding/src/point.rs:186-211:
+ *                                 0x04 || x.to_bytes() || y.to_bytes(), 65 zero bytes for the identity
+ *   fec_batch_decode_uncompressed UncompressedPoint::to_affine, point.rs:214-281 (C::Field::from_bytes,
+ *                                 x*x*x + a*x + b with the curve's get_a / get_b, then C::PointAffine::new) */
+int fec_batch_decompress(fec_ctx* ctx, fec_curve curve, const uint8_t* in /* n*33 */, uint64_t* xy /* n*8 */,
+                         uint8_t* inf /* n */, uint8_t* ok /* n */, size_t n);
+int fec_batch_encode_uncompressed(fec_ctx* ctx, fec_curve curve, const uint64_t* xy /* n*8 */,
+                                  const uint8_t* inf /* n or NULL */, uint8_t* out /* n*65 */, size_t n);
+int fec_batch_decode_uncompressed(fec_ctx* ctx, fec_curve curve, const uint8_t* in /* n*65 */, uint64_t* xy /* n*8 */,
+                                  uint8_t* inf /* n */, uint8_t* ok /* n */, size_t n);
 /* *result = 1 if the reference's batch_verify returns true for these inputs, else 0.  pk_xy / r_xy:
  * AffinePoint x, y raw limbs (n*8), pk_inf / r_inf their infinity flags (may be NULL = all finite);
  * s, a, e: Scalar::to_raw() limbs (n*4).  sides_xy (16 limbs, may be NULL) receives x, y of

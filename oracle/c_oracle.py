@@ -72,6 +72,11 @@ def lib():
         L.fo_secp256k1_schnorr_batch_verify.restype = ctypes.c_int
         L.fo_batch_compress.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t]
         L.fo_batch_compress.restype = None
+        for name in ("fo_batch_decompress", "fo_batch_decode_uncompressed"):
+            getattr(L, name).argtypes = [ctypes.c_int, p, p, p, p, ctypes.c_size_t]
+            getattr(L, name).restype = None
+        L.fo_batch_encode_uncompressed.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t]
+        L.fo_batch_encode_uncompressed.restype = None
         _lib = L
     return _lib
 
@@ -230,3 +235,33 @@ def batch_compress(curve, xy, inf=None):
     out = np.zeros((n, 33), dtype=np.uint8)
     lib().fo_batch_compress(curve, _ptr(xy), _ptr(fl) if fl is not None else None, _ptr(out), n)
     return out
+
+
+def _bytes(a, width):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint8)).reshape(-1, width)
+
+
+def batch_decompress(curve, data33):
+    """PointAffine::from_bytes per element -> (xy (n,8), inf (n,), ok (n,))."""
+    b = _bytes(data33, 33)
+    n = b.shape[0]
+    xy, inf, ok = np.zeros((n, 8), dtype=np.uint64), np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    lib().fo_batch_decompress(curve, _ptr(b), _ptr(xy), _ptr(inf), _ptr(ok), n)
+    return xy, inf, ok
+
+
+def batch_encode_uncompressed(curve, xy, inf=None):
+    p = _u64(xy).reshape(-1, 8)
+    n = p.shape[0]
+    fl = np.ascontiguousarray(np.asarray(inf, dtype=np.uint8)) if inf is not None else None
+    out = np.zeros((n, 65), dtype=np.uint8)
+    lib().fo_batch_encode_uncompressed(curve, _ptr(p), _ptr(fl) if fl is not None else None, _ptr(out), n)
+    return out
+
+
+def batch_decode_uncompressed(curve, data65):
+    b = _bytes(data65, 65)
+    n = b.shape[0]
+    xy, inf, ok = np.zeros((n, 8), dtype=np.uint64), np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    lib().fo_batch_decode_uncompressed(curve, _ptr(b), _ptr(xy), _ptr(inf), _ptr(ok), n)
+    return xy, inf, ok

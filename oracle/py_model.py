@@ -874,6 +874,148 @@ def compress(curve, x, y, inf=False):
     return bytes([0x03 if yb[31] & 1 else 0x02]) + fb(list(x))
 
 
+def to_bytes_field(curve, a):
+    """FieldElement::to_bytes: secp256k1 mont_reduce + big-endian (138-178); P-256 raw limbs big-endian
+    (288-300); Ed25519 reduce() + little-endian (295-310)."""
+    a = list(a)
+    if curve == SECP256K1:
+        a = Secp.mul(a, [1, 0, 0, 0])
+    elif curve == ED25519:
+        a = Ed.reduce(a)
+    v = sum(int(a[i]) << (64 * i) for i in range(4))
+    return v.to_bytes(32, "little" if curve == ED25519 else "big")
+
+
+def field_from_bytes(curve, b):
+    """FieldElement::from_bytes(&[u8; 32]) -> (limbs, valid): secp256k1.rs:182-212, p256.rs:303-317,
+    ed25519.rs:315-357."""
+    if curve == SECP256K1:
+        v = int.from_bytes(b, "big")
+        l = [(v >> (64 * i)) & M64 for i in range(4)]
+        valid = Secp.cmp_p(l) < 0
+        mont = Secp.mul(l, [0x000E9F61, 0x07A20000, 0x00000100, 0])  # to_montgomery (219-235)
+        return (mont if valid else [0, 0, 0, 0]), valid
+    if curve == P256:
+        v = int.from_bytes(b, "big")
+        l = [(v >> (64 * i)) & M64 for i in range(4)]
+        return l, P256c.cmp(l, P256c.P) < 0
+    l = [int.from_bytes(b[8 * i:8 * i + 8], "little") for i in range(4)]
+    is_less, is_equal = False, True
+    for i in (3, 2, 1, 0):  # 335-349: the `gt` early return fires whatever the higher limbs decided
+        lt, eq, gt = l[i] < Ed.P[i], l[i] == Ed.P[i], l[i] > Ed.P[i]
+        is_less = is_less or (is_equal and lt)
+        is_equal = is_equal and eq
+        if gt:
+            return [0, 0, 0, 0], False
+    return l, is_less
+
+
+def _secp_pow(a, e):  # trait pow, secp256k1.rs:715-735 (LSB first, result *= base, base = base.square())
+    result, base = [1, 0, 0, 0], list(a)
+    for w in e:
+        for j in range(64):
+            if (w >> j) & 1:
+                result = Secp.mul(result, base)
+            base = Secp.sqr(base)
+    return result
+
+
+def _secp_on_curve(x, y):  # PointAffine::new 856-869 / is_on_curve 978-1004
+    seven_m = Secp.mul([7, 0, 0, 0], [0x000E9F61, 0x07A20000, 0x00000100, 0])
+    return Secp.sqr(y) == Secp.add(Secp.mul(Secp.sqr(x), x), seven_m)
+
+
+P256_B = [0x3BCE3C3E27D2604B, 0x651D06B0CC53B0F6, 0xB3EBBD55769886BC, 0x5AC635D8AA3A93E7]  # p256.rs:28-33
+
+
+def _p256_rhs(x):  # x^3 - 3x + b as spelled at 1536-1543 and 1612-1618
+    x3 = P256c.mul(P256c.sqr(x), x)
+    return P256c.add(P256c.sub(x3, P256c.mul([3, 0, 0, 0], x)), P256_B)
+
+
+ED_SQRT_M1 = [0xC4EE1B274A0EA0B0, 0x2F431806AD2FE478, 0x2B4D00993DFBD7A7, 0x2B8324804FC1DF0B]  # ed25519.rs:132-137
+
+
+def _ed_sqrt(a):  # ed25519.rs:359-402
+    leg = Ed.pow(a, [0x7FFFFFFFFFFFFFF6, M64, M64, 0x3FFFFFFFFFFFFFFF])
+    if leg != [1, 0, 0, 0] and leg != [0, 0, 0, 0]:
+        return None
+    cand = Ed.pow(a, [0x1FFFFFFFFFFFFFFF, M64, M64, 0x0FFFFFFFFFFFFFFF])
+    ok1 = Ed.sqr(cand) == list(a)
+    alt = Ed.mul(cand, ED_SQRT_M1)
+    ok2 = Ed.sqr(alt) == list(a)
+    return (alt if ok2 else cand) if (ok1 or ok2) else None
+
+
+def decompress(curve, b):
+    """PointAffine::from_bytes(&[u8; 33]) -> None, or (x, y, infinity): secp256k1.rs:896-976,
+    p256.rs:1580-1639, ed25519.rs:1526-1582."""
+    if b[0] == 0x00:
+        return [0, 0, 0, 0], [0, 0, 0, 0], True
+    if b[0] not in (2, 3):
+        return None
+    x, valid = field_from_bytes(curve, b[1:33])
+    if not valid:
+        return None
+    want_odd = b[0] == 3
+    if curve == SECP256K1:
+        y2 = Secp.add(Secp.mul(Secp.sqr(x), x), [7, 0, 0, 0])     # raw seven (935)
+        s = _secp_pow(y2, [0xFF0C, 0xFFFF, 0xFFFE, 0x3FFF])      # inherent sqrt (112-131)
+        if Secp.sqr(s) != y2:
+            return None
+        parity = to_bytes_field(curve, s)[31] & 1
+        y = Secp.neg(s) if (want_odd != bool(parity)) else s
+        return (x, y, False) if _secp_on_curve(x, y) else None
+    if curve == P256:
+        y2 = _p256_rhs(x)
+        s = P256c.pow(y2, [0xC0000000, 0x40000000, 0x4000000000000000, 0x40000000C0000000])  # 320-339
+        if P256c.sqr(s) != y2:
+            return None
+        parity = to_bytes_field(curve, s)[31] & 1
+        return x, (P256c.neg(s) if (bool(parity) != want_odd) else s), False
+    x2 = Ed.sqr(x)
+    y2 = Ed.add(Ed.add(Ed.mul(x2, x), Ed.mul([0x7FFFFFDA, 0, 0, 0], x2)), x)
+    s = _ed_sqrt(y2)
+    if s is None:
+        return None
+    parity = to_bytes_field(curve, s)[31] & 1
+    return x, (Ed.neg(s) if (bool(parity) != want_odd) else s), False
+
+
+def encode_uncompressed(curve, x, y, inf=False):
+    """UncompressedPoint::from_affine (forge-ec-encoding/src/point.rs:186-211)."""
+    if inf:
+        return bytes(65)
+    return bytes([4]) + to_bytes_field(curve, x) + to_bytes_field(curve, y)
+
+
+def decode_uncompressed(curve, b):
+    """UncompressedPoint::to_affine (point.rs:214-281) -> None, or (x, y, infinity)."""
+    if b[0] == 0x00:
+        return [0, 0, 0, 0], [0, 0, 0, 0], True
+    if b[0] != 0x04:
+        return None
+    x, vx = field_from_bytes(curve, b[1:33])
+    y, vy = field_from_bytes(curve, b[33:65])
+    if not (vx and vy):
+        return None
+    F = CURVES[curve]
+    a = {SECP256K1: [0, 0, 0, 0], P256: [0xFFFFFFFC, 0xFFFFFFFF, 0xFFFFFFFE, 0xFFFFFFFF],
+         ED25519: [0x7FFFFFFFFFFFFFED, 0x7FFFFFFFFFFFF, 0, 0]}[curve]          # get_a() as written
+    bb = {SECP256K1: [7, 0, 0, 0], P256: P256_B, ED25519: [0, 0, 0, 0]}[curve]  # get_b()
+    x3 = F.mul(F.mul(x, x), x)                                                 # `x * x`, then `* x` (251-252)
+    if F.mul(y, y) != F.add(F.add(x3, F.mul(a, x)), bb):
+        return None
+    if curve == SECP256K1:
+        on = _secp_on_curve(x, y)
+    elif curve == P256:
+        on = P256c.sqr(y) == _p256_rhs(x)                                      # PointAffine::new 1535-1552
+    else:                                                                      # ed25519.rs:1476-1498
+        x2, y2 = Ed.sqr(x), Ed.sqr(y)
+        on = Ed.add(Ed.neg(x2), y2) == Ed.add([1, 0, 0, 0], Ed.mul(Ed.D, Ed.mul(x2, y2)))
+    return (x, y, False) if on else None
+
+
 CURVES = {SECP256K1: Secp, P256: P256c, ED25519: Ed}
 
 

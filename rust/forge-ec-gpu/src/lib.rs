@@ -35,6 +35,9 @@ extern "C" {
     fn fec_multi_scalar_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
     fn fec_ecdsa_verify_secp256k1(ctx: *mut FecCtx, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, status: *mut u8, n: usize) -> c_int;
     fn fec_batch_compress(ctx: *mut FecCtx, curve: c_int, xy: *const u64, inf: *const u8, out: *mut u8, n: usize) -> c_int;
+    fn fec_batch_decompress(ctx: *mut FecCtx, curve: c_int, r#in: *const u8, xy: *mut u64, inf: *mut u8, ok: *mut u8, n: usize) -> c_int;
+    fn fec_batch_encode_uncompressed(ctx: *mut FecCtx, curve: c_int, xy: *const u64, inf: *const u8, out: *mut u8, n: usize) -> c_int;
+    fn fec_batch_decode_uncompressed(ctx: *mut FecCtx, curve: c_int, r#in: *const u8, xy: *mut u64, inf: *mut u8, ok: *mut u8, n: usize) -> c_int;
     fn fec_schnorr_batch_verify_secp256k1(ctx: *mut FecCtx, pk_xy: *const u64, pk_inf: *const u8, r_xy: *const u64, r_inf: *const u8, s: *const u64, a: *const u64, e: *const u64, n: usize, result: *mut u8, sides_xy: *mut u64, sides_inf: *mut u8) -> c_int;
     fn fec_field_op(ctx: *mut FecCtx, curve: c_int, op: c_int, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
     fn fec_point_op(ctx: *mut FecCtx, curve: c_int, op: c_int, p: *const u64, q: *const u64, out: *mut u64, n: usize) -> c_int;
@@ -281,6 +284,40 @@ pub fn batch_compress<C: GpuCurve>(ctx: &mut GpuContext, points: &[C::PointAffin
     // SAFETY: as above.
     check(unsafe { fec_batch_compress(ctx.raw, C::ID, xy.as_ptr(), inf.as_ptr(), out.as_mut_ptr(), n) })?;
     Ok(out.chunks_exact(33).map(|c| <[u8; 33]>::try_from(c).unwrap()).collect())
+}
+
+/// `PointAffine::from_bytes` of every 33-byte encoding (`secp256k1.rs:896-976`, `p256.rs:1580-1639`,
+/// `ed25519.rs:1526-1582`): `None` exactly where the reference returns `None`.
+pub fn batch_decompress<C: GpuCurve>(ctx: &mut GpuContext, encoded: &[[u8; 33]]) -> Result<Vec<Option<C::PointAffine>>> {
+    let n = encoded.len();
+    let (mut xy, mut inf, mut ok) = (vec![0u64; 8 * n], vec![0u8; n], vec![0u8; n]);
+    // SAFETY: `encoded` is n contiguous 33-byte arrays; the outputs hold n elements each.
+    check(unsafe { fec_batch_decompress(ctx.raw, C::ID, encoded.as_ptr().cast(), xy.as_mut_ptr(), inf.as_mut_ptr(), ok.as_mut_ptr(), n) })?;
+    Ok((0..n).map(|i| (ok[i] != 0).then(|| C::affine_from_limbs(&xy[8 * i..8 * i + 8], inf[i] != 0))).collect())
+}
+
+/// `UncompressedPoint::from_affine` (`forge-ec-encoding/src/point.rs:186-211`): 65 bytes per point.
+pub fn batch_encode_uncompressed<C: GpuCurve>(ctx: &mut GpuContext, points: &[C::PointAffine]) -> Result<Vec<[u8; 65]>> {
+    let n = points.len();
+    let (mut xy, mut inf) = (vec![0u64; 8 * n], vec![0u8; n]);
+    for (i, a) in points.iter().enumerate() {
+        let (l, f) = C::affine_limbs(a);
+        xy[8 * i..8 * i + 8].copy_from_slice(&l);
+        inf[i] = f as u8;
+    }
+    let mut out = vec![0u8; 65 * n];
+    // SAFETY: n elements behind every pointer.
+    check(unsafe { fec_batch_encode_uncompressed(ctx.raw, C::ID, xy.as_ptr(), inf.as_ptr(), out.as_mut_ptr(), n) })?;
+    Ok(out.chunks_exact(65).map(|c| <[u8; 65]>::try_from(c).unwrap()).collect())
+}
+
+/// `UncompressedPoint::to_affine` (`point.rs:214-281`) of every 65-byte encoding.
+pub fn batch_decode_uncompressed<C: GpuCurve>(ctx: &mut GpuContext, encoded: &[[u8; 65]]) -> Result<Vec<Option<C::PointAffine>>> {
+    let n = encoded.len();
+    let (mut xy, mut inf, mut ok) = (vec![0u64; 8 * n], vec![0u8; n], vec![0u8; n]);
+    // SAFETY: `encoded` is n contiguous 65-byte arrays; the outputs hold n elements each.
+    check(unsafe { fec_batch_decode_uncompressed(ctx.raw, C::ID, encoded.as_ptr().cast(), xy.as_mut_ptr(), inf.as_mut_ptr(), ok.as_mut_ptr(), n) })?;
+    Ok((0..n).map(|i| (ok[i] != 0).then(|| C::affine_from_limbs(&xy[8 * i..8 * i + 8], inf[i] != 0))).collect())
 }
 
 /// `C::multi_scalar_multiply(points, scalars)` (`forge-ec-core/src/lib.rs:934-951`): the sum, folded

@@ -221,3 +221,43 @@ def test_forcing_vectors(oracle):
     for e in fv["cases"]:
         got = [int(v) for v in oracle.field_op(e["curve"], e["op"], e["a"], e["b"])]
         assert got == e["expect"], (e["family"], e["curve"], e["op"], e["a"], e["b"])
+
+
+def _decode_cases():
+    return _load("decode_vectors.json")["cases"]
+
+
+def test_decode_vectors(oracle):
+    """Point decoding (PointAffine::from_bytes, UncompressedPoint::{from,to}_affine): the C oracle against
+    the Python model's committed expectations (tests/golden/gen_decode.py)."""
+    cases = _decode_cases()
+    assert len(cases) > 900
+    for curve in (0, 1, 2):
+        for op, width, fn in (("decompress", 33, oracle.batch_decompress),
+                              ("decode_uncompressed", 65, oracle.batch_decode_uncompressed)):
+            cs = [c for c in cases if c["curve"] == curve and c["op"] == op]
+            data = np.frombuffer(bytes.fromhex("".join(c["in"] for c in cs)), dtype=np.uint8).reshape(-1, width)
+            xy, inf, ok = fn(curve, data)
+            for i, c in enumerate(cs):
+                got = (int(ok[i]), [int(v) for v in xy[i, :4]], [int(v) for v in xy[i, 4:]], int(inf[i]))
+                assert got == (c["ok"], c["x"], c["y"], c["inf"]), (curve, op, c["in"])
+        cs = [c for c in cases if c["curve"] == curve and c["op"] == "encode_uncompressed"]
+        xy = np.array([c["x"] + c["y"] for c in cs], dtype=np.uint64)
+        inf = np.array([c["inf"] for c in cs], dtype=np.uint8)
+        out = oracle.batch_encode_uncompressed(curve, xy, inf)
+        for i, c in enumerate(cs):
+            assert out[i].tobytes().hex() == c["out"], (curve, i)
+
+
+def test_decode_two_restatements_agree_on_fresh_inputs(oracle):
+    from oracle import py_model as M
+    rng = np.random.default_rng(77)
+    for curve in (0, 1, 2):
+        raw = rng.integers(0, 256, size=(40, 33), dtype=np.uint8)
+        raw[:, 0] = rng.choice([0, 2, 3, 3, 2, 5], size=40)
+        raw[::3, 1 if curve != 2 else 32] &= 0x3F   # keep a share of the x values below p
+        xy, inf, ok = oracle.batch_decompress(curve, raw)
+        for i in range(40):
+            r = M.decompress(curve, raw[i].tobytes())
+            got = None if not ok[i] else ([int(v) for v in xy[i, :4]], [int(v) for v in xy[i, 4:]], bool(inf[i]))
+            assert got == (None if r is None else (list(r[0]), list(r[1]), r[2])), (curve, i)

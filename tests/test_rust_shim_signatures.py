@@ -58,7 +58,7 @@ def parse_shim():
     decls = {}
     for m in re.finditer(r"fn\s+(fec_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
         name, args, ret = m.group(1), m.group(2), (m.group(3) or "()").strip()
-        params = [re.sub(r"\s+", " ", a.split(":", 1)[1].strip()) for a in args.split(",") if ":" in a]
+        params = [re.sub(r"\s+", " ", a.split(":", 1)[1].strip()) for a in args.split(",") if ":" in a]  # r#in: raw identifier
         decls[name] = (params, re.sub(r"\s+", " ", ret))
     return decls
 
