@@ -356,17 +356,50 @@ __global__ __launch_bounds__(TPB) void k_point_op(int op, const u32* __restrict_
 // Curve::multi_scalar_multiply's fold (forge-ec-core/src/lib.rs:944-948, p256.rs:2204-2208):
 //   result = identity; for i in 0..n { result += product[i] }
 // The reference's Add is neither associative nor commutative, so the order is part of the result:
-// one lane folds the n products (already computed by k_batch_mul) strictly left to right.
-template <class C>
-__global__ __launch_bounds__(64) void k_fold_sum(const u32* __restrict__ products, u32* __restrict__ out, size_t n) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  typename C::pt acc = C::identity();
+// the n products (already computed by the batch kernel) are folded strictly left to right.
+// secp256k1: each addition is spread over four lanes (secp::padd_coop, 6 instead of 16 dependent field
+// operations); P-256 / Ed25519: one lane.
+// One wavefront folds `terms` left to right from the identity with the cooperative addition.
+FEC_DEV secp::pt fold_coop_secp(const u32* __restrict__ terms, size_t n, u32* sh) {
+  using namespace secp::coop;
+  const int lane = threadIdx.x & 63;
+  secp::pt acc = secp::identity();
+  if (lane == 0) st(sh, ONE, fe_small(1));
+  // term i + 1 is fetched (one word per lane) while addition i runs, so its HBM/L2 latency is hidden
+  u32 next_word = (n != 0 && lane < 24) ? terms[lane] : 0u;
 #pragma unroll 1
   for (size_t i = 0; i < n; ++i) {
-    typename C::pt p = C::load(products + i * C::PW, 1);
-    acc = C::padd(acc, p);
+    if (lane == 0) {
+      st(sh, PX, acc.x);
+      st(sh, PY, acc.y);
+      st(sh, PZ, acc.z);
+    }
+    if (lane < 24) sh[QX * 8 + lane] = next_word;  // q = term i (X, Y, Z: slots QX..QZ are contiguous)
+    if (i + 1 < n && lane < 24) next_word = terms[(i + 1) * Secp::PW + lane];
+    sync();
+    acc = secp::padd_coop(sh);
   }
-  C::store(out, 1, acc);
+  return acc;
+}
+
+template <class C>
+__global__ __launch_bounds__(64) void k_fold_sum(const u32* __restrict__ products, u32* __restrict__ out, size_t n) {
+  if (blockIdx.x != 0) return;
+  if constexpr (C::PW == 24 && C::BYTES_BIG_ENDIAN && sizeof(typename C::pt) == sizeof(secp::pt) &&
+                __is_same(typename C::pt, secp::pt)) {
+    __shared__ __attribute__((aligned(16))) u32 sh[secp::coop::WORDS];
+    secp::pt acc = fold_coop_secp(products, n, sh);
+    if (threadIdx.x == 0) C::store(out, 1, acc);
+  } else {
+    if (threadIdx.x != 0) return;
+    typename C::pt acc = C::identity();
+#pragma unroll 1
+    for (size_t i = 0; i < n; ++i) {
+      typename C::pt p = C::load(products + i * C::PW, 1);
+      acc = C::padd(acc, p);
+    }
+    C::store(out, 1, acc);
+  }
 }
 
 // xy[i] = to_affine(points[i]) as (x, y); inf[i] = 1 where the point is the identity
@@ -516,7 +549,7 @@ __global__ __launch_bounds__(TPB, 2) void k_schnorr_terms_secp(const u32* __rest
 }
 
 // The two strictly sequential folds (s_g += ..., r_e_p += ...: 268, 281) and the comparison at 286:
-// block 0 folds the A terms, block 1 the B terms, each on one lane; the last block to finish
+// block 0 folds the A terms, block 1 the B terms, each with the four-lane cooperative addition; the last block to finish
 // converts both sums with to_affine and applies AffinePoint::ct_eq (1292-1296).
 // out: [0..7] = x, y of to_affine(s_g), [8..15] of to_affine(r_e_p) (64-bit limbs as u32 pairs);
 // flags: [0] = result, [1], [2] = the two infinity flags.
@@ -525,14 +558,10 @@ __global__ __launch_bounds__(64) void k_schnorr_fold_compare_secp(const u32* __r
                                                                   u32* __restrict__ sums, u32* __restrict__ out_xy,
                                                                   unsigned char* __restrict__ flags,
                                                                   unsigned int* __restrict__ done, size_t n) {
-  if (threadIdx.x != 0) return;
+  __shared__ __attribute__((aligned(16))) u32 sh[secp::coop::WORDS];
   const u32* terms = blockIdx.x == 0 ? terms_a : terms_b;
-  secp::pt acc = secp::identity();
-#pragma unroll 1
-  for (size_t i = 0; i < n; ++i) {
-    secp::pt p = Secp::load(terms + i * Secp::PW, 1);
-    acc = secp::padd(acc, p);
-  }
+  secp::pt acc = fold_coop_secp(terms, n, sh);  // the whole wavefront: each addition on four lanes
+  if (threadIdx.x != 0) return;
   Secp::store(sums + blockIdx.x * Secp::PW, 1, acc);
   __threadfence();
   if (atomicAdd(done, 1u) != 1u) return;  // the other fold is still running: it will finish the job

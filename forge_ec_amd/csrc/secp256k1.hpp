@@ -437,6 +437,136 @@ FEC_DEV pt padd(const pt& p, const pt& q) {
   return o;
 }
 
+// ---- Add for ProjectivePoint (1444-1498) spread over FOUR lanes of one wavefront ----------------
+// The ordered folds (Curve::multi_scalar_multiply, core lib.rs:944-948; schnorr::batch_verify 262-281)
+// are a strictly sequential chain of additions: the reference's Add is neither associative nor
+// commutative, so the order is part of the result and one addition cannot start before the previous
+// one ends.  What CAN run in parallel is the inside of one addition: its 16 field multiplications /
+// squarings form a dependency graph of depth 6 and width <= 4.  padd_coop() executes that graph level
+// by level -- the same operations on the same operands as padd_nodouble(), so the sum is bit-identical
+// -- with lanes 0..3 of the wavefront each taking one operation of the level.  Values travel between
+// lanes through 27 eight-word slots of LDS (a wavefront's LDS accesses execute in program order, so no
+// barrier is needed); the cheap field subtractions in between are done by every lane redundantly.
+//   level 1 (square)   z1s = z1^2            z2s = z2^2
+//   level 2 (Mul)      u1 = x1 z2s           u2 = x2 z1s          z1c = z1s z1      z2c = z2s z2
+//   level 3 (Mul)      s1 = y1 z2c           s2 = y2 z1c                                  h = u2 - u1, r = s2 - s1
+//   level 4 (square)   h2 = h^2              r2 = r^2
+//   level 5 (Mul)      h3 = h2 h             u1h2 = u1 h2         hz = h z1               x3 = r2 - h3 - 2 u1h2
+//   level 6 (Mul)      t = r (u1h2 - x3)     s1h3 = s1 h3         z3 = hz z2              y3 = t - s1h3
+// 6 field-operation latencies per addition instead of 16.
+namespace coop {
+enum { PX = 0, PY, PZ, QX, QY, QZ, Z1S, Z2S, U1, U2, Z1C, Z2C, S1, S2, H, R, H2, R2, H3, U1H2, HZ, T, S1H3, Z3, X3, DD, ONE, SLOTS };
+constexpr int WORDS = SLOTS * 8;
+#ifdef FEC_HOST_EMUL
+FEC_DEV fe ld(const u32* sh, int slot) {
+  fe a;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) a.w[i] = sh[slot * 8 + i];
+  return a;
+}
+FEC_DEV void st(u32* sh, int slot, const fe& a) {
+  FEC_UNROLL for (int i = 0; i < 8; ++i) sh[slot * 8 + i] = a.w[i];
+}
+#else
+// a slot is 32 bytes, 16-byte aligned (the caller's array is): two ds_read_b128 / ds_write_b128
+FEC_DEV fe ld(const u32* sh, int slot) {
+  const uint4* s4 = reinterpret_cast<const uint4*>(sh + slot * 8);
+  const uint4 lo = s4[0], hi = s4[1];
+  fe a;
+  a.w[0] = lo.x; a.w[1] = lo.y; a.w[2] = lo.z; a.w[3] = lo.w;
+  a.w[4] = hi.x; a.w[5] = hi.y; a.w[6] = hi.z; a.w[7] = hi.w;
+  return a;
+}
+FEC_DEV void st(u32* sh, int slot, const fe& a) {
+  uint4* s4 = reinterpret_cast<uint4*>(sh + slot * 8);
+  s4[0] = make_uint4(a.w[0], a.w[1], a.w[2], a.w[3]);
+  s4[1] = make_uint4(a.w[4], a.w[5], a.w[6], a.w[7]);
+}
+#endif
+#ifdef FEC_HOST_EMUL
+FEC_DEV void sync() {}
+FEC_DEV int lane_id() { return 0; }
+#else
+// A wavefront's LDS instructions execute in program order, so a read issued after another lane's
+// write (same wavefront, later instruction) returns the written data: no s_waitcnt is needed between
+// them, only compiler ordering (the fences emit no instruction at wavefront scope).
+FEC_DEV void sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+FEC_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+#endif
+FEC_DEV int pick(int lane, int a0, int a1, int a2, int a3) { return lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : (lane == 3 ? a3 : ONE))); }
+// one level: lane l (< n) computes op(slot a_l, slot b_l) into slot o_l; the other lanes work on the constant 1
+template <bool SQR>
+FEC_DEV void level(u32* sh, int n, int a0, int a1, int a2, int a3, int b0, int b1, int b2, int b3, int o0, int o1, int o2, int o3) {
+  const int lane = lane_id();
+  const fe a = ld(sh, pick(lane, a0, a1, a2, a3));
+  fe res;
+  if (SQR) {
+    res = sqr(a);
+  } else {
+    const fe b = ld(sh, pick(lane, b0, b1, b2, b3));
+    res = mul(a, b);
+  }
+  // no level overwrites a slot it reads (outputs go to fresh slots), and a wavefront's LDS accesses
+  // execute in program order, so one synchronisation per level -- after the stores -- is enough
+  if (lane < n) st(sh, pick(lane, o0, o1, o2, o3), res);
+  sync();
+}
+}  // namespace coop
+
+// sh: coop::WORDS words of LDS owned by this wavefront; slots PX..QZ hold p and q on entry (written by
+// the caller, followed by coop::sync()); slot ONE holds the constant 1.  Every lane returns the sum.
+FEC_DEV pt padd_coop(u32* sh) {
+  using namespace coop;
+#ifdef FEC_HOST_EMUL
+  const pt p0 = {ld(sh, PX), ld(sh, PY), ld(sh, PZ)}, q0 = {ld(sh, QX), ld(sh, QY), ld(sh, QZ)};
+  return padd(p0, q0);
+#else
+  const int lane = lane_id();
+  level<true>(sh, 2, PZ, QZ, ONE, ONE, ONE, ONE, ONE, ONE, Z1S, Z2S, ONE, ONE);
+  level<false>(sh, 4, PX, QX, Z1S, Z2S, Z2S, Z1S, PZ, QZ, U1, U2, Z1C, Z2C);
+  level<false>(sh, 2, PY, QY, ONE, ONE, Z2C, Z1C, ONE, ONE, S1, S2, ONE, ONE);
+  {  // level 4 with its subtraction folded in: lane 0 h = u2 - u1, lane 1 r = s2 - s1, then the squares
+    const fe d = sub(ld(sh, pick(lane, U2, S2, ONE, ONE)), ld(sh, pick(lane, U1, S1, ONE, ONE)));
+    const fe d2 = sqr(d);
+    if (lane < 2) {
+      st(sh, pick(lane, H, R, ONE, ONE), d);
+      st(sh, pick(lane, H2, R2, ONE, ONE), d2);
+    }
+    sync();
+  }
+  level<false>(sh, 3, H2, U1, H, ONE, H, H2, PZ, ONE, H3, U1H2, HZ, ONE);
+  pt o;
+  {  // level 6 with x3 and (u1h2 - x3) computed by every lane on the way in
+    const fe h3 = ld(sh, H3), u1h2 = ld(sh, U1H2), r2 = ld(sh, R2);
+    o.x = sub(sub(sub(r2, h3), u1h2), u1h2);
+    const fe dd = sub(u1h2, o.x);
+    const fe a = ld(sh, pick(lane, R, S1, HZ, ONE));
+    const fe b = fe_select(ld(sh, pick(lane, ONE, H3, QZ, ONE)), dd, lanes_where(lane == 0));
+    const fe res = mul(a, b);
+    if (lane < 3) st(sh, pick(lane, T, S1H3, Z3, ONE), res);
+    sync();
+  }
+  o.y = sub(ld(sh, T), ld(sh, S1H3));
+  o.z = ld(sh, Z3);
+  const fe u1 = ld(sh, U1), u2 = ld(sh, U2), s1 = ld(sh, S1), s2 = ld(sh, S2);
+  const pt p = {ld(sh, PX), ld(sh, PY), ld(sh, PZ)}, q = {ld(sh, QX), ld(sh, QY), ld(sh, QZ)};
+  const lmask idp = is_identity(p), idq = is_identity(q);
+  const lmask ueq = fe_eq(u1, u2);
+  if (__builtin_expect((idp | idq | ueq) != 0, 0)) {  // the early-outs of Add (1446-1473)
+    const lmask seq = fe_eq(s1, s2);
+    o = pt_select(o, identity(), uniform_mask(ueq & ~seq));
+    o = pt_select(o, p, idq);
+    o = pt_select(o, q, idp);
+    const lmask nd = uniform_mask(ueq & seq & ~idp & ~idq);
+    if (nd != 0) o = pt_select(o, pdouble(p), nd);
+  }
+  return o;
+#endif
+}
+
 // trait PointProjective::double (1375-1418); not on the ladder path.
 FEC_DEV pt pdouble_trait(const pt& p) {
   fe xx = sqr(p.x);

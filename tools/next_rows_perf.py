@@ -68,13 +68,13 @@ def main():
     t0 = time.perf_counter()
     ctx.multi_scalar_mul(0, k, p)
     emit(row="multi_scalar_multiply", curve="secp256k1", n=m, ms=round((time.perf_counter() - t0) * 1e3, 3),
-         note="products in parallel + strictly sequential fold on one lane; host pointers, PCIe included")
+         note="products in parallel + ordered fold, each addition on four lanes (secp::padd_coop); host pointers, PCIe included")
     pkxy, rxy = synth.field_elements(2 * m, 0, 73).reshape(m, 8), synth.field_elements(2 * m, 0, 74).reshape(m, 8)
     s_, a_, e_ = synth.scalars(m, 0, 75), synth.scalars(m, 0, 76), synth.scalars(m, 0, 77)
     t0 = time.perf_counter()
     ctx.schnorr_batch_verify_secp256k1(pkxy, rxy, s_, a_, e_)
     emit(row="schnorr batch_verify", curve="secp256k1", n=m, ms=round((time.perf_counter() - t0) * 1e3, 3),
-         note="3 ladders per signature in parallel + two sequential folds; host pointers, PCIe included")
+         note="3 ladders per signature in parallel + two ordered folds (four lanes per addition); host pointers, PCIe included")
 
 
 main()
