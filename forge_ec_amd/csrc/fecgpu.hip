@@ -734,11 +734,11 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
 }
 
 // out[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])   (ecdsa.rs:254-256).
-// secp256k1: one fused kernel (two ladders sharing one copy of the ladder code + the addition).
-// P-256 / Ed25519: the two multiplications run through the task-scheduler kernels (P-256: fixed and
-// variable base; Ed25519: the LDS addend-table kernel for u1*G and the scheduler for u2*Q), which skip
-// the additions of clear bits, into per-stream scratch; one point-addition pass combines them.  The
-// fused masked-ladder form of round 1 (38 spilled VGPRs for P-256) is gone.
+// Composed from the single-multiplication kernels: u1*G and u2*Q into per-stream scratch (secp256k1: the
+// 3-waves-per-SIMD ladder, fixed then variable base; P-256: the task scheduler twice; Ed25519: the LDS
+// addend-table kernel and the scheduler), then one point-addition pass in the reference's operand order.
+// The fused masked-ladder forms of round 1 (38 spilled VGPRs for P-256) are gone; FEC_SECP_2WAVE=1
+// still selects the fused secp256k1 kernel for A/B runs.
 int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, const u64* dq, u64* dout,
                       size_t n, void* stream) {
   if (n == 0) return FEC_OK;
@@ -748,7 +748,7 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
   const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
   u32* o = reinterpret_cast<u32*>(dout);
   dim3 g(grid_for(n)), b(TPB);
-  if (curve == FEC_SECP256K1) {
+  if (curve == FEC_SECP256K1 && std::getenv("FEC_SECP_2WAVE")) {  // round-1 fused form, kept for A/B runs
     Launch L(ctx, stream, "k_batch_double_mul");
     hipLaunchKernelGGL((k_batch_double_mul<Secp>), g, b, 0, L.s, a, b2, q, gen, o, n);
     return L.done();
@@ -763,8 +763,13 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
     int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
     if (rc != FEC_OK) return rc;
   }
-  Launch L(ctx, stream, curve == FEC_P256 ? "k_p256_mul_sched x2 + k_point_op" : "k_ed_fixed_base + k_ed_mul_sched + k_point_op");
-  if (curve == FEC_P256) {
+  Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op"
+                        : (curve == FEC_P256 ? "k_p256_mul_sched x2 + k_point_op" : "k_ed_fixed_base + k_ed_mul_sched + k_point_op"));
+  if (curve == FEC_SECP256K1) {  // the 3-waves-per-SIMD ladder twice (fixed G, then Q) beats the fused 2-wave kernel
+    secp_launch_mul(true, a, gen, ta, n, L.s);
+    secp_launch_mul(false, b2, q, tb, n, L.s);
+    hipLaunchKernelGGL((k_point_op<Secp>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
+  } else if (curve == FEC_P256) {
     p256_launch_mul(true, a, gen, ta, n, L.s);
     p256_launch_mul(false, b2, q, tb, n, L.s);
     hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);

@@ -122,6 +122,12 @@ FEC_DEV fe reduce_wide(const u32 c[16]) {
   return csub_p(r);  // reduce() (701)
 }
 
+FEC_DEV fe mul_small_cxx(const fe& a, u32 k) {  // FieldElement::from(k) * a  (1893-1904)
+  u32 t[16];
+  mul_wide_small(t, a, k);
+  return reduce_wide(t);
+}
+
 // Mul (498-534): exact schoolbook product, then reduce_wide_p256.  Compiler-scheduled form: the host
 // emulation's Mul and the cross-check of the hand-allocated one below.
 FEC_DEV fe mul_cxx(const fe& a, const fe& b) {
@@ -157,6 +163,28 @@ FEC_DEV fe mul(const fe& a, const fe& b) {
       : FEC_P256_MUL_CLOBBERS);
   return csub_p_top(r);
 }
+// FieldElement::from(3) * a and from(8) * a (1893, 1904): nine-word product, S = T_lo + c8*(2^256 - p)
+template <u32 K>
+FEC_DEV fe mul_small_k(const fe& a) {
+  static_assert(K == 3 || K == 8, "the doubling multiplies by 3 and 8 only");
+  fe r;
+  lmask sink, exc;
+  if (K == 3) {
+    asm(FEC_P256_MUL3_ASM
+        : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
+          "=v"(r.w[7]), "=&s"(sink), "=&s"(exc)
+        : FEC_V8(a)
+        : FEC_P256_MUL3_CLOBBERS);
+  } else {
+    asm(FEC_P256_MUL8_ASM
+        : "=v"(r.w[0]), "=v"(r.w[1]), "=v"(r.w[2]), "=v"(r.w[3]), "=v"(r.w[4]), "=v"(r.w[5]), "=v"(r.w[6]),
+          "=v"(r.w[7]), "=&s"(sink), "=&s"(exc)
+        : FEC_V8(a)
+        : FEC_P256_MUL8_CLOBBERS);
+  }
+  if (__builtin_expect(exc != 0, 0)) return mul_small_cxx(a, K);  // the sum carried out of 2^256
+  return csub_p_top(r);
+}
 FEC_DEV fe sqr(const fe& a) {
   fe r;
   lmask sink;
@@ -168,12 +196,12 @@ FEC_DEV fe sqr(const fe& a) {
   return csub_p_top(r);
 }
 #endif
+#ifdef FEC_HOST_EMUL
+FEC_DEV fe mul_small(const fe& a, u32 k) { return mul_small_cxx(a, k); }
+#else
+FEC_DEV fe mul_small(const fe& a, u32 k) { return k == 3 ? mul_small_k<3>(a) : (k == 8 ? mul_small_k<8>(a) : mul_small_cxx(a, k)); }
+#endif
 
-FEC_DEV fe mul_small(const fe& a, u32 k) {  // FieldElement::from(k) * a  (1893-1904)
-  u32 t[16];
-  mul_wide_small(t, a, k);
-  return reduce_wide(t);
-}
 
 struct pt {
   fe x, y, z;

@@ -368,6 +368,40 @@ def p256_reduce(T, R, free):
     return ins
 
 
+def p256_mul_small(VB, K):
+    """FieldElement::from(K) * a (p256.rs:1893-1904, K = 3 or 8): the nine-word product a*K, then
+    reduce_wide_p256 with c9..c15 = 0, which collapses to S = T_lo + c8*(2^224 - 2^192 - 2^96 + 1);
+    the carry of that sum out of 2^256 (c8 < 8, so about 2^-29 per lane) is the exception mask.
+    operands: %0-%7 r, %8 sink, %9 exc, %10-%17 a"""
+    A = ["%%%d" % (10 + i) for i in range(8)]
+    R = ["%%%d" % i for i in range(8)]
+    SINK, EXC = "%8", "%9"
+    Q = [VB + 2 * i for i in range(8)]
+    C = VB + 16
+    t, sx, v3, c3, v6, v7 = [v(VB + 18 + i) for i in range(6)]
+    b = Block()
+    b.e("v_mov_b32_e32 %s, 0" % v(C + 1))
+    for i in range(8):
+        b.e("v_mad_u64_u32 %s, %s, %s, %d, %s" % (vp(Q[i]), SINK, A[i], K, "0" if i == 0 else vp(C)))
+        if i < 7:
+            b.e("v_mov_b32_e32 %s, %s" % (v(C), v(Q[i] + 1)))
+    top = v(Q[7] + 1)   # c8 >= 0: the general signed formula of p256_reduce with s = 0
+    b.e("v_sub_u32_e32 %s, 0, %s" % (v3, top))                 # word 3 of c8*K: -c8
+    b.e("v_ashrrev_i32_e32 %s, 31, %s" % (c3, v3))             # its sign extension (0 or -1)
+    b.e("v_sub_u32_e32 %s, %s, %s" % (v6, c3, top))            # word 6: c3 - c8
+    b.e("v_ashrrev_i32_e32 %s, 31, %s" % (v7, v6))
+    b.e("v_add_u32_e32 %s, %s, %s" % (v7, v7, top))            # word 7: c8 + sign(word 6)
+    adds = [top, "0", "0", v3, c3, c3, v6, v7]
+    b.e("v_add_co_u32_e32 %s, vcc, %s, %s" % (R[0], v(Q[0]), adds[0]))
+    for i in range(1, 8):
+        if adds[i] == "0":
+            b.e("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (R[i], v(Q[i])))
+        else:
+            b.e("v_addc_co_u32_e32 %s, vcc, %s, %s, vcc" % (R[i], v(Q[i]), adds[i]))
+    b.e("s_mov_b64 %s, vcc" % EXC)
+    return b, list(range(VB, VB + 24))
+
+
 def p256_mul(VB):
     """operands: %0-%7 r, %8-%15 a, %16-%23 b"""
     A = ["%%%d" % (8 + i) for i in range(8)]
@@ -497,6 +531,8 @@ def main():
     add("SECP_MUL8", *secp_mul_small(SECP_TOP - 22, 8))
     add("P256_MUL", *p256_mul(256 - 32))
     add("P256_SQR", *p256_sqr(256 - 46))
+    add("P256_MUL3", *p256_mul_small(256 - 24, 3))
+    add("P256_MUL8", *p256_mul_small(256 - 24, 8))
     add("ED_MUL", *ed_mul(256 - 32))
     add("ED_SQR", *ed_sqr(256 - 46))
     with open(OUT, "w") as f:

@@ -29,6 +29,8 @@ __device__ fe run_new(const fe& a, const fe& b) {
 #endif
   if (OP == 6) return secp::mul_small(a, 3);
   if (OP == 7) return secp::mul_small(a, 8);
+  if (OP == 8) return p256::mul_small(a, 3);
+  if (OP == 9) return p256::mul_small(a, 8);
   return a;
 }
 template <int OP>
@@ -47,6 +49,8 @@ __device__ fe run_old(const fe& a, const fe& b) {
 #endif
   if (OP == 6) return secp::mul_small_cxx(a, 3);
   if (OP == 7) return secp::mul_small_cxx(a, 8);
+  if (OP == 8) return p256::mul_small_cxx(a, 3);
+  if (OP == 9) return p256::mul_small_cxx(a, 8);
   return a;
 }
 
@@ -178,8 +182,11 @@ int main() {
 #endif
   fail |= check<6>("secp mul3", a, b);
   fail |= check<7>("secp mul8", a, b);
+  fail |= check<8>("p256 mul3", a, b);
+  fail |= check<9>("p256 mul8", a, b);
   timeit<0>("secp mul", cus);
   timeit<6>("secp mul3", cus);
+  timeit<8>("p256 mul3", cus);
 #ifdef HAVE_SECP_SQR
   timeit<1>("secp sqr", cus);
 #endif
