@@ -511,6 +511,7 @@ HEADER = """// field_asm.inc -- GENERATED by tools/gen_field_asm.py; do not edit
 
 
 SECP_TOP = 168
+P256_TOP = int(os.environ.get("FEC_P256_TOP", "256"))
 
 
 def main():
@@ -518,7 +519,7 @@ def main():
     report = []
 
     def add(name, blk, regs):
-        assert regs[-1] in (255, SECP_TOP - 1) and regs[0] % 2 == 0, (name, regs[0], regs[-1])
+        assert regs[-1] in (255, SECP_TOP - 1, P256_TOP - 1) and regs[0] % 2 == 0, (name, regs[0], regs[-1])
         parts.append("#define FEC_%s_ASM \\\n" % name + blk.text().replace("\n", " \\\n") + "\n")
         parts.append("#define FEC_%s_CLOBBERS \"vcc\", " % name + clobbers(regs) + "\n")
         parts.append("// FEC_%s_ASM: %d instructions, fixed block v[%d:%d]\n" % (name, len(blk.lines), regs[0], regs[-1]))
@@ -529,10 +530,10 @@ def main():
     add("SECP_SQR", *secp_sqr(SECP_TOP - 34))
     add("SECP_MUL3", *secp_mul_small(SECP_TOP - 22, 3))
     add("SECP_MUL8", *secp_mul_small(SECP_TOP - 22, 8))
-    add("P256_MUL", *p256_mul(256 - 32))
-    add("P256_SQR", *p256_sqr(256 - 46))
-    add("P256_MUL3", *p256_mul_small(256 - 24, 3))
-    add("P256_MUL8", *p256_mul_small(256 - 24, 8))
+    add("P256_MUL", *p256_mul(P256_TOP - 32))
+    add("P256_SQR", *p256_sqr(P256_TOP - 46))
+    add("P256_MUL3", *p256_mul_small(P256_TOP - 24, 3))
+    add("P256_MUL8", *p256_mul_small(P256_TOP - 24, 8))
     add("ED_MUL", *ed_mul(256 - 32))
     add("ED_SQR", *ed_sqr(256 - 46))
     with open(OUT, "w") as f:
