@@ -809,14 +809,27 @@ int launch_compress(fec_ctx* ctx, int curve, const u64* dxy, const unsigned char
   return L.done();
 }
 
-int launch_ecdsa_verify(fec_ctx* ctx, const unsigned char* dd, const u64* dr, const u64* ds, const u64* dpk,
+// Ecdsa::<C, D>::verify for secp256k1 / P-256: the pipeline of kernels_ecdsa.hip on per-stream scratch.
+// FEC_SECP_2WAVE=1 keeps the round-1 single-kernel secp256k1 form for A/B runs.
+int launch_ecdsa_verify(fec_ctx* ctx, int curve, const unsigned char* dd, const u64* dr, const u64* ds, const u64* dpk,
                         const unsigned char* dinf, unsigned char* dstatus, size_t n, void* stream) {
   if (n == 0) return FEC_OK;
-  Launch L(ctx, stream, "k_ecdsa_verify_secp");
-  hipLaunchKernelGGL(k_ecdsa_verify_secp, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(dd),
-                     reinterpret_cast<const u32*>(dr), reinterpret_cast<const u32*>(ds),
-                     reinterpret_cast<const u32*>(dpk), dinf, reinterpret_cast<const u32*>(ctx->d_gen[FEC_SECP256K1]),
-                     dstatus, n);
+  if (curve == FEC_SECP256K1 && std::getenv("FEC_SECP_2WAVE")) {
+    Launch L(ctx, stream, "k_ecdsa_verify_secp");
+    hipLaunchKernelGGL(k_ecdsa_verify_secp, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(dd),
+                       reinterpret_cast<const u32*>(dr), reinterpret_cast<const u32*>(ds),
+                       reinterpret_cast<const u32*>(dpk), dinf, reinterpret_cast<const u32*>(ctx->d_gen[FEC_SECP256K1]),
+                       dstatus, n);
+    return L.done();
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  void* work = scratch_for(ctx, st, ecdsa_work_bytes(n));
+  if (!work) return FEC_E_OOM;
+  Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_ecdsa_pre + k_secp_mul x2 + k_ecdsa_finish"
+                                               : "k_ecdsa_pre + k_p256_mul_sched x2 + k_ecdsa_finish");
+  ecdsa_launch(curve, dd, reinterpret_cast<const u32*>(dr), reinterpret_cast<const u32*>(ds),
+               reinterpret_cast<const u32*>(dpk), dinf, reinterpret_cast<const u32*>(ctx->d_gen[curve]), dstatus, work, n,
+               L.s);
   return L.done();
 }
 
@@ -1201,23 +1214,23 @@ int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars,
   return FEC_OK;
 }
 
-int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
-                                   const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
-                                   void* stream) {
+namespace {
+int ecdsa_verify_dev(fec_ctx* ctx, int curve, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
+                     const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n, void* stream) {
   if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || (n && (!d_digests || !d_r || !d_s || !d_pk_xy || !d_status))) return FEC_E_ARG;
   if (!aligned16(d_digests) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_pk_xy)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  return launch_ecdsa_verify(ctx, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream);
+  return launch_ecdsa_verify(ctx, curve, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream);
 }
 
-int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
-                               const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) {
+int ecdsa_verify_host(fec_ctx* ctx, int curve, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
+                      const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) {
   if (is_multi(ctx)) {
     if (n && (!digests || !r || !s || !pk_xy || !status)) return FEC_E_ARG;
     return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
-      return fec_ecdsa_verify_secp256k1(c, digests + lo * 32, r + lo * 4, s + lo * 4, pk_xy + lo * 8,
-                                        pk_inf ? pk_inf + lo : nullptr, status + lo, cnt);
+      return ecdsa_verify_host(c, curve, digests + lo * 32, r + lo * 4, s + lo * 4, pk_xy + lo * 8,
+                               pk_inf ? pk_inf + lo : nullptr, status + lo, cnt);
     });
   }
   if (!ctx || (n && (!digests || !r || !s || !pk_xy || !status))) return FEC_E_ARG;
@@ -1235,9 +1248,9 @@ int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests, const uint6
   }
   int rc = ensure(ctx, 3, n);
   if (rc != FEC_OK) return rc;
-  rc = launch_ecdsa_verify(ctx, (const unsigned char*)ctx->d_buf[0], (const u64*)ctx->d_buf[1], (const u64*)ctx->d_buf[2],
-                           (const u64*)ctx->d_buf[4], pk_inf ? (const unsigned char*)ctx->d_buf[5] : nullptr,
-                           (unsigned char*)ctx->d_buf[3], n, nullptr);
+  rc = launch_ecdsa_verify(ctx, curve, (const unsigned char*)ctx->d_buf[0], (const u64*)ctx->d_buf[1],
+                           (const u64*)ctx->d_buf[2], (const u64*)ctx->d_buf[4],
+                           pk_inf ? (const unsigned char*)ctx->d_buf[5] : nullptr, (unsigned char*)ctx->d_buf[3], n, nullptr);
   if (rc != FEC_OK) return rc;
   if (hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
@@ -1245,6 +1258,26 @@ int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests, const uint6
     return FEC_E_LAUNCH;
   }
   return FEC_OK;
+}
+}  // namespace
+
+int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
+                                   const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
+                                   void* stream) {
+  return ecdsa_verify_dev(ctx, FEC_SECP256K1, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream);
+}
+int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
+                               const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) {
+  return ecdsa_verify_host(ctx, FEC_SECP256K1, digests, r, s, pk_xy, pk_inf, status, n);
+}
+int fec_ecdsa_verify_p256_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
+                              const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
+                              void* stream) {
+  return ecdsa_verify_dev(ctx, FEC_P256, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream);
+}
+int fec_ecdsa_verify_p256(fec_ctx* ctx, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
+                          const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) {
+  return ecdsa_verify_host(ctx, FEC_P256, digests, r, s, pk_xy, pk_inf, status, n);
 }
 
 // schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290)

@@ -22,4 +22,11 @@ void secp_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out
 void codec_launch(int op, int curve, const void* in, const void* in2, void* out, void* out2, void* out3, size_t n,
                   hipStream_t s);
 
+// kernels_ecdsa.hip: Ecdsa::<C, D>::verify for C = Secp256k1 / P256 (ecdsa.rs:213-281): scalar pre-pass, the two
+// multiplications through the launchers above, finishing pass.  `work` holds ecdsa_work_bytes(n) bytes.
+size_t ecdsa_work_bytes(size_t n);
+void ecdsa_launch(int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
+                  const unsigned char* pk_inf, const u32* gen, unsigned char* status, void* work, size_t n,
+                  hipStream_t s);
+
 }  // namespace fecgpu

@@ -1,0 +1,163 @@
+// kernels_ecdsa.hip -- Ecdsa::<C, D>::verify (forge-ec-signature/src/ecdsa.rs:213-281) with the digest given,
+// as a pipeline around the single-multiplication kernels:
+//   k_ecdsa_pre<E>     215-251: zero / range checks, h = Scalar::from_bytes(digest), s^-1, u1 = h * s^-1,
+//                      u2 = r * s^-1 in the curve's scalar field AS THE REFERENCE IMPLEMENTS IT, and
+//                      Q = from_affine(pk); writes u1, u2, Q and one flag byte per signature
+//   <curve>_launch_mul 254-255: multiply(G, u1) (fixed base) and multiply(Q, u2) with the curve's own kernel
+//   k_ecdsa_finish<E>  256-274: R = r1 + r2, identity check, to_affine, field_to_bytes -> Scalar::from_bytes,
+//                      comparison with r; writes status 1 valid / 0 invalid / 2 where the reference panics
+//                      (CtOption::unwrap on None at 239 or 271)
+// One signature per lane in the two small kernels; the multiplications are the measured hot-path kernels.
+#include <hip/hip_runtime.h>
+
+#include "../../include/fecgpu.h"
+#include "kernels.hpp"
+#include "p256.hpp"
+#include "secp256k1.hpp"
+#include "staging.hpp"
+
+namespace fecgpu {
+
+namespace {
+
+enum : unsigned char { F_GO = 0, F_FALSE = 1, F_PANIC = 2 };
+
+FEC_DEV fe load8(const u32* g) {
+  const uint4 a = *reinterpret_cast<const uint4*>(g), b = *reinterpret_cast<const uint4*>(g + 4);
+  fe r;
+  r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+  r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+  return r;
+}
+FEC_DEV void store8(u32* g, const fe& v) {
+  *reinterpret_cast<uint4*>(g) = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+  *reinterpret_cast<uint4*>(g + 4) = make_uint4(v.w[4], v.w[5], v.w[6], v.w[7]);
+}
+
+// secp256k1: scalar field secp256k1.rs:1953-1969, 2162-2195, 2270-2297, 2410-2456 (its N has the two top
+// limbs swapped and its Mul keeps only the low 256 bits of the product); ct_lt overridden with a true
+// comparison against that N
+struct ESecp {
+  typedef secp::pt pt;
+  FEC_DEV static unsigned char scalars(const fe& h, const fe& r, const fe& s, fe& u1, fe& u2) {
+    const bool bad = lane_of(fe_is_zero(r) | fe_is_zero(s) | secp::sc_ge_n(r) | secp::sc_ge_n(s));  // 215-228
+    const bool panic = lane_of(secp::sc_ge_n(h));                                                   // 239
+    const fe s_inv = secp::sc_inv(s);
+    u1 = secp::sc_mul(h, s_inv);                                                                    // 250-251
+    u2 = secp::sc_mul(r, s_inv);
+    return bad ? F_FALSE : (panic ? F_PANIC : F_GO);
+  }
+  FEC_DEV static unsigned char finish(const pt& a, const pt& b, const fe& r) {
+    const pt rp = secp::padd(a, b);                                                                 // 256
+    const bool ident = lane_of(secp::is_identity(rp));                                              // 259-262
+    fe x, y;
+    secp::to_affine(rp, x, y);                                                                      // 264
+    const fe xr = secp::mul(x, fe_small(1));   // FieldElement::to_bytes (138-178) = mont_reduce(x)
+    if (ident) return 0;
+    if (lane_of(secp::sc_ge_n(xr))) return 2;                                                       // 271 unwrap
+    return lane_of(fe_eq(xr, r)) ? 1 : 0;                                                           // 274
+  }
+  static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s) {
+    secp_launch_mul(fixed, k, p, o, n, s);
+  }
+};
+
+// P-256: scalar field p256.rs:875-1100, 1409-1432 (reduce_wide drops the high half of its second fold);
+// ct_lt is the trait default (forge-ec-core/src/lib.rs:497-531), a top-byte <= comparison
+struct EP256 {
+  typedef p256::pt pt;
+  FEC_DEV static unsigned char scalars(const fe& h, const fe& r, const fe& s, fe& u1, fe& u2) {
+    const p256::sc hs = p256::sc_of(h), rs = p256::sc_of(r), ss = p256::sc_of(s);
+    const p256::sc order = {{0xF3B9CAC2FC632551ULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL}};
+    const bool bad = p256::sc_is_zero(rs) || p256::sc_is_zero(ss) ||
+                     !(p256::sc_ct_lt_default(rs, order) && p256::sc_ct_lt_default(ss, order));     // 215-228
+    const bool panic = p256::sc_ge_n(hs);                                                           // 239
+    const p256::sc s_inv = p256::sc_inv(ss);   // s != 0 on every lane that is not `bad`
+    u1 = p256::sc_fe(p256::sc_mul(hs, s_inv));                                                      // 250-251
+    u2 = p256::sc_fe(p256::sc_mul(rs, s_inv));
+    return bad ? F_FALSE : (panic ? F_PANIC : F_GO);
+  }
+  FEC_DEV static unsigned char finish(const pt& a, const pt& b, const fe& r) {
+    const pt rp = p256::padd(a, b);                                                                 // 256
+    const bool ident = lane_of(p256::is_identity(rp));                                              // 259-262
+    fe x, y;
+    p256::to_affine(rp, x, y);                                                                      // 264
+    if (ident) return 0;
+    // field_to_bytes = FieldElement::to_bytes (288-300): the raw limbs; Scalar::from_bytes: valid iff < n
+    if (p256::sc_ge_n(p256::sc_of(x))) return 2;                                                    // 271 unwrap
+    return lane_of(fe_eq(x, r)) ? 1 : 0;                                                            // 274
+  }
+  static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s) {
+    p256_launch_mul(fixed, k, p, o, n, s);
+  }
+};
+
+template <class E>
+__global__ __launch_bounds__(TPB) void k_ecdsa_pre(const unsigned char* __restrict__ digests, const u32* __restrict__ rs,
+                                                   const u32* __restrict__ ss, const u32* __restrict__ pk,
+                                                   const unsigned char* __restrict__ pk_inf, u32* __restrict__ u1,
+                                                   u32* __restrict__ u2, u32* __restrict__ q,
+                                                   unsigned char* __restrict__ flags, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  // Scalar::from_bytes: big-endian bytes -> little-endian limbs
+  const fe d = load8(reinterpret_cast<const u32*>(digests + i * 32));
+  fe h;
+  FEC_UNROLL for (int w = 0; w < 8; ++w) h.w[w] = __builtin_bswap32(d.w[7 - w]);
+  const fe r = load8(rs + i * 8), s = load8(ss + i * 8);
+  fe a, b;
+  flags[i] = E::scalars(h, r, s, a, b);
+  store8(u1 + i * 8, a);
+  store8(u2 + i * 8, b);
+  // from_affine (secp256k1.rs:1365-1373, p256.rs:1859-1867): (x, y, 1), or the identity (0, 1, 0)
+  const bool inf = pk_inf != nullptr && pk_inf[i] != 0;
+  fe x = load8(pk + i * 16), y = load8(pk + i * 16 + 8), z = fe_small(1);
+  if (inf) { x = fe_zero(); y = fe_small(1); z = fe_zero(); }
+  store8(q + i * 24, x);
+  store8(q + i * 24 + 8, y);
+  store8(q + i * 24 + 16, z);
+}
+
+template <class E>
+__global__ __launch_bounds__(TPB) void k_ecdsa_finish(const u32* __restrict__ ta, const u32* __restrict__ tb,
+                                                      const u32* __restrict__ rs, const unsigned char* __restrict__ flags,
+                                                      unsigned char* __restrict__ status, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  typename E::pt a, b;
+  a.x = load8(ta + i * 24); a.y = load8(ta + i * 24 + 8); a.z = load8(ta + i * 24 + 16);
+  b.x = load8(tb + i * 24); b.y = load8(tb + i * 24 + 8); b.z = load8(tb + i * 24 + 16);
+  const unsigned char st = E::finish(a, b, load8(rs + i * 8));
+  const unsigned char f = flags[i];
+  status[i] = f == F_FALSE ? 0 : (f == F_PANIC ? 2 : st);
+}
+
+template <class E>
+void run(const unsigned char* dd, const u32* dr, const u32* ds, const u32* dpk, const unsigned char* dinf, const u32* gen,
+         unsigned char* dstatus, void* work, size_t n, hipStream_t s) {
+  char* w = static_cast<char*>(work);
+  u32* u1 = reinterpret_cast<u32*>(w);
+  u32* u2 = reinterpret_cast<u32*>(w + n * 32);
+  u32* q = reinterpret_cast<u32*>(w + n * 64);
+  u32* ta = reinterpret_cast<u32*>(w + n * 160);
+  u32* tb = reinterpret_cast<u32*>(w + n * 256);
+  unsigned char* flags = reinterpret_cast<unsigned char*>(w + n * 352);
+  const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
+  hipLaunchKernelGGL((k_ecdsa_pre<E>), g, b, 0, s, dd, dr, ds, dpk, dinf, u1, u2, q, flags, n);
+  E::launch_mul(true, u1, gen, ta, n, s);
+  E::launch_mul(false, u2, q, tb, n, s);
+  hipLaunchKernelGGL((k_ecdsa_finish<E>), g, b, 0, s, (const u32*)ta, (const u32*)tb, dr, (const unsigned char*)flags, dstatus, n);
+}
+
+}  // namespace
+
+size_t ecdsa_work_bytes(size_t n) { return n * 353; }
+
+void ecdsa_launch(int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
+                  const unsigned char* pk_inf, const u32* gen, unsigned char* status, void* work, size_t n,
+                  hipStream_t s) {
+  if (curve == FEC_SECP256K1) run<ESecp>(digests, r, s_, pk, pk_inf, gen, status, work, n, s);
+  else run<EP256>(digests, r, s_, pk, pk_inf, gen, status, work, n, s);
+}
+
+}  // namespace fecgpu

@@ -55,6 +55,13 @@ FEC_DEV lmask lanes_where(bool c) { return c ? ~0ull : 0ull; }
 FEC_DEV lmask lanes_where(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 #endif
 
+// high 64 bits of a 64 x 64 product
+#ifdef FEC_HOST_EMUL
+FEC_DEV u64 mulhi64(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) >> 64); }
+#else
+FEC_DEV u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
+#endif
+
 FEC_DEV fe fe_zero() {
   fe r;
   FEC_UNROLL for (int i = 0; i < 8; ++i) r.w[i] = 0;

@@ -410,5 +410,131 @@ FEC_DEV pt multiply(const pt& point, const u32* kw) {
   return pt_select(result, identity(), early);
 }
 
+// ---- scalar field as the reference implements it (p256.rs:875-1038, 1409-1432), for ECDSA verify ----
+// 64-bit limbs like the reference, one element per lane, ordinary (divergent) control flow: this is a
+// few hundred multiplications per signature beside the two 256-step point multiplications.
+// Mul = the exact 512-bit product, then reduce_wide (924-1020), which is NOT a reduction mod n: its
+// second folding round adds only the low four limbs of high2 * (2^256 - n) (993-998).
+struct sc { u64 l[4]; };
+FEC_DEV sc sc_of(const fe& a) {
+  sc r;
+  FEC_UNROLL for (int i = 0; i < 4; ++i) r.l[i] = (u64)a.w[2 * i] | ((u64)a.w[2 * i + 1] << 32);
+  return r;
+}
+FEC_DEV fe sc_fe(const sc& a) {
+  fe r;
+  FEC_UNROLL for (int i = 0; i < 4; ++i) { r.w[2 * i] = (u32)a.l[i]; r.w[2 * i + 1] = (u32)(a.l[i] >> 32); }
+  return r;
+}
+FEC_DEV bool sc_is_zero(const sc& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+FEC_DEV bool sc_ge_n(const sc& a) {  // compare_with_n(a) >= 0 (889-905); N at 23-24
+  const u64 N[4] = {0xF3B9CAC2FC632551ULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL};
+  u64 borrow = 0;
+  FEC_UNROLL for (int i = 0; i < 4; ++i) {
+    const u64 d = a.l[i] - N[i];
+    const u64 b1 = a.l[i] < N[i];
+    const u64 b2 = d < borrow;
+    borrow = b1 | b2;
+  }
+  return borrow == 0;
+}
+// r[0..8) = a * b exactly (row by row with a running carry, as Mul at 1413-1425 forms it)
+FEC_DEV void sc_mul_wide(const u64 (&a)[4], const u64 (&b)[4], u64 (&r)[8]) {
+  FEC_UNROLL for (int i = 0; i < 8; ++i) r[i] = 0;
+  FEC_UNROLL for (int i = 0; i < 4; ++i) {
+    u64 carry = 0;
+    FEC_UNROLL for (int j = 0; j < 4; ++j) {
+      const u64 lo = a[i] * b[j], hi = mulhi64(a[i], b[j]);
+      u64 t = r[i + j] + lo;
+      u64 c = t < lo;
+      t += carry;
+      c += t < carry;
+      r[i + j] = t;
+      carry = hi + c;  // hi <= 2^64 - 2, and c == 2 needs lo == 2^64 - 1 twice over: no wrap
+    }
+    r[i + 4] = carry;
+  }
+}
+FEC_DEV sc sc_reduce_wide(const u64 (&w)[8]) {
+  const u64 C[4] = {0x0C46353D039CDAAFULL, 0x4319055258E8617BULL, 0ULL, 0x00000000FFFFFFFFULL};  // 932-937
+  const u64 N[4] = {0xF3B9CAC2FC632551ULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL};
+  const u64 high[4] = {w[4], w[5], w[6], w[7]};
+  u64 res[8];
+  sc_mul_wide(high, C, res);  // 943-954: the u128 columns cannot overflow (C's limbs are 60, 63, 0, 32 bits)
+  u64 carry = 0;              // 957-969: + low, carries propagated
+  FEC_UNROLL for (int i = 0; i < 8; ++i) {
+    const u64 add = i < 4 ? w[i] : 0;
+    u64 t = res[i] + add;
+    u64 c = t < add;
+    t += carry;
+    c += t < carry;
+    res[i] = t;
+    carry = c;
+  }
+  sc low2;
+  FEC_UNROLL for (int i = 0; i < 4; ++i) low2.l[i] = res[i];
+  const u64 high2[4] = {res[4], res[5], res[6], res[7]};
+  if ((high2[0] | high2[1] | high2[2] | high2[3]) != 0) {  // 976
+    u64 p2[8];
+    sc_mul_wide(high2, C, p2);
+    u64 cy = 0;
+    FEC_UNROLL for (int i = 0; i < 4; ++i) {  // 993-998: product2[4..8] is never used
+      u64 t = low2.l[i] + p2[i];
+      u64 c = t < p2[i];
+      t += cy;
+      c += t < cy;
+      low2.l[i] = t;
+      cy = c;
+    }
+    if (cy > 0) {  // 1000-1007: limb i receives c * C[i], c the RUNNING carry (not + C)
+      u64 c = cy;
+      FEC_UNROLL for (int i = 0; i < 4; ++i) {
+        const u64 lo = c * C[i], hi = mulhi64(c, C[i]);
+        const u64 t = low2.l[i] + lo;
+        c = hi + (t < lo);
+        low2.l[i] = t;
+      }
+    }
+  }
+  while (sc_ge_n(low2)) {  // 1010-1019 (runs at most once: low2 < 2^256 < 2n)
+    u64 borrow = 0;
+    FEC_UNROLL for (int i = 0; i < 4; ++i) {
+      const u64 d1 = low2.l[i] - N[i];
+      const u64 b1 = low2.l[i] < N[i];
+      const u64 d2 = d1 - borrow;
+      const u64 b2 = d1 < borrow;
+      low2.l[i] = d2;
+      borrow = b1 + b2;
+    }
+  }
+  return low2;
+}
+FEC_DEV sc sc_mul(const sc& a, const sc& b) {  // 1409-1432
+  u64 wide[8];
+  sc_mul_wide(a.l, b.l, wide);
+  return sc_reduce_wide(wide);
+}
+// invert (1057-1080) = pow(n - 2) (1083-1100): limbs and bits LS -> MS, `result *= base` on a set bit,
+// base = base.square() = base * base every step
+FEC_DEV sc sc_inv(const sc& a) {
+  const u64 e[4] = {0xF3B9CAC2FC63254FULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL};
+  sc result = {{1, 0, 0, 0}}, base = a;
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll 1
+    for (int k = 0; k < 64; ++k) {
+      if ((e[i] >> k) & 1) result = sc_mul(result, base);  // exponent bits are uniform
+      base = sc_mul(base, base);
+    }
+  }
+  return result;
+}
+// Scalar::ct_lt(self, get_order()) -- P-256 keeps the trait DEFAULT (forge-ec-core/src/lib.rs:497-531):
+// over big-endian bytes, result |= eq_so_far & !borrow(other_byte - self_byte), i.e. "self_byte <=
+// other_byte" while all earlier bytes were equal.  At byte 0 the chain is trivially equal, and a byte-0
+// pair with self > other both leaves result clear and breaks the chain for good: the verdict is
+// top_byte(self) <= top_byte(other).  Against n (top byte 0xFF) that is true for every value.
+FEC_DEV bool sc_ct_lt_default(const sc& a, const sc& other) { return (a.l[3] >> 56) <= (other.l[3] >> 56); }
+
 }  // namespace p256
 }  // namespace fecgpu

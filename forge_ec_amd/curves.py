@@ -127,10 +127,7 @@ class Context:
                "fec_multi_scalar_mul")
         return out
 
-    def ecdsa_verify_secp256k1(self, digests, r, s, pk_xy, pk_inf=None):
-        """Ecdsa::<Secp256k1, D>::verify per signature with the digests supplied (ecdsa.rs:213-281).
-        digests (n,32) uint8; r, s (n,4); pk_xy (n,8) raw limbs; pk_inf (n,) uint8 or None.
-        Returns (n,) uint8: 1 valid, 0 invalid, 2 = the reference panics."""
+    def _ecdsa_verify(self, fn, what, digests, r, s, pk_xy, pk_inf):
         d = np.ascontiguousarray(np.asarray(digests, dtype=np.uint8)).reshape(-1, 32)
         rr, ss, pk = _u64(r, 4), _u64(s, 4), _u64(pk_xy, 8)
         n = d.shape[0]
@@ -140,9 +137,21 @@ class Context:
         if inf is not None and inf.shape[0] != n:
             raise ValueError("pk_inf and the signatures differ in length")  # the C side reads n bytes
         out = np.empty(n, dtype=np.uint8)
-        _check(self._lib.fec_ecdsa_verify_secp256k1(self._h, _ptr(d), _ptr(rr), _ptr(ss), _ptr(pk), _ptr(inf),
-                                                    _ptr(out), n), "fec_ecdsa_verify_secp256k1")
+        _check(fn(self._h, _ptr(d), _ptr(rr), _ptr(ss), _ptr(pk), _ptr(inf), _ptr(out), n), what)
         return out
+
+    def ecdsa_verify_secp256k1(self, digests, r, s, pk_xy, pk_inf=None):
+        """Ecdsa::<Secp256k1, D>::verify per signature with the digests supplied (ecdsa.rs:213-281).
+        digests (n,32) uint8; r, s (n,4); pk_xy (n,8) raw limbs; pk_inf (n,) uint8 or None.
+        Returns (n,) uint8: 1 valid, 0 invalid, 2 = the reference panics."""
+        return self._ecdsa_verify(self._lib.fec_ecdsa_verify_secp256k1, "fec_ecdsa_verify_secp256k1", digests, r, s,
+                                  pk_xy, pk_inf)
+
+    def ecdsa_verify_p256(self, digests, r, s, pk_xy, pk_inf=None):
+        """Ecdsa::<P256, D>::verify per signature, same conventions, in the reference's P-256 scalar
+        arithmetic (p256.rs:924-1020, 1409-1432) -- not standard ECDSA: see include/fecgpu.h."""
+        return self._ecdsa_verify(self._lib.fec_ecdsa_verify_p256, "fec_ecdsa_verify_p256", digests, r, s, pk_xy,
+                                  pk_inf)
 
     def batch_compress(self, curve, xy, inf=None):
         """PointAffine::to_bytes of each affine point (x, y, infinity) -> (n, 33) uint8."""
@@ -246,6 +255,10 @@ class Context:
     def ecdsa_verify_secp256k1_dev(self, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream=None):
         _check(self._lib.fec_ecdsa_verify_secp256k1_dev(self._h, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n,
                                                         stream), "fec_ecdsa_verify_secp256k1_dev")
+
+    def ecdsa_verify_p256_dev(self, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream=None):
+        _check(self._lib.fec_ecdsa_verify_p256_dev(self._h, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n,
+                                                   stream), "fec_ecdsa_verify_p256_dev")
 
     def generator(self, curve):
         out = np.empty(L.POINT_LIMBS[curve], dtype=np.uint64)

@@ -26,6 +26,9 @@
  *   fec_ecdsa_verify_secp256k1   Ecdsa::<Secp256k1, D>::verify per signature, digest supplied
  *                         (forge-ec-signature/src/ecdsa.rs:213-281; scalar field secp256k1.rs:1953-1969,
  *                         2162-2195, 2270-2297, 2410-2456; FieldElement::to_bytes 138-178)
+ *   fec_ecdsa_verify_p256 Ecdsa::<P256, D>::verify per signature, digest supplied (ecdsa.rs:213-281; scalar
+ *                         field p256.rs:875-1100, 1409-1432; default Scalar::ct_lt core lib.rs:497-531;
+ *                         FieldElement::to_bytes 288-300)
  *   fec_batch_compress    out[i] = PointAffine::to_bytes(&points[i]) -> [u8; 33] (secp256k1.rs:875-896,
  *                         p256.rs:1558-1578, ed25519.rs:1505-1525; the bytes forge-ec-encoding's
  *                         CompressedPoint::from_affine builds, point.rs:38-67), with each curve's
@@ -146,6 +149,15 @@ int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars 
 int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests /* n*32 */, const uint64_t* r /* n*4 */,
                                const uint64_t* s /* n*4 */, const uint64_t* pk_xy /* n*8 */,
                                const uint8_t* pk_inf /* n or NULL */, uint8_t* status /* n */, size_t n);
+/* The same for C = P256.  Parity mode means the reference's P-256 scalar field exactly: its Mul is the
+ * exact product followed by reduce_wide (p256.rs:924-1020), whose second folding round drops the high
+ * half of high2 * (2^256 - n), so products are NOT a*b mod n; and its range check on r and s is the
+ * Scalar trait's default ct_lt (forge-ec-core/src/lib.rs:497-531), a top-byte <= comparison that every
+ * value passes.  A signature made by a conforming signer therefore does not verify here (nor in the
+ * reference); fec_canon_ecdsa_verify is the standard verification. */
+int fec_ecdsa_verify_p256(fec_ctx* ctx, const uint8_t* digests /* n*32 */, const uint64_t* r /* n*4 */,
+                          const uint64_t* s /* n*4 */, const uint64_t* pk_xy /* n*8 */,
+                          const uint8_t* pk_inf /* n or NULL */, uint8_t* status /* n */, size_t n);
 /* xy: n*8 limbs (x then y, e.g. from fec_batch_to_affine), inf: n flags or NULL (all finite), out: n*33 bytes */
 int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* out,
                        size_t n);
@@ -203,6 +215,9 @@ int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1
 int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
                                    const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
                                    void* stream);
+int fec_ecdsa_verify_p256_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
+                              const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
+                              void* stream);
 /* d_out must be 4-byte aligned */
 int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf,
                            uint8_t* d_out, size_t n, void* stream);

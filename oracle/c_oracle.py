@@ -68,6 +68,12 @@ def lib():
         L.fo_secp256k1_ecdsa_verify.restype = ctypes.c_int
         L.fo_batch_secp256k1_ecdsa_verify.argtypes = [p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
         L.fo_batch_secp256k1_ecdsa_verify.restype = None
+        L.fo_p256_scalar_op.argtypes = [ctypes.c_char_p, p, p, p]
+        L.fo_p256_scalar_op.restype = ctypes.c_int
+        L.fo_p256_ecdsa_verify.argtypes = [p, p, p, p, ctypes.c_int]
+        L.fo_p256_ecdsa_verify.restype = ctypes.c_int
+        L.fo_batch_p256_ecdsa_verify.argtypes = [p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_p256_ecdsa_verify.restype = None
         L.fo_secp256k1_schnorr_batch_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, p, p]
         L.fo_secp256k1_schnorr_batch_verify.restype = ctypes.c_int
         L.fo_batch_compress.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t]
@@ -210,6 +216,29 @@ def batch_secp256k1_ecdsa_verify(digests, r, s, pk_xy, pk_inf=None, nthreads=1):
     out = np.zeros(n, dtype=np.uint8)
     lib().fo_batch_secp256k1_ecdsa_verify(_ptr(digests), _ptr(r), _ptr(s), _ptr(pk_xy),
                                           _ptr(inf) if inf is not None else None, _ptr(out), n, nthreads)
+    return out
+
+
+def p256_scalar_op(op, a, b=None):
+    """P-256 Scalar Mul ('mul', p256.rs:1409-1432) or invert ('inv', 1057-1080): -> (limbs, ok)."""
+    a = _u64(a)
+    b = _u64(b if b is not None else [0, 0, 0, 0])
+    r = np.zeros(4, dtype=np.uint64)
+    rc = lib().fo_p256_scalar_op(op.encode(), _ptr(a), _ptr(b), _ptr(r))
+    if rc < 0:
+        raise ValueError("fo_p256_scalar_op rc=%d" % rc)
+    return r, rc == 0
+
+
+def batch_p256_ecdsa_verify(digests, r, s, pk_xy, pk_inf=None, nthreads=1):
+    """As batch_secp256k1_ecdsa_verify, for Ecdsa::<P256, D>::verify."""
+    digests = np.ascontiguousarray(np.asarray(digests, dtype=np.uint8)).reshape(-1, 32)
+    r, s, pk_xy = _u64(r), _u64(s), _u64(pk_xy)
+    n = digests.shape[0]
+    inf = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+    out = np.zeros(n, dtype=np.uint8)
+    lib().fo_batch_p256_ecdsa_verify(_ptr(digests), _ptr(r), _ptr(s), _ptr(pk_xy),
+                                     _ptr(inf) if inf is not None else None, _ptr(out), n, nthreads)
     return out
 
 

@@ -794,6 +794,156 @@ static jpt n_multiply(const jpt* point, const u64 k[4]) {
   return result;
 }
 
+/* ---- P-256 scalar field (p256.rs:875-1038, 1409-1432) and Ecdsa::<P256, D>::verify -------------
+ * The scalar Mul is an exact schoolbook product followed by reduce_wide (924-1020), which is NOT a
+ * reduction modulo n: the second folding round adds only the low four limbs of high2 * (2^256 - n)
+ * (993-998) and drops the rest.  Restated limb for limb. */
+static const u64 NS_N[4] = {0xF3B9CAC2FC632551ULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL,
+                            0xFFFFFFFF00000000ULL};                                  /* p256.rs:23-24 */
+static const u64 NS_C[4] = {0x0C46353D039CDAAFULL, 0x4319055258E8617BULL, 0x0000000000000000ULL,
+                            0x00000000FFFFFFFFULL};                                  /* TWO_256_MINUS_N 932-937 */
+static void ns_sub_n_while_ge(u64 v[4]) {                                          /* 1007-1017 / 911-920 */
+  while (n_cmp(v, NS_N) >= 0) {
+    u64 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+      u64 d1 = v[i] - NS_N[i];
+      u64 b1 = v[i] < NS_N[i];
+      u64 d2 = d1 - borrow;
+      u64 b2 = d1 < borrow;
+      v[i] = d2;
+      borrow = b1 + b2;
+    }
+  }
+}
+static void ns_times_c(const u64 h[4], u128 prod[8]) {                             /* 943-954 / 979-990 */
+  for (int i = 0; i < 8; ++i) prod[i] = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) prod[i + j] += (u128)h[i] * (u128)NS_C[j];
+  for (int i = 0; i < 7; ++i) {
+    prod[i + 1] += prod[i] >> 64;
+    prod[i] &= (u128)0xFFFFFFFFFFFFFFFFULL;
+  }
+}
+static void ns_reduce_wide(const u64 wide[8], u64 out[4]) {                        /* 924-1020 */
+  u128 product[8], result[8];
+  ns_times_c(wide + 4, product);
+  for (int i = 0; i < 4; ++i) result[i] = product[i] + (u128)wide[i];
+  for (int i = 4; i < 8; ++i) result[i] = product[i];
+  for (int i = 0; i < 7; ++i) {
+    result[i + 1] += result[i] >> 64;
+    result[i] &= (u128)0xFFFFFFFFFFFFFFFFULL;
+  }
+  u64 low2[4] = {(u64)result[0], (u64)result[1], (u64)result[2], (u64)result[3]};
+  u64 high2[4] = {(u64)result[4], (u64)result[5], (u64)result[6], (u64)result[7]};
+  if (high2[0] | high2[1] | high2[2] | high2[3]) {
+    u128 product2[8];
+    ns_times_c(high2, product2);
+    u128 carry = 0;
+    for (int i = 0; i < 4; ++i) {                  /* only product2[0..4] is used (993-998) */
+      u128 sum = (u128)low2[i] + product2[i] + carry;
+      low2[i] = (u64)sum;
+      carry = sum >> 64;
+    }
+    if (carry > 0) {                               /* 1000-1007 */
+      u128 c = carry;
+      for (int i = 0; i < 4; ++i) {
+        u128 sum = (u128)low2[i] + c * (u128)NS_C[i];
+        low2[i] = (u64)sum;
+        c = sum >> 64;
+      }
+    }
+  }
+  ns_sub_n_while_ge(low2);
+  memcpy(out, low2, 32);
+}
+static void ns_mul(const u64 a[4], const u64 b[4], u64 r[4]) {                     /* 1409-1432 */
+  u64 res[8] = {0};
+  for (int i = 0; i < 4; ++i) {
+    u64 carry = 0;
+    for (int j = 0; j < 4; ++j) {
+      u128 p = (u128)a[i] * (u128)b[j] + (u128)res[i + j] + (u128)carry;
+      res[i + j] = (u64)p;
+      carry = (u64)(p >> 64);
+    }
+    res[i + 4] = carry;
+  }
+  ns_reduce_wide(res, r);
+}
+static int ns_inv(const u64 a[4], u64 r[4]) {                                      /* 1057-1080, pow 1083-1100 */
+  if ((a[0] | a[1] | a[2] | a[3]) == 0) { memset(r, 0, 32); return 0; }
+  static const u64 e[4] = {0xF3B9CAC2FC63254FULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL};
+  u64 result[4] = {1, 0, 0, 0}, base[4], t[4];
+  memcpy(base, a, 32);
+  for (int i = 0; i < 4; ++i) {
+    u64 x = e[i];
+    for (int k = 0; k < 64; ++k) {
+      if (x & 1) { ns_mul(result, base, t); memcpy(result, t, 32); }
+      ns_mul(base, base, t);                       /* square() = s * s (1103-1106) */
+      memcpy(base, t, 32);
+      x >>= 1;
+    }
+  }
+  memcpy(r, result, 32);
+  return 1;
+}
+static int ns_from_bytes_be(const unsigned char b[32], u64 l[4]) {                  /* 1041-1055 */
+  l[0] = l[1] = l[2] = l[3] = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) l[i] |= (u64)b[31 - (i * 8 + j)] << (j * 8);
+  return n_cmp(l, NS_N) < 0;
+}
+/* Scalar::ct_lt, the trait default (forge-ec-core/src/lib.rs:497-531; P-256 does not override it): on
+ * big-endian bytes, with `is_lt = !borrow(other - self)`, i.e. self_byte <= other_byte -- so the verdict is
+ * decided by the first byte pair alone: true iff self's top byte <= other's (equal bytes set it, a greater
+ * byte clears the equality chain).  Restated as written. */
+static int ns_ct_lt(const u64 a[4], const u64 b[4]) {
+  int result = 0, eq_so_far = 1;
+  for (int i = 0; i < 32; ++i) {
+    unsigned char sb = (unsigned char)(a[3 - i / 8] >> (56 - 8 * (i % 8)));
+    unsigned char ob = (unsigned char)(b[3 - i / 8] >> (56 - 8 * (i % 8)));
+    int is_lt = !(ob < sb);
+    int is_eq = sb == ob;
+    result |= eq_so_far & is_lt;
+    eq_so_far &= is_eq;
+  }
+  return result;
+}
+/* forge-ec-signature/src/ecdsa.rs:213-281 for C = P256 with the digest given: 1 valid, 0 invalid,
+ * 2 where the reference panics (CtOption::unwrap on None) */
+int fo_p256_ecdsa_verify(const unsigned char digest[32], const u64 r[4], const u64 s[4], const u64 pk_xy[8],
+                         int pk_inf) {
+  if ((r[0] | r[1] | r[2] | r[3]) == 0 || (s[0] | s[1] | s[2] | s[3]) == 0) return 0;
+  if (!(ns_ct_lt(r, NS_N) & ns_ct_lt(s, NS_N))) return 0;
+  u64 h[4];
+  if (!ns_from_bytes_be(digest, h)) return 2;               /* 239 unwrap */
+  u64 s_inv[4];
+  if (!ns_inv(s, s_inv)) return 0;
+  u64 u1[4], u2[4];
+  ns_mul(h, s_inv, u1);
+  ns_mul(r, s_inv, u2);
+  jpt g = n_generator();
+  jpt q = n_identity();                                     /* from_affine 1859-1867 */
+  if (!pk_inf) {
+    for (int i = 0; i < 4; ++i) { q.x.v[i] = pk_xy[i]; q.y.v[i] = pk_xy[4 + i]; }
+    q.z = fe_small(1);
+  }
+  jpt r1 = n_multiply(&g, u1);
+  jpt r2 = n_multiply(&q, u2);
+  jpt rp = n_padd(&r1, &r2);
+  if (n_is_identity(&rp)) return 0;
+  fe x, y;
+  n_to_affine(&rp, &x, &y);
+  /* field_to_bytes = FieldElement::to_bytes (288-300): the raw limbs big-endian; Scalar::from_bytes of
+   * them: the same limbs, valid iff < n (271 unwrap) */
+  if (n_cmp(x.v, NS_N) >= 0) return 2;
+  return x.v[0] == r[0] && x.v[1] == r[1] && x.v[2] == r[2] && x.v[3] == r[3];
+}
+int fo_p256_scalar_op(const char* op, const u64 a[4], const u64 b[4], u64 r[4]) {
+  if (!strcmp(op, "mul")) { ns_mul(a, b, r); return 0; }
+  if (!strcmp(op, "inv")) { return ns_inv(a, r) ? 0 : 1; }
+  return -2;
+}
+
 /* =====================================================================================
  * Ed25519  (ed25519.rs)
  * ===================================================================================== */
@@ -1151,6 +1301,28 @@ static void* vworker(void* arg) {
                                                    j->inf ? j->inf[i] : 0);
   return NULL;
 }
+typedef struct { const unsigned char* d; const u64 *r, *s, *pk; const uint8_t* inf; uint8_t* out; size_t lo, hi; } pv_t;
+static void* pvworker(void* arg) {
+  pv_t* j = (pv_t*)arg;
+  for (size_t i = j->lo; i < j->hi; ++i)
+    j->out[i] = (uint8_t)fo_p256_ecdsa_verify(j->d + 32 * i, j->r + 4 * i, j->s + 4 * i, j->pk + 8 * i,
+                                               j->inf ? j->inf[i] : 0);
+  return NULL;
+}
+void fo_batch_p256_ecdsa_verify(const unsigned char* digests, const u64* r, const u64* s, const u64* pk_xy,
+                                const uint8_t* pk_inf, uint8_t* out, size_t n, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 64) nthreads = 64;
+  pthread_t th[64];
+  pv_t jobs[64];
+  for (int t = 0; t < nthreads; ++t) {
+    pv_t j = {digests, r, s, pk_xy, pk_inf, out, n * t / nthreads, n * (t + 1) / nthreads};
+    jobs[t] = j;
+    pthread_create(&th[t], NULL, pvworker, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+}
+
 void fo_batch_secp256k1_ecdsa_verify(const unsigned char* digests, const u64* r, const u64* s, const u64* pk_xy,
                                      const uint8_t* pk_inf, uint8_t* out, size_t n, int nthreads) {
   if (nthreads < 1) nthreads = 1;

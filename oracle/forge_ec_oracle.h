@@ -66,6 +66,14 @@ void fo_batch_secp256k1_ecdsa_verify(const unsigned char* digests, const uint64_
                                      const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* out, size_t n,
                                      int nthreads);
 
+/* ---- P-256 scalar field (p256.rs:875-1038, 1409-1432) + ECDSA verify for C = P256 ---- */
+int fo_p256_scalar_op(const char* op, const uint64_t a[4], const uint64_t b[4], uint64_t r[4]);
+int fo_p256_ecdsa_verify(const unsigned char digest[32], const uint64_t r[4], const uint64_t s[4],
+                         const uint64_t pk_xy[8], int pk_inf);
+void fo_batch_p256_ecdsa_verify(const unsigned char* digests, const uint64_t* r, const uint64_t* s,
+                                const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* out, size_t n,
+                                int nthreads);
+
 /* schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290) with the challenges
  * e_i and the random weights a_i supplied; 1 = true, 0 = false.  sides / sides_inf (optional): the
  * two affine points the reference compares at 286 */

@@ -832,6 +832,109 @@ def secp256k1_ecdsa_verify(digest, r, s, pk_xy, pk_inf=False):
     return 1 if xr == list(r) else 0
 
 
+class P256Scalar:
+    """p256.rs Scalar (875-1038, 1409-1432).  Whole-integer arithmetic where the reference's u128 limb
+    loops are exact (no u128 column overflows: the constant's limbs are 60, 63, 0 and 32 bits wide), limb
+    loops where they are not an integer identity."""
+    N = 0xFFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551  # :23-24
+    C = [0x0C46353D039CDAAF, 0x4319055258E8617B, 0, 0x00000000FFFFFFFF]  # TWO_256_MINUS_N :932-937
+    M256 = (1 << 256) - 1
+
+    @staticmethod
+    def val(l):
+        return l[0] | (l[1] << 64) | (l[2] << 128) | (l[3] << 192)
+
+    @staticmethod
+    def limbs(v):
+        return [(v >> (64 * i)) & M64 for i in range(4)]
+
+    @staticmethod
+    def reduce_wide(w):  # :924-1020; w an integer below 2^512
+        S = P256Scalar
+        cv = S.val(S.C)
+        first = (w & S.M256) + (w >> 256) * cv  # product + low, carries propagated: exact, below 2^481
+        low2, high2 = first & S.M256, first >> 256
+        if high2 != 0:
+            # 993-998: only product2[0..4] is added -- the high half of high2 * C is dropped
+            t = low2 + ((high2 * cv) & S.M256)
+            low2, carry = t & S.M256, t >> 256
+            if carry > 0:  # 1000-1007: limb i receives c * C[i] with c the running carry, not C itself
+                l = S.limbs(low2)
+                c = carry
+                for i in range(4):
+                    sm = l[i] + c * S.C[i]
+                    assert sm <= M128
+                    l[i] = sm & M64
+                    c = sm >> 64
+                low2 = S.val(l)
+        while low2 >= S.N:  # 1010-1019 (a borrow chain that is exact for low2 >= n)
+            low2 -= S.N
+        return low2
+
+    @staticmethod
+    def mul(a, b):  # :1409-1432 -- the schoolbook product is exact
+        S = P256Scalar
+        return S.limbs(S.reduce_wide(S.val(a) * S.val(b)))
+
+    @staticmethod
+    def inv(a):  # :1057-1080 with pow :1083-1100 (LSB first; square() = s * s)
+        S = P256Scalar
+        if _is_zero(a):
+            return None
+        e = S.N - 2
+        assert S.limbs(e) == [0xF3B9CAC2FC63254F, 0xBCE6FAADA7179E84, M64, 0xFFFFFFFF00000000]
+        result, base = [1, 0, 0, 0], list(a)
+        for k in range(256):
+            if (e >> k) & 1:
+                result = S.mul(result, base)
+            base = S.mul(base, base)
+        return result
+
+    @staticmethod
+    def from_bytes_be(b):  # :1041-1055
+        v = int.from_bytes(bytes(b), "big")
+        return P256Scalar.limbs(v), v < P256Scalar.N
+
+    @staticmethod
+    def ct_lt_default(a, b):  # forge-ec-core/src/lib.rs:497-531 (P-256 keeps the trait default)
+        ab = P256Scalar.val(a).to_bytes(32, "big")
+        bb = P256Scalar.val(b).to_bytes(32, "big")
+        result, eq_so_far = False, True
+        for i in range(32):
+            borrow1 = bb[i] < ab[i]  # other_byte.overflowing_sub(self_byte)
+            result = result or (eq_so_far and not borrow1)
+            eq_so_far = eq_so_far and ab[i] == bb[i]
+        return result
+
+
+def p256_ecdsa_verify(digest, r, s, pk_xy, pk_inf=False):
+    """ecdsa.rs:213-281 for C = P256 with the digest supplied.  1 valid, 0 invalid, 2 = the reference
+    panics (unwrap of a None CtOption at :239 or :271)."""
+    S, F = P256Scalar, P256c
+    if _is_zero(r) or _is_zero(s):
+        return 0
+    order = S.limbs(S.N)
+    if not (S.ct_lt_default(r, order) and S.ct_lt_default(s, order)):
+        return 0
+    h, ok = S.from_bytes_be(list(digest))
+    if not ok:
+        return 2
+    s_inv = S.inv(s)
+    if s_inv is None:
+        return 0
+    u1 = S.mul(h, s_inv)
+    u2 = S.mul(r, s_inv)
+    q = F.identity() if pk_inf else (list(pk_xy[0:4]), list(pk_xy[4:8]), [1, 0, 0, 0])  # from_affine :1859-1867
+    rp = F.padd(F.multiply(F.generator(), u1), F.multiply(q, u2))
+    if F.is_identity(rp):
+        return 0
+    x, _, _ = F.to_affine(rp)
+    # field_to_bytes = FieldElement::to_bytes (:288-300): raw limbs, big-endian; Scalar::from_bytes of them
+    if S.val(x) >= S.N:
+        return 2
+    return 1 if list(x) == list(r) else 0
+
+
 def secp256k1_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e):
     """schnorr.rs:194-290 with challenges e and weights a supplied.  -> (result, sides, sides_inf):
     sides = x, y of to_affine(s_g) then x, y of to_affine(r_e_p) (what line 286 compares)."""

@@ -33,6 +33,7 @@ extern "C" {
     fn fec_batch_double_mul(ctx: *mut FecCtx, curve: c_int, u1: *const u64, u2: *const u64, q: *const u64, out: *mut u64, n: usize) -> c_int;
     fn fec_batch_to_affine(ctx: *mut FecCtx, curve: c_int, points: *const u64, xy: *mut u64, inf: *mut u8, n: usize) -> c_int;
     fn fec_multi_scalar_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_ecdsa_verify_p256(ctx: *mut FecCtx, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, status: *mut u8, n: usize) -> c_int;
     fn fec_ecdsa_verify_secp256k1(ctx: *mut FecCtx, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, status: *mut u8, n: usize) -> c_int;
     fn fec_batch_compress(ctx: *mut FecCtx, curve: c_int, xy: *const u64, inf: *const u8, out: *mut u8, n: usize) -> c_int;
     fn fec_batch_decompress(ctx: *mut FecCtx, curve: c_int, r#in: *const u8, xy: *mut u64, inf: *mut u8, ok: *mut u8, n: usize) -> c_int;
@@ -44,6 +45,7 @@ extern "C" {
     fn fec_batch_mul_dev(ctx: *mut FecCtx, curve: c_int, d_scalars: *const u64, d_points: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_mul_fixed_dev(ctx: *mut FecCtx, curve: c_int, d_scalars: *const u64, d_base: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_double_mul_dev(ctx: *mut FecCtx, curve: c_int, d_u1: *const u64, d_u2: *const u64, d_q: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
+    fn fec_ecdsa_verify_p256_dev(ctx: *mut FecCtx, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_ecdsa_verify_secp256k1_dev(ctx: *mut FecCtx, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_compress_dev(ctx: *mut FecCtx, curve: c_int, d_xy: *const u64, d_inf: *const u8, d_out: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_to_affine_dev(ctx: *mut FecCtx, curve: c_int, d_points: *const u64, d_xy: *mut u64, d_inf: *mut u8, n: usize, stream: *mut c_void) -> c_int;
@@ -365,6 +367,27 @@ pub fn ecdsa_verify_batch_secp256k1(ctx: &mut GpuContext, digests: &[[u8; 32]], 
     Ok(status.iter().map(|&v| match v { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid }).collect())
 }
 
+/// `Ecdsa::<P256, D>::verify` per element, in the reference's own P-256 scalar arithmetic
+/// (`p256.rs:924-1020`, `1409-1432`; range check = the default `Scalar::ct_lt`, core `lib.rs:497-531`).
+pub fn ecdsa_verify_batch_p256(ctx: &mut GpuContext, digests: &[[u8; 32]], r: &[p256::Scalar], s: &[p256::Scalar], public_keys: &[p256::AffinePoint]) -> Result<Vec<VerifyStatus>> {
+    let n = digests.len();
+    if r.len() != n || s.len() != n || public_keys.len() != n {
+        return Err(Error::ValidationError);
+    }
+    type C = p256::P256;
+    let (rr, ss) = (pack_scalars::<C>(r), pack_scalars::<C>(s));
+    let (mut xy, mut inf) = (vec![0u64; 8 * n], vec![0u8; n]);
+    for (i, a) in public_keys.iter().enumerate() {
+        let (l, f) = C::affine_limbs(a);
+        xy[8 * i..8 * i + 8].copy_from_slice(&l);
+        inf[i] = f as u8;
+    }
+    let mut status = vec![0u8; n];
+    // SAFETY: `digests` is n contiguous 32-byte arrays; the other buffers hold n elements each.
+    check(unsafe { fec_ecdsa_verify_p256(ctx.raw, digests.as_ptr().cast(), rr.as_ptr(), ss.as_ptr(), xy.as_ptr(), inf.as_ptr(), status.as_mut_ptr(), n) })?;
+    Ok(status.iter().map(|&v| match v { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid }).collect())
+}
+
 /// `schnorr::batch_verify::<Secp256k1, D>` from line 258 on (`forge-ec-signature/src/schnorr.rs:194-290`):
 /// the caller hashes (challenges `e`, 236-256) and draws the weights (`a`, 228-233) with the
 /// reference's own code and passes them as scalars.
@@ -453,6 +476,14 @@ pub mod dev {
     /// As [`batch_mul`].
     pub unsafe fn ecdsa_verify_secp256k1(ctx: &mut GpuContext, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
         check(fec_ecdsa_verify_secp256k1_dev(ctx.raw, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream))
+    }
+
+    /// `fec_ecdsa_verify_p256_dev`.
+    ///
+    /// # Safety
+    /// As [`batch_mul`].
+    pub unsafe fn ecdsa_verify_p256(ctx: &mut GpuContext, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_ecdsa_verify_p256_dev(ctx.raw, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream))
     }
 
     /// `fec_generator_dev`: device address of the ctx's generator of `curve` (valid for the ctx's lifetime).

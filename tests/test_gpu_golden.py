@@ -8,6 +8,7 @@ The committed fixtures fed DIRECTLY through libfecgpu.so (C ABI) on the GPU -- n
                                      word 1 and closing reduce, Ed25519 reduce_wide's small-addition carries)
   tests/golden/reference_kats.json   the known answers the reference's own unit tests hold
   tests/golden/secp256k1_sqr_ripple_operands.json
+  tests/golden/ecdsa_p256_vectors.json  Ecdsa::<P256, D>::verify cases of every status
 
 Bit-exact.  Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
@@ -125,3 +126,11 @@ def test_secp256k1_square_ripple_fixture_on_the_gpu(gpu_ctx, oracle):
     got = gpu_ctx.field_op(0, OP["sqr"], a)
     want = _u64([[int(v) for v in oracle.field_op(0, "sqr", row)] for row in a])
     assert np.array_equal(got, want)
+
+
+def test_p256_ecdsa_vectors_on_the_gpu(gpu_ctx):
+    v = _load("ecdsa_p256_vectors.json")["verify"]
+    dg = np.frombuffer(bytes.fromhex("".join(c["digest"] for c in v)), dtype=np.uint8).reshape(-1, 32)
+    got = gpu_ctx.ecdsa_verify_p256(dg, _u64([c["r"] for c in v]), _u64([c["s"] for c in v]), _u64([c["pk"] for c in v]),
+                                    np.array([c["pk_inf"] for c in v], dtype=np.uint8))
+    assert [int(x) for x in got] == [c["status"] for c in v]

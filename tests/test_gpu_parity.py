@@ -399,6 +399,71 @@ def test_ecdsa_verify_secp256k1_matches_oracle(gpu_ctx, oracle):
     assert np.array_equal(gpu_ctx.ecdsa_verify_secp256k1(dg, r, s, pk, None), want2)
 
 
+def _p256_ecdsa_cases(oracle, n_random, n_valid):
+    """As _ecdsa_cases for Ecdsa::<P256, D>::verify.  r or s >= n are NOT rejected by the reference (its
+    ct_lt is the trait default, a top-byte <= comparison): those lanes run the whole computation."""
+    rng = np.random.default_rng(199)
+    order = V.ORDER[1]
+    total = n_random + n_valid + 10
+    dg = rng.integers(0, 256, size=(total, 32), dtype=np.uint8)
+    dg[:, 0] &= 0x7F
+    r = V.scalars(total, 1, 391)
+    s = V.scalars(total, 1, 392)
+    pk = np.ascontiguousarray(np.concatenate([V.field_elements(total, 1, 393), V.field_elements(total, 1, 394)], axis=1))
+    inf = np.zeros(total, dtype=np.uint8)
+    g = oracle.generator(1)
+    made = 0
+    for i in range(n_random, n_random + n_valid):
+        inf[i] = 1    # R = multiply(G, h * s^-1) regardless of r: set r to the x the reference derives
+        h = np.array(V.limbs_of(int.from_bytes(dg[i].tobytes(), "big")), dtype=np.uint64)
+        s_inv, ok = oracle.p256_scalar_op("inv", s[i])
+        u1 = oracle.p256_scalar_op("mul", h, s_inv)[0]
+        xy, is_inf = oracle.to_affine(1, oracle.multiply(1, g, u1))
+        if not is_inf and 0 < V.int_of(xy[:4]) < order:
+            r[i] = xy[:4]
+            made += 1
+    base = n_random + n_valid
+    r[base + 0] = 0                                     # r == 0            -> 0
+    s[base + 1] = 0                                     # s == 0            -> 0
+    r[base + 2] = V.limbs_of(order)                     # r == n: passes the default ct_lt
+    s[base + 3] = V.limbs_of((1 << 256) - 1)            # s >= n: passes it too
+    dg[base + 4] = 0xFF                                 # digest >= n       -> 2 (unwrap panics)
+    dg[base + 5] = np.frombuffer(order.to_bytes(32, "big"), dtype=np.uint8)  # digest == n -> 2
+    inf[base + 6] = 1                                   # Q at infinity, random r -> 0
+    dg[base + 7] = 0                                    # h == 0: u1 == 0, R = u2*Q
+    dg[base + 8] = 0xFF                                 # digest >= n but r == 0: the zero check wins -> 0
+    r[base + 8] = 0
+    pk[base + 9] = 0                                    # public key (0, 0), not flagged as infinity
+    return dg, r, s, pk, inf, made
+
+
+def test_ecdsa_verify_p256_matches_oracle(gpu_ctx, oracle):
+    """Ecdsa::<P256, D>::verify end to end in the reference's P-256 scalar arithmetic: every status the
+    reference can produce, including signatures that VERIFY under it; host and device-pointer entry points."""
+    dg, r, s, pk, inf, made = _p256_ecdsa_cases(oracle, 600, 60)
+    assert made >= 40
+    want = oracle.batch_p256_ecdsa_verify(dg, r, s, pk, inf, nthreads=8)
+    got = gpu_ctx.ecdsa_verify_p256(dg, r, s, pk, inf)
+    assert set(int(v) for v in want) == {0, 1, 2}
+    assert int((want == 1).sum()) == made
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, "first mismatch at %d: got %d want %d" % (bad[0], got[bad[0]], want[bad[0]])
+    want2 = oracle.batch_p256_ecdsa_verify(dg, r, s, pk, None, nthreads=8)
+    assert np.array_equal(gpu_ctx.ecdsa_verify_p256(dg, r, s, pk, None), want2)
+    # device-pointer form, on a caller stream
+    import torch
+    n = dg.shape[0]
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev) for a in (dg, r, s, pk, inf)]
+    st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    gpu_ctx.ecdsa_verify_p256_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(),
+                                  st.data_ptr(), n, stream.cuda_stream)
+    stream.synchronize()
+    assert np.array_equal(st.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_multi_scalar_multiply_matches_sequential_fold(gpu_ctx, oracle, curve):
     """Curve::multi_scalar_multiply (core lib.rs:934-951): result = identity; result += product[i]

@@ -148,3 +148,39 @@ def test_secp256k1_scalar_field(emu, oracle):
         if ok:
             emu.he_secp_scalar_op(1, _p(ai), None, _p(out))
             assert np.array_equal(out, want)
+
+
+def test_p256_scalar_field(emu, oracle):
+    """P-256 Scalar Mul (exact product, then the reference's lossy reduce_wide), invert, the default ct_lt
+    and compare_with_n as the device headers compute them, vs the C oracle and the Python model."""
+    from oracle import py_model as M
+    S = M.P256Scalar
+    n = S.N
+    vals = [0, 1, 2, 3, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, 1 << 128, 1 << 192, n - 2, n - 1, n, n + 1,
+            (1 << 256) - n, (1 << 256) - 1, 1 << 255, (1 << 224) - 1, 0xFF << 248, 0xFE << 248]
+    a = np.concatenate([np.array([V.limbs_of(v) for v in vals], dtype=np.uint64), V.scalars(60, 1, 55),
+                        V.splitmix64(400, V.SEED, 56).reshape(-1, 4)])
+    b = np.concatenate([np.array([V.limbs_of(v) for v in reversed(vals)], dtype=np.uint64), V.scalars(60, 1, 57),
+                        V.splitmix64(400, V.SEED, 58).reshape(-1, 4)])
+    out = np.zeros(4, dtype=np.uint64)
+    second_round = carry_round = 0
+    for i in range(a.shape[0]):
+        ai, bi = np.ascontiguousarray(a[i]), np.ascontiguousarray(b[i])
+        emu.he_p256_scalar_op(0, _p(ai), _p(bi), _p(out))
+        assert np.array_equal(out, oracle.p256_scalar_op("mul", ai, bi)[0]), i
+        la, lb = [int(v) for v in ai], [int(v) for v in bi]
+        assert [int(v) for v in out] == S.mul(la, lb)
+        w = S.val(la) * S.val(lb)
+        first = (w & S.M256) + (w >> 256) * S.val(S.C)
+        second_round += (first >> 256) != 0
+        carry_round += (first >> 256) != 0 and ((first & S.M256) + (((first >> 256) * S.val(S.C)) & S.M256)) >> 256 != 0
+        assert emu.he_p256_scalar_op(2, _p(ai), _p(bi), None) == int(S.ct_lt_default(la, lb))
+        assert emu.he_p256_scalar_op(3, _p(ai), None, None) == int(S.val(la) >= n)
+    # every branch of reduce_wide is taken by these operands: no second round, second round, its carry round
+    assert 0 < second_round < a.shape[0] and carry_round > 50
+    for i in range(0, 24):
+        ai = np.ascontiguousarray(a[i])
+        want, ok = oracle.p256_scalar_op("inv", ai)
+        if ok:
+            emu.he_p256_scalar_op(1, _p(ai), None, _p(out))
+            assert np.array_equal(out, want)

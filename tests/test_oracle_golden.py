@@ -261,3 +261,46 @@ def test_decode_two_restatements_agree_on_fresh_inputs(oracle):
             r = M.decompress(curve, raw[i].tobytes())
             got = None if not ok[i] else ([int(v) for v in xy[i, :4]], [int(v) for v in xy[i, 4:]], bool(inf[i]))
             assert got == (None if r is None else (list(r[0]), list(r[1]), r[2])), (curve, i)
+
+
+def test_p256_ecdsa_vectors(oracle):
+    """P-256 scalar field + Ecdsa::<P256, D>::verify: the C oracle against the Python model's committed
+    expectations (tests/golden/gen_ecdsa_p256.py)."""
+    with open(os.path.join(HERE, "golden", "ecdsa_p256_vectors.json")) as f:
+        gv = json.load(f)
+    assert len(gv["scalar_mul"]) > 100 and len(gv["verify"]) >= 19
+    for c in gv["scalar_mul"]:
+        assert [int(v) for v in oracle.p256_scalar_op("mul", c["a"], c["b"])[0]] == c["mul"]
+    v = gv["verify"]
+    dg = np.frombuffer(bytes.fromhex("".join(c["digest"] for c in v)), dtype=np.uint8).reshape(-1, 32)
+    got = oracle.batch_p256_ecdsa_verify(dg, [c["r"] for c in v], [c["s"] for c in v], [c["pk"] for c in v],
+                                         [c["pk_inf"] for c in v], nthreads=4)
+    assert [int(x) for x in got] == [c["status"] for c in v]
+    assert {c["status"] for c in v} == {0, 1, 2}
+
+
+def test_p256_ecdsa_two_restatements_agree_on_fresh_inputs(oracle):
+    from oracle import py_model as M
+    S = M.P256Scalar
+    a = V.splitmix64(160, V.SEED, 611).reshape(-1, 4)
+    b = V.scalars(40, 1, 612)
+    not_mod_n = 0
+    for i in range(40):
+        la, lb = [int(v) for v in a[i]], [int(v) for v in b[i]]
+        m = S.mul(la, lb)
+        assert m == [int(v) for v in oracle.p256_scalar_op("mul", la, lb)[0]]
+        not_mod_n += S.val(m) != (S.val(la) * S.val(lb)) % S.N
+    # the reference's Mul is not multiplication modulo n (reduce_wide drops the high half of its second fold)
+    assert not_mod_n > 30
+    assert S.inv([int(v) for v in b[0]]) == [int(v) for v in oracle.p256_scalar_op("inv", b[0])[0]]
+    rng = np.random.default_rng(17)
+    for i in range(3):
+        dg = rng.integers(0, 256, size=32, dtype=np.uint8)
+        dg[0] &= 0x7F
+        r, s = [int(v) for v in b[2 * i + 1]], [int(v) for v in b[2 * i + 2]]
+        pk = [int(v) for v in V.field_elements(2, 1, 613 + i).reshape(-1)]
+        want = M.p256_ecdsa_verify(bytes(dg), r, s, pk, pk_inf=(i == 2))
+        assert want == int(oracle.batch_p256_ecdsa_verify(dg, [r], [s], [pk], [1 if i == 2 else 0])[0])
+    # the default ct_lt is a top-byte <= comparison (core lib.rs:497-531)
+    for x, y in ((1, 2), (2, 1), (0xFF << 248, 0xFE << 248), (0xFE << 248, 0xFF << 248), (S.N + 1, S.N), (S.N, S.N)):
+        assert S.ct_lt_default(S.limbs(x), S.limbs(y)) == ((x >> 248) <= (y >> 248))

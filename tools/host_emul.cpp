@@ -73,6 +73,16 @@ extern "C" int he_secp_scalar_op(int op, const uint64_t* a, const uint64_t* b, u
   return 0;
 }
 
+// P-256 scalar field as the reference implements it (p256.rs:924-1020, 1409-1432): op 0 = mul, 1 = inv,
+// 2 = the default ct_lt (a vs b), 3 = a >= n
+extern "C" int he_p256_scalar_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  p256::sc x = p256::sc_of(ld(a));
+  if (op == 2) return p256::sc_ct_lt_default(x, p256::sc_of(ld(b))) ? 1 : 0;
+  if (op == 3) return p256::sc_ge_n(x) ? 1 : 0;
+  st(out, p256::sc_fe(op == 0 ? p256::sc_mul(x, p256::sc_of(ld(b))) : p256::sc_inv(x)));
+  return 0;
+}
+
 // ---- canonical-math mode (canon_curves.hpp): checked against oracle/canon_model.py ----
 // curve: 0 = secp256k1, 1 = P-256
 #include "../forge_ec_amd/csrc/canon_curves.hpp"
