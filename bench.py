@@ -114,7 +114,8 @@ def committed_pmc(workload, n):
     ignored -- the fields are then null and say why."""
     import glob
     from forge_ec_amd import build as fbuild
-    here = fbuild.source_hash()
+    tu = fbuild.WORKLOAD_TU.get(workload)
+    here = fbuild.tu_closure_hash(tu) if tu else fbuild.source_hash()   # the kernel's translation unit + its includes
     stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*", "*", "pmc.json")), reverse=True):
         try:
@@ -124,14 +125,14 @@ def committed_pmc(workload, n):
         if t.get("workload") != workload or t.get("units_per_launch") != n:
             continue
         rel = os.path.relpath(path, ROOT)
-        if t.get("source_hash") != here:
+        if t.get("kernel_source_hash", t.get("source_hash")) != here:
             stale = stale or rel
             continue
         d = t.get("derived", {})
         return {"traffic": d.get("hbm_bytes_per_launch"),
                 "valu_busy_pct": t.get("counters", {}).get("VALUBusy", {}).get("per_launch"),
-                "source": "%s: committed rocprofv3 PMC pass of this build (source hash %s), not measured by this run"
-                          % (rel, here[:12])}
+                "source": "%s: committed rocprofv3 PMC pass of this kernel's sources (%s + includes, hash %s), not measured by this run"
+                          % (rel, tu, here[:12])}
     why = ("only a stale PMC pass exists (%s, other source hash)" % stale) if stale else "no committed PMC pass for this workload"
     return {"traffic": None, "valu_busy_pct": None, "source": why}
 

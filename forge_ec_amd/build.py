@@ -39,13 +39,35 @@ def up_to_date():
         return False
 
 
-def _tu_hash(src):
-    """Hash of one translation unit: its own source, every shared header and the flags."""
+def tu_closure_hash(src):
+    """Hash of one translation unit and of exactly the files it #includes from csrc/ (transitively), plus
+    the flags: what determines the code of the kernels defined in `src`.  A committed PMC pass stays
+    attributable to a kernel for as long as this hash stands, whatever else changes in the library."""
+    import re
+    seen, todo = [], [src]
+    while todo:
+        rel = todo.pop()
+        if rel in seen or not os.path.exists(os.path.join(SRC_DIR, rel)):
+            continue
+        seen.append(rel)
+        with open(os.path.join(SRC_DIR, rel), "r") as f:
+            todo += re.findall(r'^\s*#\s*include\s+"([^"/]+)"', f.read(), flags=re.M)
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for rel in [src] + HEADERS:
+    for rel in sorted(seen):
         with open(os.path.join(SRC_DIR, rel), "rb") as f:
             h.update(rel.encode() + b"\0" + f.read())
     return h.hexdigest()
+
+
+# the translation unit that defines the dominant kernel of each bench workload
+WORKLOAD_TU = {"secp256k1-var": "kernels_secp.hip", "secp256k1-fixed": "kernels_secp.hip",
+               "p256-var": "kernels_p256.hip", "p256-fixed": "kernels_p256.hip",
+               "ed25519-var": "kernels_ed.hip", "ed25519-fixed": "fecgpu.hip", "secp256k1-double": "kernels_secp.hip"}
+
+
+def _tu_hash(src):
+    """Hash of one translation unit: its own source, the headers it includes (transitively) and the flags."""
+    return tu_closure_hash(src)
 
 
 def build(force=False, verbose=False):

@@ -833,6 +833,29 @@ int launch_ecdsa_verify(fec_ctx* ctx, int curve, const unsigned char* dd, const 
   return L.done();
 }
 
+// Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211, 430-447):
+// A = from_affine(pk); s*G by the LDS addend-table kernel, k*A by the task scheduler; R + k*A, the two
+// to_affine, the difference and is_identity in one finishing pass.  Work area: A, s*G, k*A (3 x 128 B).
+int launch_eddsa_verify(fec_ctx* ctx, const u64* dr, const unsigned char* drinf, const u64* dpk, const unsigned char* dpinf,
+                        const u64* ds, const u64* dk, unsigned char* dstatus, size_t n, void* stream) {
+  if (n == 0) return FEC_OK;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  char* work = static_cast<char*>(scratch_for(ctx, st, n * 384));
+  if (!work) return FEC_E_OOM;
+  u32* a = reinterpret_cast<u32*>(work);
+  u32* sg = reinterpret_cast<u32*>(work + n * 128);
+  u32* ka = reinterpret_cast<u32*>(work + n * 256);
+  int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
+  if (rc != FEC_OK) return rc;
+  Launch L(ctx, stream, "k_eddsa_pre + k_ed_fixed_base + k_ed_mul_sched + k_eddsa_finish");
+  eddsa_pre_launch(reinterpret_cast<const u32*>(dpk), dpinf, a, n, L.s);
+  hipLaunchKernelGGL(k_ed_fixed_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(ds),
+                     reinterpret_cast<const u32*>(ctx->d_gen[FEC_ED25519]), ctx->d_ed_table, sg, n);
+  ed_launch_mul(reinterpret_cast<const u32*>(dk), a, ka, n, L.s);
+  eddsa_finish_launch(sg, ka, reinterpret_cast<const u32*>(dr), drinf, dstatus, n, L.s);
+  return L.done();
+}
+
 int launch_field(fec_ctx* ctx, int curve, int op, const u64* da, const u64* db, u64* dout, size_t n,
                  void* stream = nullptr) {
   if (n == 0) return FEC_OK;
@@ -1278,6 +1301,52 @@ int fec_ecdsa_verify_p256_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint
 int fec_ecdsa_verify_p256(fec_ctx* ctx, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
                           const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) {
   return ecdsa_verify_host(ctx, FEC_P256, digests, r, s, pk_xy, pk_inf, status, n);
+}
+
+int fec_eddsa_verify_ed25519_dev(fec_ctx* ctx, const uint64_t* d_r_xy, const uint8_t* d_r_inf, const uint64_t* d_pk_xy,
+                                 const uint8_t* d_pk_inf, const uint64_t* d_s, const uint64_t* d_k, uint8_t* d_status,
+                                 size_t n, void* stream) {
+  if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
+  if (!ctx || (n && (!d_r_xy || !d_pk_xy || !d_s || !d_k || !d_status))) return FEC_E_ARG;
+  if (!aligned16(d_r_xy) || !aligned16(d_pk_xy) || !aligned16(d_s) || !aligned16(d_k)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_eddsa_verify(ctx, d_r_xy, d_r_inf, d_pk_xy, d_pk_inf, d_s, d_k, d_status, n, stream);
+}
+
+int fec_eddsa_verify_ed25519(fec_ctx* ctx, const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* pk_xy,
+                             const uint8_t* pk_inf, const uint64_t* s, const uint64_t* k, uint8_t* status, size_t n) {
+  if (is_multi(ctx)) {
+    if (n && (!r_xy || !pk_xy || !s || !k || !status)) return FEC_E_ARG;
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_eddsa_verify_ed25519(c, r_xy + lo * 8, r_inf ? r_inf + lo : nullptr, pk_xy + lo * 8,
+                                      pk_inf ? pk_inf + lo : nullptr, s + lo * 4, k + lo * 4, status + lo, cnt);
+    });
+  }
+  if (!ctx || (n && (!r_xy || !pk_xy || !s || !k || !status))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  const void* hin[6] = {r_xy, pk_xy, s, k, r_inf, pk_inf};
+  const size_t bytes[6] = {n * 64, n * 64, n * 32, n * 32, n, n};
+  const int slot[6] = {0, 1, 2, 4, 5, 6};
+  for (int i = 0; i < 6; ++i) {
+    if (!hin[i]) continue;
+    int rc = ensure(ctx, slot[i], bytes[i]);
+    if (rc != FEC_OK) return rc;
+    if (hipMemcpyAsync(ctx->d_buf[slot[i]], hin[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  }
+  int rc = ensure(ctx, 3, n);
+  if (rc != FEC_OK) return rc;
+  rc = launch_eddsa_verify(ctx, (const u64*)ctx->d_buf[0], r_inf ? (const unsigned char*)ctx->d_buf[5] : nullptr,
+                           (const u64*)ctx->d_buf[1], pk_inf ? (const unsigned char*)ctx->d_buf[6] : nullptr,
+                           (const u64*)ctx->d_buf[2], (const u64*)ctx->d_buf[4], (unsigned char*)ctx->d_buf[3], n, nullptr);
+  if (rc != FEC_OK) return rc;
+  if (hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  return FEC_OK;
 }
 
 // schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290)

@@ -29,4 +29,11 @@ void ecdsa_launch(int curve, const unsigned char* digests, const u32* r, const u
                   const unsigned char* pk_inf, const u32* gen, unsigned char* status, void* work, size_t n,
                   hipStream_t s);
 
+// kernels_ecdsa.hip: Eddsa verify around the Ed25519 multiplications (eddsa.rs:174-211, 430-447).
+// eddsa_pre_launch: a[i] = from_affine(pk[i]) (32 words); eddsa_finish_launch: status from sg = multiply(G, s),
+// ka = multiply(A, k), R.
+void eddsa_pre_launch(const u32* pk, const unsigned char* pk_inf, u32* a, size_t n, hipStream_t s);
+void eddsa_finish_launch(const u32* sg, const u32* ka, const u32* r_xy, const unsigned char* r_inf, unsigned char* status,
+                         size_t n, hipStream_t s);
+
 }  // namespace fecgpu

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/fecgpu.h"
+#include "ed25519.hpp"
 #include "kernels.hpp"
 #include "p256.hpp"
 #include "secp256k1.hpp"
@@ -149,7 +150,59 @@ void run(const unsigned char* dd, const u32* dr, const u32* ds, const u32* dpk, 
   hipLaunchKernelGGL((k_ecdsa_finish<E>), g, b, 0, s, (const u32*)ta, (const u32*)tb, dr, (const unsigned char*)flags, dstatus, n);
 }
 
+// ---- Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211, 430-447) ----
+FEC_DEV ed::pt ed_from_affine(const fe& x, const fe& y, bool inf) {  // ed25519.rs:1813-1826
+  ed::pt p;
+  p.x = x; p.y = y; p.z = fe_small(1); p.t = ed::mul(x, y);
+  return ed::pt_select(p, ed::identity(), lanes_where(inf));
+}
+FEC_DEV ed::pt ed_load32(const u32* g) {
+  ed::pt p;
+  p.x = load8(g); p.y = load8(g + 8); p.z = load8(g + 16); p.t = load8(g + 24);
+  return p;
+}
+
+// A = from_affine(pk) as the base of multiply(A, k)
+__global__ __launch_bounds__(TPB) void k_eddsa_pre(const u32* __restrict__ pk, const unsigned char* __restrict__ pk_inf,
+                                                   u32* __restrict__ a, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const bool inf = pk_inf != nullptr && pk_inf[i] != 0;
+  const ed::pt p = ed_from_affine(load8(pk + i * 16), load8(pk + i * 16 + 8), inf);
+  store8(a + i * 32, p.x); store8(a + i * 32 + 8, p.y); store8(a + i * 32 + 16, p.z); store8(a + i * 32 + 24, p.t);
+}
+
+// sg = multiply(G, s), ka = multiply(A, k): R + ka, both to_affine, from_affine(..) - from_affine(..), is_identity
+__global__ __launch_bounds__(TPB) void k_eddsa_finish(const u32* __restrict__ sg, const u32* __restrict__ ka,
+                                                      const u32* __restrict__ r_xy, const unsigned char* __restrict__ r_inf,
+                                                      unsigned char* __restrict__ status, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const ed::pt s_g = ed_load32(sg + i * 32), k_a = ed_load32(ka + i * 32);
+  const ed::pt r = ed_from_affine(load8(r_xy + i * 16), load8(r_xy + i * 16 + 8), false);
+  const ed::pt rk = ed::padd(r, k_a);                                                     // 200 / 435
+  // to_affine (1793-1811) unwraps z.invert(): a zero z of a point that is not the identity panics
+  const bool panic = lane_of((~ed::is_identity(s_g) & fe_is_zero(s_g.z)) | (~ed::is_identity(rk) & fe_is_zero(rk.z)));
+  fe x1, y1, x2, y2;
+  const lmask i1 = ed::to_affine(s_g, x1, y1), i2 = ed::to_affine(rk, x2, y2);           // 204-205 / 439-440
+  const ed::pt p1 = ed_from_affine(x1, y1, lane_of(i1));
+  ed::pt p2 = ed_from_affine(x2, y2, lane_of(i2));
+  p2.x = ed::neg(p2.x);                                                                    // negate 1834-1841
+  p2.t = ed::neg(p2.t);
+  const bool same = lane_of(ed::is_identity(ed::padd(p1, p2)));                           // Sub 1936-1947; 210 / 446
+  const bool rinf = r_inf != nullptr && r_inf[i] != 0;                                     // 174-177
+  status[i] = rinf ? 0 : (panic ? 2 : (same ? 1 : 0));
+}
+
 }  // namespace
+
+void eddsa_pre_launch(const u32* pk, const unsigned char* pk_inf, u32* a, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_eddsa_pre, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, pk, pk_inf, a, n);
+}
+void eddsa_finish_launch(const u32* sg, const u32* ka, const u32* r_xy, const unsigned char* r_inf, unsigned char* status,
+                         size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_eddsa_finish, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, sg, ka, r_xy, r_inf, status, n);
+}
 
 size_t ecdsa_work_bytes(size_t n) { return n * 353; }
 

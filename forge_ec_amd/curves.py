@@ -153,6 +153,25 @@ class Context:
         return self._ecdsa_verify(self._lib.fec_ecdsa_verify_p256, "fec_ecdsa_verify_p256", digests, r, s, pk_xy,
                                   pk_inf)
 
+    def eddsa_verify_ed25519(self, r_xy, r_inf, pk_xy, pk_inf, s, k):
+        """Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211,
+        430-447): r_xy, pk_xy (n,8) raw limbs; r_inf, pk_inf (n,) uint8 or None; s, k (n,4) scalars
+        (k = from_bytes_reduced(hash)).  Returns (n,) uint8: 1 true, 0 false, 2 = the reference panics."""
+        rr, pk, ss, kk = _u64(r_xy, 8), _u64(pk_xy, 8), _u64(s, 4), _u64(k, 4)
+        n = ss.shape[0]
+        if not (rr.shape[0] == pk.shape[0] == kk.shape[0] == n):
+            raise ValueError("inputs differ in length")
+        flags = []
+        for f in (r_inf, pk_inf):
+            a = np.ascontiguousarray(np.asarray(f, dtype=np.uint8)).reshape(-1) if f is not None else None
+            if a is not None and a.shape[0] != n:
+                raise ValueError("flags and signatures differ in length")  # the C side reads n bytes
+            flags.append(a)
+        out = np.empty(n, dtype=np.uint8)
+        _check(self._lib.fec_eddsa_verify_ed25519(self._h, _ptr(rr), _ptr(flags[0]), _ptr(pk), _ptr(flags[1]), _ptr(ss),
+                                                  _ptr(kk), _ptr(out), n), "fec_eddsa_verify_ed25519")
+        return out
+
     def batch_compress(self, curve, xy, inf=None):
         """PointAffine::to_bytes of each affine point (x, y, infinity) -> (n, 33) uint8."""
         p = _u64(xy, 8)
@@ -255,6 +274,10 @@ class Context:
     def ecdsa_verify_secp256k1_dev(self, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream=None):
         _check(self._lib.fec_ecdsa_verify_secp256k1_dev(self._h, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n,
                                                         stream), "fec_ecdsa_verify_secp256k1_dev")
+
+    def eddsa_verify_ed25519_dev(self, d_r_xy, d_r_inf, d_pk_xy, d_pk_inf, d_s, d_k, d_status, n, stream=None):
+        _check(self._lib.fec_eddsa_verify_ed25519_dev(self._h, d_r_xy, d_r_inf, d_pk_xy, d_pk_inf, d_s, d_k, d_status, n,
+                                                      stream), "fec_eddsa_verify_ed25519_dev")
 
     def ecdsa_verify_p256_dev(self, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream=None):
         _check(self._lib.fec_ecdsa_verify_p256_dev(self._h, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n,

@@ -29,6 +29,9 @@
  *   fec_ecdsa_verify_p256 Ecdsa::<P256, D>::verify per signature, digest supplied (ecdsa.rs:213-281; scalar
  *                         field p256.rs:875-1100, 1409-1432; default Scalar::ct_lt core lib.rs:497-531;
  *                         FieldElement::to_bytes 288-300)
+ *   fec_eddsa_verify_ed25519   Eddsa::<Ed25519, D>::verify / Ed25519::verify after the hash and the decoding
+ *                         (forge-ec-signature/src/eddsa.rs:174-211, 430-447; from_affine ed25519.rs:1813-1826,
+ *                         negate 1834-1841, Sub 1936-1947, to_affine 1793-1811)
  *   fec_batch_compress    out[i] = PointAffine::to_bytes(&points[i]) -> [u8; 33] (secp256k1.rs:875-896,
  *                         p256.rs:1558-1578, ed25519.rs:1505-1525; the bytes forge-ec-encoding's
  *                         CompressedPoint::from_affine builds, point.rs:38-67), with each curve's
@@ -158,6 +161,18 @@ int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests /* n*32 */, 
 int fec_ecdsa_verify_p256(fec_ctx* ctx, const uint8_t* digests /* n*32 */, const uint64_t* r /* n*4 */,
                           const uint64_t* s /* n*4 */, const uint64_t* pk_xy /* n*8 */,
                           const uint8_t* pk_inf /* n or NULL */, uint8_t* status /* n */, size_t n);
+/* EdDSA verification as the reference computes it, from the point computation on
+ * (Eddsa::<Ed25519, D>::verify, forge-ec-signature/src/eddsa.rs:174-211, and Ed25519::verify, 430-447 -- the
+ * same lines of arithmetic).  The caller hashes and decodes with the reference's own code (or
+ * fec_batch_decompress) and passes: r_xy / r_inf = the signature point R (AffinePoint limbs and infinity
+ * flag; the generic verify returns false for an infinite R), pk_xy / pk_inf = the public key A, s = the
+ * signature scalar, k = Scalar::from_bytes_reduced(hash).  The message special cases at 157-170 / 361-374
+ * are the caller's.  status[i] = 1 true, 0 false, 2 where the reference panics (to_affine unwraps the
+ * inverse of a zero z of a point that is not the identity, ed25519.rs:1805). */
+int fec_eddsa_verify_ed25519(fec_ctx* ctx, const uint64_t* r_xy /* n*8 */, const uint8_t* r_inf /* n or NULL */,
+                             const uint64_t* pk_xy /* n*8 */, const uint8_t* pk_inf /* n or NULL */,
+                             const uint64_t* s /* n*4 */, const uint64_t* k /* n*4 */, uint8_t* status /* n */,
+                             size_t n);
 /* xy: n*8 limbs (x then y, e.g. from fec_batch_to_affine), inf: n flags or NULL (all finite), out: n*33 bytes */
 int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* out,
                        size_t n);
@@ -218,6 +233,9 @@ int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const
 int fec_ecdsa_verify_p256_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
                               const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
                               void* stream);
+int fec_eddsa_verify_ed25519_dev(fec_ctx* ctx, const uint64_t* d_r_xy, const uint8_t* d_r_inf, const uint64_t* d_pk_xy,
+                                 const uint8_t* d_pk_inf, const uint64_t* d_s, const uint64_t* d_k, uint8_t* d_status,
+                                 size_t n, void* stream);
 /* d_out must be 4-byte aligned */
 int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf,
                            uint8_t* d_out, size_t n, void* stream);

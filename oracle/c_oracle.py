@@ -74,6 +74,8 @@ def lib():
         L.fo_p256_ecdsa_verify.restype = ctypes.c_int
         L.fo_batch_p256_ecdsa_verify.argtypes = [p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
         L.fo_batch_p256_ecdsa_verify.restype = None
+        L.fo_batch_ed25519_eddsa_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_ed25519_eddsa_verify.restype = None
         L.fo_secp256k1_schnorr_batch_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, p, p]
         L.fo_secp256k1_schnorr_batch_verify.restype = ctypes.c_int
         L.fo_batch_compress.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t]
@@ -239,6 +241,19 @@ def batch_p256_ecdsa_verify(digests, r, s, pk_xy, pk_inf=None, nthreads=1):
     out = np.zeros(n, dtype=np.uint8)
     lib().fo_batch_p256_ecdsa_verify(_ptr(digests), _ptr(r), _ptr(s), _ptr(pk_xy),
                                      _ptr(inf) if inf is not None else None, _ptr(out), n, nthreads)
+    return out
+
+
+def batch_ed25519_eddsa_verify(r_xy, r_inf, pk_xy, pk_inf, s, k, nthreads=1):
+    """Eddsa verify from the point computation on: r_xy, pk_xy (n,8) raw limbs, flags (n,) or None, s, k (n,4)
+    -> (n,) uint8 status (1 true, 0 false, 2 the reference panics)."""
+    r_xy, pk_xy, s, k = _u64(r_xy), _u64(pk_xy), _u64(s), _u64(k)
+    n = s.size // 4
+    ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)) if r_inf is not None else None
+    pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+    out = np.zeros(n, dtype=np.uint8)
+    lib().fo_batch_ed25519_eddsa_verify(_ptr(r_xy), _ptr(ri) if ri is not None else None, _ptr(pk_xy),
+                                        _ptr(pi) if pi is not None else None, _ptr(s), _ptr(k), _ptr(out), n, nthreads)
     return out
 
 

@@ -1301,6 +1301,62 @@ static void* vworker(void* arg) {
                                                    j->inf ? j->inf[i] : 0);
   return NULL;
 }
+/* ---- Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on
+ * (forge-ec-signature/src/eddsa.rs:174-211 and 430-447; the hashing and the message special cases at
+ * 157-170 / 361-374 stay with the caller): k = from_bytes_reduced(hash) and s are given as scalars.
+ * 1 = true, 0 = false, 2 = the reference panics (to_affine's z.invert().unwrap() on z == 0 of a point
+ * that is not the identity, ed25519.rs:1805 with invert 603-621). */
+static ept e_from_affine(const u64 xy[8], int inf) {                    /* ed25519.rs:1813-1826 */
+  if (inf) return e_identity();
+  fe x = ld(xy), y = ld(xy + 4);
+  ept p = {x, y, fe_small(1), e_mul(x, y)};
+  return p;
+}
+static ept e_negate(const ept* p) {                                      /* 1834-1841 */
+  ept r = {e_neg(p->x), p->y, p->z, e_neg(p->t)};
+  return r;
+}
+int fo_ed25519_eddsa_verify(const u64 r_xy[8], int r_inf, const u64 pk_xy[8], int pk_inf, const u64 s[4],
+                            const u64 k[4]) {
+  if (r_inf) return 0;                                                   /* eddsa.rs:174-177 */
+  ept g = e_generator();
+  ept s_g = e_multiply(&g, s);                                           /* 196 / 431 */
+  ept a = e_from_affine(pk_xy, pk_inf);
+  ept k_a = e_multiply(&a, k);                                           /* 199 / 434 */
+  ept r = e_from_affine(r_xy, 0);
+  ept rk = e_padd(&r, &k_a);                                             /* 200 / 435 */
+  if ((!e_is_identity(&s_g) && fe_is_zero(&s_g.z)) || (!e_is_identity(&rk) && fe_is_zero(&rk.z))) return 2;
+  fe x1, y1, x2, y2;
+  int i1 = e_to_affine(&s_g, &x1, &y1), i2 = e_to_affine(&rk, &x2, &y2); /* 204-205 / 439-440 */
+  u64 a1[8], a2[8];
+  st(a1, x1); st(a1 + 4, y1); st(a2, x2); st(a2 + 4, y2);
+  ept p1 = e_from_affine(a1, i1), p2 = e_from_affine(a2, i2);
+  ept n2 = e_negate(&p2);                                                /* Sub = self + rhs.negate(), 1936-1947 */
+  ept diff = e_padd(&p1, &n2);                                           /* 210 / 446 */
+  return e_is_identity(&diff);
+}
+typedef struct { const u64 *r, *pk, *s, *k; const uint8_t *rinf, *pinf; uint8_t* out; size_t lo, hi; } ev_t;
+static void* evworker(void* arg) {
+  ev_t* j = (ev_t*)arg;
+  for (size_t i = j->lo; i < j->hi; ++i)
+    j->out[i] = (uint8_t)fo_ed25519_eddsa_verify(j->r + 8 * i, j->rinf ? j->rinf[i] : 0, j->pk + 8 * i,
+                                                  j->pinf ? j->pinf[i] : 0, j->s + 4 * i, j->k + 4 * i);
+  return NULL;
+}
+void fo_batch_ed25519_eddsa_verify(const u64* r_xy, const uint8_t* r_inf, const u64* pk_xy, const uint8_t* pk_inf,
+                                   const u64* s, const u64* k, uint8_t* out, size_t n, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 64) nthreads = 64;
+  pthread_t th[64];
+  ev_t jobs[64];
+  for (int t = 0; t < nthreads; ++t) {
+    ev_t j = {r_xy, pk_xy, s, k, r_inf, pk_inf, out, n * t / nthreads, n * (t + 1) / nthreads};
+    jobs[t] = j;
+    pthread_create(&th[t], NULL, evworker, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+}
+
 typedef struct { const unsigned char* d; const u64 *r, *s, *pk; const uint8_t* inf; uint8_t* out; size_t lo, hi; } pv_t;
 static void* pvworker(void* arg) {
   pv_t* j = (pv_t*)arg;

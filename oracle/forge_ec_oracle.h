@@ -74,6 +74,14 @@ void fo_batch_p256_ecdsa_verify(const unsigned char* digests, const uint64_t* r,
                                 const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* out, size_t n,
                                 int nthreads);
 
+/* Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211, 430-447),
+ * s and k = from_bytes_reduced(hash) given: 1 true, 0 false, 2 the reference panics */
+int fo_ed25519_eddsa_verify(const uint64_t r_xy[8], int r_inf, const uint64_t pk_xy[8], int pk_inf,
+                            const uint64_t s[4], const uint64_t k[4]);
+void fo_batch_ed25519_eddsa_verify(const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* pk_xy,
+                                   const uint8_t* pk_inf, const uint64_t* s, const uint64_t* k, uint8_t* out,
+                                   size_t n, int nthreads);
+
 /* schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290) with the challenges
  * e_i and the random weights a_i supplied; 1 = true, 0 = false.  sides / sides_inf (optional): the
  * two affine points the reference compares at 286 */

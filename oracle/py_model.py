@@ -935,6 +935,41 @@ def p256_ecdsa_verify(digest, r, s, pk_xy, pk_inf=False):
     return 1 if list(x) == list(r) else 0
 
 
+def ed25519_eddsa_verify(r_xy, r_inf, pk_xy, pk_inf, s, k):
+    """Eddsa::<Ed25519, D>::verify (eddsa.rs:174-211) / Ed25519::verify (430-447) from the point computation
+    on, s and k = from_bytes_reduced(hash) given.  1 true, 0 false, 2 = the reference panics
+    (to_affine unwraps the inverse of a zero z, ed25519.rs:1805)."""
+    F = Ed
+
+    def from_affine(xy, inf):  # ed25519.rs:1813-1826
+        if inf:
+            return F.identity()
+        x, y = list(xy[0:4]), list(xy[4:8])
+        return (x, y, [1, 0, 0, 0], F.mul(x, y))
+
+    def affine_or_panic(p):  # 1793-1811
+        if F.is_identity(p):
+            return ([0] * 8, True)
+        if _is_zero(p[2]):
+            raise ZeroDivisionError
+        x, y, _ = F.to_affine(p)
+        return (list(x) + list(y), False)
+
+    if r_inf:
+        return 0  # eddsa.rs:174-177
+    s_g = F.multiply(F.generator(), list(s))
+    k_a = F.multiply(from_affine(pk_xy, pk_inf), list(k))
+    rk = F.padd(from_affine(r_xy, False), k_a)
+    try:
+        a1, i1 = affine_or_panic(s_g)
+        a2, i2 = affine_or_panic(rk)
+    except ZeroDivisionError:
+        return 2
+    p2 = from_affine(a2, i2)
+    neg = (F.neg(p2[0]), p2[1], p2[2], F.neg(p2[3]))  # negate 1834-1841; Sub = self + rhs.negate() 1936-1947
+    return 1 if F.is_identity(F.padd(from_affine(a1, i1), neg)) else 0
+
+
 def secp256k1_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e):
     """schnorr.rs:194-290 with challenges e and weights a supplied.  -> (result, sides, sides_inf):
     sides = x, y of to_affine(s_g) then x, y of to_affine(r_e_p) (what line 286 compares)."""

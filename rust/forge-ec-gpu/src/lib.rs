@@ -33,6 +33,7 @@ extern "C" {
     fn fec_batch_double_mul(ctx: *mut FecCtx, curve: c_int, u1: *const u64, u2: *const u64, q: *const u64, out: *mut u64, n: usize) -> c_int;
     fn fec_batch_to_affine(ctx: *mut FecCtx, curve: c_int, points: *const u64, xy: *mut u64, inf: *mut u8, n: usize) -> c_int;
     fn fec_multi_scalar_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_eddsa_verify_ed25519(ctx: *mut FecCtx, r_xy: *const u64, r_inf: *const u8, pk_xy: *const u64, pk_inf: *const u8, s: *const u64, k: *const u64, status: *mut u8, n: usize) -> c_int;
     fn fec_ecdsa_verify_p256(ctx: *mut FecCtx, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, status: *mut u8, n: usize) -> c_int;
     fn fec_ecdsa_verify_secp256k1(ctx: *mut FecCtx, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, status: *mut u8, n: usize) -> c_int;
     fn fec_batch_compress(ctx: *mut FecCtx, curve: c_int, xy: *const u64, inf: *const u8, out: *mut u8, n: usize) -> c_int;
@@ -45,6 +46,7 @@ extern "C" {
     fn fec_batch_mul_dev(ctx: *mut FecCtx, curve: c_int, d_scalars: *const u64, d_points: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_mul_fixed_dev(ctx: *mut FecCtx, curve: c_int, d_scalars: *const u64, d_base: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_double_mul_dev(ctx: *mut FecCtx, curve: c_int, d_u1: *const u64, d_u2: *const u64, d_q: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
+    fn fec_eddsa_verify_ed25519_dev(ctx: *mut FecCtx, d_r_xy: *const u64, d_r_inf: *const u8, d_pk_xy: *const u64, d_pk_inf: *const u8, d_s: *const u64, d_k: *const u64, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_ecdsa_verify_p256_dev(ctx: *mut FecCtx, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_ecdsa_verify_secp256k1_dev(ctx: *mut FecCtx, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_compress_dev(ctx: *mut FecCtx, curve: c_int, d_xy: *const u64, d_inf: *const u8, d_out: *mut u8, n: usize, stream: *mut c_void) -> c_int;
@@ -388,6 +390,32 @@ pub fn ecdsa_verify_batch_p256(ctx: &mut GpuContext, digests: &[[u8; 32]], r: &[
     Ok(status.iter().map(|&v| match v { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid }).collect())
 }
 
+/// `Eddsa::<Ed25519, D>::verify` / `Ed25519::verify` per element from the point computation on
+/// (`forge-ec-signature/src/eddsa.rs:174-211`, `430-447`).  The caller keeps the hashing and the message
+/// special cases (157-170 / 361-374): `k[i] = Scalar::from_bytes_reduced(&hash_i[0..32])`, `sig_r[i]` and
+/// `public_keys[i]` decoded with `PointAffine::from_bytes`.
+pub fn eddsa_verify_batch_ed25519(ctx: &mut GpuContext, sig_r: &[ed25519::AffinePoint], sig_s: &[ed25519::Scalar], public_keys: &[ed25519::AffinePoint], k: &[ed25519::Scalar]) -> Result<Vec<VerifyStatus>> {
+    let n = sig_r.len();
+    if sig_s.len() != n || public_keys.len() != n || k.len() != n {
+        return Err(Error::ValidationError);
+    }
+    type C = ed25519::Ed25519;
+    let (ss, kk) = (pack_scalars::<C>(sig_s), pack_scalars::<C>(k));
+    let (mut rxy, mut rinf, mut pxy, mut pinf) = (vec![0u64; 8 * n], vec![0u8; n], vec![0u64; 8 * n], vec![0u8; n]);
+    for i in 0..n {
+        let (l, f) = C::affine_limbs(&sig_r[i]);
+        rxy[8 * i..8 * i + 8].copy_from_slice(&l);
+        rinf[i] = f as u8;
+        let (l, f) = C::affine_limbs(&public_keys[i]);
+        pxy[8 * i..8 * i + 8].copy_from_slice(&l);
+        pinf[i] = f as u8;
+    }
+    let mut status = vec![0u8; n];
+    // SAFETY: every buffer holds n elements of the width the header states.
+    check(unsafe { fec_eddsa_verify_ed25519(ctx.raw, rxy.as_ptr(), rinf.as_ptr(), pxy.as_ptr(), pinf.as_ptr(), ss.as_ptr(), kk.as_ptr(), status.as_mut_ptr(), n) })?;
+    Ok(status.iter().map(|&v| match v { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid }).collect())
+}
+
 /// `schnorr::batch_verify::<Secp256k1, D>` from line 258 on (`forge-ec-signature/src/schnorr.rs:194-290`):
 /// the caller hashes (challenges `e`, 236-256) and draws the weights (`a`, 228-233) with the
 /// reference's own code and passes them as scalars.
@@ -476,6 +504,14 @@ pub mod dev {
     /// As [`batch_mul`].
     pub unsafe fn ecdsa_verify_secp256k1(ctx: &mut GpuContext, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
         check(fec_ecdsa_verify_secp256k1_dev(ctx.raw, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream))
+    }
+
+    /// `fec_eddsa_verify_ed25519_dev`.
+    ///
+    /// # Safety
+    /// As [`batch_mul`].
+    pub unsafe fn eddsa_verify_ed25519(ctx: &mut GpuContext, d_r_xy: *const u64, d_r_inf: *const u8, d_pk_xy: *const u64, d_pk_inf: *const u8, d_s: *const u64, d_k: *const u64, d_status: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_eddsa_verify_ed25519_dev(ctx.raw, d_r_xy, d_r_inf, d_pk_xy, d_pk_inf, d_s, d_k, d_status, n, stream))
     }
 
     /// `fec_ecdsa_verify_p256_dev`.

@@ -9,6 +9,7 @@ The committed fixtures fed DIRECTLY through libfecgpu.so (C ABI) on the GPU -- n
   tests/golden/reference_kats.json   the known answers the reference's own unit tests hold
   tests/golden/secp256k1_sqr_ripple_operands.json
   tests/golden/ecdsa_p256_vectors.json  Ecdsa::<P256, D>::verify cases of every status
+  tests/golden/eddsa_ed25519_vectors.json  Eddsa verify (point computation on) cases of every status
 
 Bit-exact.  Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
@@ -133,4 +134,12 @@ def test_p256_ecdsa_vectors_on_the_gpu(gpu_ctx):
     dg = np.frombuffer(bytes.fromhex("".join(c["digest"] for c in v)), dtype=np.uint8).reshape(-1, 32)
     got = gpu_ctx.ecdsa_verify_p256(dg, _u64([c["r"] for c in v]), _u64([c["s"] for c in v]), _u64([c["pk"] for c in v]),
                                     np.array([c["pk_inf"] for c in v], dtype=np.uint8))
+    assert [int(x) for x in got] == [c["status"] for c in v]
+
+
+def test_eddsa_ed25519_vectors_on_the_gpu(gpu_ctx):
+    v = _load("eddsa_ed25519_vectors.json")["verify"]
+    got = gpu_ctx.eddsa_verify_ed25519(_u64([c["r"] for c in v]), np.array([c["r_inf"] for c in v], dtype=np.uint8),
+                                       _u64([c["pk"] for c in v]), np.array([c["pk_inf"] for c in v], dtype=np.uint8),
+                                       _u64([c["s"] for c in v]), _u64([c["k"] for c in v]))
     assert [int(x) for x in got] == [c["status"] for c in v]

@@ -399,6 +399,56 @@ def test_ecdsa_verify_secp256k1_matches_oracle(gpu_ctx, oracle):
     assert np.array_equal(gpu_ctx.ecdsa_verify_secp256k1(dg, r, s, pk, None), want2)
 
 
+def test_eddsa_verify_ed25519_matches_oracle(gpu_ctx, oracle):
+    """Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211, 430-447):
+    random inputs, signatures that verify under the reference's arithmetic, infinite R, zero scalars, the
+    panic input of the fixture; host and device-pointer entry points."""
+    import json
+    import os
+    import torch
+    n_random, n_valid = 500, 60
+    n = n_random + n_valid + 6
+    s, k = V.scalars(n, 2, 821), V.scalars(n, 2, 822)
+    pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 823), V.field_elements(n, 2, 824)], axis=1))
+    r = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 825), V.field_elements(n, 2, 826)], axis=1))
+    pinf, rinf = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    g = oracle.generator(2)
+    sg = oracle.batch_mul_fixed(2, s[n_random:n_random + n_valid], g, nthreads=8)
+    axy, ainf = oracle.batch_to_affine(2, sg, nthreads=8)
+    for j in range(n_valid):
+        i = n_random + j
+        r[i] = axy[j]
+        if j % 2:
+            pinf[i] = 1       # A at infinity: R + k*A = from_affine(R)
+        else:
+            k[i] = 0          # k = 0: multiply's early-out gives the identity as well
+    base = n_random + n_valid
+    rinf[base + 0] = 1        # infinite R -> false
+    s[base + 1] = 0           # s*G = identity
+    k[base + 2] = 0
+    pinf[base + 3] = 1
+    r[base + 4] = 0           # R = (0, 0), not flagged
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eddsa_ed25519_vectors.json")) as f:
+        panic = [c for c in json.load(f)["verify"] if c["status"] == 2][0]
+    r[base + 5], pk[base + 5], s[base + 5], k[base + 5] = panic["r"], panic["pk"], panic["s"], panic["k"]
+    want = oracle.batch_ed25519_eddsa_verify(r, rinf, pk, pinf, s, k, nthreads=8)
+    assert int((want == 1).sum()) >= n_valid and set(int(v) for v in want) == {0, 1, 2}
+    got = gpu_ctx.eddsa_verify_ed25519(r, rinf, pk, pinf, s, k)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, "first mismatch at %d: got %d want %d" % (bad[0], got[bad[0]], want[bad[0]])
+    want2 = oracle.batch_ed25519_eddsa_verify(r, None, pk, None, s, k, nthreads=8)
+    assert np.array_equal(gpu_ctx.eddsa_verify_ed25519(r, None, pk, None, s, k), want2)
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev) for a in (r, rinf, pk, pinf, s, k)]
+    st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    gpu_ctx.eddsa_verify_ed25519_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(),
+                                     t[5].data_ptr(), st.data_ptr(), n, stream.cuda_stream)
+    stream.synchronize()
+    assert np.array_equal(st.cpu().numpy(), want)
+
+
 def _p256_ecdsa_cases(oracle, n_random, n_valid):
     """As _ecdsa_cases for Ecdsa::<P256, D>::verify.  r or s >= n are NOT rejected by the reference (its
     ct_lt is the trait default, a top-byte <= comparison): those lanes run the whole computation."""

@@ -304,3 +304,36 @@ def test_p256_ecdsa_two_restatements_agree_on_fresh_inputs(oracle):
     # the default ct_lt is a top-byte <= comparison (core lib.rs:497-531)
     for x, y in ((1, 2), (2, 1), (0xFF << 248, 0xFE << 248), (0xFE << 248, 0xFF << 248), (S.N + 1, S.N), (S.N, S.N)):
         assert S.ct_lt_default(S.limbs(x), S.limbs(y)) == ((x >> 248) <= (y >> 248))
+
+
+def _eddsa_fixture():
+    with open(os.path.join(HERE, "golden", "eddsa_ed25519_vectors.json")) as f:
+        return json.load(f)["verify"]
+
+
+def test_eddsa_ed25519_vectors(oracle):
+    """Eddsa verify from the point computation on (eddsa.rs:174-211, 430-447): the C oracle against the Python
+    model's committed expectations (tests/golden/gen_eddsa_ed25519.py), every status."""
+    v = _eddsa_fixture()
+    got = oracle.batch_ed25519_eddsa_verify([c["r"] for c in v], [c["r_inf"] for c in v], [c["pk"] for c in v],
+                                            [c["pk_inf"] for c in v], [c["s"] for c in v], [c["k"] for c in v], nthreads=4)
+    assert [int(x) for x in got] == [c["status"] for c in v]
+    assert {c["status"] for c in v} == {0, 1, 2}
+
+
+def test_eddsa_two_restatements_agree_on_fresh_inputs(oracle):
+    from oracle import py_model as M
+    n = 6
+    s, k = V.scalars(n, 2, 811), V.scalars(n, 2, 812)
+    pk = np.concatenate([V.field_elements(n, 2, 813), V.field_elements(n, 2, 814)], axis=1)
+    r = np.concatenate([V.field_elements(n, 2, 815), V.field_elements(n, 2, 816)], axis=1)
+    pinf, rinf = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    g = oracle.generator(2)
+    for i in (0, 1):   # verifies: A at infinity, R = to_affine(multiply(G, s))
+        pinf[i] = 1
+        r[i] = oracle.to_affine(2, oracle.multiply(2, g, s[i]))[0]
+    rinf[2] = 1
+    got = oracle.batch_ed25519_eddsa_verify(r, rinf, pk, pinf, s, k)
+    want = [M.ed25519_eddsa_verify([int(x) for x in r[i]], int(rinf[i]), [int(x) for x in pk[i]], int(pinf[i]),
+                                   [int(x) for x in s[i]], [int(x) for x in k[i]]) for i in range(n)]
+    assert [int(x) for x in got] == want and want[:3] == [1, 1, 0]

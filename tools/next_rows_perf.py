@@ -62,6 +62,16 @@ def main():
             best = min(best, ctx.last_kernel_ms()[0])
         emit(row="ecdsa_verify (parity)", curve=NAMES[c], n=n, ms=round(best, 4), M_per_s=round(n / best / 1e3, 2),
              kernels=ctx.last_kernel_ms()[1])
+    # EdDSA verify from the point computation on: from_affine + fixed-base table kernel + scheduler + finishing pass
+    rr, pp = dev(synth.field_elements(2 * n, 2, 65)), dev(synth.field_elements(2 * n, 2, 66))
+    sg, kk = dev(synth.scalars(n, 2, 67)), dev(synth.scalars(n, 2, 68))
+    status = torch.empty(n, dtype=torch.uint8, device="cuda")
+    best = 1e9
+    for _ in range(3):
+        ctx.eddsa_verify_ed25519_dev(rr.data_ptr(), None, pp.data_ptr(), None, sg.data_ptr(), kk.data_ptr(), status.data_ptr(), n, st)
+        best = min(best, ctx.last_kernel_ms()[0])
+    emit(row="eddsa_verify (parity)", curve="ed25519", n=n, ms=round(best, 4), M_per_s=round(n / best / 1e3, 2),
+         kernels=ctx.last_kernel_ms()[1])
     # host-pointer rows with a sequential fold: modest sizes
     m = 1 << 12
     ctx.set_timing(False)
