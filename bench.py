@@ -115,7 +115,7 @@ def committed_pmc(workload, n):
     import glob
     from forge_ec_amd import build as fbuild
     tu = fbuild.WORKLOAD_TU.get(workload)
-    here = fbuild.tu_closure_hash(tu) if tu else fbuild.source_hash()   # the kernel's translation unit + its includes
+    here = fbuild.tu_closure_hash(tu, kernel_code_only=True) if tu else fbuild.source_hash()   # the kernel's translation unit + its includes
     stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*", "*", "pmc.json")), reverse=True):
         try:
@@ -204,10 +204,12 @@ def main():
                                      d_out[buf].data_ptr(), n, stream)
         ms = None
         if timed:
-            ms = ctx.last_kernel_ms()[0]  # HIP events on the launch stream (syncs this launch)
+            ms, launched["name"] = ctx.last_kernel_ms()  # HIP events on the launch stream (syncs this launch)
         if gather is not None:
             gather[buf].start(d_out[buf])
         return ms
+
+    launched = {"name": None}  # the kernel(s) the library reports for the timed launch
 
     def barrier():
         if dist is not None:
@@ -258,12 +260,7 @@ def main():
         total = n * world * args.steps
         value = total / elapsed
         achieved = n * alg / (kernel_ms * 1e-3)
-        kname = {"var": "k_batch_mul<%s,var>", "fixed": "k_batch_mul<%s,fixed>",
-                 "double": "k_batch_double_mul<%s>"}[kind] % curve
-        if workload == "ed25519-fixed":
-            kname = "k_ed_fixed_base"
-        if workload == "p256-var":
-            kname = "k_p256_mul_sched"
+        kname = launched["name"]  # as the library names the launch (the rocprofv3 kernel-stats row has the same stem)
         pmc = committed_pmc(workload, n)
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is an N = 1 measurement

@@ -39,7 +39,10 @@ def up_to_date():
         return False
 
 
-def tu_closure_hash(src):
+DECLARATION_ONLY = ("kernels.hpp",)  # launcher prototypes: no effect on any kernel's code
+
+
+def tu_closure_hash(src, kernel_code_only=False):
     """Hash of one translation unit and of exactly the files it #includes from csrc/ (transitively), plus
     the flags: what determines the code of the kernels defined in `src`.  A committed PMC pass stays
     attributable to a kernel for as long as this hash stands, whatever else changes in the library."""
@@ -47,7 +50,7 @@ def tu_closure_hash(src):
     seen, todo = [], [src]
     while todo:
         rel = todo.pop()
-        if rel in seen or not os.path.exists(os.path.join(SRC_DIR, rel)):
+        if rel in seen or not os.path.exists(os.path.join(SRC_DIR, rel)) or (kernel_code_only and rel in DECLARATION_ONLY):
             continue
         seen.append(rel)
         with open(os.path.join(SRC_DIR, rel), "r") as f:
@@ -62,7 +65,7 @@ def tu_closure_hash(src):
 # the translation unit that defines the dominant kernel of each bench workload
 WORKLOAD_TU = {"secp256k1-var": "kernels_secp.hip", "secp256k1-fixed": "kernels_secp.hip",
                "p256-var": "kernels_p256.hip", "p256-fixed": "kernels_p256.hip",
-               "ed25519-var": "kernels_ed.hip", "ed25519-fixed": "fecgpu.hip", "secp256k1-double": "kernels_secp.hip"}
+               "ed25519-var": "kernels_ed.hip", "ed25519-fixed": "kernels_ed.hip", "secp256k1-double": "kernels_secp.hip"}
 
 
 def _tu_hash(src):

@@ -180,87 +180,7 @@ __global__ __launch_bounds__(TPB) void k_batch_mul(const u32* __restrict__ scala
 
 // P-256 Curve::multiply lives in kernels_p256.hip (workgroup task scheduler).
 
-// table[j] = 2^j * base by the reference's own doubling chain (ed25519.rs:2089): one lane, 255
-// sequential additions; 32 words per entry, dense.  Runs once per base point.
-__global__ __launch_bounds__(64) void k_ed_build_table(const u32* __restrict__ base, u32* __restrict__ table) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  ed::pt a = Ed::load(base, 1);
-#pragma unroll 1
-  for (int j = 0; j < 256; ++j) {
-    Ed::store(table + j * 32, 1, a);
-    a = ed::padd(a, a);
-  }
-}
-
-// Ed25519 fixed-base: out[i] = multiply(base, scalars[i]) from the LDS addend table.
-// A lane performs one addition per set bit of its scalar, so a wavefront runs for the largest
-// popcount among its 64 lanes.  The workgroup therefore bins its 256 scalars by popcount (counting
-// sort through LDS) and hands each wavefront one quartile -- rotated by workgroup so that no SIMD
-// always gets the heavy quartile: the four wavefronts then run about 123 + 128 + 134 + 150
-// iterations instead of 4 x 148.  Only the lane -> element assignment changes; every element sees
-// exactly the additions the reference performs, in the reference's order.
-__global__ __launch_bounds__(TPB) void k_ed_fixed_base(const u32* __restrict__ scalars,
-                                                       const u32* __restrict__ base,
-                                                       const u32* __restrict__ table,
-                                                       u32* __restrict__ out, size_t n) {
-  __shared__ u32 lds_k[8 * TPB];
-  __shared__ u32 lds_t[256 * ed::ED_TSTRIDE];
-  __shared__ u32 lds_o[Ed::PW * TPB];
-  __shared__ int lds_bin[260];
-  __shared__ unsigned short lds_perm[TPB];
-  const int valid = block_valid(n);
-  const size_t first = (size_t)blockIdx.x * TPB;
-  const int e = threadIdx.x;
-  stage_in<8>(lds_k, scalars + first * 8, valid);
-  for (int v = threadIdx.x; v < 256 * 32 / 4; v += TPB) {  // 32 KiB table, 16-byte loads (L2-resident)
-    uint4 x = *reinterpret_cast<const uint4*>(table + (size_t)v * 4);
-    int j = (v * 4) / 32, w = (v * 4) % 32;
-    u32* d = lds_t + j * ed::ED_TSTRIDE + w;
-    d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-  }
-  for (int v = e; v < 260; v += TPB) lds_bin[v] = 0;
-  __syncthreads();
-  // ---- counting sort of the workgroup's elements by popcount ----
-  int pc = 0;
-  if (e < valid) {
-    FEC_UNROLL for (int w = 0; w < 8; ++w) pc += __builtin_popcount(lds_k[w * TPB + e]);
-  }
-  atomicAdd(&lds_bin[pc + 1], 1);  // padding lanes count as popcount 0 and sort to the front
-  __syncthreads();
-  if (e < 64) {  // inclusive prefix over the 257 bins by one wavefront: 5 bins per lane, then a wave scan
-    int loc[5], sum = 0;
-    FEC_UNROLL for (int j = 0; j < 5; ++j) {
-      const int idx = e * 5 + j;
-      loc[j] = idx < 258 ? lds_bin[idx] : 0;
-      sum += loc[j];
-    }
-    int run = sum;
-    FEC_UNROLL for (int d = 1; d < 64; d <<= 1) {
-      const int up = __shfl_up(run, d, 64);
-      if (e >= d) run += up;
-    }
-    int excl = run - sum;
-    FEC_UNROLL for (int j = 0; j < 5; ++j) {
-      const int idx = e * 5 + j;
-      excl += loc[j];
-      if (idx < 258) lds_bin[idx] = excl;  // lds_bin[b + 1] = number of elements with popcount <= b
-    }
-  }
-  __syncthreads();
-  const int pos = atomicAdd(&lds_bin[pc], 1);  // lds_bin[pc] = first slot of this popcount
-  lds_perm[pos] = (unsigned short)e;
-  __syncthreads();
-  // wavefront w of workgroup b takes quartile (w + b) mod 4 of the sorted list
-  const int slot = ((((e >> 6) + (int)blockIdx.x) & 3) << 6) | (e & 63);
-  const int src = lds_perm[slot];
-  if (src < valid) {
-    ed::pt b = Ed::load(base, 1);
-    ed::pt r = ed::multiply_fixed(b, lds_t, lds_k + src);
-    Ed::store(lds_o + src, TPB, r);
-  }
-  __syncthreads();
-  stage_out<Ed::PW>(out + first * Ed::PW, lds_o, valid);
-}
+// Ed25519 fixed-base (k_ed_build_table, k_ed_fixed_base) and variable-base kernels live in kernels_ed.hip.
 
 // out[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])     (ecdsa.rs:254-256)
 template <class C>
@@ -685,8 +605,7 @@ int ensure_ed_table(fec_ctx* ctx, const u64* d_base, const u64* host_base, hipSt
     return FEC_E_OOM;
   }
   if (host_base && ctx->ed_table_valid && std::memcmp(host_base, ctx->ed_table_base, 128) == 0) return FEC_OK;
-  hipLaunchKernelGGL(k_ed_build_table, dim3(1), dim3(64), 0, s, reinterpret_cast<const u32*>(d_base),
-                     ctx->d_ed_table);
+  ed_build_table_launch(reinterpret_cast<const u32*>(d_base), ctx->d_ed_table, s);
   if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
   ctx->ed_table_valid = host_base != nullptr;
   if (host_base) std::memcpy(ctx->ed_table_base, host_base, 128);
@@ -700,8 +619,8 @@ int launch_ed_fixed(fec_ctx* ctx, const u64* ds, const u64* dbase, const u64* ho
   int rc = ensure_ed_table(ctx, dbase, host_base, s);
   if (rc != FEC_OK) return rc;
   Launch L(ctx, stream, "k_ed_fixed_base");
-  hipLaunchKernelGGL(k_ed_fixed_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(ds),
-                     reinterpret_cast<const u32*>(dbase), ctx->d_ed_table, reinterpret_cast<u32*>(dout), n);
+  ed_fixed_launch(reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(dbase), ctx->d_ed_table,
+                  reinterpret_cast<u32*>(dout), n, L.s);
   return L.done();
 }
 
@@ -712,10 +631,15 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
   const u32* p = reinterpret_cast<const u32*>(dp);
   u32* o = reinterpret_cast<u32*>(dout);
   dim3 g(grid_for(n)), b(TPB);
-  Launch L(ctx, stream, fixed ? "k_batch_mul<fixed>" : "k_batch_mul<var>");
+  const bool secp2 = curve == FEC_SECP256K1 && std::getenv("FEC_SECP_2WAVE");
+  const char* name = curve == FEC_SECP256K1 ? (secp2 ? (fixed ? "k_batch_mul<Secp,fixed>" : "k_batch_mul<Secp,var>")
+                                                     : (fixed ? "k_secp_mul<fixed>" : "k_secp_mul<var>"))
+                     : curve == FEC_P256    ? (fixed ? "k_p256_mul_sched<fixed>" : "k_p256_mul_sched<var>")
+                                            : (fixed ? "k_batch_mul<Ed,fixed>" : "k_ed_mul_pers");
+  Launch L(ctx, stream, name);
   switch (curve) {
     case FEC_SECP256K1:
-      if (std::getenv("FEC_SECP_2WAVE")) {  // the round-1 register-resident form (2 waves per SIMD), kept for A/B runs
+      if (secp2) {  // the round-1 register-resident form (2 waves per SIMD), kept for A/B runs
         if (fixed) hipLaunchKernelGGL((k_batch_mul<Secp, true>), g, b, 0, L.s, s, p, o, n);
         else hipLaunchKernelGGL((k_batch_mul<Secp, false>), g, b, 0, L.s, s, p, o, n);
       } else {
@@ -764,7 +688,7 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
     if (rc != FEC_OK) return rc;
   }
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op"
-                        : (curve == FEC_P256 ? "k_p256_mul_sched x2 + k_point_op" : "k_ed_fixed_base + k_ed_mul_sched + k_point_op"));
+                        : (curve == FEC_P256 ? "k_p256_mul_sched x2 + k_point_op" : "k_ed_fixed_base + k_ed_mul_pers + k_point_op"));
   if (curve == FEC_SECP256K1) {  // the 3-waves-per-SIMD ladder twice (fixed G, then Q) beats the fused 2-wave kernel
     secp_launch_mul(true, a, gen, ta, n, L.s);
     secp_launch_mul(false, b2, q, tb, n, L.s);
@@ -774,7 +698,7 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
     p256_launch_mul(false, b2, q, tb, n, L.s);
     hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   } else {
-    hipLaunchKernelGGL(k_ed_fixed_base, g, b, 0, L.s, a, gen, ctx->d_ed_table, ta, n);
+    ed_fixed_launch(a, gen, ctx->d_ed_table, ta, n, L.s);
     ed_launch_mul(b2, q, tb, n, L.s);
     hipLaunchKernelGGL((k_point_op<Ed>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   }
@@ -847,10 +771,10 @@ int launch_eddsa_verify(fec_ctx* ctx, const u64* dr, const unsigned char* drinf,
   u32* ka = reinterpret_cast<u32*>(work + n * 256);
   int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
   if (rc != FEC_OK) return rc;
-  Launch L(ctx, stream, "k_eddsa_pre + k_ed_fixed_base + k_ed_mul_sched + k_eddsa_finish");
+  Launch L(ctx, stream, "k_eddsa_pre + k_ed_fixed_base + k_ed_mul_pers + k_eddsa_finish");
   eddsa_pre_launch(reinterpret_cast<const u32*>(dpk), dpinf, a, n, L.s);
-  hipLaunchKernelGGL(k_ed_fixed_base, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(ds),
-                     reinterpret_cast<const u32*>(ctx->d_gen[FEC_ED25519]), ctx->d_ed_table, sg, n);
+  ed_fixed_launch(reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(ctx->d_gen[FEC_ED25519]),
+                  ctx->d_ed_table, sg, n, L.s);
   ed_launch_mul(reinterpret_cast<const u32*>(dk), a, ka, n, L.s);
   eddsa_finish_launch(sg, ka, reinterpret_cast<const u32*>(dr), drinf, dstatus, n, L.s);
   return L.done();

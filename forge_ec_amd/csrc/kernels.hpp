@@ -9,9 +9,13 @@ namespace fecgpu {
 // kernels_p256.hip: P-256 Curve::multiply, workgroup task scheduler.  out[i] = multiply(fixed ? points[0] : points[i], scalars[i])
 void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
 
-// kernels_ed.hip: Ed25519 variable-base Curve::multiply, workgroup task scheduler.  `out` doubles as the
-// running result of every element during the launch.
+// kernels_ed.hip: Ed25519 variable-base Curve::multiply, persistent workgroup task scheduler (one workgroup
+// per CU, element state in LDS, slots refilled from the workgroup's range).
 void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
+// kernels_ed.hip: Ed25519 fixed-base multiply from the 256-entry addend table of `base` (table[j] = 2^j * base by
+// the reference's own doubling chain, built once per base by ed_build_table_launch; 256 * 32 words).
+void ed_build_table_launch(const u32* base, u32* table, hipStream_t s);
+void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, hipStream_t s);
 
 // kernels_secp.hip: secp256k1 Curve::multiply, lane-per-element ladder at three wavefronts per SIMD.
 void secp_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);

@@ -1,5 +1,5 @@
-// kernels_ed.hip -- Ed25519 variable-base Curve::multiply (ed25519.rs:2062-2097) as a workgroup-level
-// task scheduler (the design of kernels_p256.hip).
+// kernels_ed.hip -- Ed25519 variable-base Curve::multiply (ed25519.rs:2062-2097) as a persistent
+// workgroup-level task scheduler (the queue design of kernels_p256.hip).
 //
 //   result = identity; addend = point
 //   for i in 0..256 { s = result + addend; result = bit(i) ? s : result; addend = addend.double() }
@@ -8,13 +8,9 @@
 // additions of clear bits are dead work, and so is the last doubling.  Round 1 executed them all
 // (lock-step lanes: 2 x 9 field multiplications per step).  Here every element runs exactly the
 // operations whose results are used, in the reference's order -- A_i (only if bit i is set), then D_i
-// (for i < 255) -- and a workgroup's four wavefronts pull BATCHES of 64 elements that all need an
+// (for i < 255) -- and a workgroup's wavefronts pull BATCHES of 64 elements that all need an
 // addition or all need a doubling from two ready queues in LDS.  The doubling is the reference's
 // double() = self + self (1828-1832), whose four self-products are formed with the exact squaring.
-//
-// State: the addend of each of the workgroup's E = 512 elements lives in LDS (32 words); the running
-// `result` lives in the element's slot of the OUTPUT array (it is read and rewritten by ~128 addition
-// batches per element and stays L2-resident; when the element finishes, its slot holds the answer).
 #include <hip/hip_runtime.h>
 
 #include "../../include/fecgpu.h"
@@ -26,8 +22,6 @@ namespace fecgpu {
 
 namespace {
 
-constexpr int EE = 512;  // elements per workgroup (384 measured: 25.4 vs 25.0 ms, fabric writes 14.1 vs 16.7 GB)
-constexpr int RING = 512;  // ring capacity (power of two >= EE)
 enum { C_TICKET = 0, C_HEAD_D, C_TAIL_D, C_HEAD_A, C_TAIL_A, C_INFLIGHT, C_REMAIN, C_ERR, C_SERVING, C_WORDS };
 
 FEC_DEV ed::pt ld_lds(const u32* l, int stride) {
@@ -76,76 +70,174 @@ FEC_DEV u32 scalar_bit(const u32* scalars, size_t g, int i) { return (scalars[g 
 
 }  // namespace
 
-__global__ __launch_bounds__(TPB, 2) void k_ed_mul_sched(const u32* __restrict__ scalars,
-                                                      const u32* __restrict__ points,
-                                                      u32* __restrict__ out, size_t n) {
-  __shared__ u32 lds_ad[32 * EE];             // addend of element e: word w at lds_ad[w * EE + e]
-  __shared__ unsigned short lds_step[EE];     // current step i of element e (A_i / D_i pending)
-  __shared__ unsigned short lds_q[2][RING];     // ready rings: [0] needs the doubling D_i, [1] needs the addition A_i
-  __shared__ int lds_ctl[C_WORDS];
-  const size_t first = (size_t)blockIdx.x * EE;
-  const int valid = (n - first) < (size_t)EE ? (int)(n - first) : EE;
+namespace {
+// a point as 32 consecutive words (x, y, z, t), word loads (any alignment the callers use)
+FEC_DEV ed::pt ld_words(const u32* g) {
+  ed::pt p;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) { p.x.w[i] = g[i]; p.y.w[i] = g[8 + i]; p.z.w[i] = g[16 + i]; p.t.w[i] = g[24 + i]; }
+  return p;
+}
+FEC_DEV void st_words(u32* g, const ed::pt& p) {
+  FEC_UNROLL for (int i = 0; i < 8; ++i) { g[i] = p.x.w[i]; g[8 + i] = p.y.w[i]; g[16 + i] = p.z.w[i]; g[24 + i] = p.t.w[i]; }
+}
+}  // namespace
+
+// table[j] = 2^j * base by the reference's own doubling chain (ed25519.rs:2089): one lane, 255
+// sequential additions; 32 words per entry, dense.  Runs once per base point.
+__global__ __launch_bounds__(64) void k_ed_build_table(const u32* __restrict__ base, u32* __restrict__ table) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ed::pt a = ld_words(base);
+#pragma unroll 1
+  for (int j = 0; j < 256; ++j) {
+    st_words(table + j * 32, a);
+    a = ed::padd(a, a);
+  }
+}
+
+// Ed25519 fixed-base: out[i] = multiply(base, scalars[i]) from the LDS addend table.
+// A lane performs one addition per set bit of its scalar, so a wavefront runs for the largest
+// popcount among its 64 lanes.  The workgroup therefore bins its 256 scalars by popcount (counting
+// sort through LDS) and hands each wavefront one quartile -- rotated by workgroup so that no SIMD
+// always gets the heavy quartile: the four wavefronts then run about 123 + 128 + 134 + 150
+// iterations instead of 4 x 148.  Only the lane -> element assignment changes; every element sees
+// exactly the additions the reference performs, in the reference's order.
+__global__ __launch_bounds__(TPB) void k_ed_fixed_base(const u32* __restrict__ scalars,
+                                                       const u32* __restrict__ base,
+                                                       const u32* __restrict__ table,
+                                                       u32* __restrict__ out, size_t n) {
+  __shared__ u32 lds_k[8 * TPB];
+  __shared__ u32 lds_t[256 * ed::ED_TSTRIDE];
+  __shared__ u32 lds_o[32 * TPB];
+  __shared__ int lds_bin[260];
+  __shared__ unsigned short lds_perm[TPB];
+  const int valid = block_valid(n);
+  const size_t first = (size_t)blockIdx.x * TPB;
+  const int e = threadIdx.x;
+  stage_in<8>(lds_k, scalars + first * 8, valid);
+  for (int v = threadIdx.x; v < 256 * 32 / 4; v += TPB) {  // 32 KiB table, 16-byte loads (L2-resident)
+    uint4 x = *reinterpret_cast<const uint4*>(table + (size_t)v * 4);
+    int j = (v * 4) / 32, w = (v * 4) % 32;
+    u32* d = lds_t + j * ed::ED_TSTRIDE + w;
+    d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+  }
+  for (int v = e; v < 260; v += TPB) lds_bin[v] = 0;
+  __syncthreads();
+  // ---- counting sort of the workgroup's elements by popcount ----
+  int pc = 0;
+  if (e < valid) {
+    FEC_UNROLL for (int w = 0; w < 8; ++w) pc += __builtin_popcount(lds_k[w * TPB + e]);
+  }
+  atomicAdd(&lds_bin[pc + 1], 1);  // padding lanes count as popcount 0 and sort to the front
+  __syncthreads();
+  if (e < 64) {  // inclusive prefix over the 257 bins by one wavefront: 5 bins per lane, then a wave scan
+    int loc[5], sum = 0;
+    FEC_UNROLL for (int j = 0; j < 5; ++j) {
+      const int idx = e * 5 + j;
+      loc[j] = idx < 258 ? lds_bin[idx] : 0;
+      sum += loc[j];
+    }
+    int run = sum;
+    FEC_UNROLL for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(run, d, 64);
+      if (e >= d) run += up;
+    }
+    int excl = run - sum;
+    FEC_UNROLL for (int j = 0; j < 5; ++j) {
+      const int idx = e * 5 + j;
+      excl += loc[j];
+      if (idx < 258) lds_bin[idx] = excl;  // lds_bin[b + 1] = number of elements with popcount <= b
+    }
+  }
+  __syncthreads();
+  const int pos = atomicAdd(&lds_bin[pc], 1);  // lds_bin[pc] = first slot of this popcount
+  lds_perm[pos] = (unsigned short)e;
+  __syncthreads();
+  // wavefront w of workgroup b takes quartile (w + b) mod 4 of the sorted list
+  const int slot = ((((e >> 6) + (int)blockIdx.x) & 3) << 6) | (e & 63);
+  const int src = lds_perm[slot];
+  if (src < valid) {
+    ed::pt b = ld_words(base);
+    ed::pt r = ed::multiply_fixed(b, lds_t, lds_k + src);
+    st_lds(lds_o + src, TPB, r);
+  }
+  __syncthreads();
+  stage_out<32>(out + first * 32, lds_o, valid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One workgroup of EIGHT wavefronts per CU owns a contiguous RANGE of elements and keeps PS = 592 of them
+// in flight in LDS slots -- addend AND running result (256 B per slot, 148 KiB) -- refilling a slot from
+// the range the moment its element finishes: no workgroup tail until the whole range is done (elements of
+// different generations share the queues), and HBM sees each point once in and once out.  (The first form
+// of this round, 512 elements per workgroup with the running result in the OUTPUT array, moved 30.5 GB
+// through the fabric per 2^20 batch against 0.3 GB algorithmic -- every one of ~128 additions per element
+// read and rewrote 128 B -- at 22.9 ms; this form: 22.5 ms.)  Each element still sees exactly the
+// reference's operation sequence.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr int PT = 512;     // threads per workgroup: 8 wavefronts, two per SIMD
+constexpr int PS = 592;     // element slots per workgroup (8 x 64 in flight + 80 queued)
+constexpr int PRING = 1024;  // ring capacity (power of two >= PS)
+enum { P_NEXT = C_WORDS, P_WORDS };
+}  // namespace
+
+__global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ scalars, const u32* __restrict__ points,
+                                                    u32* __restrict__ out, size_t n, unsigned per_wg) {
+  __shared__ u32 lds_ad[32 * PS];              // addend of slot e: word w at lds_ad[w * PS + e]
+  __shared__ u32 lds_rs[32 * PS];              // running result of slot e
+  __shared__ u32 lds_gid[PS];                  // element of slot e, relative to the workgroup's range
+  __shared__ unsigned short lds_step[PS];      // current step i of slot e (A_i / D_i pending)
+  __shared__ unsigned short lds_q[2][PRING];   // ready rings: [0] needs the doubling D_i, [1] needs the addition A_i
+  __shared__ int lds_ctl[P_WORDS];
+  const size_t lo = (size_t)blockIdx.x * per_wg;
+  const int range = (n - lo) < (size_t)per_wg ? (int)(n - lo) : (int)per_wg;
   const int tid = threadIdx.x, lane = tid & 63;
   volatile int* ctl = lds_ctl;
-
-  // ---- stage in: addend = point (coalesced 16-byte loads), result = identity in the output slot,
-  //      and the element's first pending operation: A_0 if bit 0 is set, else D_0 ----
-  for (int v = tid; v < EE * 32 / 4; v += TPB) {
-    const int e = (v * 4) / 32, w = (v * 4) % 32;
-    uint4 x = make_uint4(0, 0, 0, 0);
-    if (e < valid) x = *reinterpret_cast<const uint4*>(points + first * 32 + (size_t)v * 4);
-    lds_ad[(w + 0) * EE + e] = x.x;
-    lds_ad[(w + 1) * EE + e] = x.y;
-    lds_ad[(w + 2) * EE + e] = x.z;
-    lds_ad[(w + 3) * EE + e] = x.w;
-  }
   if (tid == 0) {
-    FEC_UNROLL for (int w = 0; w < C_WORDS; ++w) lds_ctl[w] = 0;
-    lds_ctl[C_REMAIN] = valid;
+    FEC_UNROLL for (int w = 0; w < P_WORDS; ++w) lds_ctl[w] = 0;
+    lds_ctl[C_REMAIN] = range < PS ? range : PS;   // live slots
   }
-  __syncthreads();
-  for (int base = 0; base < EE; base += TPB) {  // initial queues: ordered compaction of the two kinds
-    const int e = base + tid;
-    int kind0 = 3;
-    if (e < valid) {
-      st_glb(out + (first + e) * 32, ed::identity());
-      lds_step[e] = 0;
-      kind0 = scalar_bit(scalars, first + e, 0) ? 1 : 0;
-    }
-    const lmask m_d = __builtin_amdgcn_ballot_w64(kind0 == 0), m_a = __builtin_amdgcn_ballot_w64(kind0 == 1);
-    const lmask below = (1ull << lane) - 1;
-    for (int w = 0; w < TPB / 64; ++w) {  // the four wavefronts append in turn
-      if ((tid >> 6) == w) {
-        const int t_d = ctl[C_TAIL_D], t_a = ctl[C_TAIL_A];
-        if (kind0 == 0) lds_q[0][(t_d + __builtin_popcountll(m_d & below)) & (RING - 1)] = (unsigned short)e;
-        if (kind0 == 1) lds_q[1][(t_a + __builtin_popcountll(m_a & below)) & (RING - 1)] = (unsigned short)e;
-        if (lane == 0) {
-          ctl[C_TAIL_D] = t_d + __builtin_popcountll(m_d);
-          ctl[C_TAIL_A] = t_a + __builtin_popcountll(m_a);
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // the identity results must be visible to whichever wavefront runs the element's first addition.  Every
-  // access to an element's slot comes from THIS workgroup (one CU, one vector L1, write-through), so
-  // workgroup-scope ordering is enough; an agent-scope fence would write back / invalidate L2 across the
-  // 8 XCDs on every batch (measured: 238 ms instead of 20 ms per 2^20 batch).
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
 
-  // ---- the scheduler loop (see kernels_p256.hip): push the finished batch, pop the next, compute ----
+  // Claims the next element of the range for slot `e` (lane-private): loads its point as the addend, sets
+  // result = identity, step = 0.  multiply's early-outs (2063-2066: identity point or zero scalar) are
+  // answered at once and the slot takes the next element.  Returns the first pending operation
+  // (1 = A_0 if bit 0 is set, else 0 = D_0), or 2 when the range is used up (the slot dies).
+  auto claim = [&](int e) -> int {
+    for (;;) {
+      const int rel = atomicAdd(&lds_ctl[P_NEXT], 1);
+      if (rel >= range) return 2;
+      const size_t g = lo + rel;
+      const ed::pt base = ld_glb(points + g * 32);
+      u32 any = 0;
+      FEC_UNROLL for (int w = 0; w < 8; ++w) any |= scalars[g * 8 + w];
+      if (any == 0 || lane_of(ed::is_identity(base))) {
+        st_glb(out + g * 32, ed::identity());
+        continue;
+      }
+      st_lds(lds_ad + e, PS, base);
+      st_lds(lds_rs + e, PS, ed::identity());
+      lds_gid[e] = (u32)rel;
+      lds_step[e] = 0;
+      return (scalars[g * 8] & 1u) ? 1 : 0;
+    }
+  };
+
   int kind = -1, count = 0;
-  int e = 0;
-  int nxt = 3;  // 0 D-ready, 1 A-ready, 2 finished, 3 none
+  int e = tid;
+  int nxt = 3;  // 0 D-ready, 1 A-ready, 2 slot died, 3 none
   unsigned spins = 0;
+  bool first_fill = true;
+  // initial fill: slots 0..511 now, slots 512..PS-1 on the second pass; both enter the queues through the
+  // ordinary push of the scheduler loop
+  nxt = tid < range ? claim(e) : 3;  // a counted slot that finds the range used up (early-outs took more) dies: 2
   for (;;) {
     const lmask m_d = __builtin_amdgcn_ballot_w64(nxt == 0), m_a = __builtin_amdgcn_ballot_w64(nxt == 1);
     const int n_d = __builtin_popcountll(m_d), n_a = __builtin_popcountll(m_a);
     const int n_fin = __builtin_popcountll(__builtin_amdgcn_ballot_w64(nxt == 2));
     const lmask below = (1ull << lane) - 1;
     const int rank_d = __builtin_popcountll(m_d & below), rank_a = __builtin_popcountll(m_a & below);
-    if (count == 0) {  // nothing to push: wait OUTSIDE the lock on hints
+    if (n_d + n_a + n_fin == 0 && !first_fill) {  // nothing to push: wait OUTSIDE the lock on hints
       const int q_d = ctl[C_TAIL_D] - ctl[C_HEAD_D], q_a = ctl[C_TAIL_A] - ctl[C_HEAD_A];
       const int fl = ctl[C_INFLIGHT], rem = ctl[C_REMAIN];
       int th0 = rem >> 3;
@@ -167,8 +259,8 @@ __global__ __launch_bounds__(TPB, 2) void k_ed_mul_sched(const u32* __restrict__
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     int t_d = ctl[C_TAIL_D], t_a = ctl[C_TAIL_A];
-    if (nxt == 0) lds_q[0][(t_d + rank_d) & (RING - 1)] = (unsigned short)e;
-    if (nxt == 1) lds_q[1][(t_a + rank_a) & (RING - 1)] = (unsigned short)e;
+    if (nxt == 0) lds_q[0][(t_d + rank_d) & (PRING - 1)] = (unsigned short)e;
+    if (nxt == 1) lds_q[1][(t_a + rank_a) & (PRING - 1)] = (unsigned short)e;
     t_d += n_d;
     t_a += n_a;
     int inflight = ctl[C_INFLIGHT] - count;
@@ -179,10 +271,12 @@ __global__ __launch_bounds__(TPB, 2) void k_ed_mul_sched(const u32* __restrict__
     int th = remain >> 3;
     th = th < 1 ? 1 : (th > 64 ? 64 : th);
     int pick = -1;
-    if (av_a >= th && av_a >= av_d) pick = 1;
-    else if (av_d >= th) pick = 0;
-    else if (av_a >= th) pick = 1;
-    else if (inflight == 0 && (av_a | av_d) != 0) pick = av_a > av_d ? 1 : 0;
+    if (!first_fill) {  // the first pass only pushes (its second half of the initial fill is still to come)
+      if (av_a >= th && av_a >= av_d) pick = 1;
+      else if (av_d >= th) pick = 0;
+      else if (av_a >= th) pick = 1;
+      else if (inflight == 0 && (av_a | av_d) != 0) pick = av_a > av_d ? 1 : 0;
+    }
     int start = 0;
     count = 0;
     if (pick == 0) {
@@ -195,7 +289,7 @@ __global__ __launch_bounds__(TPB, 2) void k_ed_mul_sched(const u32* __restrict__
       h_a += count;
     }
     inflight += count;
-    const bool finished = (remain == 0 && inflight == 0) || err != 0;
+    const bool finished = (!first_fill && remain == 0 && inflight == 0) || err != 0;
     if (lane == 0) {
       ctl[C_TAIL_D] = t_d;
       ctl[C_TAIL_A] = t_a;
@@ -210,56 +304,75 @@ __global__ __launch_bounds__(TPB, 2) void k_ed_mul_sched(const u32* __restrict__
     kind = pick;
     nxt = 3;
     if (finished) break;
+    if (first_fill) {  // second half of the initial fill: slots PT..PS-1
+      first_fill = false;
+      e = PT + tid;
+      if (e < PS && e < range) nxt = claim(e);
+      continue;
+    }
     if (kind < 0) continue;
     spins = 0;
     const bool active = lane < count;
-    e = active ? lds_q[kind][(start + lane) & (RING - 1)] : 0;
+    e = active ? lds_q[kind][(start + lane) & (PRING - 1)] : 0;
     ed::pt ad = ed::identity();
-    if (active) ad = ld_lds(lds_ad + e, EE);
+    if (active) ad = ld_lds(lds_ad + e, PS);
     int step = active ? lds_step[e] : 0;
+    bool fin = false;
+    ed::pt res = ed::identity();
     if (kind == 1) {  // A_i: result = result + addend  (2083-2086, bit i set)
-      u32* slot = out + (first + e) * 32;
-      ed::pt r = active ? ld_glb(slot) : ed::identity();
-      ed::pt s = ed::padd(r, ad);
+      ed::pt r = active ? ld_lds(lds_rs + e, PS) : ed::identity();
+      res = ed::padd(r, ad);
       if (active) {
-        st_glb(slot, s);
-        nxt = step == 255 ? 2 : 0;  // then D_i -- except the last doubling, whose result is never used
+        fin = step == 255;  // the last doubling is never used
+        if (!fin) st_lds(lds_rs + e, PS, res);
+        nxt = 0;            // then D_i
       }
     } else {  // D_i: addend = addend.double()  (2089), then step i + 1
       ed::pt d = ed::pdbl(ad);
       if (active) {
-        st_lds(lds_ad + e, EE, d);
+        st_lds(lds_ad + e, PS, d);
         ++step;
         lds_step[e] = (unsigned short)step;
-        const u32 bit = scalar_bit(scalars, first + e, step);
-        nxt = bit ? 1 : (step == 255 ? 2 : 0);
+        const u32 bit = scalar_bit(scalars, lo + lds_gid[e], step);
+        fin = !bit && step == 255;
+        nxt = bit ? 1 : 0;
+        if (fin) res = ld_lds(lds_rs + e, PS);
       }
     }
-    // a result slot may be picked up by another wavefront of this workgroup next: the workgroup-scope
-    // release fence inside the critical section (s_waitcnt vmcnt(0)) orders this batch's stores before
-    // the queue entries that hand the elements on
+    if (fin) {  // the element is done: its result goes out, the slot takes the next element of the range
+      st_glb(out + (lo + lds_gid[e]) * 32, res);
+      nxt = claim(e);
+    }
+    // slots are lane-private between the pop and the push; the workgroup-scope release fence inside the
+    // critical section orders this batch's LDS stores before the queue entries that hand the slots on
   }
   __syncthreads();
-  // ---- the early-outs of multiply (2063-2066): identity point or zero scalar -> identity ----
-  for (int el = tid; el < valid; el += TPB) {
-    const size_t g = first + el;
-    u32 any = 0;
-    FEC_UNROLL for (int w = 0; w < 8; ++w) any |= scalars[g * 8 + w];
-    const ed::pt base = ld_glb(points + g * 32);
-    const bool ident = lane_of(ed::is_identity(base));
-    if (lds_ctl[C_ERR] != 0) {  // watchdog fired (cannot happen): all-zero results fail every parity check loudly
-      ed::pt z;
-      z.x = z.y = z.z = z.t = fe_zero();
-      st_glb(out + g * 32, z);
-    } else if (any == 0 || ident) {
-      st_glb(out + g * 32, ed::identity());
-    }
+  if (lds_ctl[C_ERR] != 0) {  // watchdog fired (cannot happen): all-zero results fail every parity check loudly
+    ed::pt z;
+    z.x = z.y = z.z = z.t = fe_zero();
+    for (int el = tid; el < range; el += PT) st_glb(out + (lo + el) * 32, z);
   }
 }
 
+void ed_build_table_launch(const u32* base, u32* table, hipStream_t s) {
+  hipLaunchKernelGGL(k_ed_build_table, dim3(1), dim3(64), 0, s, base, table);
+}
+void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_ed_fixed_base, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, scalars, base, table, out, n);
+}
+
 void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s) {
-  const unsigned grid = (unsigned)((n + EE - 1) / EE);
-  hipLaunchKernelGGL(k_ed_mul_sched, dim3(grid), dim3(TPB), 0, s, scalars, points, out, n);
+  // one workgroup per CU, each with a contiguous range of at least 64 elements
+  static const unsigned cus = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return (unsigned)v;
+  }();
+  size_t grid = (n + 63) / 64;
+  if (grid > cus) grid = cus;
+  const unsigned per_wg = (unsigned)((n + grid - 1) / grid);
+  grid = (n + per_wg - 1) / per_wg;
+  hipLaunchKernelGGL(k_ed_mul_pers, dim3((unsigned)grid), dim3(PT), 0, s, scalars, points, out, n, per_wg);
 }
 
 }  // namespace fecgpu

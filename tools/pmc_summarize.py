@@ -53,7 +53,7 @@ def main():
     from forge_ec_amd import build as fbuild
     # the library sources must be the ones that were profiled: run this right after the passes
     out = {"workload": workload, "units_per_launch": units, "source_hash": fbuild.source_hash(),
-           "kernel_tu": fbuild.WORKLOAD_TU.get(workload), "kernel_source_hash": fbuild.tu_closure_hash(fbuild.WORKLOAD_TU[workload]) if workload in fbuild.WORKLOAD_TU else None,
+           "kernel_tu": fbuild.WORKLOAD_TU.get(workload), "kernel_source_hash": fbuild.tu_closure_hash(fbuild.WORKLOAD_TU[workload], kernel_code_only=True) if workload in fbuild.WORKLOAD_TU else None,
            "source_dir": src, "code_object": meta, "counters": counters, "kernel_stats": stats,
            "duration_under_pmc_ms": (sum(durs) / len(durs)) if durs else None}
     c = {k: v["per_launch"] for k, v in counters.items()}
