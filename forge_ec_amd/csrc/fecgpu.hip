@@ -1227,6 +1227,86 @@ int fec_ecdsa_verify_p256(fec_ctx* ctx, const uint8_t* digests, const uint64_t* 
   return ecdsa_verify_host(ctx, FEC_P256, digests, r, s, pk_xy, pk_inf, status, n);
 }
 
+// Ecdsa::<C, D>::batch_verify (forge-ec-signature/src/ecdsa.rs:287-391), C = Secp256k1 / P256, with the digests
+// and the weights a_i (302-306) supplied.  The per-signature scalars and the 2n multiplications run in
+// parallel; the loop's early returns (first failing signature in index order), the ORDERED fold
+// r_sum += r_i (358) and the ordered scalar sum (368-372) are reproduced exactly.
+int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
+                           const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* a, size_t n, uint8_t* result,
+                           uint64_t* detail) {
+  FEC_FIRST_DEVICE(ctx);
+  if (!ctx || !result || (n && (!digests || !r || !s || !pk_xy || !a))) return FEC_E_ARG;
+  if (curve != FEC_SECP256K1 && curve != FEC_P256) return FEC_E_UNSUPPORTED;
+  *result = 0;
+  if (detail) std::memset(detail, 0, 16 * sizeof(uint64_t));
+  if (n == 0) return FEC_OK;                                   // 289-291: false
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  // slots: 0 digests, 1 r, 2 s, 3 pk, 4 a, 5 pk_inf, 6 work area, 7 r_sum + detail + result
+  const void* hin[6] = {digests, r, s, pk_xy, a, pk_inf};
+  const size_t bytes[6] = {n * 32, n * 32, n * 32, n * 64, n * 32, n};
+  int rc = FEC_OK;
+  for (int i = 0; i < 6 && rc == FEC_OK; ++i)
+    if (hin[i]) rc = ensure(ctx, i, bytes[i]);
+  if (rc == FEC_OK) rc = ensure(ctx, 6, ecdsa_batch_work_bytes(n));
+  if (rc == FEC_OK) rc = ensure(ctx, 7, 96 + 128 + 16);
+  if (rc != FEC_OK) return rc;
+  for (int i = 0; i < 6; ++i)
+    if (hin[i] && hipMemcpyAsync(ctx->d_buf[i], hin[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      return FEC_E_DEVICE;
+  char* work = static_cast<char*>(ctx->d_buf[6]);
+  char* tail = static_cast<char*>(ctx->d_buf[7]);
+  {
+    Launch L(ctx, nullptr, "k_ecdsa_pre");
+    ecdsa_batch_pre_launch(curve, (const unsigned char*)ctx->d_buf[0], (const u32*)ctx->d_buf[1], (const u32*)ctx->d_buf[2],
+                           (const u32*)ctx->d_buf[3], pk_inf ? (const unsigned char*)ctx->d_buf[5] : nullptr,
+                           (const u32*)ctx->d_buf[4], work, n, L.s);
+    rc = L.done();
+    if (rc != FEC_OK) return rc;
+  }
+  // the loop returns at the first signature that fails a check (317-342): nothing after it is computed
+  std::vector<unsigned char> flags(n);
+  if (hipMemcpyAsync(flags.data(), work + n * 352, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (flags[i] != 0) {
+      *result = flags[i] == 2 ? 2 : 0;
+      return FEC_OK;
+    }
+  u32* ta = reinterpret_cast<u32*>(work + n * 160);
+  u32* tb = reinterpret_cast<u32*>(work + n * 256);
+  {
+    Launch L(ctx, nullptr, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op + k_fold_sum + k_ecdsa_batch_finish"
+                                                  : "k_p256_mul_sched x2 + k_point_op + k_fold_sum + k_ecdsa_batch_finish");
+    ecdsa_batch_mul_launch(curve, reinterpret_cast<const u32*>(ctx->d_gen[curve]), work, n, L.s);
+    const dim3 g(grid_for(n)), b(TPB);
+    if (curve == FEC_SECP256K1) {  // r_i = r1 + r2 (355), then r_sum += r_i in index order (358)
+      hipLaunchKernelGGL((k_point_op<Secp>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, ta, n);
+      hipLaunchKernelGGL((k_fold_sum<Secp>), dim3(1), dim3(64), 0, L.s, (const u32*)ta, (u32*)tail, n);
+    } else {
+      hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, ta, n);
+      hipLaunchKernelGGL((k_fold_sum<P256>), dim3(1), dim3(64), 0, L.s, (const u32*)ta, (u32*)tail, n);
+    }
+    ecdsa_batch_finish_launch(curve, (const u32*)tail, work, n, (unsigned char*)(tail + 96 + 128), (u32*)(tail + 96), L.s);
+    rc = L.done();
+    if (rc != FEC_OK) return rc;
+  }
+  unsigned char res = 0;
+  uint64_t det[16];
+  if (hipMemcpyAsync(&res, tail + 96 + 128, 1, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(det, tail + 96, 128, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  *result = res;
+  if (detail) std::memcpy(detail, det, 128);
+  return FEC_OK;
+}
+
 int fec_eddsa_verify_ed25519_dev(fec_ctx* ctx, const uint64_t* d_r_xy, const uint8_t* d_r_inf, const uint64_t* d_pk_xy,
                                  const uint8_t* d_pk_inf, const uint64_t* d_s, const uint64_t* d_k, uint8_t* d_status,
                                  size_t n, void* stream) {

@@ -33,6 +33,16 @@ void ecdsa_launch(int curve, const unsigned char* digests, const u32* r, const u
                   const unsigned char* pk_inf, const u32* gen, unsigned char* status, void* work, size_t n,
                   hipStream_t s);
 
+// kernels_ecdsa.hip: Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391) in three parts around the point fold that
+// fecgpu.hip owns.  Work area (ecdsa_batch_work_bytes): u1 +0, u2 +32n, Q +64n, ta +160n, tb +256n, flags +352n
+// (one byte per signature: 0 go, 1 the loop returns false here, 2 it panics here), a_i * r_i after that.
+size_t ecdsa_batch_work_bytes(size_t n);
+void ecdsa_batch_pre_launch(int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
+                            const unsigned char* pk_inf, const u32* weights, void* work, size_t n, hipStream_t s);
+void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hipStream_t s);
+void ecdsa_batch_finish_launch(int curve, const u32* r_sum, const void* work, size_t n, unsigned char* result, u32* detail,
+                               hipStream_t s);
+
 // kernels_ecdsa.hip: Eddsa verify around the Ed25519 multiplications (eddsa.rs:174-211, 430-447).
 // eddsa_pre_launch: a[i] = from_affine(pk[i]) (32 words); eddsa_finish_launch: status from sg = multiply(G, s),
 // ka = multiply(A, k), R.

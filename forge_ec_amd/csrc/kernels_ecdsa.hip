@@ -48,16 +48,20 @@ struct ESecp {
     u2 = secp::sc_mul(r, s_inv);
     return bad ? F_FALSE : (panic ? F_PANIC : F_GO);
   }
-  FEC_DEV static unsigned char finish(const pt& a, const pt& b, const fe& r) {
-    const pt rp = secp::padd(a, b);                                                                 // 256
-    const bool ident = lane_of(secp::is_identity(rp));                                              // 259-262
+  // identity -> false (259-262); x of to_affine (264) through FieldElement::to_bytes (138-178, a Montgomery
+  // reduction) read as a scalar: >= n panics (271 unwrap), else compared with `target` (274)
+  FEC_DEV static unsigned char compare_x(const pt& rp, const fe& target) {
+    const bool ident = lane_of(secp::is_identity(rp));
     fe x, y;
-    secp::to_affine(rp, x, y);                                                                      // 264
-    const fe xr = secp::mul(x, fe_small(1));   // FieldElement::to_bytes (138-178) = mont_reduce(x)
+    secp::to_affine(rp, x, y);
+    const fe xr = secp::mul(x, fe_small(1));
     if (ident) return 0;
-    if (lane_of(secp::sc_ge_n(xr))) return 2;                                                       // 271 unwrap
-    return lane_of(fe_eq(xr, r)) ? 1 : 0;                                                           // 274
+    if (lane_of(secp::sc_ge_n(xr))) return 2;
+    return lane_of(fe_eq(xr, target)) ? 1 : 0;
   }
+  FEC_DEV static unsigned char finish(const pt& a, const pt& b, const fe& r) { return compare_x(secp::padd(a, b), r); }  // 256
+  FEC_DEV static fe wmul(const fe& a, const fe& b) { return secp::sc_mul(a, b); }   // impl Mul for Scalar
+  FEC_DEV static fe wadd(const fe& a, const fe& b) { return secp::sc_add(a, b); }   // impl Add for Scalar
   static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s) {
     secp_launch_mul(fixed, k, p, o, n, s);
   }
@@ -78,16 +82,19 @@ struct EP256 {
     u2 = p256::sc_fe(p256::sc_mul(rs, s_inv));
     return bad ? F_FALSE : (panic ? F_PANIC : F_GO);
   }
-  FEC_DEV static unsigned char finish(const pt& a, const pt& b, const fe& r) {
-    const pt rp = p256::padd(a, b);                                                                 // 256
-    const bool ident = lane_of(p256::is_identity(rp));                                              // 259-262
+  // identity -> false (259-262); x of to_affine (264); field_to_bytes = FieldElement::to_bytes (288-300): the raw
+  // limbs; Scalar::from_bytes: valid iff < n, else the unwrap at 271 panics; compared with `target` (274)
+  FEC_DEV static unsigned char compare_x(const pt& rp, const fe& target) {
+    const bool ident = lane_of(p256::is_identity(rp));
     fe x, y;
-    p256::to_affine(rp, x, y);                                                                      // 264
+    p256::to_affine(rp, x, y);
     if (ident) return 0;
-    // field_to_bytes = FieldElement::to_bytes (288-300): the raw limbs; Scalar::from_bytes: valid iff < n
-    if (p256::sc_ge_n(p256::sc_of(x))) return 2;                                                    // 271 unwrap
-    return lane_of(fe_eq(x, r)) ? 1 : 0;                                                            // 274
+    if (p256::sc_ge_n(p256::sc_of(x))) return 2;
+    return lane_of(fe_eq(x, target)) ? 1 : 0;
   }
+  FEC_DEV static unsigned char finish(const pt& a, const pt& b, const fe& r) { return compare_x(p256::padd(a, b), r); }  // 256
+  FEC_DEV static fe wmul(const fe& a, const fe& b) { return p256::sc_fe(p256::sc_mul(p256::sc_of(a), p256::sc_of(b))); }
+  FEC_DEV static fe wadd(const fe& a, const fe& b) { return p256::sc_fe(p256::sc_add(p256::sc_of(a), p256::sc_of(b))); }
   static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s) {
     p256_launch_mul(fixed, k, p, o, n, s);
   }
@@ -96,9 +103,10 @@ struct EP256 {
 template <class E>
 __global__ __launch_bounds__(TPB) void k_ecdsa_pre(const unsigned char* __restrict__ digests, const u32* __restrict__ rs,
                                                    const u32* __restrict__ ss, const u32* __restrict__ pk,
-                                                   const unsigned char* __restrict__ pk_inf, u32* __restrict__ u1,
+                                                   const unsigned char* __restrict__ pk_inf,
+                                                   const u32* __restrict__ weights, u32* __restrict__ u1,
                                                    u32* __restrict__ u2, u32* __restrict__ q,
-                                                   unsigned char* __restrict__ flags, size_t n) {
+                                                   unsigned char* __restrict__ flags, u32* __restrict__ ar, size_t n) {
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
   // Scalar::from_bytes: big-endian bytes -> little-endian limbs
@@ -108,6 +116,12 @@ __global__ __launch_bounds__(TPB) void k_ecdsa_pre(const unsigned char* __restri
   const fe r = load8(rs + i * 8), s = load8(ss + i * 8);
   fe a, b;
   flags[i] = E::scalars(h, r, s, a, b);
+  if (weights != nullptr) {  // batch_verify (ecdsa.rs:349-350, 370): a_i * u1, a_i * u2, a_i * r_i
+    const fe w = load8(weights + i * 8);
+    a = E::wmul(w, a);
+    b = E::wmul(w, b);
+    store8(ar + i * 8, E::wmul(w, r));
+  }
   store8(u1 + i * 8, a);
   store8(u2 + i * 8, b);
   // from_affine (secp256k1.rs:1365-1373, p256.rs:1859-1867): (x, y, 1), or the identity (0, 1, 0)
@@ -144,10 +158,47 @@ void run(const unsigned char* dd, const u32* dr, const u32* ds, const u32* dpk, 
   u32* tb = reinterpret_cast<u32*>(w + n * 256);
   unsigned char* flags = reinterpret_cast<unsigned char*>(w + n * 352);
   const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
-  hipLaunchKernelGGL((k_ecdsa_pre<E>), g, b, 0, s, dd, dr, ds, dpk, dinf, u1, u2, q, flags, n);
+  hipLaunchKernelGGL((k_ecdsa_pre<E>), g, b, 0, s, dd, dr, ds, dpk, dinf, (const u32*)nullptr, u1, u2, q, flags,
+                     (u32*)nullptr, n);
   E::launch_mul(true, u1, gen, ta, n, s);
   E::launch_mul(false, u2, q, tb, n, s);
   hipLaunchKernelGGL((k_ecdsa_finish<E>), g, b, 0, s, (const u32*)ta, (const u32*)tb, dr, (const unsigned char*)flags, dstatus, n);
+}
+
+// ---- Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391), the part after the ordered point fold ----
+// One wavefront: r_scalar_sum = sum of a_i * r_i in index order (368-372; the reference's scalar Add is not a
+// group law, so the order is part of the result), then 361-384 on r_sum.  result: 1 true, 0 false, 2 panics.
+// detail: 24 words r_sum, 8 words r_scalar_sum.
+template <class E>
+__global__ __launch_bounds__(64) void k_ecdsa_batch_finish(const u32* __restrict__ r_sum, const u32* __restrict__ ar,
+                                                          size_t n, unsigned char* __restrict__ result,
+                                                          u32* __restrict__ detail) {
+  __shared__ u32 sh[64 * 8];
+  const int lane = threadIdx.x;
+  fe total = fe_zero();
+  for (size_t base = 0; base < n; base += 64) {
+    const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
+    if (lane < cnt) {
+      const fe t = load8(ar + (base + lane) * 8);
+      FEC_UNROLL for (int w = 0; w < 8; ++w) sh[lane * 8 + w] = t.w[w];
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll 1
+      for (int j = 0; j < cnt; ++j) {
+        fe t;
+        FEC_UNROLL for (int w = 0; w < 8; ++w) t.w[w] = sh[j * 8 + w];
+        total = E::wadd(total, t);
+      }
+    }
+    __syncthreads();
+  }
+  if (lane != 0) return;
+  typename E::pt p;
+  p.x = load8(r_sum); p.y = load8(r_sum + 8); p.z = load8(r_sum + 16);
+  result[0] = E::compare_x(p, total);
+  store8(detail, p.x); store8(detail + 8, p.y); store8(detail + 16, p.z);
+  store8(detail + 24, total);
 }
 
 // ---- Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211, 430-447) ----
@@ -205,6 +256,38 @@ void eddsa_finish_launch(const u32* sg, const u32* ka, const u32* r_xy, const un
 }
 
 size_t ecdsa_work_bytes(size_t n) { return n * 353; }
+
+// batch_verify, first half: work area as ecdsa_launch plus ar at +n*353 rounded up to 16 (n * 32 bytes).
+size_t ecdsa_batch_work_bytes(size_t n) { return ((n * 353 + 15) & ~(size_t)15) + n * 32; }
+void ecdsa_batch_pre_launch(int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
+                            const unsigned char* pk_inf, const u32* weights, void* work, size_t n, hipStream_t s) {
+  char* w = static_cast<char*>(work);
+  u32* u1 = reinterpret_cast<u32*>(w);
+  u32* u2 = reinterpret_cast<u32*>(w + n * 32);
+  u32* q = reinterpret_cast<u32*>(w + n * 64);
+  unsigned char* flags = reinterpret_cast<unsigned char*>(w + n * 352);
+  u32* ar = reinterpret_cast<u32*>(w + ((n * 353 + 15) & ~(size_t)15));
+  const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_ecdsa_pre<ESecp>), g, b, 0, s, digests, r, s_, pk, pk_inf, weights, u1, u2, q, flags, ar, n);
+  else hipLaunchKernelGGL((k_ecdsa_pre<EP256>), g, b, 0, s, digests, r, s_, pk, pk_inf, weights, u1, u2, q, flags, ar, n);
+}
+// second half: ta = multiply(G, a*u1), tb = multiply(Q, a*u2)
+void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hipStream_t s) {
+  char* w = static_cast<char*>(work);
+  const u32* u1 = reinterpret_cast<const u32*>(w);
+  const u32* u2 = reinterpret_cast<const u32*>(w + n * 32);
+  const u32* q = reinterpret_cast<const u32*>(w + n * 64);
+  u32* ta = reinterpret_cast<u32*>(w + n * 160);
+  u32* tb = reinterpret_cast<u32*>(w + n * 256);
+  if (curve == FEC_SECP256K1) { ESecp::launch_mul(true, u1, gen, ta, n, s); ESecp::launch_mul(false, u2, q, tb, n, s); }
+  else { EP256::launch_mul(true, u1, gen, ta, n, s); EP256::launch_mul(false, u2, q, tb, n, s); }
+}
+void ecdsa_batch_finish_launch(int curve, const u32* r_sum, const void* work, size_t n, unsigned char* result, u32* detail,
+                               hipStream_t s) {
+  const u32* ar = reinterpret_cast<const u32*>(static_cast<const char*>(work) + ((n * 353 + 15) & ~(size_t)15));
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_ecdsa_batch_finish<ESecp>), dim3(1), dim3(64), 0, s, r_sum, ar, n, result, detail);
+  else hipLaunchKernelGGL((k_ecdsa_batch_finish<EP256>), dim3(1), dim3(64), 0, s, r_sum, ar, n, result, detail);
+}
 
 void ecdsa_launch(int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
                   const unsigned char* pk_inf, const u32* gen, unsigned char* status, void* work, size_t n,

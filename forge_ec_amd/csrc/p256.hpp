@@ -514,6 +514,34 @@ FEC_DEV sc sc_mul(const sc& a, const sc& b) {  // 1409-1432
   sc_mul_wide(a.l, b.l, wide);
   return sc_reduce_wide(wide);
 }
+// Add (1352-1375): on a carry out of the top limb reduce() still sees only the low 256 bits
+FEC_DEV sc sc_add(const sc& a, const sc& b) {
+  const u64 N[4] = {0xF3B9CAC2FC632551ULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL};
+  sc r;
+  u64 carry = 0;
+  FEC_UNROLL for (int i = 0; i < 4; ++i) {
+    const u64 s1 = a.l[i] + b.l[i];
+    const u64 o1 = s1 < a.l[i];
+    const u64 s2 = s1 + carry;
+    const u64 o2 = s2 < s1;
+    r.l[i] = s2;
+    carry = o1 + o2;
+  }
+  if (carry > 0 || sc_ge_n(r)) {
+    while (sc_ge_n(r)) {  // reduce (911-920)
+      u64 borrow = 0;
+      FEC_UNROLL for (int i = 0; i < 4; ++i) {
+        const u64 d1 = r.l[i] - N[i];
+        const u64 b1 = r.l[i] < N[i];
+        const u64 d2 = d1 - borrow;
+        const u64 b2 = d1 < borrow;
+        r.l[i] = d2;
+        borrow = b1 + b2;
+      }
+    }
+  }
+  return r;
+}
 // invert (1057-1080) = pow(n - 2) (1083-1100): limbs and bits LS -> MS, `result *= base` on a set bit,
 // base = base.square() = base * base every step
 FEC_DEV sc sc_inv(const sc& a) {

@@ -754,6 +754,12 @@ FEC_DEV fe sc_mul(const fe& a, const fe& b) {
   FEC_UNROLL for (int i = 0; i < 8; ++i) r.w[i] = t[i];
   return sc_reduce(r);
 }
+// Add for Scalar (2358-2378): the 256-bit sum with its carry out DROPPED, then one reduce()
+FEC_DEV fe sc_add(const fe& a, const fe& b) {
+  fe t;
+  (void)add256(t, a, b);
+  return sc_reduce(t);
+}
 // invert for Scalar (2162-2195): a^(n-2), limbs LS->MS, bits MS->LS; `square()` is s * s
 FEC_DEV fe sc_inv(const fe& a) {
   const u64 e[4] = {0xBFD25E8CD036413FULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFEULL};

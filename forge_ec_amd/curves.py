@@ -153,6 +153,24 @@ class Context:
         return self._ecdsa_verify(self._lib.fec_ecdsa_verify_p256, "fec_ecdsa_verify_p256", digests, r, s, pk_xy,
                                   pk_inf)
 
+    def ecdsa_batch_verify(self, curve, digests, r, s, pk_xy, pk_inf, a):
+        """Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391) for secp256k1 / P-256 with the digests and the weights
+        a (n,4) supplied.  Returns (result, detail): result 1 true, 0 false, 2 = the reference panics; detail
+        (16,) uint64 = r_sum (12 limbs) and r_scalar_sum (4), zero when the loop returned early."""
+        d = np.ascontiguousarray(np.asarray(digests, dtype=np.uint8)).reshape(-1, 32)
+        rr, ss, pk, aa = _u64(r, 4), _u64(s, 4), _u64(pk_xy, 8), _u64(a, 4)
+        n = d.shape[0]
+        if not (rr.shape[0] == ss.shape[0] == pk.shape[0] == aa.shape[0] == n):
+            raise ValueError("inputs differ in length")
+        inf = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)).reshape(-1) if pk_inf is not None else None
+        if inf is not None and inf.shape[0] != n:
+            raise ValueError("pk_inf and the signatures differ in length")  # the C side reads n bytes
+        res = np.zeros(1, dtype=np.uint8)
+        detail = np.zeros(16, dtype=np.uint64)
+        _check(self._lib.fec_ecdsa_batch_verify(self._h, curve, _ptr(d), _ptr(rr), _ptr(ss), _ptr(pk), _ptr(inf), _ptr(aa),
+                                                n, _ptr(res), _ptr(detail)), "fec_ecdsa_batch_verify")
+        return int(res[0]), detail
+
     def eddsa_verify_ed25519(self, r_xy, r_inf, pk_xy, pk_inf, s, k):
         """Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211,
         430-447): r_xy, pk_xy (n,8) raw limbs; r_inf, pk_inf (n,) uint8 or None; s, k (n,4) scalars

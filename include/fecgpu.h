@@ -29,6 +29,8 @@
  *   fec_ecdsa_verify_p256 Ecdsa::<P256, D>::verify per signature, digest supplied (ecdsa.rs:213-281; scalar
  *                         field p256.rs:875-1100, 1409-1432; default Scalar::ct_lt core lib.rs:497-531;
  *                         FieldElement::to_bytes 288-300)
+ *   fec_ecdsa_batch_verify   Ecdsa::<C, D>::batch_verify for secp256k1 / P-256 (ecdsa.rs:287-391; scalar Add
+ *                         secp256k1.rs:2358-2378, p256.rs:1352-1375)
  *   fec_eddsa_verify_ed25519   Eddsa::<Ed25519, D>::verify / Ed25519::verify after the hash and the decoding
  *                         (forge-ec-signature/src/eddsa.rs:174-211, 430-447; from_affine ed25519.rs:1813-1826,
  *                         negate 1834-1841, Sub 1936-1947, to_affine 1793-1811)
@@ -161,6 +163,19 @@ int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests /* n*32 */, 
 int fec_ecdsa_verify_p256(fec_ctx* ctx, const uint8_t* digests /* n*32 */, const uint64_t* r /* n*4 */,
                           const uint64_t* s /* n*4 */, const uint64_t* pk_xy /* n*8 */,
                           const uint8_t* pk_inf /* n or NULL */, uint8_t* status /* n */, size_t n);
+/* Ecdsa::<C, D>::batch_verify (forge-ec-signature/src/ecdsa.rs:287-391) for curve = FEC_SECP256K1 or FEC_P256
+ * (FEC_E_UNSUPPORTED otherwise), everything after the hashes: digests, r, s, pk as for fec_ecdsa_verify_*;
+ * a = the n weights the reference draws at 302-306 (the caller draws them with the reference's own
+ * Scalar::random and passes the limbs).  *result = 1 true, 0 false, 2 where the reference panics (unwrap at
+ * 334 or 381); n == 0 gives false (289-291).  The scalars and the 2n multiplications run in parallel; the
+ * loop's early return at the first failing signature, the ordered fold r_sum += r_i and the ordered scalar
+ * sum are the reference's (its Add is not associative), so this is meant for moderate n (about 4 us per
+ * signature in the fold).  detail (16 limbs, or NULL): r_sum (12 Jacobian limbs) and r_scalar_sum (4), zero
+ * when the loop returned early.  Host pointers only. */
+int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests /* n*32 */, const uint64_t* r /* n*4 */,
+                           const uint64_t* s /* n*4 */, const uint64_t* pk_xy /* n*8 */,
+                           const uint8_t* pk_inf /* n or NULL */, const uint64_t* a /* n*4 */, size_t n,
+                           uint8_t* result, uint64_t* detail /* 16 or NULL */);
 /* EdDSA verification as the reference computes it, from the point computation on
  * (Eddsa::<Ed25519, D>::verify, forge-ec-signature/src/eddsa.rs:174-211, and Ed25519::verify, 430-447 -- the
  * same lines of arithmetic).  The caller hashes and decodes with the reference's own code (or

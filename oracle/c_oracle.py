@@ -74,6 +74,8 @@ def lib():
         L.fo_p256_ecdsa_verify.restype = ctypes.c_int
         L.fo_batch_p256_ecdsa_verify.argtypes = [p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
         L.fo_batch_p256_ecdsa_verify.restype = None
+        L.fo_ecdsa_batch_verify.argtypes = [ctypes.c_int, p, p, p, p, p, p, ctypes.c_size_t, p]
+        L.fo_ecdsa_batch_verify.restype = ctypes.c_int
         L.fo_batch_ed25519_eddsa_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
         L.fo_batch_ed25519_eddsa_verify.restype = None
         L.fo_secp256k1_schnorr_batch_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, p, p]
@@ -242,6 +244,21 @@ def batch_p256_ecdsa_verify(digests, r, s, pk_xy, pk_inf=None, nthreads=1):
     lib().fo_batch_p256_ecdsa_verify(_ptr(digests), _ptr(r), _ptr(s), _ptr(pk_xy),
                                      _ptr(inf) if inf is not None else None, _ptr(out), n, nthreads)
     return out
+
+
+def ecdsa_batch_verify(curve, digests, r, s, pk_xy, pk_inf, a):
+    """Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391), curve 0 / 1: -> (status, detail (16,) uint64 = r_sum,
+    r_scalar_sum)."""
+    digests = np.ascontiguousarray(np.asarray(digests, dtype=np.uint8)).reshape(-1, 32)
+    r, s, pk_xy, a = _u64(r), _u64(s), _u64(pk_xy), _u64(a)
+    n = digests.shape[0]
+    inf = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+    detail = np.zeros(16, dtype=np.uint64)
+    rc = lib().fo_ecdsa_batch_verify(curve, _ptr(digests), _ptr(r), _ptr(s), _ptr(pk_xy),
+                                     _ptr(inf) if inf is not None else None, _ptr(a), n, _ptr(detail))
+    if rc < 0:
+        raise ValueError("fo_ecdsa_batch_verify rc=%d" % rc)
+    return rc, detail
 
 
 def batch_ed25519_eddsa_verify(r_xy, r_inf, pk_xy, pk_inf, s, k, nthreads=1):

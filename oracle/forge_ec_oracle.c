@@ -452,9 +452,12 @@ int fo_secp256k1_ecdsa_verify(const unsigned char digest[32], const u64 r[4], co
 }
 
 /* scalar-field ops for tests: op in {"mul","inv"} */
+static void ks_add(const u64 a[4], const u64 b[4], u64 r[4]);
+static void ns_add(const u64 a[4], const u64 b[4], u64 r[4]);
 int fo_secp256k1_scalar_op(const char* op, const u64 a[4], const u64 b[4], u64 r[4]) {
   if (!strcmp(op, "mul")) { ks_mul(a, b, r); return 0; }
   if (!strcmp(op, "inv")) { return ks_inv(a, r) ? 0 : 1; }
+  if (!strcmp(op, "add")) { ks_add(a, b, r); return 0; }
   return -2;
 }
 
@@ -941,6 +944,7 @@ int fo_p256_ecdsa_verify(const unsigned char digest[32], const u64 r[4], const u
 int fo_p256_scalar_op(const char* op, const u64 a[4], const u64 b[4], u64 r[4]) {
   if (!strcmp(op, "mul")) { ns_mul(a, b, r); return 0; }
   if (!strcmp(op, "inv")) { return ns_inv(a, r) ? 0 : 1; }
+  if (!strcmp(op, "add")) { ns_add(a, b, r); return 0; }
   return -2;
 }
 
@@ -1335,6 +1339,95 @@ int fo_ed25519_eddsa_verify(const u64 r_xy[8], int r_inf, const u64 pk_xy[8], in
   ept diff = e_padd(&p1, &n2);                                           /* 210 / 446 */
   return e_is_identity(&diff);
 }
+/* ---- Ecdsa::<C, D>::batch_verify (forge-ec-signature/src/ecdsa.rs:287-391) for C = Secp256k1 (curve 0) and
+ * P256 (curve 1), digests and the weights a_i (302-306: Scalar::random of the reference's OsRng) supplied.
+ * 1 true, 0 false, 2 = the reference panics (unwrap at 334 or 381).  The loop returns at the FIRST signature
+ * that fails a check; r_sum and the scalar sum are folded strictly in index order.  detail (may be NULL):
+ * [0..12) r_sum (Jacobian limbs), [12..16) r_scalar_sum -- zero when the loop returned early. */
+static void ks_add(const u64 a[4], const u64 b[4], u64 r[4]) {            /* secp256k1.rs:2358-2378 */
+  u64 carry = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 s1 = a[i] + b[i];
+    int c1 = s1 < a[i];
+    u64 s2 = s1 + carry;
+    int c2 = s2 < s1;
+    r[i] = s2;
+    carry = (c1 || c2) ? 1 : 0;
+  }
+  ks_reduce(r);                                                            /* the carry out is dropped */
+}
+static void ns_add(const u64 a[4], const u64 b[4], u64 r[4]) {            /* p256.rs:1352-1375 */
+  u64 carry = 0;
+  for (int i = 0; i < 4; ++i) {
+    u64 s1 = a[i] + b[i];
+    u64 o1 = s1 < a[i];
+    u64 s2 = s1 + carry;
+    u64 o2 = s2 < s1;
+    r[i] = s2;
+    carry = o1 + o2;
+  }
+  if (carry > 0 || n_cmp(r, NS_N) >= 0) ns_sub_n_while_ge(r);             /* reduce() sees only the low 256 bits */
+}
+int fo_ecdsa_batch_verify(int curve, const unsigned char* digests, const u64* r, const u64* s, const u64* pk_xy,
+                          const uint8_t* pk_inf, const u64* a, size_t n, u64* detail) {
+  if (detail) memset(detail, 0, 16 * sizeof(u64));
+  if (curve != 0 && curve != 1) return -1;
+  if (n == 0) return 0;                                                    /* 289-291 */
+  jpt r_sum = curve == 0 ? k_identity() : n_identity();                    /* 310 */
+  for (size_t i = 0; i < n; ++i) {
+    const u64 *ri = r + 4 * i, *si = s + 4 * i, *ai = a + 4 * i;
+    if ((ri[0] | ri[1] | ri[2] | ri[3]) == 0 || (si[0] | si[1] | si[2] | si[3]) == 0) return 0;   /* 317-319 */
+    u64 h[4], s_inv[4], u1[4], u2[4], au1[4], au2[4];
+    jpt q, r1, r2, ri_pt;
+    if (curve == 0) {
+      if (ks_ge_n(ri) || ks_ge_n(si)) return 0;                            /* 322-327 */
+      if (!ks_from_bytes_be(digests + 32 * i, h)) return 2;                /* 334 */
+      if (!ks_inv(si, s_inv)) return 0;                                    /* 338-342 */
+      ks_mul(h, s_inv, u1); ks_mul(ri, s_inv, u2);                         /* 345-346 */
+      ks_mul(ai, u1, au1); ks_mul(ai, u2, au2);                            /* 349-350 */
+      jpt g = k_generator();
+      q = k_identity();
+      if (!(pk_inf && pk_inf[i])) { q.x = ld(pk_xy + 8 * i); q.y = ld(pk_xy + 8 * i + 4); q.z = fe_small(1); }
+      r1 = k_multiply(&g, au1); r2 = k_multiply(&q, au2);                  /* 353-354 */
+      ri_pt = k_padd(&r1, &r2);                                            /* 355 */
+      r_sum = k_padd(&r_sum, &ri_pt);                                      /* 358 */
+    } else {
+      if (!(ns_ct_lt(ri, NS_N) & ns_ct_lt(si, NS_N))) return 0;
+      if (!ns_from_bytes_be(digests + 32 * i, h)) return 2;
+      if (!ns_inv(si, s_inv)) return 0;
+      ns_mul(h, s_inv, u1); ns_mul(ri, s_inv, u2);
+      ns_mul(ai, u1, au1); ns_mul(ai, u2, au2);
+      jpt g = n_generator();
+      q = n_identity();
+      if (!(pk_inf && pk_inf[i])) { q.x = ld(pk_xy + 8 * i); q.y = ld(pk_xy + 8 * i + 4); q.z = fe_small(1); }
+      r1 = n_multiply(&g, au1); r2 = n_multiply(&q, au2);
+      ri_pt = n_padd(&r1, &r2);
+      r_sum = n_padd(&r_sum, &ri_pt);
+    }
+  }
+  u64 sum[4] = {0, 0, 0, 0}, t[4], ar[4];                                  /* 368-372 */
+  for (size_t i = 0; i < n; ++i) {
+    if (curve == 0) { ks_mul(a + 4 * i, r + 4 * i, ar); ks_add(sum, ar, t); }
+    else { ns_mul(a + 4 * i, r + 4 * i, ar); ns_add(sum, ar, t); }
+    memcpy(sum, t, 32);
+  }
+  if (detail) { stj(detail, r_sum); memcpy(detail + 12, sum, 32); }
+  if (curve == 0 ? k_is_identity(&r_sum) : n_is_identity(&r_sum)) return 0;  /* 361-364 */
+  fe x, y;
+  u64 xs[4];
+  if (curve == 0) {
+    k_to_affine(&r_sum, &x, &y);                                           /* 376 */
+    fe xr = k_mul(x, fe_small(1));                                         /* to_bytes = mont_reduce */
+    if (ks_ge_n(xr.v)) return 2;                                           /* 381 */
+    memcpy(xs, xr.v, 32);
+  } else {
+    n_to_affine(&r_sum, &x, &y);
+    if (n_cmp(x.v, NS_N) >= 0) return 2;
+    memcpy(xs, x.v, 32);
+  }
+  return xs[0] == sum[0] && xs[1] == sum[1] && xs[2] == sum[2] && xs[3] == sum[3];   /* 384 */
+}
+
 typedef struct { const u64 *r, *pk, *s, *k; const uint8_t *rinf, *pinf; uint8_t* out; size_t lo, hi; } ev_t;
 static void* evworker(void* arg) {
   ev_t* j = (ev_t*)arg;

@@ -74,6 +74,12 @@ void fo_batch_p256_ecdsa_verify(const unsigned char* digests, const uint64_t* r,
                                 const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* out, size_t n,
                                 int nthreads);
 
+/* Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391), C = Secp256k1 (0) or P256 (1), digests and weights a_i given:
+ * 1 true, 0 false, 2 the reference panics, -1 bad curve; detail (16 limbs or NULL) = r_sum, r_scalar_sum */
+int fo_ecdsa_batch_verify(int curve, const unsigned char* digests, const uint64_t* r, const uint64_t* s,
+                          const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* a, size_t n,
+                          uint64_t* detail);
+
 /* Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211, 430-447),
  * s and k = from_bytes_reduced(hash) given: 1 true, 0 false, 2 the reference panics */
 int fo_ed25519_eddsa_verify(const uint64_t r_xy[8], int r_inf, const uint64_t pk_xy[8], int pk_inf,

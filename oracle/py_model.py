@@ -762,6 +762,11 @@ class SecpScalar:
         return a
 
     @staticmethod
+    def add(a, b):  # :2358-2378 -- the carry out of the top limb is dropped, then one reduce()
+        v = (sum(x << (64 * i) for i, x in enumerate(a)) + sum(x << (64 * i) for i, x in enumerate(b))) & ((1 << 256) - 1)
+        return SecpScalar.reduce([(v >> (64 * i)) & M64 for i in range(4)])
+
+    @staticmethod
     def mul(a, b):  # :2410-2456 -- keeps only t[0..4] of the 512-bit product
         t = [0] * 8
         for i in range(4):
@@ -877,6 +882,16 @@ class P256Scalar:
         return S.limbs(S.reduce_wide(S.val(a) * S.val(b)))
 
     @staticmethod
+    def add(a, b):  # :1352-1375 -- on a carry out, reduce() still sees only the low 256 bits
+        S = P256Scalar
+        t = S.val(a) + S.val(b)
+        low = t & S.M256
+        if (t >> 256) > 0 or low >= S.N:
+            while low >= S.N:
+                low -= S.N
+        return S.limbs(low)
+
+    @staticmethod
     def inv(a):  # :1057-1080 with pow :1083-1100 (LSB first; square() = s * s)
         S = P256Scalar
         if _is_zero(a):
@@ -933,6 +948,54 @@ def p256_ecdsa_verify(digest, r, s, pk_xy, pk_inf=False):
     if S.val(x) >= S.N:
         return 2
     return 1 if list(x) == list(r) else 0
+
+
+def ecdsa_batch_verify(curve, digests, r, s, pk_xy, pk_inf, a):
+    """Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391) for C = Secp256k1 (curve 0) / P256 (curve 1) with the
+    digests and the weights a_i supplied.  Returns (status, r_sum, r_scalar_sum): status 1 true, 0 false,
+    2 = the reference panics; the sums are None when the loop returned early."""
+    n = len(digests)
+    if n == 0:
+        return 0, None, None  # 289-291
+    S, F = (SecpScalar, Secp) if curve == SECP256K1 else (P256Scalar, P256c)
+    order = SecpScalar.N if curve == SECP256K1 else P256Scalar.limbs(P256Scalar.N)
+    r_sum = F.identity()
+    for i in range(n):
+        ri, si, ai = list(r[i]), list(s[i]), list(a[i])
+        if _is_zero(ri) or _is_zero(si):
+            return 0, None, None
+        if curve == SECP256K1:
+            if S.ge_n(ri) or S.ge_n(si):
+                return 0, None, None
+        elif not (S.ct_lt_default(ri, order) and S.ct_lt_default(si, order)):
+            return 0, None, None
+        h, ok = S.from_bytes_be(list(digests[i]))
+        if not ok:
+            return 2, None, None  # 334
+        s_inv = S.inv(si)
+        if s_inv is None:
+            return 0, None, None
+        au1 = S.mul(ai, S.mul(h, s_inv))  # 345-350
+        au2 = S.mul(ai, S.mul(ri, s_inv))
+        inf = bool(pk_inf[i]) if pk_inf is not None else False
+        q = F.identity() if inf else (list(pk_xy[i][0:4]), list(pk_xy[i][4:8]), [1, 0, 0, 0])
+        r_i = F.padd(F.multiply(F.generator(), au1), F.multiply(q, au2))  # 353-355
+        r_sum = F.padd(r_sum, r_i)  # 358
+    total = [0, 0, 0, 0]
+    for i in range(n):  # 368-372
+        total = S.add(total, S.mul(list(a[i]), list(r[i])))
+    if F.is_identity(r_sum):
+        return 0, r_sum, total  # 361-364
+    x, _, _ = F.to_affine(r_sum)
+    if curve == SECP256K1:
+        xs = F.mul(x, [1, 0, 0, 0])  # FieldElement::to_bytes = mont_reduce
+        if S.ge_n(xs):
+            return 2, r_sum, total
+    else:
+        xs = list(x)
+        if S.val(xs) >= S.N:
+            return 2, r_sum, total
+    return (1 if xs == total else 0), r_sum, total
 
 
 def ed25519_eddsa_verify(r_xy, r_inf, pk_xy, pk_inf, s, k):

@@ -33,6 +33,7 @@ extern "C" {
     fn fec_batch_double_mul(ctx: *mut FecCtx, curve: c_int, u1: *const u64, u2: *const u64, q: *const u64, out: *mut u64, n: usize) -> c_int;
     fn fec_batch_to_affine(ctx: *mut FecCtx, curve: c_int, points: *const u64, xy: *mut u64, inf: *mut u8, n: usize) -> c_int;
     fn fec_multi_scalar_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_ecdsa_batch_verify(ctx: *mut FecCtx, curve: c_int, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, a: *const u64, n: usize, result: *mut u8, detail: *mut u64) -> c_int;
     fn fec_eddsa_verify_ed25519(ctx: *mut FecCtx, r_xy: *const u64, r_inf: *const u8, pk_xy: *const u64, pk_inf: *const u8, s: *const u64, k: *const u64, status: *mut u8, n: usize) -> c_int;
     fn fec_ecdsa_verify_p256(ctx: *mut FecCtx, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, status: *mut u8, n: usize) -> c_int;
     fn fec_ecdsa_verify_secp256k1(ctx: *mut FecCtx, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, status: *mut u8, n: usize) -> c_int;
@@ -388,6 +389,27 @@ pub fn ecdsa_verify_batch_p256(ctx: &mut GpuContext, digests: &[[u8; 32]], r: &[
     // SAFETY: `digests` is n contiguous 32-byte arrays; the other buffers hold n elements each.
     check(unsafe { fec_ecdsa_verify_p256(ctx.raw, digests.as_ptr().cast(), rr.as_ptr(), ss.as_ptr(), xy.as_ptr(), inf.as_ptr(), status.as_mut_ptr(), n) })?;
     Ok(status.iter().map(|&v| match v { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid }).collect())
+}
+
+/// `Ecdsa::<C, D>::batch_verify` (`forge-ec-signature/src/ecdsa.rs:287-391`) for `C` = secp256k1 or P-256 from
+/// line 310 on: the caller hashes (`digests[i] = D::digest(msgs[i])`) and draws the weights `a` (302-306) with
+/// the reference's own `Scalar::random`.
+pub fn ecdsa_batch_verify<C: GpuCurve>(ctx: &mut GpuContext, digests: &[[u8; 32]], r: &[C::Scalar], s: &[C::Scalar], public_keys: &[C::PointAffine], a: &[C::Scalar]) -> Result<VerifyStatus> {
+    let n = digests.len();
+    if r.len() != n || s.len() != n || public_keys.len() != n || a.len() != n {
+        return Err(Error::ValidationError);
+    }
+    let (rr, ss, aa) = (pack_scalars::<C>(r), pack_scalars::<C>(s), pack_scalars::<C>(a));
+    let (mut xy, mut inf) = (vec![0u64; 8 * n], vec![0u8; n]);
+    for (i, p) in public_keys.iter().enumerate() {
+        let (l, f) = C::affine_limbs(p);
+        xy[8 * i..8 * i + 8].copy_from_slice(&l);
+        inf[i] = f as u8;
+    }
+    let mut result = 0u8;
+    // SAFETY: every buffer holds n elements of the width the header states; detail may be null.
+    check(unsafe { fec_ecdsa_batch_verify(ctx.raw, C::ID, digests.as_ptr().cast(), rr.as_ptr(), ss.as_ptr(), xy.as_ptr(), inf.as_ptr(), aa.as_ptr(), n, &mut result, core::ptr::null_mut()) })?;
+    Ok(match result { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid })
 }
 
 /// `Eddsa::<Ed25519, D>::verify` / `Ed25519::verify` per element from the point computation on

@@ -10,6 +10,7 @@ The committed fixtures fed DIRECTLY through libfecgpu.so (C ABI) on the GPU -- n
   tests/golden/secp256k1_sqr_ripple_operands.json
   tests/golden/ecdsa_p256_vectors.json  Ecdsa::<P256, D>::verify cases of every status
   tests/golden/eddsa_ed25519_vectors.json  Eddsa verify (point computation on) cases of every status
+  tests/golden/ecdsa_batch_vectors.json  Ecdsa::batch_verify (secp256k1, P-256): status and both folded sums
 
 Bit-exact.  Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
@@ -143,3 +144,15 @@ def test_eddsa_ed25519_vectors_on_the_gpu(gpu_ctx):
                                        _u64([c["pk"] for c in v]), np.array([c["pk_inf"] for c in v], dtype=np.uint8),
                                        _u64([c["s"] for c in v]), _u64([c["k"] for c in v]))
     assert [int(x) for x in got] == [c["status"] for c in v]
+
+
+def test_ecdsa_batch_verify_vectors_on_the_gpu(gpu_ctx):
+    for c in _load("ecdsa_batch_vectors.json")["cases"]:
+        dg = np.frombuffer(bytes.fromhex("".join(c["digests"])), dtype=np.uint8).reshape(-1, 32)
+        st, detail = gpu_ctx.ecdsa_batch_verify(c["curve"], dg, _u64(c["r"]), _u64(c["s"]), _u64(c["pk"]),
+                                                np.array(c["pk_inf"], dtype=np.uint8), _u64(c["a"]))
+        assert st == c["status"], c["note"]
+        if c["r_sum"] is not None:
+            assert [int(v) for v in detail] == c["r_sum"] + c["scalar_sum"], c["note"]
+        else:
+            assert not detail.any()

@@ -449,6 +449,60 @@ def test_eddsa_verify_ed25519_matches_oracle(gpu_ctx, oracle):
     assert np.array_equal(st.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("curve", [0, 1])
+def test_ecdsa_batch_verify_matches_oracle(gpu_ctx, oracle, curve):
+    """Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391) at n = 300: a batch that verifies under the reference's
+    arithmetic, random batches (final comparison fails; both folded sums compared), and the loop's early exits
+    in index order."""
+    n = 300
+    order = 0xFFFFFFFFFFFFFFFEFFFFFFFFFFFFFFFFBAAEDCE6AF48A03BBFD25E8CD0364141 if curve == 0 else V.ORDER[1]
+    op = oracle.secp256k1_scalar_op if curve == 0 else oracle.p256_scalar_op
+    rng = np.random.default_rng(1200 + curve)
+    dg = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    dg[:, 0] &= 0x7F
+    r, s, a = V.scalars(n, curve, 871), V.scalars(n, curve, 872), V.scalars(n, curve, 873)
+    pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 874), V.field_elements(n, curve, 875)], axis=1))
+
+    def both(dg, r, s, pk, inf, a):
+        want, wd = oracle.ecdsa_batch_verify(curve, dg, r, s, pk, inf, a)
+        got, gd = gpu_ctx.ecdsa_batch_verify(curve, dg, r, s, pk, inf, a)
+        assert got == want
+        assert np.array_equal(gd, wd)
+        return want, wd
+
+    st, detail = both(dg, r, s, pk, None, a)
+    assert st == 0 and detail.any()
+    # all keys at infinity: r_sum does not depend on r; last weight 1, last r = x(r_sum) - (ordered sum of the rest)
+    inf = np.ones(n, dtype=np.uint8)
+    made = False
+    for attempt in range(8):
+        a2, r2 = a.copy(), r.copy()
+        a2[n - 1] = [1, 0, 0, 0]
+        r2[0] = V.scalars(1, curve, 880 + attempt)[0]
+        _, d = oracle.ecdsa_batch_verify(curve, dg, r2, s, pk, inf, a2)
+        xy, is_inf = oracle.to_affine(curve, d[:12])
+        xs = V.int_of(oracle.field_op(0, "mul", xy[:4], np.array([1, 0, 0, 0], dtype=np.uint64))) if curve == 0 else V.int_of(xy[:4])
+        partial = np.zeros(4, dtype=np.uint64)
+        for i in range(n - 1):
+            partial = op("add", partial, op("mul", a2[i], r2[i])[0])[0]
+        if not is_inf and 0 < xs < order and xs > V.int_of(partial):
+            r2[n - 1] = V.limbs_of(xs - V.int_of(partial))
+            made = True
+            break
+    assert made
+    assert both(dg, r2, s, pk, inf, a2)[0] == 1
+    # early exits: the first failing signature in index order decides
+    r3 = r.copy(); r3[200] = 0
+    assert both(dg, r3, s, pk, None, a)[0] == 0
+    dg4 = dg.copy(); dg4[17] = 0xFF
+    assert both(dg4, r3, s, pk, None, a)[0] == 2       # panic at 17 before the r = 0 at 200
+    s5 = s.copy(); s5[3] = 0
+    assert both(dg4, r, s5, pk, None, a)[0] == 0       # s = 0 at 3 before the panic at 17
+    assert both(dg[:1], r[:1], s[:1], pk[:1], None, a[:1])[0] == 0
+    got, gd = gpu_ctx.ecdsa_batch_verify(curve, dg[:0], r[:0], s[:0], pk[:0], None, a[:0])
+    assert got == 0 and not gd.any()                   # empty batch: false
+
+
 def _p256_ecdsa_cases(oracle, n_random, n_valid):
     """As _ecdsa_cases for Ecdsa::<P256, D>::verify.  r or s >= n are NOT rejected by the reference (its
     ct_lt is the trait default, a top-byte <= comparison): those lanes run the whole computation."""

@@ -184,3 +184,20 @@ def test_p256_scalar_field(emu, oracle):
         if ok:
             emu.he_p256_scalar_op(1, _p(ai), None, _p(out))
             assert np.array_equal(out, want)
+
+
+def test_scalar_add_both_curves(emu, oracle):
+    """Scalar Add as the device headers compute it (secp256k1: carry dropped, one reduce; P-256: reduce() sees
+    only the low 256 bits after a carry out) vs the oracle."""
+    out = np.zeros(4, dtype=np.uint64)
+    for curve, fn, op in ((0, emu.he_secp_scalar_op, oracle.secp256k1_scalar_op), (1, emu.he_p256_scalar_op, oracle.p256_scalar_op)):
+        n = V.ORDER[curve]
+        nref = 0xFFFFFFFFFFFFFFFEFFFFFFFFFFFFFFFFBAAEDCE6AF48A03BBFD25E8CD0364141 if curve == 0 else n
+        vals = [0, 1, n - 1, n, nref - 1, nref, nref + 1, (1 << 256) - 1, 1 << 255, (1 << 256) - nref, (1 << 256) - nref - 1]
+        pairs = [(V.limbs_of(x), V.limbs_of(y)) for x in vals for y in vals]
+        w = V.splitmix64(800, V.SEED, 650 + curve).reshape(-1, 4)
+        pairs += [([int(v) for v in w[i]], [int(v) for v in w[i + 1]]) for i in range(0, 200, 2)]
+        for x, y in pairs:
+            ax, ay = np.array(x, dtype=np.uint64), np.array(y, dtype=np.uint64)
+            fn(4, _p(ax), _p(ay), _p(out))
+            assert np.array_equal(out, op("add", ax, ay)[0]), (curve, x, y)

@@ -337,3 +337,39 @@ def test_eddsa_two_restatements_agree_on_fresh_inputs(oracle):
     want = [M.ed25519_eddsa_verify([int(x) for x in r[i]], int(rinf[i]), [int(x) for x in pk[i]], int(pinf[i]),
                                    [int(x) for x in s[i]], [int(x) for x in k[i]]) for i in range(n)]
     assert [int(x) for x in got] == want and want[:3] == [1, 1, 0]
+
+
+def _batch_fixture():
+    with open(os.path.join(HERE, "golden", "ecdsa_batch_vectors.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_ecdsa_batch_verify_vectors(oracle):
+    """Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391), secp256k1 and P-256: the C oracle against the Python
+    model's committed expectations (status and both folded sums), tests/golden/gen_ecdsa_batch.py."""
+    cases = _batch_fixture()
+    assert {(c["curve"], c["status"]) for c in cases} == {(k, st) for k in (0, 1) for st in (0, 1, 2)}
+    for c in cases:
+        dg = np.frombuffer(bytes.fromhex("".join(c["digests"])), dtype=np.uint8).reshape(-1, 32)
+        st, detail = oracle.ecdsa_batch_verify(c["curve"], dg, c["r"], c["s"], c["pk"], c["pk_inf"], c["a"])
+        assert st == c["status"], c["note"]
+        if c["r_sum"] is not None:
+            assert [int(v) for v in detail] == c["r_sum"] + c["scalar_sum"], c["note"]
+        else:
+            assert not detail.any()
+    assert oracle.ecdsa_batch_verify(0, np.zeros((0, 32), dtype=np.uint8), [], [], [], None, [])[0] == 0   # empty: false
+
+
+def test_scalar_add_two_restatements_agree(oracle):
+    from oracle import py_model as M
+    for curve, S, op in ((0, M.SecpScalar, oracle.secp256k1_scalar_op), (1, M.P256Scalar, oracle.p256_scalar_op)):
+        n = V.ORDER[curve]
+        nref = 0xFFFFFFFFFFFFFFFEFFFFFFFFFFFFFFFFBAAEDCE6AF48A03BBFD25E8CD0364141 if curve == 0 else n
+        vals = [0, 1, n - 1, n, nref - 1, nref, nref + 1, (1 << 256) - 1, 1 << 255, (1 << 256) - nref]
+        for x in vals:
+            for y in vals:
+                assert [int(v) for v in op("add", V.limbs_of(x), V.limbs_of(y))[0]] == S.add(V.limbs_of(x), V.limbs_of(y))
+        w = V.splitmix64(320, V.SEED, 640 + curve).reshape(-1, 4)
+        for i in range(0, 80, 2):
+            la, lb = [int(v) for v in w[i]], [int(v) for v in w[i + 1]]
+            assert [int(v) for v in op("add", la, lb)[0]] == S.add(la, lb)

@@ -65,21 +65,21 @@ extern "C" int he_to_affine(int curve, const uint64_t* p, uint64_t* xy) {
   return inf ? 1 : 0;
 }
 
-// secp256k1 scalar field (mod n) as the reference implements it: op 0 = mul, 1 = inv
+// secp256k1 scalar field (mod n) as the reference implements it: op 0 = mul, 1 = inv, 4 = add
 extern "C" int he_secp_scalar_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
   fe x = ld(a), r;
-  if (op == 0) r = secp::sc_mul(x, ld(b)); else r = secp::sc_inv(x);
+  if (op == 0) r = secp::sc_mul(x, ld(b)); else if (op == 4) r = secp::sc_add(x, ld(b)); else r = secp::sc_inv(x);
   st(out, r);
   return 0;
 }
 
 // P-256 scalar field as the reference implements it (p256.rs:924-1020, 1409-1432): op 0 = mul, 1 = inv,
-// 2 = the default ct_lt (a vs b), 3 = a >= n
+// 2 = the default ct_lt (a vs b), 3 = a >= n, 4 = add
 extern "C" int he_p256_scalar_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
   p256::sc x = p256::sc_of(ld(a));
   if (op == 2) return p256::sc_ct_lt_default(x, p256::sc_of(ld(b))) ? 1 : 0;
   if (op == 3) return p256::sc_ge_n(x) ? 1 : 0;
-  st(out, p256::sc_fe(op == 0 ? p256::sc_mul(x, p256::sc_of(ld(b))) : p256::sc_inv(x)));
+  st(out, p256::sc_fe(op == 0 ? p256::sc_mul(x, p256::sc_of(ld(b))) : op == 4 ? p256::sc_add(x, p256::sc_of(ld(b))) : p256::sc_inv(x)));
   return 0;
 }
 

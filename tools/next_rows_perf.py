@@ -86,6 +86,17 @@ def main():
     ctx.schnorr_batch_verify_secp256k1(pkxy, rxy, s_, a_, e_)
     emit(row="schnorr batch_verify", curve="secp256k1", n=m, ms=round((time.perf_counter() - t0) * 1e3, 3),
          note="3 ladders per signature in parallel + two ordered folds (four lanes per addition); host pointers, PCIe included")
+    for c in (0, 1):
+        dgb = np.frombuffer(synth.scalars(m, c, 81).tobytes(), dtype=np.uint8).reshape(m, 32).copy()
+        dgb[:, 0] &= 0x7F
+        rb, sb, ab = synth.scalars(m, c, 82), synth.scalars(m, c, 83), synth.scalars(m, c, 84)
+        pkb = synth.field_elements(2 * m, c, 85).reshape(m, 8)
+        ctx.ecdsa_batch_verify(c, dgb, rb, sb, pkb, None, ab)  # first call sizes the work areas
+        t0 = time.perf_counter()
+        ctx.ecdsa_batch_verify(c, dgb, rb, sb, pkb, None, ab)
+        emit(row="ecdsa batch_verify", curve=NAMES[c], n=m, ms=round((time.perf_counter() - t0) * 1e3, 3),
+             note="scalars + 2 multiplications per signature in parallel, then the ordered point fold%s and the ordered "
+                  "scalar sum; host pointers, PCIe included" % (" (four lanes per addition)" if c == 0 else " (one lane)"))
 
 
 main()
