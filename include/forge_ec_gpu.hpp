@@ -240,6 +240,168 @@ inline bool batch_verify(GpuContext& ctx, const std::vector<AffinePoint<FEC_SECP
 }
 }  // namespace schnorr
 
+// Outcome of a verification as the reference computes it: its boolean, or the fact that it panics
+// (CtOption::unwrap on None) on this input.
+enum class Verify : uint8_t { False = 0, True = 1, ReferencePanics = 2 };
+
+namespace detail {
+template <fec_curve C>
+inline void pack_affine(const std::vector<AffinePoint<C>>& pts, std::vector<uint64_t>& xy, std::vector<uint8_t>& inf) {
+  xy.resize(pts.size() * 8);
+  inf.resize(pts.size());
+  for (size_t i = 0; i < pts.size(); ++i) {
+    for (int l = 0; l < 4; ++l) {
+      xy[i * 8 + l] = pts[i].x_.raw[l];
+      xy[i * 8 + 4 + l] = pts[i].y_.raw[l];
+    }
+    inf[i] = pts[i].infinity;
+  }
+}
+inline std::vector<Verify> statuses(const std::vector<uint8_t>& st) {
+  std::vector<Verify> r(st.size());
+  for (size_t i = 0; i < st.size(); ++i) r[i] = st[i] == 1 ? Verify::True : (st[i] == 2 ? Verify::ReferencePanics : Verify::False);
+  return r;
+}
+}  // namespace detail
+
+namespace ecdsa {
+// forge_ec_signature::ecdsa::Signature<C> { r: Scalar, s: Scalar }
+template <fec_curve C>
+struct Signature {
+  Scalar<C> r, s;
+};
+using Digest = std::array<uint8_t, 32>;
+// Ecdsa::<C, D>::verify per element (forge-ec-signature/src/ecdsa.rs:213-281), C = Secp256k1 or P256, with
+// digests[i] = D::digest(msg_i): everything after the hash on the GPU.
+template <fec_curve C>
+inline std::vector<Verify> verify(GpuContext& ctx, const std::vector<AffinePoint<C>>& public_keys,
+                                  const std::vector<Digest>& digests, const std::vector<Signature<C>>& sigs) {
+  static_assert(C == FEC_SECP256K1 || C == FEC_P256, "Ecdsa is built for secp256k1 and P-256");
+  const size_t n = sigs.size();
+  if (public_keys.size() != n || digests.size() != n) throw Error(FEC_E_ARG);
+  std::vector<uint64_t> pk, r(n * 4), s(n * 4);
+  std::vector<uint8_t> inf, st(n);
+  detail::pack_affine<C>(public_keys, pk, inf);
+  for (size_t i = 0; i < n; ++i)
+    for (int l = 0; l < 4; ++l) {
+      r[i * 4 + l] = sigs[i].r.raw[l];
+      s[i * 4 + l] = sigs[i].s.raw[l];
+    }
+  const uint8_t* d = reinterpret_cast<const uint8_t*>(digests.data());
+  if (C == FEC_SECP256K1) check(fec_ecdsa_verify_secp256k1(ctx.raw(), d, r.data(), s.data(), pk.data(), inf.data(), st.data(), n));
+  else check(fec_ecdsa_verify_p256(ctx.raw(), d, r.data(), s.data(), pk.data(), inf.data(), st.data(), n));
+  return detail::statuses(st);
+}
+// Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391) with the weights of 302-306 drawn by the caller.
+template <fec_curve C>
+inline Verify batch_verify(GpuContext& ctx, const std::vector<AffinePoint<C>>& public_keys,
+                           const std::vector<Digest>& digests, const std::vector<Signature<C>>& sigs,
+                           const std::vector<Scalar<C>>& weights) {
+  static_assert(C == FEC_SECP256K1 || C == FEC_P256, "Ecdsa is built for secp256k1 and P-256");
+  const size_t n = sigs.size();
+  if (public_keys.size() != n || digests.size() != n) return Verify::False;   // 289-291
+  if (weights.size() != n) throw Error(FEC_E_ARG);
+  std::vector<uint64_t> pk, r(n * 4), s(n * 4);
+  std::vector<uint8_t> inf;
+  detail::pack_affine<C>(public_keys, pk, inf);
+  for (size_t i = 0; i < n; ++i)
+    for (int l = 0; l < 4; ++l) {
+      r[i * 4 + l] = sigs[i].r.raw[l];
+      s[i * 4 + l] = sigs[i].s.raw[l];
+    }
+  uint8_t result = 0;
+  check(fec_ecdsa_batch_verify(ctx.raw(), C, reinterpret_cast<const uint8_t*>(digests.data()), r.data(), s.data(), pk.data(),
+                               inf.data(), reinterpret_cast<const uint64_t*>(weights.data()), n, &result, nullptr));
+  return result == 1 ? Verify::True : (result == 2 ? Verify::ReferencePanics : Verify::False);
+}
+}  // namespace ecdsa
+
+namespace eddsa {
+// forge_ec_signature::eddsa::Signature<Ed25519> { r: AffinePoint, s: Scalar }
+struct Signature {
+  AffinePoint<FEC_ED25519> r;
+  Scalar<FEC_ED25519> s;
+};
+// Eddsa::<Ed25519, D>::verify (forge-ec-signature/src/eddsa.rs:174-211) per element from the point computation
+// on: challenges[i] = Scalar::from_bytes_reduced(H(R_i || A_i || m_i)) by the caller (179-193), who also
+// keeps the message special cases of 157-170.
+inline std::vector<Verify> verify(GpuContext& ctx, const std::vector<AffinePoint<FEC_ED25519>>& public_keys,
+                                  const std::vector<Signature>& sigs, const std::vector<Scalar<FEC_ED25519>>& challenges) {
+  const size_t n = sigs.size();
+  if (public_keys.size() != n || challenges.size() != n) throw Error(FEC_E_ARG);
+  std::vector<AffinePoint<FEC_ED25519>> rs(n);
+  std::vector<uint64_t> pk, rxy, s(n * 4);
+  std::vector<uint8_t> pinf, rinf, st(n);
+  for (size_t i = 0; i < n; ++i) {
+    rs[i] = sigs[i].r;
+    for (int l = 0; l < 4; ++l) s[i * 4 + l] = sigs[i].s.raw[l];
+  }
+  detail::pack_affine<FEC_ED25519>(public_keys, pk, pinf);
+  detail::pack_affine<FEC_ED25519>(rs, rxy, rinf);
+  check(fec_eddsa_verify_ed25519(ctx.raw(), rxy.data(), rinf.data(), pk.data(), pinf.data(), s.data(),
+                                 reinterpret_cast<const uint64_t*>(challenges.data()), st.data(), n));
+  return detail::statuses(st);
+}
+}  // namespace eddsa
+
+namespace encoding {
+// PointAffine::from_bytes(&[u8; 33]) per element (secp256k1.rs:896-976, p256.rs:1580-1639, ed25519.rs:1526-1582):
+// nullopt-like `ok[i] == 0` where the reference returns None.
+template <fec_curve C>
+struct Decoded {
+  std::vector<AffinePoint<C>> points;
+  std::vector<uint8_t> ok;
+};
+template <fec_curve C>
+inline Decoded<C> unpack(const std::vector<uint64_t>& xy, const std::vector<uint8_t>& inf, std::vector<uint8_t> ok) {
+  Decoded<C> d{std::vector<AffinePoint<C>>(ok.size()), std::move(ok)};
+  for (size_t i = 0; i < d.points.size(); ++i) {
+    for (int l = 0; l < 4; ++l) {
+      d.points[i].x_.raw[l] = xy[i * 8 + l];
+      d.points[i].y_.raw[l] = xy[i * 8 + 4 + l];
+    }
+    d.points[i].infinity = inf[i] != 0;
+  }
+  return d;
+}
+template <fec_curve C>
+inline Decoded<C> from_bytes(GpuContext& ctx, const std::vector<std::array<uint8_t, 33>>& enc) {
+  const size_t n = enc.size();
+  std::vector<uint64_t> xy(n * 8);
+  std::vector<uint8_t> inf(n), ok(n);
+  check(fec_batch_decompress(ctx.raw(), C, reinterpret_cast<const uint8_t*>(enc.data()), xy.data(), inf.data(), ok.data(), n));
+  return unpack<C>(xy, inf, std::move(ok));
+}
+// PointAffine::to_bytes -> [u8; 33]
+template <fec_curve C>
+inline std::vector<std::array<uint8_t, 33>> to_bytes(GpuContext& ctx, const std::vector<AffinePoint<C>>& pts) {
+  std::vector<uint64_t> xy;
+  std::vector<uint8_t> inf;
+  detail::pack_affine<C>(pts, xy, inf);
+  std::vector<std::array<uint8_t, 33>> out(pts.size());
+  check(fec_batch_compress(ctx.raw(), C, xy.data(), inf.data(), reinterpret_cast<uint8_t*>(out.data()), pts.size()));
+  return out;
+}
+// forge-ec-encoding UncompressedPoint::{from_affine, to_affine} (point.rs:186-281): the 65-byte form both ways
+template <fec_curve C>
+inline std::vector<std::array<uint8_t, 65>> to_uncompressed(GpuContext& ctx, const std::vector<AffinePoint<C>>& pts) {
+  std::vector<uint64_t> xy;
+  std::vector<uint8_t> inf;
+  detail::pack_affine<C>(pts, xy, inf);
+  std::vector<std::array<uint8_t, 65>> out(pts.size());
+  check(fec_batch_encode_uncompressed(ctx.raw(), C, xy.data(), inf.data(), reinterpret_cast<uint8_t*>(out.data()), pts.size()));
+  return out;
+}
+template <fec_curve C>
+inline Decoded<C> from_uncompressed(GpuContext& ctx, const std::vector<std::array<uint8_t, 65>>& enc) {
+  const size_t n = enc.size();
+  std::vector<uint64_t> xy(n * 8);
+  std::vector<uint8_t> inf(n), ok(n);
+  check(fec_batch_decode_uncompressed(ctx.raw(), C, reinterpret_cast<const uint8_t*>(enc.data()), xy.data(), inf.data(), ok.data(), n));
+  return unpack<C>(xy, inf, std::move(ok));
+}
+}  // namespace encoding
+
 // ---- canonical-math mode (include/fecgpu_canon.h): the REAL curves, NOT reference parity -----------
 // Plain-integer limbs; affine points as {x, y}; status 0 finite / 1 infinity / 2 rejected input.
 namespace canon {

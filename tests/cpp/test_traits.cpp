@@ -5,6 +5,7 @@
 // build: g++ -std=c++17 -I include tests/cpp/test_traits.cpp -L forge_ec_amd -lfecgpu -o test_traits
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "forge_ec_gpu.hpp"
 using namespace forge_ec;
@@ -130,6 +131,82 @@ static void batch_api() {
   CHECK(threw, "length mismatch -> Error");
 }
 
+// The signature layer and the codecs through the C++ mirror, in the style of the reference's own tests:
+// properties that hold under the reference's arithmetic, no external expected values.
+static void signature_layer_and_codecs() {
+  GpuContext ctx(0);
+  // Ecdsa::verify (ecdsa.rs:213-281): r = 0 or s = 0 is false (215-217); a digest >= n panics in the reference (239)
+  for (int which = 0; which < 2; ++which) {
+    auto run = [&](auto curve_tag) {
+      constexpr fec_curve C = decltype(curve_tag)::value;
+      using Cv = Curve<C>;
+      std::vector<typename Cv::PointAffine> pks(3);
+      std::vector<ecdsa::Digest> dg(3);
+      std::vector<ecdsa::Signature<C>> sigs(3);
+      auto g = Cv::generator();
+      for (uint64_t i = 0; i < 3; ++i) {
+        pks[i] = Cv::to_affine(Cv::multiply(g, Scalar<C>::from(5 + i)));
+        dg[i].fill(0);
+        dg[i][31] = (uint8_t)(7 + i);
+        sigs[i].r = Scalar<C>::from(11 + i);
+        sigs[i].s = Scalar<C>::from(13 + i);
+      }
+      sigs[1].r = Scalar<C>::from(0);
+      dg[2].fill(0xFF);
+      auto st = ecdsa::verify<C>(ctx, pks, dg, sigs);
+      CHECK(st[1] == Verify::False, "ECDSA verify: r = 0 is false");
+      CHECK(st[2] == Verify::ReferencePanics, "ECDSA verify: digest >= n is where the reference panics");
+      // batch_verify (287-391): mismatched lengths and the empty batch are false; the first failing signature decides
+      std::vector<Scalar<C>> w{Scalar<C>::from(3), Scalar<C>::from(5), Scalar<C>::from(7)};
+      CHECK(ecdsa::batch_verify<C>(ctx, {}, {}, {}, {}) == Verify::False, "ECDSA batch_verify: empty batch is false (289-291)");
+      CHECK(ecdsa::batch_verify<C>(ctx, pks, dg, sigs, w) == Verify::False, "ECDSA batch_verify: r = 0 at index 1 returns false before the panic at 2");
+      sigs[1].r = Scalar<C>::from(12);
+      CHECK(ecdsa::batch_verify<C>(ctx, pks, dg, sigs, w) == Verify::ReferencePanics, "ECDSA batch_verify: now the digest at index 2 panics");
+    };
+    if (which == 0) run(std::integral_constant<fec_curve, FEC_SECP256K1>{});
+    else run(std::integral_constant<fec_curve, FEC_P256>{});
+  }
+  // Eddsa::verify (eddsa.rs:174-211): with the public key at infinity R + k*A = R, so R = to_affine(s*G) verifies;
+  // any other R does not; an infinite R is false (174-177)
+  {
+    auto g = Ed25519::generator();
+    std::vector<Ed25519::PointAffine> pks(3);
+    std::vector<eddsa::Signature> sigs(3);
+    std::vector<Ed25519::ScalarT> k(3);
+    for (uint64_t i = 0; i < 3; ++i) {
+      pks[i].infinity = true;
+      sigs[i].s = Ed25519::ScalarT::from(1000 + i);
+      sigs[i].r = Ed25519::to_affine(Ed25519::multiply(g, sigs[i].s));
+      k[i] = Ed25519::ScalarT::from(77 + i);
+    }
+    sigs[1].r = Ed25519::to_affine(Ed25519::multiply(g, Ed25519::ScalarT::from(999)));
+    sigs[2].r.infinity = true;
+    auto st = eddsa::verify(ctx, pks, sigs, k);
+    CHECK(st[0] == Verify::True, "EdDSA verify: R = s*G with A at infinity verifies");
+    CHECK(st[1] == Verify::False, "EdDSA verify: another R does not");
+    CHECK(st[2] == Verify::False, "EdDSA verify: an infinite R is false (174-177)");
+  }
+  // codecs: to_bytes of the identity is 0x00 + zeros and decodes back to the identity on every curve;
+  // the uncompressed form of an affine point carries its coordinates' to_bytes after the 0x04 tag
+  {
+    std::vector<Secp256k1::PointAffine> id(1);
+    id[0].infinity = true;
+    auto enc = encoding::to_bytes<FEC_SECP256K1>(ctx, id);
+    bool zeros = true;
+    for (uint8_t b : enc[0]) zeros = zeros && b == 0;
+    CHECK(zeros, "to_bytes(identity) is 33 zero bytes");
+    auto dec = encoding::from_bytes<FEC_SECP256K1>(ctx, enc);
+    CHECK(dec.ok[0] == 1 && dec.points[0].infinity, "from_bytes of the identity encoding is Some(identity)");
+    std::vector<P256::PointAffine> p(1);
+    p[0] = P256::to_affine(P256::generator());
+    auto u = encoding::to_uncompressed<FEC_P256>(ctx, p);
+    CHECK(u[0][0] == 0x04 && u[0][1] == 0x6B && u[0][32] == 0x96 && u[0][33] == 0x4F && u[0][64] == 0xF5,
+          "UncompressedPoint::from_affine(G) = 04 || Gx || Gy (P-256: to_bytes is the raw limbs)");
+    auto back = encoding::from_uncompressed<FEC_P256>(ctx, u);
+    CHECK(back.ok.size() == 1, "UncompressedPoint::to_affine returns one verdict per input");
+  }
+}
+
 // canonical-math mode through the C++ mirror: published points and a round trip
 static void canonical_mode() {
   GpuContext ctx(0);
@@ -161,6 +238,7 @@ int main() {
     p256_field_and_point_arithmetic();
     ed25519_field_and_scalar_multiplication();
     batch_api();
+    signature_layer_and_codecs();
   } catch (const Error& e) {
     std::printf("FAIL: %s\n", e.what());
     return 2;
