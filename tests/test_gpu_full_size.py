@@ -122,3 +122,62 @@ def test_whole_batch_is_bit_exact(gpu_ctx, oracle, curve):
     want = oracle.batch_mul(curve, k, p, nthreads=16)
     bad = np.nonzero((out != want).any(axis=1))[0]
     assert bad.size == 0, "first mismatching rows: %s" % bad[:5]
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_ecdsa_verify_2p20(gpu_ctx, oracle, curve):
+    """Ecdsa::<C, D>::verify over 2^20 signatures (secp256k1, P-256): an oracle-checked sample, batch invariance
+    on a ragged sub-batch, and signatures that verify under the reference's arithmetic scattered through it."""
+    n = 1 << 20
+    rng = np.random.default_rng(3100 + curve)
+    dg = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    dg[::5, 0] &= 0x7F                       # a fifth of the digests are certainly below n; others may panic (status 2)
+    r, s = V.scalars(n, curve, 3101), V.scalars(n, curve, 3102)
+    pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 3103), V.field_elements(n, curve, 3104)], axis=1))
+    inf = np.zeros(n, dtype=np.uint8)
+    idx = _sample_idx(n, 1200, 7)[::4]
+    # with the key at infinity R = multiply(G, h / s) whatever r is: set r to the x the reference derives there
+    ver = idx[::3]
+    op = oracle.secp256k1_scalar_op if curve == 0 else oracle.p256_scalar_op
+    g = oracle.generator(curve)
+    one = np.array([1, 0, 0, 0], dtype=np.uint64)
+    for i in ver:
+        inf[i] = 1
+        dg[i, 0] &= 0x7F
+        h = np.array(V.limbs_of(int.from_bytes(dg[i].tobytes(), "big")), dtype=np.uint64)
+        u1 = op("mul", h, op("inv", s[i])[0])[0]
+        xy, is_inf = oracle.to_affine(curve, oracle.multiply(curve, g, u1))
+        x = oracle.field_op(0, "mul", xy[:4], one) if curve == 0 else xy[:4]
+        if not is_inf:
+            r[i] = x
+    fn = gpu_ctx.ecdsa_verify_secp256k1 if curve == 0 else gpu_ctx.ecdsa_verify_p256
+    ofn = oracle.batch_secp256k1_ecdsa_verify if curve == 0 else oracle.batch_p256_ecdsa_verify
+    got = fn(dg, r, s, pk, inf)
+    want = ofn(dg[idx], r[idx], s[idx], pk[idx], inf[idx], nthreads=16)
+    assert np.array_equal(got[idx], want)
+    assert int((want == 1).sum()) >= len(ver) // 4 and set(int(v) for v in np.unique(got)) <= {0, 1, 2}
+    lo = 345679
+    assert np.array_equal(fn(dg[lo:lo + 777], r[lo:lo + 777], s[lo:lo + 777], pk[lo:lo + 777], inf[lo:lo + 777]), got[lo:lo + 777])
+
+
+def test_eddsa_verify_2p20(gpu_ctx, oracle):
+    """Eddsa verify (Ed25519, from the point computation on) over 2^20 signatures: oracle-checked sample with
+    verifying signatures in it, and batch invariance."""
+    n = 1 << 20
+    s, k = V.scalars(n, 2, 3201), V.scalars(n, 2, 3202)
+    pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 3203), V.field_elements(n, 2, 3204)], axis=1))
+    r = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 3205), V.field_elements(n, 2, 3206)], axis=1))
+    pinf, rinf = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    idx = _sample_idx(n, 1200, 8)[::4]
+    ver = idx[::3]
+    axy, _ = oracle.batch_to_affine(2, oracle.batch_mul_fixed(2, s[ver], oracle.generator(2), nthreads=16), nthreads=16)
+    r[ver] = axy
+    pinf[ver] = 1
+    rinf[idx[1::9]] = 1
+    got = gpu_ctx.eddsa_verify_ed25519(r, rinf, pk, pinf, s, k)
+    want = oracle.batch_ed25519_eddsa_verify(r[idx], rinf[idx], pk[idx], pinf[idx], s[idx], k[idx], nthreads=16)
+    assert np.array_equal(got[idx], want)
+    assert int((want == 1).sum()) >= len(ver) // 2
+    lo = 234571
+    sl = slice(lo, lo + 777)
+    assert np.array_equal(gpu_ctx.eddsa_verify_ed25519(r[sl], rinf[sl], pk[sl], pinf[sl], s[sl], k[sl]), got[sl])
