@@ -277,8 +277,9 @@ __global__ __launch_bounds__(TPB) void k_point_op(int op, const u32* __restrict_
 //   result = identity; for i in 0..n { result += product[i] }
 // The reference's Add is neither associative nor commutative, so the order is part of the result:
 // the n products (already computed by the batch kernel) are folded strictly left to right.
-// secp256k1: each addition is spread over four lanes (secp::padd_coop, 6 instead of 16 dependent field
-// operations); P-256 / Ed25519: one lane.
+// Each addition is spread over a few lanes of the wavefront (secp::padd_coop: four lanes, 6 instead of 16
+// dependent field operations; p256::padd_coop: five lanes, 5 instead of 16; ed::padd_coop: four lanes, 3
+// instead of 9) -- the same products on the same operands, so the sums are bit-identical.
 // One wavefront folds `terms` left to right from the identity with the cooperative addition.
 FEC_DEV secp::pt fold_coop_secp(const u32* __restrict__ terms, size_t n, u32* sh) {
   using namespace secp::coop;
@@ -302,23 +303,68 @@ FEC_DEV secp::pt fold_coop_secp(const u32* __restrict__ terms, size_t n, u32* sh
   return acc;
 }
 
+// P-256: the same fold with p256::padd_coop (five lanes, 5 instead of 16 dependent field operations)
+FEC_DEV p256::pt fold_coop_p256(const u32* __restrict__ terms, size_t n, u32* sh) {
+  using namespace p256::coop;
+  const int lane = threadIdx.x & 63;
+  p256::pt acc = p256::identity();
+  if (lane == 0) coopx::st(sh, ONE, fe_small(1));
+  u32 next_word = (n != 0 && lane < 24) ? terms[lane] : 0u;
+#pragma unroll 1
+  for (size_t i = 0; i < n; ++i) {
+    if (lane == 0) {
+      coopx::st(sh, PX, acc.x);
+      coopx::st(sh, PY, acc.y);
+      coopx::st(sh, PZ, acc.z);
+    }
+    if (lane < 24) sh[QX * 8 + lane] = next_word;  // q = term i (X, Y, Z: slots QX..QZ are contiguous)
+    if (i + 1 < n && lane < 24) next_word = terms[(i + 1) * P256::PW + lane];
+    coopx::sync();
+    acc = p256::padd_coop(sh);
+  }
+  return acc;
+}
+// Ed25519: ed::padd_coop (four lanes, 3 instead of 9 dependent field operations)
+FEC_DEV ed::pt fold_coop_ed(const u32* __restrict__ terms, size_t n, u32* sh) {
+  using namespace ed::coop;
+  const int lane = threadIdx.x & 63;
+  ed::pt acc = ed::identity();
+  if (lane == 0) {
+    coopx::st(sh, ONE, fe_small(1));
+    coopx::st(sh, DCONST, ed::D_());
+  }
+  u32 next_word = (n != 0 && lane < 32) ? terms[lane] : 0u;
+#pragma unroll 1
+  for (size_t i = 0; i < n; ++i) {
+    if (lane == 0) {
+      coopx::st(sh, PX, acc.x);
+      coopx::st(sh, PY, acc.y);
+      coopx::st(sh, PZ, acc.z);
+      coopx::st(sh, PT, acc.t);
+    }
+    if (lane < 32) sh[QX * 8 + lane] = next_word;  // q = term i (X, Y, Z, T: slots QX..QT are contiguous)
+    if (i + 1 < n && lane < 32) next_word = terms[(i + 1) * Ed::PW + lane];
+    coopx::sync();
+    acc = ed::padd_coop(sh);
+  }
+  return acc;
+}
+
 template <class C>
 __global__ __launch_bounds__(64) void k_fold_sum(const u32* __restrict__ products, u32* __restrict__ out, size_t n) {
   if (blockIdx.x != 0) return;
-  if constexpr (C::PW == 24 && C::BYTES_BIG_ENDIAN && sizeof(typename C::pt) == sizeof(secp::pt) &&
-                __is_same(typename C::pt, secp::pt)) {
+  if constexpr (__is_same(typename C::pt, secp::pt)) {
     __shared__ __attribute__((aligned(16))) u32 sh[secp::coop::WORDS];
     secp::pt acc = fold_coop_secp(products, n, sh);
     if (threadIdx.x == 0) C::store(out, 1, acc);
+  } else if constexpr (__is_same(typename C::pt, p256::pt)) {
+    __shared__ __attribute__((aligned(16))) u32 sh[p256::coop::WORDS];
+    p256::pt acc = fold_coop_p256(products, n, sh);
+    if (threadIdx.x == 0) C::store(out, 1, acc);
   } else {
-    if (threadIdx.x != 0) return;
-    typename C::pt acc = C::identity();
-#pragma unroll 1
-    for (size_t i = 0; i < n; ++i) {
-      typename C::pt p = C::load(products + i * C::PW, 1);
-      acc = C::padd(acc, p);
-    }
-    C::store(out, 1, acc);
+    __shared__ __attribute__((aligned(16))) u32 sh[ed::coop::WORDS];
+    ed::pt acc = fold_coop_ed(products, n, sh);
+    if (threadIdx.x == 0) C::store(out, 1, acc);
   }
 }
 

@@ -8,6 +8,7 @@
 // bounded are unrolled to that bound, with the proof next to them.
 #pragma once
 #include "limbs.hpp"
+#include "coop.hpp"
 
 namespace fecgpu {
 namespace p256 {
@@ -281,6 +282,83 @@ FEC_DEV pt padd(const pt& p, const pt& q) {
     o = pt_select(o, d, nd);
   }
   return o;
+}
+
+// ---- Add (1938-2007) spread over up to FIVE lanes of one wavefront (see coop.hpp) ----------------------------
+// The same sixteen products on the same operands as padd_nodouble() (square() is self * self in the reference,
+// so every one is a Mul), level by level:
+//   level 1   z1z1 = z1 z1     z2z2 = z2 z2     t1 = y1 z2      t2 = y2 z1      zz = (z1+z2)(z1+z2)
+//   level 2   u1 = x1 z2z2     u2 = x2 z1z1     s1 = t1 z2z2    s2 = t2 z1z1
+//             h = u2 - u1, r = 2 (s2 - s1), hh = 2 h, zs = zz - z1z1 - z2z2
+//   level 3   i = hh hh        rr = r r         z3 = zs h
+//   level 4   j = h i          v = u1 i                         x3 = rr - j - 2 v
+//   level 5   t = r (v - x3)   w = (2 s1) j                     y3 = t - w
+// 5 field-operation latencies per addition instead of 16.
+namespace coop {
+enum { PX = 0, PY, PZ, QX, QY, QZ, ZSUM, Z1Z1, Z2Z2, T1, T2, ZZ, U1, U2, S1, S2, H, R, HH, ZS, I, RR, Z3, J, V, DD, S1D, T, W, ONE, SLOTS };
+constexpr int WORDS = SLOTS * 8;
+// lane l (< n) multiplies slot a_l by slot b_l into slot o_l; the other lanes work on the constant 1
+FEC_DEV void level(u32* sh, int n, int a0, int a1, int a2, int a3, int a4, int b0, int b1, int b2, int b3, int b4, int o0,
+                   int o1, int o2, int o3, int o4) {
+  using namespace coopx;
+  const int lane = lane_id();
+  const fe a = ld(sh, pick(lane, a0, a1, a2, a3, a4, ONE)), b = ld(sh, pick(lane, b0, b1, b2, b3, b4, ONE));
+  const fe res = mul(a, b);
+  if (lane < n) st(sh, pick(lane, o0, o1, o2, o3, o4, ONE), res);
+  sync();
+}
+}  // namespace coop
+
+// sh: coop::WORDS words of LDS owned by this wavefront (16-byte aligned); slots PX..QZ hold p and q on entry
+// (written by the caller, followed by coopx::sync()); slot ONE holds the constant 1.  Every lane returns the sum.
+FEC_DEV pt padd_coop(u32* sh) {
+  using namespace coop;
+  using coopx::ld;
+  using coopx::st;
+  const pt p = {ld(sh, PX), ld(sh, PY), ld(sh, PZ)}, q = {ld(sh, QX), ld(sh, QY), ld(sh, QZ)};
+#ifdef FEC_HOST_EMUL
+  return padd(p, q);
+#else
+  const int lane = coopx::lane_id();
+  if (lane == 0) st(sh, ZSUM, add(p.z, q.z));
+  coopx::sync();
+  level(sh, 5, PZ, QZ, PY, QY, ZSUM, PZ, QZ, QZ, PZ, ZSUM, Z1Z1, Z2Z2, T1, T2, ZZ);
+  level(sh, 4, PX, QX, T1, T2, ONE, Z2Z2, Z1Z1, Z2Z2, Z1Z1, ONE, U1, U2, S1, S2, ONE);
+  const fe u1 = ld(sh, U1), u2 = ld(sh, U2), s1 = ld(sh, S1), s2 = ld(sh, S2);
+  const fe h = sub(u2, u1);
+  const fe s21 = sub(s2, s1);
+  const fe r = add(s21, s21);
+  if (lane == 0) {
+    st(sh, H, h);
+    st(sh, R, r);
+    st(sh, HH, add(h, h));
+    st(sh, ZS, sub(sub(ld(sh, ZZ), ld(sh, Z1Z1)), ld(sh, Z2Z2)));
+    st(sh, S1D, add(s1, s1));
+  }
+  coopx::sync();
+  level(sh, 3, HH, R, ZS, ONE, ONE, HH, R, H, ONE, ONE, I, RR, Z3, ONE, ONE);
+  level(sh, 2, H, U1, ONE, ONE, ONE, I, I, ONE, ONE, ONE, J, V, ONE, ONE, ONE);
+  const fe j = ld(sh, J), v = ld(sh, V);
+  pt o;
+  o.x = sub(sub(sub(ld(sh, RR), j), v), v);
+  if (lane == 0) st(sh, DD, sub(v, o.x));
+  coopx::sync();
+  level(sh, 2, R, S1D, ONE, ONE, ONE, DD, J, ONE, ONE, ONE, T, W, ONE, ONE, ONE);
+  o.y = sub(ld(sh, T), ld(sh, W));
+  o.z = ld(sh, Z3);
+  const lmask idp = is_identity(p), idq = is_identity(q);
+  const lmask ueq = fe_eq(u1, u2);
+  if (__builtin_expect((idp | idq | ueq) != 0, 0)) {  // the early-outs of Add, as in padd_nodouble / padd
+    const lmask same = uniform_mask(ueq & fe_eq(s1, s2));
+    const lmask opposite = uniform_mask(ueq & fe_eq(s1, neg(s2)));
+    o = pt_select(o, identity(), opposite);
+    o = pt_select(o, p, idq);
+    o = pt_select(o, q, idp);
+    const lmask nd = uniform_mask(same & ~idp & ~idq);
+    if (nd != 0) o = pt_select(o, pdouble(p), nd);
+  }
+  return o;
+#endif
 }
 
 // pow (376-393), LSB first: `if e & 1 { result *= base }; base = base.square()`

@@ -80,6 +80,14 @@ def main():
     ctx.multi_scalar_mul(0, k, p)
     emit(row="multi_scalar_multiply", curve="secp256k1", n=m, ms=round((time.perf_counter() - t0) * 1e3, 3),
          note="products in parallel + ordered fold, each addition on four lanes (secp::padd_coop); host pointers, PCIe included")
+    for c in (1, 2):
+        kc, pc = synth.scalars(m, c, 71), synth.points(m, c, 72)
+        ctx.multi_scalar_mul(c, kc, pc)
+        t0 = time.perf_counter()
+        ctx.multi_scalar_mul(c, kc, pc)
+        emit(row="multi_scalar_multiply", curve=NAMES[c], n=m, ms=round((time.perf_counter() - t0) * 1e3, 3),
+             note="products in parallel + ordered fold, each addition on %s; host pointers, PCIe included"
+                  % ("five lanes (p256::padd_coop)" if c == 1 else "four lanes (ed::padd_coop)"))
     pkxy, rxy = synth.field_elements(2 * m, 0, 73).reshape(m, 8), synth.field_elements(2 * m, 0, 74).reshape(m, 8)
     s_, a_, e_ = synth.scalars(m, 0, 75), synth.scalars(m, 0, 76), synth.scalars(m, 0, 77)
     t0 = time.perf_counter()
@@ -96,7 +104,7 @@ def main():
         ctx.ecdsa_batch_verify(c, dgb, rb, sb, pkb, None, ab)
         emit(row="ecdsa batch_verify", curve=NAMES[c], n=m, ms=round((time.perf_counter() - t0) * 1e3, 3),
              note="scalars + 2 multiplications per signature in parallel, then the ordered point fold%s and the ordered "
-                  "scalar sum; host pointers, PCIe included" % (" (four lanes per addition)" if c == 0 else " (one lane)"))
+                  "scalar sum; host pointers, PCIe included" % (" (four lanes per addition)" if c == 0 else " (five lanes per addition)"))
 
 
 main()
