@@ -77,9 +77,9 @@ struct EP256 {
     const bool bad = p256::sc_is_zero(rs) || p256::sc_is_zero(ss) ||
                      !(p256::sc_ct_lt_default(rs, order) && p256::sc_ct_lt_default(ss, order));     // 215-228
     const bool panic = p256::sc_ge_n(hs);                                                           // 239
-    const p256::sc s_inv = p256::sc_inv(ss);   // s != 0 on every lane that is not `bad`
-    u1 = p256::sc_fe(p256::sc_mul(hs, s_inv));                                                      // 250-251
-    u2 = p256::sc_fe(p256::sc_mul(rs, s_inv));
+    const fe s_inv = p256::sc_inv32(s);        // s != 0 on every lane that is not `bad`
+    u1 = p256::sc_mul32(h, s_inv);                                                                  // 250-251
+    u2 = p256::sc_mul32(r, s_inv);
     return bad ? F_FALSE : (panic ? F_PANIC : F_GO);
   }
   // identity -> false (259-262); x of to_affine (264); field_to_bytes = FieldElement::to_bytes (288-300): the raw
@@ -93,7 +93,7 @@ struct EP256 {
     return lane_of(fe_eq(x, target)) ? 1 : 0;
   }
   FEC_DEV static unsigned char finish(const pt& a, const pt& b, const fe& r) { return compare_x(p256::padd(a, b), r); }  // 256
-  FEC_DEV static fe wmul(const fe& a, const fe& b) { return p256::sc_fe(p256::sc_mul(p256::sc_of(a), p256::sc_of(b))); }
+  FEC_DEV static fe wmul(const fe& a, const fe& b) { return p256::sc_mul32(a, b); }
   FEC_DEV static fe wadd(const fe& a, const fe& b) { return p256::sc_fe(p256::sc_add(p256::sc_of(a), p256::sc_of(b))); }
   static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s) {
     p256_launch_mul(fixed, k, p, o, n, s);

@@ -106,6 +106,15 @@ FEC_DEV lmask sub256(fe& r, const fe& a, const fe& b) {
   }
   return bo ? ~0ull : 0ull;
 }
+FEC_DEV lmask add256_cin(fe& r, const fe& a, const fe& b, lmask cin) {
+  u64 c = cin ? 1 : 0;
+  for (int i = 0; i < 8; ++i) {
+    u64 s = (u64)a.w[i] + b.w[i] + c;
+    r.w[i] = (u32)s;
+    c = s >> 32;
+  }
+  return c ? ~0ull : 0ull;
+}
 // r = a + b mod 2^256, top += carry-out;  r = a - b mod 2^256, top -= borrow-out
 FEC_DEV void add256c(fe& r, const fe& a, const fe& b, u32& top) { top += add256(r, a, b) ? 1u : 0u; }
 FEC_DEV void sub256c(fe& r, const fe& a, const fe& b, u32& top) { top -= sub256(r, a, b) ? 1u : 0u; }

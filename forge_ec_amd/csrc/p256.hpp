@@ -516,82 +516,81 @@ FEC_DEV bool sc_ge_n(const sc& a) {  // compare_with_n(a) >= 0 (889-905); N at 2
   }
   return borrow == 0;
 }
-// r[0..8) = a * b exactly (row by row with a running carry, as Mul at 1413-1425 forms it)
-FEC_DEV void sc_mul_wide(const u64 (&a)[4], const u64 (&b)[4], u64 (&r)[8]) {
-  FEC_UNROLL for (int i = 0; i < 8; ++i) r[i] = 0;
+// Mul (1409-1432) = the exact 512-bit product, then reduce_wide (924-1020), on 32-bit words and branch-free:
+//   first  = low + high * C, exact (943-969; the reference's u128 columns cannot overflow: C's 64-bit limbs are
+//            60, 63, 0 and 32 bits wide);
+//   second : low2 += the LOW FOUR LIMBS of high2 * C only (993-998) -- computed unconditionally: high2 == 0
+//            contributes zero, exactly like the skipped branch at 976;
+//   carry  : if that addition carries out, limb i receives c * C[i] with c the RUNNING carry (1000-1007), i.e.
+//            C is added limb by limb only for as long as each limb addition itself carries;
+//   last   : while >= n subtract n (runs at most once: low2 < 2^256 < 2n).
+FEC_DEV fe SC_C_() {  // TWO_256_MINUS_N (932-937)
+  fe c;
+  c.w[0] = 0x039CDAAFu; c.w[1] = 0x0C46353Du; c.w[2] = 0x58E8617Bu; c.w[3] = 0x43190552u;
+  c.w[4] = 0; c.w[5] = 0; c.w[6] = 0xFFFFFFFFu; c.w[7] = 0;
+  return c;
+}
+FEC_DEV fe SC_N_() {  // 23-24
+  fe n;
+  n.w[0] = 0xFC632551u; n.w[1] = 0xF3B9CAC2u; n.w[2] = 0xA7179E84u; n.w[3] = 0xBCE6FAADu;
+  n.w[4] = 0xFFFFFFFFu; n.w[5] = 0xFFFFFFFFu; n.w[6] = 0x00000000u; n.w[7] = 0xFFFFFFFFu;
+  return n;
+}
+FEC_DEV fe sc_reduce_wide(const u32 (&w)[16]) {
+  fe low, high;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) { low.w[i] = w[i]; high.w[i] = w[8 + i]; }
+  u32 p[16];
+  mul_wide(p, high, SC_C_());
+  fe plo, phi;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) { plo.w[i] = p[i]; phi.w[i] = p[8 + i]; }
+  fe low2, high2;
+  const lmask c0 = add256(low2, plo, low);
+  (void)add256_cin(high2, phi, fe_zero(), c0);            // first < 2^481: no carry out of the top
+  u32 p2[8];
+  mul_low256(p2, high2, SC_C_());
+  fe p2f;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) p2f.w[i] = p2[i];
+  fe sum;
+  const lmask cy = add256(sum, low2, p2f);
+  // the carry round in the reference's 64-bit limbs, selected where the addition carried
+  const u64 C[4] = {0x0C46353D039CDAAFULL, 0x4319055258E8617BULL, 0ULL, 0x00000000FFFFFFFFULL};
+  fe fixed;
+  u64 c = 1;
   FEC_UNROLL for (int i = 0; i < 4; ++i) {
-    u64 carry = 0;
-    FEC_UNROLL for (int j = 0; j < 4; ++j) {
-      const u64 lo = a[i] * b[j], hi = mulhi64(a[i], b[j]);
-      u64 t = r[i + j] + lo;
-      u64 c = t < lo;
-      t += carry;
-      c += t < carry;
-      r[i + j] = t;
-      carry = hi + c;  // hi <= 2^64 - 2, and c == 2 needs lo == 2^64 - 1 twice over: no wrap
-    }
-    r[i + 4] = carry;
+    const u64 l = (u64)sum.w[2 * i] | ((u64)sum.w[2 * i + 1] << 32);
+    const u64 lo = c * C[i], hi = mulhi64(c, C[i]);
+    const u64 t = l + lo;
+    c = hi + (t < lo);
+    fixed.w[2 * i] = (u32)t;
+    fixed.w[2 * i + 1] = (u32)(t >> 32);
   }
+  const fe v = fe_select(sum, fixed, cy);
+  fe d;
+  const lmask borrow = sub256(d, v, SC_N_());
+  return fe_select(d, v, borrow);
 }
-FEC_DEV sc sc_reduce_wide(const u64 (&w)[8]) {
-  const u64 C[4] = {0x0C46353D039CDAAFULL, 0x4319055258E8617BULL, 0ULL, 0x00000000FFFFFFFFULL};  // 932-937
-  const u64 N[4] = {0xF3B9CAC2FC632551ULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL};
-  const u64 high[4] = {w[4], w[5], w[6], w[7]};
-  u64 res[8];
-  sc_mul_wide(high, C, res);  // 943-954: the u128 columns cannot overflow (C's limbs are 60, 63, 0, 32 bits)
-  u64 carry = 0;              // 957-969: + low, carries propagated
-  FEC_UNROLL for (int i = 0; i < 8; ++i) {
-    const u64 add = i < 4 ? w[i] : 0;
-    u64 t = res[i] + add;
-    u64 c = t < add;
-    t += carry;
-    c += t < carry;
-    res[i] = t;
-    carry = c;
-  }
-  sc low2;
-  FEC_UNROLL for (int i = 0; i < 4; ++i) low2.l[i] = res[i];
-  const u64 high2[4] = {res[4], res[5], res[6], res[7]};
-  if ((high2[0] | high2[1] | high2[2] | high2[3]) != 0) {  // 976
-    u64 p2[8];
-    sc_mul_wide(high2, C, p2);
-    u64 cy = 0;
-    FEC_UNROLL for (int i = 0; i < 4; ++i) {  // 993-998: product2[4..8] is never used
-      u64 t = low2.l[i] + p2[i];
-      u64 c = t < p2[i];
-      t += cy;
-      c += t < cy;
-      low2.l[i] = t;
-      cy = c;
-    }
-    if (cy > 0) {  // 1000-1007: limb i receives c * C[i], c the RUNNING carry (not + C)
-      u64 c = cy;
-      FEC_UNROLL for (int i = 0; i < 4; ++i) {
-        const u64 lo = c * C[i], hi = mulhi64(c, C[i]);
-        const u64 t = low2.l[i] + lo;
-        c = hi + (t < lo);
-        low2.l[i] = t;
-      }
-    }
-  }
-  while (sc_ge_n(low2)) {  // 1010-1019 (runs at most once: low2 < 2^256 < 2n)
-    u64 borrow = 0;
-    FEC_UNROLL for (int i = 0; i < 4; ++i) {
-      const u64 d1 = low2.l[i] - N[i];
-      const u64 b1 = low2.l[i] < N[i];
-      const u64 d2 = d1 - borrow;
-      const u64 b2 = d1 < borrow;
-      low2.l[i] = d2;
-      borrow = b1 + b2;
-    }
-  }
-  return low2;
+FEC_DEV fe sc_mul32(const fe& a, const fe& b) {
+  u32 t[16];
+  mul_wide(t, a, b);
+  return sc_reduce_wide(t);
 }
-FEC_DEV sc sc_mul(const sc& a, const sc& b) {  // 1409-1432
-  u64 wide[8];
-  sc_mul_wide(a.l, b.l, wide);
-  return sc_reduce_wide(wide);
+FEC_DEV sc sc_mul(const sc& a, const sc& b) { return sc_of(sc_mul32(sc_fe(a), sc_fe(b))); }  // 1409-1432
+// invert (1057-1080) = pow(n - 2) (1083-1100): limbs and bits LS -> MS, `result *= base` on a set bit,
+// base = base.square() = base * base every step
+FEC_DEV fe sc_inv32(const fe& a) {
+  const u64 e[4] = {0xF3B9CAC2FC63254FULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL};
+  fe result = fe_small(1), base = a;
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll 1
+    for (int k = 0; k < 64; ++k) {
+      if ((e[i] >> k) & 1) result = sc_mul32(result, base);  // exponent bits are uniform
+      base = sc_mul32(base, base);
+    }
+  }
+  return result;
 }
+FEC_DEV sc sc_inv(const sc& a) { return sc_of(sc_inv32(sc_fe(a))); }
 // Add (1352-1375): on a carry out of the top limb reduce() still sees only the low 256 bits
 FEC_DEV sc sc_add(const sc& a, const sc& b) {
   const u64 N[4] = {0xF3B9CAC2FC632551ULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL};
@@ -619,21 +618,6 @@ FEC_DEV sc sc_add(const sc& a, const sc& b) {
     }
   }
   return r;
-}
-// invert (1057-1080) = pow(n - 2) (1083-1100): limbs and bits LS -> MS, `result *= base` on a set bit,
-// base = base.square() = base * base every step
-FEC_DEV sc sc_inv(const sc& a) {
-  const u64 e[4] = {0xF3B9CAC2FC63254FULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL};
-  sc result = {{1, 0, 0, 0}}, base = a;
-#pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll 1
-    for (int k = 0; k < 64; ++k) {
-      if ((e[i] >> k) & 1) result = sc_mul(result, base);  // exponent bits are uniform
-      base = sc_mul(base, base);
-    }
-  }
-  return result;
 }
 // Scalar::ct_lt(self, get_order()) -- P-256 keeps the trait DEFAULT (forge-ec-core/src/lib.rs:497-531):
 // over big-endian bytes, result |= eq_so_far & !borrow(other_byte - self_byte), i.e. "self_byte <=

@@ -47,7 +47,23 @@ def test_multi_ctx_other_elementwise_calls(oracle):
             assert np.array_equal(ctx.field_op(curve, 2, a, b), one.field_op(curve, 2, a, b))
             assert np.array_equal(ctx.point_op(curve, 0, q, V.points(n, curve, 46)),
                                   one.point_op(curve, 0, q, V.points(n, curve, 46)))
+        # the verification pipelines shard per signature
+        rng = np.random.default_rng(5)
+        dg = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        for curve, name in ((0, "ecdsa_verify_secp256k1"), (1, "ecdsa_verify_p256")):
+            r, s = V.scalars(n, curve, 51), V.scalars(n, curve, 52)
+            pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 53), V.field_elements(n, curve, 54)], axis=1))
+            inf = (rng.integers(0, 8, size=n) == 0).astype(np.uint8)
+            assert np.array_equal(getattr(ctx, name)(dg, r, s, pk, inf), getattr(one, name)(dg, r, s, pk, inf))
+        s, k = V.scalars(n, 2, 55), V.scalars(n, 2, 56)
+        pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 57), V.field_elements(n, 2, 58)], axis=1))
+        r = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 59), V.field_elements(n, 2, 60)], axis=1))
+        inf = (rng.integers(0, 8, size=n) == 0).astype(np.uint8)
+        assert np.array_equal(ctx.eddsa_verify_ed25519(r, None, pk, inf, s, k), one.eddsa_verify_ed25519(r, None, pk, inf, s, k))
         # not element-wise: runs on devices[0]
+        a = V.scalars(64, 1, 61)
+        assert ctx.ecdsa_batch_verify(1, dg[:64], V.scalars(64, 1, 62), V.scalars(64, 1, 63), pk[:64], None, a)[0] == \
+            one.ecdsa_batch_verify(1, dg[:64], V.scalars(64, 1, 62), V.scalars(64, 1, 63), pk[:64], None, a)[0]
         assert np.array_equal(ctx.generator(0), one.generator(0))
         k, p = V.scalars(64, 0, 47), V.points(64, 0, 48)
         assert np.array_equal(ctx.multi_scalar_mul(0, k, p), one.multi_scalar_mul(0, k, p))
