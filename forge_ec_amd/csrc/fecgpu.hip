@@ -826,6 +826,19 @@ int launch_eddsa_verify(fec_ctx* ctx, const u64* dr, const unsigned char* drinf,
   return L.done();
 }
 
+// KeyExchange::derive_shared_secret for secp256k1 / P-256 on per-stream scratch (kernels_ecdsa.hip)
+int launch_ecdh(fec_ctx* ctx, int curve, const u64* dsk, const u64* dpk, const unsigned char* dinf, unsigned char* dout,
+                unsigned char* dstatus, size_t n, void* stream) {
+  if (n == 0) return FEC_OK;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  void* work = scratch_for(ctx, st, ecdh_work_bytes(n));
+  if (!work) return FEC_E_OOM;
+  Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_ecdh_pre + k_secp_mul + k_ecdh_finish" : "k_ecdh_pre + k_p256_mul_sched + k_ecdh_finish");
+  ecdh_launch(curve, reinterpret_cast<const u32*>(dsk), reinterpret_cast<const u32*>(dpk), dinf, reinterpret_cast<u32*>(dout),
+              dstatus, work, n, L.s);
+  return L.done();
+}
+
 int launch_field(fec_ctx* ctx, int curve, int op, const u64* da, const u64* db, u64* dout, size_t n,
                  void* stream = nullptr) {
   if (n == 0) return FEC_OK;
@@ -1350,6 +1363,60 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
   }
   *result = res;
   if (detail) std::memcpy(detail, det, 128);
+  return FEC_OK;
+}
+
+int fec_batch_ecdh_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_private_keys, const uint64_t* d_pk_xy,
+                       const uint8_t* d_pk_inf, uint8_t* d_secrets, uint8_t* d_status, size_t n, void* stream) {
+  if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
+  if (!ctx || (n && (!d_private_keys || !d_pk_xy || !d_secrets || !d_status))) return FEC_E_ARG;
+  if (curve != FEC_SECP256K1 && curve != FEC_P256) return FEC_E_UNSUPPORTED;   // Ed25519 has no KeyExchange impl
+  if (!aligned16(d_private_keys) || !aligned16(d_pk_xy) || !aligned16(d_secrets)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_ecdh(ctx, curve, d_private_keys, d_pk_xy, d_pk_inf, d_secrets, d_status, n, stream);
+}
+
+int fec_batch_ecdh(fec_ctx* ctx, fec_curve curve, const uint64_t* private_keys, const uint64_t* pk_xy, const uint8_t* pk_inf,
+                   uint8_t* secrets, uint8_t* status, size_t n) {
+  if (curve != FEC_SECP256K1 && curve != FEC_P256) return FEC_E_UNSUPPORTED;
+  if (is_multi(ctx)) {
+    if (n && (!private_keys || !pk_xy || !secrets || !status)) return FEC_E_ARG;
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_batch_ecdh(c, curve, private_keys + lo * 4, pk_xy + lo * 8, pk_inf ? pk_inf + lo : nullptr, secrets + lo * 32,
+                            status + lo, cnt);
+    });
+  }
+  if (!ctx || (n && (!private_keys || !pk_xy || !secrets || !status))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  // slots: 0 private keys, 1 public keys, 2 infinity flags, 3 status, 4 secrets
+  const void* hin[3] = {private_keys, pk_xy, pk_inf};
+  const size_t bytes[3] = {n * 32, n * 64, n};
+  for (int i = 0; i < 3; ++i) {
+    if (!hin[i]) continue;
+    int rc = ensure(ctx, i, bytes[i]);
+    if (rc != FEC_OK) return rc;
+    if (hipMemcpyAsync(ctx->d_buf[i], hin[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  }
+  int rc = ensure(ctx, 3, n);
+  if (rc == FEC_OK) rc = ensure(ctx, 4, n * 32);
+  if (rc != FEC_OK) return rc;
+  rc = launch_ecdh(ctx, curve, (const u64*)ctx->d_buf[0], (const u64*)ctx->d_buf[1],
+                   pk_inf ? (const unsigned char*)ctx->d_buf[2] : nullptr, (unsigned char*)ctx->d_buf[4],
+                   (unsigned char*)ctx->d_buf[3], n, nullptr);
+  if (rc != FEC_OK) return rc;
+  if (hipMemcpyAsync(secrets, ctx->d_buf[4], n * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
+  // the private keys, the shared points and the secrets were staged in ctx-owned device memory: clear it
+  (void)hipMemsetAsync(ctx->d_buf[0], 0, n * 32, ctx->stream);
+  (void)hipMemsetAsync(ctx->d_buf[4], 0, n * 32, ctx->stream);
+  if (void* work = scratch_for(ctx, ctx->stream, ecdh_work_bytes(n))) (void)hipMemsetAsync(work, 0, ecdh_work_bytes(n), ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
   return FEC_OK;
 }
 

@@ -43,6 +43,12 @@ void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hip
 void ecdsa_batch_finish_launch(int curve, const u32* r_sum, const void* work, size_t n, unsigned char* result, u32* detail,
                                hipStream_t s);
 
+// kernels_ecdsa.hip: KeyExchange::derive_shared_secret for secp256k1 / P-256 (secp256k1.rs:1884-1904, p256.rs:2281-2312):
+// validation + from_affine, the variable-base multiplication, to_affine + x.to_bytes().  out: 8 words (32 bytes) per element.
+size_t ecdh_work_bytes(size_t n);
+void ecdh_launch(int curve, const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* out, unsigned char* status,
+                 void* work, size_t n, hipStream_t s);
+
 // kernels_ecdsa.hip: Eddsa verify around the Ed25519 multiplications (eddsa.rs:174-211, 430-447).
 // eddsa_pre_launch: a[i] = from_affine(pk[i]) (32 words); eddsa_finish_launch: status from sg = multiply(G, s),
 // ka = multiply(A, k), R.

@@ -60,6 +60,10 @@ struct ESecp {
     return lane_of(fe_eq(xr, target)) ? 1 : 0;
   }
   FEC_DEV static unsigned char finish(const pt& a, const pt& b, const fe& r) { return compare_x(secp::padd(a, b), r); }  // 256
+  // KeyExchange for Secp256k1 (secp256k1.rs:1884-1904) does not validate the public key
+  FEC_DEV static bool pk_valid(const fe&, const fe&, bool) { return true; }
+  FEC_DEV static fe x_value(const fe& x) { return secp::mul(x, fe_small(1)); }      // FieldElement::to_bytes (138-178)
+  FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return secp::to_affine(p, x, y); }
   FEC_DEV static fe wmul(const fe& a, const fe& b) { return secp::sc_mul(a, b); }   // impl Mul for Scalar
   FEC_DEV static fe wadd(const fe& a, const fe& b) { return secp::sc_add(a, b); }   // impl Add for Scalar
   static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s) {
@@ -93,6 +97,12 @@ struct EP256 {
     return lane_of(fe_eq(x, target)) ? 1 : 0;
   }
   FEC_DEV static unsigned char finish(const pt& a, const pt& b, const fe& r) { return compare_x(p256::padd(a, b), r); }  // 256
+  // validate_public_key (p256.rs:2304-2312): !is_identity & validate_point (2187-2191) = is_on_curve (1636-1656)
+  FEC_DEV static bool pk_valid(const fe& x, const fe& y, bool inf) {
+    return !inf && lane_of(fe_eq(p256::sqr(y), p256::curve_rhs(x)));
+  }
+  FEC_DEV static fe x_value(const fe& x) { return x; }                               // FieldElement::to_bytes (288-300)
+  FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return p256::to_affine(p, x, y); }
   FEC_DEV static fe wmul(const fe& a, const fe& b) { return p256::sc_mul32(a, b); }
   FEC_DEV static fe wadd(const fe& a, const fe& b) { return p256::sc_fe(p256::sc_add(p256::sc_of(a), p256::sc_of(b))); }
   static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s) {
@@ -201,6 +211,51 @@ __global__ __launch_bounds__(64) void k_ecdsa_batch_finish(const u32* __restrict
   store8(detail + 24, total);
 }
 
+// ---- KeyExchange::derive_shared_secret (secp256k1.rs:1884-1904, p256.rs:2281-2302) ----
+// pre: public-key validation (P-256 only) and from_affine; the multiplication is the curve's own kernel;
+// finish: to_affine, identity -> Err, else x.to_bytes().  status: 0 Ok, 1 Err(InvalidPublicKey), 2 Err (identity).
+template <class E>
+__global__ __launch_bounds__(TPB) void k_ecdh_pre(const u32* __restrict__ pk, const unsigned char* __restrict__ pk_inf,
+                                                  u32* __restrict__ q, unsigned char* __restrict__ flags, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const bool inf = pk_inf != nullptr && pk_inf[i] != 0;
+  fe x = load8(pk + i * 16), y = load8(pk + i * 16 + 8), z = fe_small(1);
+  flags[i] = E::pk_valid(x, y, inf) ? 0 : 1;
+  if (inf) { x = fe_zero(); y = fe_small(1); z = fe_zero(); }   // from_affine of the identity: (0, 1, 0)
+  store8(q + i * 24, x);
+  store8(q + i * 24 + 8, y);
+  store8(q + i * 24 + 16, z);
+}
+template <class E>
+__global__ __launch_bounds__(TPB) void k_ecdh_finish(const u32* __restrict__ t, const unsigned char* __restrict__ flags,
+                                                     u32* __restrict__ out, unsigned char* __restrict__ status, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  typename E::pt p;
+  p.x = load8(t + i * 24); p.y = load8(t + i * 24 + 8); p.z = load8(t + i * 24 + 16);
+  fe x, y;
+  const bool ident = lane_of(E::to_affine(p, x, y));
+  const fe v = E::x_value(x);
+  const unsigned char st = flags[i] != 0 ? 1 : (ident ? 2 : 0);
+  fe o;  // big-endian bytes of the value, as eight words in memory order; zero unless Ok
+  FEC_UNROLL for (int w = 0; w < 8; ++w) o.w[w] = st == 0 ? __builtin_bswap32(v.w[7 - w]) : 0u;
+  store8(out + i * 8, o);
+  status[i] = st;
+}
+template <class E>
+void run_ecdh(const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* out, unsigned char* status, void* work, size_t n,
+              hipStream_t s) {
+  char* w = static_cast<char*>(work);
+  u32* q = reinterpret_cast<u32*>(w);
+  u32* t = reinterpret_cast<u32*>(w + n * 96);
+  unsigned char* flags = reinterpret_cast<unsigned char*>(w + n * 192);
+  const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
+  hipLaunchKernelGGL((k_ecdh_pre<E>), g, b, 0, s, pk, pk_inf, q, flags, n);
+  E::launch_mul(false, sk, q, t, n, s);
+  hipLaunchKernelGGL((k_ecdh_finish<E>), g, b, 0, s, (const u32*)t, (const unsigned char*)flags, out, status, n);
+}
+
 // ---- Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211, 430-447) ----
 FEC_DEV ed::pt ed_from_affine(const fe& x, const fe& y, bool inf) {  // ed25519.rs:1813-1826
   ed::pt p;
@@ -256,6 +311,13 @@ void eddsa_finish_launch(const u32* sg, const u32* ka, const u32* r_xy, const un
 }
 
 size_t ecdsa_work_bytes(size_t n) { return n * 353; }
+
+size_t ecdh_work_bytes(size_t n) { return n * 193; }
+void ecdh_launch(int curve, const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* out, unsigned char* status,
+                 void* work, size_t n, hipStream_t s) {
+  if (curve == FEC_SECP256K1) run_ecdh<ESecp>(sk, pk, pk_inf, out, status, work, n, s);
+  else run_ecdh<EP256>(sk, pk, pk_inf, out, status, work, n, s);
+}
 
 // batch_verify, first half: work area as ecdsa_launch plus ar at +n*353 rounded up to 16 (n * 32 bytes).
 size_t ecdsa_batch_work_bytes(size_t n) { return ((n * 353 + 15) & ~(size_t)15) + n * 32; }

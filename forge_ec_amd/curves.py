@@ -153,6 +153,22 @@ class Context:
         return self._ecdsa_verify(self._lib.fec_ecdsa_verify_p256, "fec_ecdsa_verify_p256", digests, r, s, pk_xy,
                                   pk_inf)
 
+    def batch_ecdh(self, curve, private_keys, pk_xy, pk_inf=None):
+        """KeyExchange::derive_shared_secret per element (secp256k1.rs:1884-1904, p256.rs:2281-2312).  Returns
+        (secrets (n,32) uint8, status (n,) uint8): 0 Ok, 1 Err(InvalidPublicKey) (P-256), 2 Err (identity).
+        NOT FOR PRODUCTION SECRETS: parity mode reproduces reference behaviour; see include/fecgpu.h."""
+        kk, pk = _u64(private_keys, 4), _u64(pk_xy, 8)
+        n = kk.shape[0]
+        if pk.shape[0] != n:
+            raise ValueError("inputs differ in length")
+        inf = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)).reshape(-1) if pk_inf is not None else None
+        if inf is not None and inf.shape[0] != n:
+            raise ValueError("pk_inf and the keys differ in length")  # the C side reads n bytes
+        out = np.zeros((n, 32), dtype=np.uint8)
+        st = np.zeros(n, dtype=np.uint8)
+        _check(self._lib.fec_batch_ecdh(self._h, curve, _ptr(kk), _ptr(pk), _ptr(inf), _ptr(out), _ptr(st), n), "fec_batch_ecdh")
+        return out, st
+
     def ecdsa_batch_verify(self, curve, digests, r, s, pk_xy, pk_inf, a):
         """Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391) for secp256k1 / P-256 with the digests and the weights
         a (n,4) supplied.  Returns (result, detail): result 1 true, 0 false, 2 = the reference panics; detail
@@ -292,6 +308,10 @@ class Context:
     def ecdsa_verify_secp256k1_dev(self, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream=None):
         _check(self._lib.fec_ecdsa_verify_secp256k1_dev(self._h, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n,
                                                         stream), "fec_ecdsa_verify_secp256k1_dev")
+
+    def batch_ecdh_dev(self, curve, d_private_keys, d_pk_xy, d_pk_inf, d_secrets, d_status, n, stream=None):
+        _check(self._lib.fec_batch_ecdh_dev(self._h, curve, d_private_keys, d_pk_xy, d_pk_inf, d_secrets, d_status, n, stream),
+               "fec_batch_ecdh_dev")
 
     def eddsa_verify_ed25519_dev(self, d_r_xy, d_r_inf, d_pk_xy, d_pk_inf, d_s, d_k, d_status, n, stream=None):
         _check(self._lib.fec_eddsa_verify_ed25519_dev(self._h, d_r_xy, d_r_inf, d_pk_xy, d_pk_inf, d_s, d_k, d_status, n,

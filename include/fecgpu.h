@@ -29,6 +29,8 @@
  *   fec_ecdsa_verify_p256 Ecdsa::<P256, D>::verify per signature, digest supplied (ecdsa.rs:213-281; scalar
  *                         field p256.rs:875-1100, 1409-1432; default Scalar::ct_lt core lib.rs:497-531;
  *                         FieldElement::to_bytes 288-300)
+ *   fec_batch_ecdh        KeyExchange::derive_shared_secret for secp256k1 / P-256 (secp256k1.rs:1884-1904,
+ *                         p256.rs:2281-2312)
  *   fec_ecdsa_batch_verify   Ecdsa::<C, D>::batch_verify for secp256k1 / P-256 (ecdsa.rs:287-391; scalar Add
  *                         secp256k1.rs:2358-2378, p256.rs:1352-1375)
  *   fec_eddsa_verify_ed25519   Eddsa::<Ed25519, D>::verify / Ed25519::verify after the hash and the decoding
@@ -163,6 +165,18 @@ int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests /* n*32 */, 
 int fec_ecdsa_verify_p256(fec_ctx* ctx, const uint8_t* digests /* n*32 */, const uint64_t* r /* n*4 */,
                           const uint64_t* s /* n*4 */, const uint64_t* pk_xy /* n*8 */,
                           const uint8_t* pk_inf /* n or NULL */, uint8_t* status /* n */, size_t n);
+/* KeyExchange::derive_shared_secret per element (forge-ec-curves/src/secp256k1.rs:1884-1904, p256.rs:2281-2302;
+ * the pattern of forge-ec-examples/src/ecdh.rs:40-49), curve = FEC_SECP256K1 or FEC_P256 (Ed25519 implements no
+ * KeyExchange: FEC_E_UNSUPPORTED).  secrets[i] = the 32 bytes of Ok(x.to_bytes()) of to_affine(multiply(
+ * from_affine(pk_i), sk_i)); status[i] = 0 Ok, 1 Err(InvalidPublicKey) -- P-256 only: validate_public_key
+ * (2304-2312) = not the identity and is_on_curve (1636-1656), which under the reference's Sub rejects about half
+ * of the true curve points -- 2 Err because the product is the identity (secrets[i] is zero for 1 and 2).
+ * secp256k1 does not validate the key.  SECRETS: the host-pointer form clears its device staging (keys, shared
+ * points, secrets) before returning; the P-256 multiplication is a task scheduler whose batch composition
+ * depends on the key bits, i.e. NOT constant-time -- like the rest of parity mode this reproduces reference
+ * behaviour and is not a hardened ECDH. */
+int fec_batch_ecdh(fec_ctx* ctx, fec_curve curve, const uint64_t* private_keys /* n*4 */, const uint64_t* pk_xy /* n*8 */,
+                   const uint8_t* pk_inf /* n or NULL */, uint8_t* secrets /* n*32 */, uint8_t* status /* n */, size_t n);
 /* Ecdsa::<C, D>::batch_verify (forge-ec-signature/src/ecdsa.rs:287-391) for curve = FEC_SECP256K1 or FEC_P256
  * (FEC_E_UNSUPPORTED otherwise), everything after the hashes: digests, r, s, pk as for fec_ecdsa_verify_*;
  * a = the n weights the reference draws at 302-306 (the caller draws them with the reference's own
@@ -248,6 +262,9 @@ int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const
 int fec_ecdsa_verify_p256_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
                               const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
                               void* stream);
+/* d_secrets 16-byte aligned; the caller owns (and clears) every buffer */
+int fec_batch_ecdh_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_private_keys, const uint64_t* d_pk_xy,
+                       const uint8_t* d_pk_inf, uint8_t* d_secrets, uint8_t* d_status, size_t n, void* stream);
 int fec_eddsa_verify_ed25519_dev(fec_ctx* ctx, const uint64_t* d_r_xy, const uint8_t* d_r_inf, const uint64_t* d_pk_xy,
                                  const uint8_t* d_pk_inf, const uint64_t* d_s, const uint64_t* d_k, uint8_t* d_status,
                                  size_t n, void* stream);

@@ -316,6 +316,34 @@ inline Verify batch_verify(GpuContext& ctx, const std::vector<AffinePoint<C>>& p
 }
 }  // namespace ecdsa
 
+namespace key_exchange {
+// KeyExchange::derive_shared_secret per element (secp256k1.rs:1884-1904, p256.rs:2281-2312): Ok(32 bytes) or the
+// reference's error.  Reproduces reference behaviour (parity mode); not a hardened ECDH -- see fecgpu.h.
+enum class Outcome : uint8_t { Ok = 0, InvalidPublicKey = 1, IdentityProduct = 2 };
+struct SharedSecret {
+  Outcome outcome;
+  std::array<uint8_t, 32> bytes;
+};
+template <fec_curve C>
+inline std::vector<SharedSecret> derive_shared_secret(GpuContext& ctx, const std::vector<Scalar<C>>& private_keys,
+                                                      const std::vector<AffinePoint<C>>& public_keys) {
+  static_assert(C == FEC_SECP256K1 || C == FEC_P256, "KeyExchange is implemented for secp256k1 and P-256");
+  const size_t n = private_keys.size();
+  if (public_keys.size() != n) throw Error(FEC_E_ARG);
+  std::vector<uint64_t> pk;
+  std::vector<uint8_t> inf, st(n), sec(n * 32);
+  detail::pack_affine<C>(public_keys, pk, inf);
+  check(fec_batch_ecdh(ctx.raw(), C, reinterpret_cast<const uint64_t*>(private_keys.data()), pk.data(), inf.data(), sec.data(),
+                       st.data(), n));
+  std::vector<SharedSecret> r(n);
+  for (size_t i = 0; i < n; ++i) {
+    r[i].outcome = static_cast<Outcome>(st[i]);
+    for (int b = 0; b < 32; ++b) r[i].bytes[b] = sec[i * 32 + b];
+  }
+  return r;
+}
+}  // namespace key_exchange
+
 namespace eddsa {
 // forge_ec_signature::eddsa::Signature<Ed25519> { r: AffinePoint, s: Scalar }
 struct Signature {

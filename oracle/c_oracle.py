@@ -76,6 +76,8 @@ def lib():
         L.fo_batch_p256_ecdsa_verify.restype = None
         L.fo_ecdsa_batch_verify.argtypes = [ctypes.c_int, p, p, p, p, p, p, ctypes.c_size_t, p]
         L.fo_ecdsa_batch_verify.restype = ctypes.c_int
+        L.fo_batch_ecdh.argtypes = [ctypes.c_int, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_ecdh.restype = None
         L.fo_batch_ed25519_eddsa_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
         L.fo_batch_ed25519_eddsa_verify.restype = None
         L.fo_secp256k1_schnorr_batch_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, p, p]
@@ -259,6 +261,17 @@ def ecdsa_batch_verify(curve, digests, r, s, pk_xy, pk_inf, a):
     if rc < 0:
         raise ValueError("fo_ecdsa_batch_verify rc=%d" % rc)
     return rc, detail
+
+
+def batch_ecdh(curve, sk, pk_xy, pk_inf=None, nthreads=1):
+    """KeyExchange::derive_shared_secret per element (curve 0 / 1): -> (secrets (n,32) uint8, status (n,) uint8)."""
+    sk, pk_xy = _u64(sk), _u64(pk_xy)
+    n = sk.size // 4
+    inf = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+    out = np.zeros((n, 32), dtype=np.uint8)
+    st = np.zeros(n, dtype=np.uint8)
+    lib().fo_batch_ecdh(curve, _ptr(sk), _ptr(pk_xy), _ptr(inf) if inf is not None else None, _ptr(out), _ptr(st), n, nthreads)
+    return out, st
 
 
 def batch_ed25519_eddsa_verify(r_xy, r_inf, pk_xy, pk_inf, s, k, nthreads=1):

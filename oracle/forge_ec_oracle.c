@@ -1818,3 +1818,53 @@ void fo_batch_to_affine(int curve, const u64* points, u64* xy, uint8_t* inf, siz
   job_t j = {3, curve, NULL, NULL, points, xy, inf, 0, 0};
   run_jobs(j, n, nthreads);
 }
+
+/* ---- KeyExchange::derive_shared_secret (secp256k1.rs:1884-1904, p256.rs:2281-2302) ---------------------------
+ * curve 0 (Secp256k1): multiply(from_affine(pk), sk), to_affine; identity -> Err(InvalidEncoding) (status 2);
+ *   else Ok(x.to_bytes()).  No validation of the public key.
+ * curve 1 (P256): validate_public_key (2304-2312) = !is_identity & validate_point (2187-2191) = is_on_curve
+ *   (1636-1656), else Err(InvalidPublicKey) (status 1); then as above with Err(KeyExchangeError) (status 2).
+ * Ed25519 does not implement KeyExchange.  out: 32 bytes per element (zero unless status 0). */
+int fo_ecdh(int curve, const u64 sk[4], const u64 pk_xy[8], int pk_inf, unsigned char out[32]) {
+  memset(out, 0, 32);
+  fe x, y;
+  if (curve == 0) {
+    jpt q = k_identity();
+    if (!pk_inf) { q.x = ld(pk_xy); q.y = ld(pk_xy + 4); q.z = fe_small(1); }
+    jpt sp = k_multiply(&q, sk);
+    if (k_to_affine(&sp, &x, &y)) return 2;
+    field_to_bytes(0, x, out);
+    return 0;
+  }
+  if (curve != 1) return -1;
+  fe px = ld(pk_xy), py = ld(pk_xy + 4);
+  fe lhs = n_mul(py, py);                       /* y.square() = self * self */
+  fe rhs = n_rhs(px);
+  int on_curve = pk_inf ? 1 : (lhs.v[0] == rhs.v[0] && lhs.v[1] == rhs.v[1] && lhs.v[2] == rhs.v[2] && lhs.v[3] == rhs.v[3]);
+  if (pk_inf || !on_curve) return 1;
+  jpt q = {px, py, fe_small(1)};
+  jpt sp = n_multiply(&q, sk);
+  if (n_to_affine(&sp, &x, &y)) return 2;
+  field_to_bytes(1, x, out);
+  return 0;
+}
+typedef struct { int curve; const u64 *sk, *pk; const uint8_t* inf; unsigned char* out; uint8_t* st; size_t lo, hi; } dh_t;
+static void* dhworker(void* arg) {
+  dh_t* j = (dh_t*)arg;
+  for (size_t i = j->lo; i < j->hi; ++i)
+    j->st[i] = (uint8_t)fo_ecdh(j->curve, j->sk + 4 * i, j->pk + 8 * i, j->inf ? j->inf[i] : 0, j->out + 32 * i);
+  return NULL;
+}
+void fo_batch_ecdh(int curve, const u64* sk, const u64* pk_xy, const uint8_t* pk_inf, unsigned char* out, uint8_t* status,
+                   size_t n, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 64) nthreads = 64;
+  pthread_t th[64];
+  dh_t jobs[64];
+  for (int t = 0; t < nthreads; ++t) {
+    dh_t j = {curve, sk, pk_xy, pk_inf, out, status, n * t / nthreads, n * (t + 1) / nthreads};
+    jobs[t] = j;
+    pthread_create(&th[t], NULL, dhworker, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+}

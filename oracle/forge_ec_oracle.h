@@ -80,6 +80,12 @@ int fo_ecdsa_batch_verify(int curve, const unsigned char* digests, const uint64_
                           const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* a, size_t n,
                           uint64_t* detail);
 
+/* KeyExchange::derive_shared_secret (secp256k1.rs:1884-1904, p256.rs:2281-2312): status 0 = Ok(out), 1 =
+ * Err(InvalidPublicKey) (P-256 validation), 2 = Err for an identity result; -1 for a curve without KeyExchange */
+int fo_ecdh(int curve, const uint64_t sk[4], const uint64_t pk_xy[8], int pk_inf, unsigned char out[32]);
+void fo_batch_ecdh(int curve, const uint64_t* sk, const uint64_t* pk_xy, const uint8_t* pk_inf, unsigned char* out,
+                   uint8_t* status, size_t n, int nthreads);
+
 /* Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211, 430-447),
  * s and k = from_bytes_reduced(hash) given: 1 true, 0 false, 2 the reference panics */
 int fo_ed25519_eddsa_verify(const uint64_t r_xy[8], int r_inf, const uint64_t pk_xy[8], int pk_inf,

@@ -1235,3 +1235,24 @@ def double_mul(curve, u1, u2, q):
     """R = multiply(G,u1) + multiply(Q,u2)  (forge-ec-signature/src/ecdsa.rs:254-256)."""
     F = CURVES[curve]
     return F.padd(F.multiply(F.generator(), u1), F.multiply(q, u2))
+
+
+def ecdh(curve, sk, pk_xy, pk_inf=False):
+    """KeyExchange::derive_shared_secret (secp256k1.rs:1884-1904; p256.rs:2281-2302 with validate_public_key
+    2304-2312 -> validate_point 2187-2191 -> is_on_curve 1636-1656).  Returns (status, 32 bytes): 0 = Ok(bytes),
+    1 = Err(InvalidPublicKey) (P-256 only), 2 = Err because the product is the identity."""
+    x, y = list(pk_xy[0:4]), list(pk_xy[4:8])
+    if curve == SECP256K1:
+        F = Secp
+    elif curve == P256:
+        F = P256c
+        if pk_inf or F.sqr(y) != _p256_rhs(x):
+            return 1, bytes(32)
+    else:
+        raise ValueError("Ed25519 does not implement KeyExchange")
+    q = F.identity() if pk_inf else (x, y, [1, 0, 0, 0])
+    ax, _, inf = F.to_affine(F.multiply(q, list(sk)))
+    if inf:
+        return 2, bytes(32)
+    return 0, bytes(to_bytes_field(curve, ax))
+

@@ -33,6 +33,8 @@ extern "C" {
     fn fec_batch_double_mul(ctx: *mut FecCtx, curve: c_int, u1: *const u64, u2: *const u64, q: *const u64, out: *mut u64, n: usize) -> c_int;
     fn fec_batch_to_affine(ctx: *mut FecCtx, curve: c_int, points: *const u64, xy: *mut u64, inf: *mut u8, n: usize) -> c_int;
     fn fec_multi_scalar_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_batch_ecdh(ctx: *mut FecCtx, curve: c_int, private_keys: *const u64, pk_xy: *const u64, pk_inf: *const u8, secrets: *mut u8, status: *mut u8, n: usize) -> c_int;
+    fn fec_batch_ecdh_dev(ctx: *mut FecCtx, curve: c_int, d_private_keys: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_secrets: *mut u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_ecdsa_batch_verify(ctx: *mut FecCtx, curve: c_int, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, a: *const u64, n: usize, result: *mut u8, detail: *mut u64) -> c_int;
     fn fec_eddsa_verify_ed25519(ctx: *mut FecCtx, r_xy: *const u64, r_inf: *const u8, pk_xy: *const u64, pk_inf: *const u8, s: *const u64, k: *const u64, status: *mut u8, n: usize) -> c_int;
     fn fec_ecdsa_verify_p256(ctx: *mut FecCtx, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, status: *mut u8, n: usize) -> c_int;
@@ -391,6 +393,31 @@ pub fn ecdsa_verify_batch_p256(ctx: &mut GpuContext, digests: &[[u8; 32]], r: &[
     Ok(status.iter().map(|&v| match v { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid }).collect())
 }
 
+/// `KeyExchange::derive_shared_secret` per element (`secp256k1.rs:1884-1904`, `p256.rs:2281-2312`) for secp256k1 and
+/// P-256: `Ok(secret)` or the reference's error (`InvalidPublicKey` from P-256's validation; `InvalidEncoding` /
+/// `KeyExchangeError` when the product is the identity).  Reproduces reference behaviour; not a hardened ECDH.
+pub fn batch_derive_shared_secret<C: GpuCurve>(ctx: &mut GpuContext, private_keys: &[C::Scalar], public_keys: &[C::PointAffine]) -> Result<Vec<Result<[u8; 32]>>> {
+    let n = private_keys.len();
+    if public_keys.len() != n {
+        return Err(Error::ValidationError);
+    }
+    let kk = pack_scalars::<C>(private_keys);
+    let (mut xy, mut inf) = (vec![0u64; 8 * n], vec![0u8; n]);
+    for (i, p) in public_keys.iter().enumerate() {
+        let (l, f) = C::affine_limbs(p);
+        xy[8 * i..8 * i + 8].copy_from_slice(&l);
+        inf[i] = f as u8;
+    }
+    let (mut secrets, mut status) = (vec![0u8; 32 * n], vec![0u8; n]);
+    // SAFETY: every buffer holds n elements of the width the header states.
+    check(unsafe { fec_batch_ecdh(ctx.raw, C::ID, kk.as_ptr(), xy.as_ptr(), inf.as_ptr(), secrets.as_mut_ptr(), status.as_mut_ptr(), n) })?;
+    Ok((0..n).map(|i| match status[i] {
+        0 => { let mut s = [0u8; 32]; s.copy_from_slice(&secrets[32 * i..32 * i + 32]); Ok(s) }
+        1 => Err(Error::InvalidPublicKey),
+        _ => Err(if C::ID == 0 { Error::InvalidEncoding } else { Error::KeyExchangeError }),
+    }).collect())
+}
+
 /// `Ecdsa::<C, D>::batch_verify` (`forge-ec-signature/src/ecdsa.rs:287-391`) for `C` = secp256k1 or P-256 from
 /// line 310 on: the caller hashes (`digests[i] = D::digest(msgs[i])`) and draws the weights `a` (302-306) with
 /// the reference's own `Scalar::random`.
@@ -526,6 +553,14 @@ pub mod dev {
     /// As [`batch_mul`].
     pub unsafe fn ecdsa_verify_secp256k1(ctx: &mut GpuContext, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
         check(fec_ecdsa_verify_secp256k1_dev(ctx.raw, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream))
+    }
+
+    /// `fec_batch_ecdh_dev`.
+    ///
+    /// # Safety
+    /// As [`batch_mul`]; the caller owns and clears every buffer.
+    pub unsafe fn batch_ecdh(ctx: &mut GpuContext, curve: c_int, d_private_keys: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_secrets: *mut u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_batch_ecdh_dev(ctx.raw, curve, d_private_keys, d_pk_xy, d_pk_inf, d_secrets, d_status, n, stream))
     }
 
     /// `fec_eddsa_verify_ed25519_dev`.

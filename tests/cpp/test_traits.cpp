@@ -186,6 +186,20 @@ static void signature_layer_and_codecs() {
     CHECK(st[1] == Verify::False, "EdDSA verify: another R does not");
     CHECK(st[2] == Verify::False, "EdDSA verify: an infinite R is false (174-177)");
   }
+  // KeyExchange::derive_shared_secret (secp256k1.rs:1884-1904): the secret is x.to_bytes() of multiply(pk, sk) --
+  // the same bytes PointAffine::to_bytes carries after its tag; a zero private key gives the identity -> Err
+  {
+    auto g = Secp256k1::generator();
+    std::vector<Secp256k1::ScalarT> sk{Secp256k1::ScalarT::from(0x1234567), Secp256k1::ScalarT::from(0)};
+    std::vector<Secp256k1::PointAffine> pk(2, Secp256k1::to_affine(Secp256k1::multiply(g, Secp256k1::ScalarT::from(99))));
+    auto r = key_exchange::derive_shared_secret<FEC_SECP256K1>(ctx, sk, pk);
+    auto shared = Secp256k1::to_affine(Secp256k1::multiply(Secp256k1::multiply(g, Secp256k1::ScalarT::from(99)), sk[0]));
+    auto enc = encoding::to_bytes<FEC_SECP256K1>(ctx, {shared});
+    bool same = r[0].outcome == key_exchange::Outcome::Ok;
+    for (int b = 0; b < 32; ++b) same = same && r[0].bytes[b] == enc[0][1 + b];
+    CHECK(same, "derive_shared_secret == x.to_bytes() of to_affine(multiply(pk, sk))");
+    CHECK(r[1].outcome == key_exchange::Outcome::IdentityProduct, "zero private key: the product is the identity -> Err");
+  }
   // codecs: to_bytes of the identity is 0x00 + zeros and decodes back to the identity on every curve;
   // the uncompressed form of an affine point carries its coordinates' to_bytes after the 0x04 tag
   {

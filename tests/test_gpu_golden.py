@@ -10,6 +10,7 @@ The committed fixtures fed DIRECTLY through libfecgpu.so (C ABI) on the GPU -- n
   tests/golden/secp256k1_sqr_ripple_operands.json
   tests/golden/ecdsa_p256_vectors.json  Ecdsa::<P256, D>::verify cases of every status
   tests/golden/eddsa_ed25519_vectors.json  Eddsa verify (point computation on) cases of every status
+  tests/golden/ecdh_vectors.json  KeyExchange::derive_shared_secret (secp256k1, P-256): status and secret
   tests/golden/ecdsa_batch_vectors.json  Ecdsa::batch_verify (secp256k1, P-256): status and both folded sums
 
 Bit-exact.  Run on the GPU box:  python -m pytest tests -m gpu -x -q
@@ -156,3 +157,13 @@ def test_ecdsa_batch_verify_vectors_on_the_gpu(gpu_ctx):
             assert [int(v) for v in detail] == c["r_sum"] + c["scalar_sum"], c["note"]
         else:
             assert not detail.any()
+
+
+def test_ecdh_vectors_on_the_gpu(gpu_ctx):
+    cases = _load("ecdh_vectors.json")["cases"]
+    for curve in (0, 1):
+        cs = [c for c in cases if c["curve"] == curve]
+        out, st = gpu_ctx.batch_ecdh(curve, _u64([c["sk"] for c in cs]), _u64([c["pk"] for c in cs]),
+                                     np.array([c["pk_inf"] for c in cs], dtype=np.uint8))
+        assert [int(v) for v in st] == [c["status"] for c in cs]
+        assert [bytes(o).hex() for o in out] == [c["secret"] for c in cs]

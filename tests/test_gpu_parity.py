@@ -503,6 +503,57 @@ def test_ecdsa_batch_verify_matches_oracle(gpu_ctx, oracle, curve):
     assert got == 0 and not gd.any()                   # empty batch: false
 
 
+def _p256_true_points(n, seed):
+    """n affine points of the real P-256 (x, y as limbs): the reference's is_on_curve accepts about half of them."""
+    import random
+    p = V.PRIME[1]
+    b = 0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B
+    rng = random.Random(seed)
+    rows = []
+    while len(rows) < n:
+        x = rng.randrange(p)
+        rhs = (x * x * x - 3 * x + b) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        if y * y % p == rhs:
+            rows.append(V.limbs_of(x) + V.limbs_of(y))
+    return np.array(rows, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_batch_ecdh_matches_oracle(gpu_ctx, oracle, curve):
+    """KeyExchange::derive_shared_secret per element (secp256k1.rs:1884-1904, p256.rs:2281-2312): secrets and
+    statuses against the oracle -- accepted and rejected public keys, infinite keys, zero private keys -- through
+    the host and the device-pointer entry points."""
+    import torch
+    n = 1500
+    sk = V.scalars(n, curve, 931)
+    pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 932), V.field_elements(n, curve, 933)], axis=1))
+    if curve == 1:
+        pk[: n - 100] = _p256_true_points(n - 100, 934)      # the last 100 stay off-curve
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[7::97] = 1
+    sk[11::113] = 0
+    want, wst = oracle.batch_ecdh(curve, sk, pk, inf, nthreads=8)
+    got, gst = gpu_ctx.batch_ecdh(curve, sk, pk, inf)
+    assert np.array_equal(gst, wst) and np.array_equal(got, want)
+    expect = {0, 2} if curve == 0 else {0, 1, 2}
+    assert set(int(v) for v in np.unique(wst)) == expect and int((wst == 0).sum()) > n // 3
+    w2, s2 = oracle.batch_ecdh(curve, sk, pk, None, nthreads=8)
+    g2, t2 = gpu_ctx.batch_ecdh(curve, sk, pk, None)
+    assert np.array_equal(t2, s2) and np.array_equal(g2, w2)
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev) for a in (sk, pk, inf)]
+    sec = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+    st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    gpu_ctx.batch_ecdh_dev(curve, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), sec.data_ptr(), st.data_ptr(), n, stream.cuda_stream)
+    stream.synchronize()
+    assert np.array_equal(st.cpu().numpy(), wst) and np.array_equal(sec.cpu().numpy().reshape(n, 32), want)
+    with pytest.raises(Exception):
+        gpu_ctx.batch_ecdh(2, sk, pk, inf)                    # Ed25519 implements no KeyExchange
+
+
 def _p256_ecdsa_cases(oracle, n_random, n_valid):
     """As _ecdsa_cases for Ecdsa::<P256, D>::verify.  r or s >= n are NOT rejected by the reference (its
     ct_lt is the trait default, a top-byte <= comparison): those lanes run the whole computation."""

@@ -373,3 +373,16 @@ def test_scalar_add_two_restatements_agree(oracle):
         for i in range(0, 80, 2):
             la, lb = [int(v) for v in w[i]], [int(v) for v in w[i + 1]]
             assert [int(v) for v in op("add", la, lb)[0]] == S.add(la, lb)
+
+
+def test_ecdh_vectors(oracle):
+    """KeyExchange::derive_shared_secret (secp256k1.rs:1884-1904, p256.rs:2281-2312): the C oracle against the
+    Python model's committed expectations (tests/golden/gen_ecdh.py), every status of both curves."""
+    with open(os.path.join(HERE, "golden", "ecdh_vectors.json")) as f:
+        cases = json.load(f)["cases"]
+    assert {(c["curve"], c["status"]) for c in cases} == {(0, 0), (0, 2), (1, 0), (1, 1), (1, 2)}
+    for curve in (0, 1):
+        cs = [c for c in cases if c["curve"] == curve]
+        out, st = oracle.batch_ecdh(curve, [c["sk"] for c in cs], [c["pk"] for c in cs], [c["pk_inf"] for c in cs], nthreads=4)
+        assert [int(v) for v in st] == [c["status"] for c in cs]
+        assert [bytes(o).hex() for o in out] == [c["secret"] for c in cs]

@@ -62,6 +62,17 @@ def main():
             best = min(best, ctx.last_kernel_ms()[0])
         emit(row="ecdsa_verify (parity)", curve=NAMES[c], n=n, ms=round(best, 4), M_per_s=round(n / best / 1e3, 2),
              kernels=ctx.last_kernel_ms()[1])
+    # ECDH: validation + from_affine, the variable-base multiplication, to_affine + x.to_bytes()
+    for c in (0, 1):
+        kk, pp = dev(synth.scalars(n, c, 91)), dev(synth.field_elements(2 * n, c, 92))
+        sec = torch.empty(n * 32, dtype=torch.uint8, device="cuda")
+        status = torch.empty(n, dtype=torch.uint8, device="cuda")
+        best = 1e9
+        for _ in range(3):
+            ctx.batch_ecdh_dev(c, kk.data_ptr(), pp.data_ptr(), None, sec.data_ptr(), status.data_ptr(), n, st)
+            best = min(best, ctx.last_kernel_ms()[0])
+        emit(row="derive_shared_secret (ECDH, parity)", curve=NAMES[c], n=n, ms=round(best, 4), M_per_s=round(n / best / 1e3, 2),
+             kernels=ctx.last_kernel_ms()[1])
     # EdDSA verify from the point computation on: from_affine + fixed-base table kernel + scheduler + finishing pass
     rr, pp = dev(synth.field_elements(2 * n, 2, 65)), dev(synth.field_elements(2 * n, 2, 66))
     sg, kk = dev(synth.scalars(n, 2, 67)), dev(synth.scalars(n, 2, 68))
