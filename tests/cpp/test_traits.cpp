@@ -193,7 +193,15 @@ static void signature_layer_and_codecs() {
     std::vector<Secp256k1::ScalarT> sk{Secp256k1::ScalarT::from(0x1234567), Secp256k1::ScalarT::from(0)};
     std::vector<Secp256k1::PointAffine> pk(2, Secp256k1::to_affine(Secp256k1::multiply(g, Secp256k1::ScalarT::from(99))));
     auto r = key_exchange::derive_shared_secret<FEC_SECP256K1>(ctx, sk, pk);
-    auto shared = Secp256k1::to_affine(Secp256k1::multiply(Secp256k1::multiply(g, Secp256k1::ScalarT::from(99)), sk[0]));
+    // from_affine (1365-1373): (x, y, one()) -- the product depends on the REPRESENTATION of the point under the
+    // reference's arithmetic, so the shared point is rebuilt from the affine key exactly as derive_shared_secret does
+    Secp256k1::PointProjective q;
+    for (int l = 0; l < 4; ++l) {
+      q.c[l] = pk[0].x_.raw[l];
+      q.c[4 + l] = pk[0].y_.raw[l];
+    }
+    q.c[8] = 1;
+    auto shared = Secp256k1::to_affine(Secp256k1::multiply(q, sk[0]));
     auto enc = encoding::to_bytes<FEC_SECP256K1>(ctx, {shared});
     bool same = r[0].outcome == key_exchange::Outcome::Ok;
     for (int b = 0; b < 32; ++b) same = same && r[0].bytes[b] == enc[0][1 + b];
