@@ -156,62 +156,8 @@ struct Ed {
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-// out[i] = Curve::multiply(FIXED ? base : points[i], scalars[i])
-template <class C, bool FIXED>
-__global__ __launch_bounds__(TPB) void k_batch_mul(const u32* __restrict__ scalars,
-                                                   const u32* __restrict__ points,
-                                                   u32* __restrict__ out, size_t n) {
-  __shared__ u32 lds_k[8 * TPB];
-  __shared__ u32 lds_p[C::PW * TPB];
-  const int valid = block_valid(n);
-  const size_t first = (size_t)blockIdx.x * TPB;
-  stage_in<8>(lds_k, scalars + first * 8, valid);
-  if (!FIXED) stage_in<C::PW>(lds_p, points + first * C::PW, valid);
-  __syncthreads();
-  const int e = threadIdx.x;
-  if (e < valid) {
-    typename C::pt p = FIXED ? C::load(points, 1) : C::load(lds_p + e, TPB);
-    typename C::pt r = C::multiply(p, lds_k + e);
-    C::store(lds_p + e, TPB, r);
-  }
-  __syncthreads();
-  stage_out<C::PW>(out + first * C::PW, lds_p, valid);
-}
-
-// P-256 Curve::multiply lives in kernels_p256.hip (workgroup task scheduler).
-
-// Ed25519 fixed-base (k_ed_build_table, k_ed_fixed_base) and variable-base kernels live in kernels_ed.hip.
-
-// out[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])     (ecdsa.rs:254-256)
-template <class C>
-__global__ __launch_bounds__(TPB, 2) void k_batch_double_mul(const u32* __restrict__ u1,
-                                                          const u32* __restrict__ u2,
-                                                          const u32* __restrict__ q,
-                                                          const u32* __restrict__ gen,
-                                                          u32* __restrict__ out, size_t n) {
-  __shared__ u32 lds_k[2][8 * TPB];
-  __shared__ u32 lds_p[C::PW * TPB];
-  const int valid = block_valid(n);
-  const size_t first = (size_t)blockIdx.x * TPB;
-  stage_in<8>(lds_k[0], u1 + first * 8, valid);
-  stage_in<8>(lds_k[1], u2 + first * 8, valid);
-  stage_in<C::PW>(lds_p, q + first * C::PW, valid);
-  __syncthreads();
-  const int e = threadIdx.x;
-  if (e < valid) {
-    typename C::pt r[2];
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {  // one copy of the ladder in the code object
-      typename C::pt base = pass == 0 ? C::load(gen, 1) : C::load(lds_p + e, TPB);
-      typename C::pt m = C::multiply(base, lds_k[pass] + e);
-      if (pass == 0) r[0] = m; else r[1] = m;
-    }
-    typename C::pt s = C::padd(r[0], r[1]);
-    C::store(lds_p + e, TPB, s);
-  }
-  __syncthreads();
-  stage_out<C::PW>(out + first * C::PW, lds_p, valid);
-}
+// Curve::multiply lives in kernels_secp.hip (three-waves-per-SIMD ladder), kernels_p256.hip and kernels_ed.hip
+// (persistent task schedulers, LDS addend-table kernel); u1*G + u2*Q is composed from them (launch_double_mul).
 
 template <class C>
 __global__ __launch_bounds__(TPB) void k_field_op(int op, const u32* __restrict__ a,
@@ -389,65 +335,6 @@ __global__ __launch_bounds__(TPB) void k_to_affine(const u32* __restrict__ point
   }
   __syncthreads();
   stage_out<16>(xy + first * 16, lds_p, valid);
-}
-
-// Ecdsa::<Secp256k1, D>::verify (forge-ec-signature/src/ecdsa.rs:213-281) with the digest given:
-// status[i] = 1 valid, 0 invalid, 2 where the reference panics (CtOption::unwrap on None: the
-// digest or the affine x read as a scalar is >= n).  Everything after the hash runs here: the
-// range checks, h, s^-1, u1, u2 in the reference's scalar field (its Mul keeps only the low 256
-// bits of the product), u1*G + u2*Q with one ladder instance, to_affine, FieldElement::to_bytes
-// (a Montgomery reduction of x) and the comparison with r.
-__global__ __launch_bounds__(TPB, 2) void k_ecdsa_verify_secp(const u32* __restrict__ digests,
-                                                           const u32* __restrict__ rs, const u32* __restrict__ ss,
-                                                           const u32* __restrict__ pk, const unsigned char* __restrict__ pk_inf,
-                                                           const u32* __restrict__ gen, unsigned char* __restrict__ status,
-                                                           size_t n) {
-  __shared__ u32 lds_a[8 * TPB];      // digest words, then u1
-  __shared__ u32 lds_b[8 * TPB];      // r (kept), 
-  __shared__ u32 lds_c[8 * TPB];      // s, then u2
-  __shared__ u32 lds_p[16 * TPB];     // public key x, y
-  const int valid = block_valid(n);
-  const size_t first = (size_t)blockIdx.x * TPB;
-  stage_in<8>(lds_a, digests + first * 8, valid);
-  stage_in<8>(lds_b, rs + first * 8, valid);
-  stage_in<8>(lds_c, ss + first * 8, valid);
-  stage_in<16>(lds_p, pk + first * 16, valid);
-  __syncthreads();
-  const int e = threadIdx.x;
-  if (e < valid) {
-    fe r = load_fe(lds_b + e, TPB), s = load_fe(lds_c + e, TPB), h;
-    // trait Scalar::from_bytes (2270-2297): big-endian bytes -> little-endian limbs
-    FEC_UNROLL for (int w = 0; w < 8; ++w) h.w[w] = __builtin_bswap32(lds_a[(7 - w) * TPB + e]);
-    lmask bad = fe_is_zero(r) | fe_is_zero(s) | secp::sc_ge_n(r) | secp::sc_ge_n(s);  // 215-228 -> false
-    lmask panic = secp::sc_ge_n(h) & ~bad;                                            // 239 unwrap
-    fe s_inv = secp::sc_inv(s);
-    fe u1 = secp::sc_mul(h, s_inv), u2 = secp::sc_mul(r, s_inv);                      // 250-251
-    store_fe(lds_a + e, TPB, u1);   // a lane reads and writes only its own LDS column
-    store_fe(lds_c + e, TPB, u2);
-    secp::pt q;                                                                        // from_affine 1365-1373
-    q.x = load_fe(lds_p + e, TPB);
-    q.y = load_fe(lds_p + 8 * TPB + e, TPB);
-    q.z = fe_small(1);
-    const bool inf = pk_inf != nullptr && pk_inf[first + e] != 0;
-    q = secp::pt_select(q, secp::identity(), lanes_where(inf));
-    secp::pt acc[2];
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {  // one copy of the ladder in the code object
-      secp::pt base = pass == 0 ? Secp::load(gen, 1) : q;
-      secp::pt m = secp::multiply(base, pass == 0 ? lds_a + e : lds_c + e);
-      if (pass == 0) acc[0] = m; else acc[1] = m;
-    }
-    secp::pt rp = secp::padd(acc[0], acc[1]);                                          // 254-256
-    lmask ident = secp::is_identity(rp);                                               // 259-262 -> false
-    fe x, y;
-    secp::to_affine(rp, x, y);                                                         // 264
-    fe xr = secp::mul(x, fe_small(1));           // FieldElement::to_bytes (138-178) = mont_reduce(x)
-    lmask panic2 = secp::sc_ge_n(xr) & ~(bad | panic | ident);                         // 271 unwrap
-    lmask ok = fe_eq(xr, r) & ~(bad | panic | ident | panic2);                         // 274
-    const int lane = threadIdx.x & 63;
-    unsigned char st = ((ok >> lane) & 1) ? 1 : ((((panic | panic2) >> lane) & 1) ? 2 : 0);
-    status[first + e] = st;
-  }
 }
 
 // schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290), the per-signature
@@ -673,32 +560,18 @@ int launch_ed_fixed(fec_ctx* ctx, const u64* ds, const u64* dbase, const u64* ho
 int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp, u64* dout, size_t n,
                void* stream) {
   if (n == 0) return FEC_OK;
+  if (fixed && curve == FEC_ED25519) return launch_ed_fixed(ctx, ds, dp, nullptr, dout, n, stream);  // LDS addend table
   const u32* s = reinterpret_cast<const u32*>(ds);
   const u32* p = reinterpret_cast<const u32*>(dp);
   u32* o = reinterpret_cast<u32*>(dout);
-  dim3 g(grid_for(n)), b(TPB);
-  const bool secp2 = curve == FEC_SECP256K1 && std::getenv("FEC_SECP_2WAVE");
-  const char* name = curve == FEC_SECP256K1 ? (secp2 ? (fixed ? "k_batch_mul<Secp,fixed>" : "k_batch_mul<Secp,var>")
-                                                     : (fixed ? "k_secp_mul<fixed>" : "k_secp_mul<var>"))
+  const char* name = curve == FEC_SECP256K1 ? (fixed ? "k_secp_mul<fixed>" : "k_secp_mul<var>")
                      : curve == FEC_P256    ? (fixed ? "k_p256_mul_sched<fixed>" : "k_p256_mul_sched<var>")
-                                            : (fixed ? "k_batch_mul<Ed,fixed>" : "k_ed_mul_pers");
+                                            : "k_ed_mul_pers";
   Launch L(ctx, stream, name);
   switch (curve) {
-    case FEC_SECP256K1:
-      if (secp2) {  // the round-1 register-resident form (2 waves per SIMD), kept for A/B runs
-        if (fixed) hipLaunchKernelGGL((k_batch_mul<Secp, true>), g, b, 0, L.s, s, p, o, n);
-        else hipLaunchKernelGGL((k_batch_mul<Secp, false>), g, b, 0, L.s, s, p, o, n);
-      } else {
-        secp_launch_mul(fixed, s, p, o, n, L.s);
-      }
-      break;
-    case FEC_P256:
-      p256_launch_mul(fixed, s, p, o, n, L.s);
-      break;
-    default:
-      if (fixed) hipLaunchKernelGGL((k_batch_mul<Ed, true>), g, b, 0, L.s, s, p, o, n);
-      else ed_launch_mul(s, p, o, n, L.s);
-      break;
+    case FEC_SECP256K1: secp_launch_mul(fixed, s, p, o, n, L.s); break;
+    case FEC_P256: p256_launch_mul(fixed, s, p, o, n, L.s); break;
+    default: ed_launch_mul(s, p, o, n, L.s); break;
   }
   return L.done();
 }
@@ -707,8 +580,7 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
 // Composed from the single-multiplication kernels: u1*G and u2*Q into per-stream scratch (secp256k1: the
 // 3-waves-per-SIMD ladder, fixed then variable base; P-256: the task scheduler twice; Ed25519: the LDS
 // addend-table kernel and the scheduler), then one point-addition pass in the reference's operand order.
-// The fused masked-ladder forms of round 1 (38 spilled VGPRs for P-256) are gone; FEC_SECP_2WAVE=1
-// still selects the fused secp256k1 kernel for A/B runs.
+// The fused masked-ladder forms of round 1 are gone (secp256k1: 64.9 ms fused against 60.7 ms composed).
 int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, const u64* dq, u64* dout,
                       size_t n, void* stream) {
   if (n == 0) return FEC_OK;
@@ -718,11 +590,6 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
   const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
   u32* o = reinterpret_cast<u32*>(dout);
   dim3 g(grid_for(n)), b(TPB);
-  if (curve == FEC_SECP256K1 && std::getenv("FEC_SECP_2WAVE")) {  // round-1 fused form, kept for A/B runs
-    Launch L(ctx, stream, "k_batch_double_mul");
-    hipLaunchKernelGGL((k_batch_double_mul<Secp>), g, b, 0, L.s, a, b2, q, gen, o, n);
-    return L.done();
-  }
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   const size_t pb = (size_t)plimbs(curve) * 8;
   char* scratch = static_cast<char*>(scratch_for(ctx, st, 2 * n * pb));
@@ -780,18 +647,10 @@ int launch_compress(fec_ctx* ctx, int curve, const u64* dxy, const unsigned char
 }
 
 // Ecdsa::<C, D>::verify for secp256k1 / P-256: the pipeline of kernels_ecdsa.hip on per-stream scratch.
-// FEC_SECP_2WAVE=1 keeps the round-1 single-kernel secp256k1 form for A/B runs.
+// (The single-kernel secp256k1 form of round 1 measured 70.7 ms per 2^20 against 65.7 ms for this pipeline.)
 int launch_ecdsa_verify(fec_ctx* ctx, int curve, const unsigned char* dd, const u64* dr, const u64* ds, const u64* dpk,
                         const unsigned char* dinf, unsigned char* dstatus, size_t n, void* stream) {
   if (n == 0) return FEC_OK;
-  if (curve == FEC_SECP256K1 && std::getenv("FEC_SECP_2WAVE")) {
-    Launch L(ctx, stream, "k_ecdsa_verify_secp");
-    hipLaunchKernelGGL(k_ecdsa_verify_secp, dim3(grid_for(n)), dim3(TPB), 0, L.s, reinterpret_cast<const u32*>(dd),
-                       reinterpret_cast<const u32*>(dr), reinterpret_cast<const u32*>(ds),
-                       reinterpret_cast<const u32*>(dpk), dinf, reinterpret_cast<const u32*>(ctx->d_gen[FEC_SECP256K1]),
-                       dstatus, n);
-    return L.done();
-  }
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   void* work = scratch_for(ctx, st, ecdsa_work_bytes(n));
   if (!work) return FEC_E_OOM;
