@@ -685,6 +685,20 @@ int launch_eddsa_verify(fec_ctx* ctx, const u64* dr, const unsigned char* drinf,
   return L.done();
 }
 
+// Curve::validate_point per affine point (kernels_ecdsa.hip)
+int launch_validate(fec_ctx* ctx, int curve, const u64* dxy, const unsigned char* dinf, unsigned char* dok, size_t n, void* stream) {
+  if (n == 0) return FEC_OK;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  void* work = nullptr;
+  if (validate_work_bytes(curve, n)) {
+    work = scratch_for(ctx, st, validate_work_bytes(curve, n));
+    if (!work) return FEC_E_OOM;
+  }
+  Launch L(ctx, stream, curve == FEC_ED25519 ? "k_ed_validate_pre + k_ed_mul_pers x2 + k_ed_validate_finish" : "k_validate_weierstrass");
+  validate_launch(curve, reinterpret_cast<const u32*>(dxy), dinf, dok, work, n, L.s);
+  return L.done();
+}
+
 // KeyExchange::derive_shared_secret for secp256k1 / P-256 on per-stream scratch (kernels_ecdsa.hip)
 int launch_ecdh(fec_ctx* ctx, int curve, const u64* dsk, const u64* dpk, const unsigned char* dinf, unsigned char* dout,
                 unsigned char* dstatus, size_t n, void* stream) {
@@ -1222,6 +1236,43 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
   }
   *result = res;
   if (detail) std::memcpy(detail, det, 128);
+  return FEC_OK;
+}
+
+int fec_batch_validate_point_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf, uint8_t* d_ok,
+                                 size_t n, void* stream) {
+  if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
+  if (!ctx || !curve_ok(curve) || (n && (!d_xy || !d_ok))) return FEC_E_ARG;
+  if (!aligned16(d_xy)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_validate(ctx, curve, d_xy, d_inf, d_ok, n, stream);
+}
+
+int fec_batch_validate_point(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* ok, size_t n) {
+  if (!curve_ok(curve)) return FEC_E_ARG;
+  if (is_multi(ctx)) {
+    if (n && (!xy || !ok)) return FEC_E_ARG;
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_batch_validate_point(c, curve, xy + lo * 8, inf ? inf + lo : nullptr, ok + lo, cnt);
+    });
+  }
+  if (!ctx || (n && (!xy || !ok))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  int rc = ensure(ctx, 0, n * 64);
+  if (rc == FEC_OK && inf) rc = ensure(ctx, 1, n);
+  if (rc == FEC_OK) rc = ensure(ctx, 2, n);
+  if (rc != FEC_OK) return rc;
+  if (hipMemcpyAsync(ctx->d_buf[0], xy, n * 64, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  if (inf && hipMemcpyAsync(ctx->d_buf[1], inf, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  rc = launch_validate(ctx, curve, (const u64*)ctx->d_buf[0], inf ? (const unsigned char*)ctx->d_buf[1] : nullptr,
+                       (unsigned char*)ctx->d_buf[2], n, nullptr);
+  if (rc != FEC_OK) return rc;
+  if (hipMemcpyAsync(ok, ctx->d_buf[2], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return FEC_E_LAUNCH;
+  }
   return FEC_OK;
 }
 

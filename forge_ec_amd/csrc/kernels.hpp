@@ -43,6 +43,11 @@ void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hip
 void ecdsa_batch_finish_launch(int curve, const u32* r_sum, const void* work, size_t n, unsigned char* result, u32* detail,
                                hipStream_t s);
 
+// kernels_ecdsa.hip: Curve::validate_point per affine point (secp256k1 / P-256: is_on_curve; Ed25519: the trait default
+// with its two multiplications).  `work` holds validate_work_bytes(curve, n) bytes (0 for the Weierstrass curves).
+size_t validate_work_bytes(int curve, size_t n);
+void validate_launch(int curve, const u32* xy, const unsigned char* inf, unsigned char* ok, void* work, size_t n, hipStream_t s);
+
 // kernels_ecdsa.hip: KeyExchange::derive_shared_secret for secp256k1 / P-256 (secp256k1.rs:1884-1904, p256.rs:2281-2312):
 // validation + from_affine, the variable-base multiplication, to_affine + x.to_bytes().  out: 8 words (32 bytes) per element.
 size_t ecdh_work_bytes(size_t n);

@@ -256,6 +256,38 @@ void run_ecdh(const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* ou
   hipLaunchKernelGGL((k_ecdh_finish<E>), g, b, 0, s, (const u32*)t, (const unsigned char*)flags, out, status, n);
 }
 
+// ---- Curve::validate_point ----
+// secp256k1 (secp256k1.rs:2722-2726) and P-256 (p256.rs:2187-2191): PointAffine::is_on_curve, the infinity flag
+// counting as on the curve -- one pass.
+template <int CURVE>
+__global__ __launch_bounds__(TPB) void k_validate_weierstrass(const u32* __restrict__ xy, const unsigned char* __restrict__ inf,
+                                                              unsigned char* __restrict__ ok, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const fe x = load8(xy + i * 16), y = load8(xy + i * 16 + 8);
+  const bool on = CURVE == FEC_SECP256K1 ? lane_of(secp::affine_on_curve(x, y)) : lane_of(fe_eq(p256::sqr(y), p256::curve_rhs(x)));
+  ok[i] = ((inf != nullptr && inf[i] != 0) || on) ? 1 : 0;
+}
+// Ed25519 keeps the trait default (forge-ec-core/src/lib.rs:905-925): is_on_curve (ed25519.rs:1719-1744) AND
+// multiply(multiply(from_affine(p), 8), L).is_identity() -- two runs of the variable-base kernel with constant
+// scalars between a pre pass (from_affine, on-curve flag) and a finishing pass.
+__global__ __launch_bounds__(TPB) void k_fill_scalar(u32* __restrict__ dst, uint4 lo, uint4 hi, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  *reinterpret_cast<uint4*>(dst + i * 8) = lo;
+  *reinterpret_cast<uint4*>(dst + i * 8 + 4) = hi;
+}
+__global__ __launch_bounds__(TPB) void k_ed_validate_pre(const u32* __restrict__ xy, const unsigned char* __restrict__ inf,
+                                                         u32* __restrict__ a, unsigned char* __restrict__ flags, size_t n);
+__global__ __launch_bounds__(TPB) void k_ed_validate_finish(const u32* __restrict__ t, const unsigned char* __restrict__ flags,
+                                                            unsigned char* __restrict__ ok, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  ed::pt p;
+  p.x = load8(t + i * 32); p.y = load8(t + i * 32 + 8); p.z = load8(t + i * 32 + 16); p.t = load8(t + i * 32 + 24);
+  ok[i] = (flags[i] != 0 && lane_of(ed::is_identity(p))) ? 1 : 0;
+}
+
 // ---- Eddsa::<Ed25519, D>::verify / Ed25519::verify from the point computation on (eddsa.rs:174-211, 430-447) ----
 FEC_DEV ed::pt ed_from_affine(const fe& x, const fe& y, bool inf) {  // ed25519.rs:1813-1826
   ed::pt p;
@@ -275,6 +307,24 @@ __global__ __launch_bounds__(TPB) void k_eddsa_pre(const u32* __restrict__ pk, c
   if (i >= n) return;
   const bool inf = pk_inf != nullptr && pk_inf[i] != 0;
   const ed::pt p = ed_from_affine(load8(pk + i * 16), load8(pk + i * 16 + 8), inf);
+  store8(a + i * 32, p.x); store8(a + i * 32 + 8, p.y); store8(a + i * 32 + 16, p.z); store8(a + i * 32 + 24, p.t);
+}
+
+// PointAffine::is_on_curve (ed25519.rs:1719-1744) / PointAffine::new (1476-1498): -x^2 + y^2 == 1 + d x^2 y^2
+FEC_DEV lmask ed_affine_on_curve(const fe& x, const fe& y) {
+  const fe x2 = ed::mul(x, x), y2 = ed::mul(y, y);
+  const fe lhs = ed::add(ed::neg(x2), y2);
+  const fe rhs = ed::add(fe_small(1), ed::mul(ed::D_(), ed::mul(x2, y2)));
+  return fe_eq(lhs, rhs);
+}
+__global__ __launch_bounds__(TPB) void k_ed_validate_pre(const u32* __restrict__ xy, const unsigned char* __restrict__ inf,
+                                                         u32* __restrict__ a, unsigned char* __restrict__ flags, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const bool is_inf = inf != nullptr && inf[i] != 0;
+  const fe x = load8(xy + i * 16), y = load8(xy + i * 16 + 8);
+  flags[i] = (is_inf || lane_of(ed_affine_on_curve(x, y))) ? 1 : 0;
+  const ed::pt p = ed_from_affine(x, y, is_inf);
   store8(a + i * 32, p.x); store8(a + i * 32 + 8, p.y); store8(a + i * 32 + 16, p.z); store8(a + i * 32 + 24, p.t);
 }
 
@@ -311,6 +361,31 @@ void eddsa_finish_launch(const u32* sg, const u32* ka, const u32* r_xy, const un
 }
 
 size_t ecdsa_work_bytes(size_t n) { return n * 353; }
+
+// Curve::validate_point.  Work (Ed25519 only): point A (128 n), scalars (32 n), products T1, T2 (128 n each), flags (n).
+size_t validate_work_bytes(int curve, size_t n) { return curve == FEC_ED25519 ? n * 417 : 0; }
+void validate_launch(int curve, const u32* xy, const unsigned char* inf, unsigned char* ok, void* work, size_t n, hipStream_t s) {
+  const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
+  if (curve == FEC_SECP256K1) {
+    hipLaunchKernelGGL((k_validate_weierstrass<FEC_SECP256K1>), g, b, 0, s, xy, inf, ok, n);
+  } else if (curve == FEC_P256) {
+    hipLaunchKernelGGL((k_validate_weierstrass<FEC_P256>), g, b, 0, s, xy, inf, ok, n);
+  } else {
+    char* w = static_cast<char*>(work);
+    u32* a = reinterpret_cast<u32*>(w);
+    u32* k = reinterpret_cast<u32*>(w + n * 128);
+    u32* t1 = reinterpret_cast<u32*>(w + n * 160);
+    u32* t2 = reinterpret_cast<u32*>(w + n * 288);
+    unsigned char* flags = reinterpret_cast<unsigned char*>(w + n * 416);
+    hipLaunchKernelGGL(k_ed_validate_pre, g, b, 0, s, xy, inf, a, flags, n);
+    hipLaunchKernelGGL(k_fill_scalar, g, b, 0, s, k, make_uint4(8, 0, 0, 0), make_uint4(0, 0, 0, 0), n);          // Scalar::from(8)
+    ed_launch_mul(k, a, t1, n, s);                                                                            // clear_cofactor
+    hipLaunchKernelGGL(k_fill_scalar, g, b, 0, s, k, make_uint4(0x5CF5D3EDu, 0x5812631Au, 0xA2F79CD6u, 0x14DEF9DEu),
+                       make_uint4(0, 0, 0, 0x10000000u), n);                                                  // order() = L
+    ed_launch_mul(k, t1, t2, n, s);
+    hipLaunchKernelGGL(k_ed_validate_finish, g, b, 0, s, (const u32*)t2, (const unsigned char*)flags, ok, n);
+  }
+}
 
 size_t ecdh_work_bytes(size_t n) { return n * 193; }
 void ecdh_launch(int curve, const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* out, unsigned char* status,

@@ -153,6 +153,17 @@ class Context:
         return self._ecdsa_verify(self._lib.fec_ecdsa_verify_p256, "fec_ecdsa_verify_p256", digests, r, s, pk_xy,
                                   pk_inf)
 
+    def batch_validate_point(self, curve, xy, inf=None):
+        """Curve::validate_point per affine point (x, y, infinity): (n,) uint8, 1 valid / 0 not."""
+        p = _u64(xy, 8)
+        n = p.shape[0]
+        fl = np.ascontiguousarray(np.asarray(inf, dtype=np.uint8)).reshape(-1) if inf is not None else None
+        if fl is not None and fl.shape[0] != n:
+            raise ValueError("flags and points differ in length")  # the C side reads n bytes
+        ok = np.zeros(n, dtype=np.uint8)
+        _check(self._lib.fec_batch_validate_point(self._h, curve, _ptr(p), _ptr(fl), _ptr(ok), n), "fec_batch_validate_point")
+        return ok
+
     def batch_ecdh(self, curve, private_keys, pk_xy, pk_inf=None):
         """KeyExchange::derive_shared_secret per element (secp256k1.rs:1884-1904, p256.rs:2281-2312).  Returns
         (secrets (n,32) uint8, status (n,) uint8): 0 Ok, 1 Err(InvalidPublicKey) (P-256), 2 Err (identity).
@@ -308,6 +319,9 @@ class Context:
     def ecdsa_verify_secp256k1_dev(self, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream=None):
         _check(self._lib.fec_ecdsa_verify_secp256k1_dev(self._h, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n,
                                                         stream), "fec_ecdsa_verify_secp256k1_dev")
+
+    def batch_validate_point_dev(self, curve, d_xy, d_inf, d_ok, n, stream=None):
+        _check(self._lib.fec_batch_validate_point_dev(self._h, curve, d_xy, d_inf, d_ok, n, stream), "fec_batch_validate_point_dev")
 
     def batch_ecdh_dev(self, curve, d_private_keys, d_pk_xy, d_pk_inf, d_secrets, d_status, n, stream=None):
         _check(self._lib.fec_batch_ecdh_dev(self._h, curve, d_private_keys, d_pk_xy, d_pk_inf, d_secrets, d_status, n, stream),

@@ -29,6 +29,7 @@
  *   fec_ecdsa_verify_p256 Ecdsa::<P256, D>::verify per signature, digest supplied (ecdsa.rs:213-281; scalar
  *                         field p256.rs:875-1100, 1409-1432; default Scalar::ct_lt core lib.rs:497-531;
  *                         FieldElement::to_bytes 288-300)
+ *   fec_batch_validate_point   Curve::validate_point (secp256k1.rs:2722-2726, p256.rs:2187-2191, core lib.rs:905-925)
  *   fec_batch_ecdh        KeyExchange::derive_shared_secret for secp256k1 / P-256 (secp256k1.rs:1884-1904,
  *                         p256.rs:2281-2312)
  *   fec_ecdsa_batch_verify   Ecdsa::<C, D>::batch_verify for secp256k1 / P-256 (ecdsa.rs:287-391; scalar Add
@@ -165,6 +166,14 @@ int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests /* n*32 */, 
 int fec_ecdsa_verify_p256(fec_ctx* ctx, const uint8_t* digests /* n*32 */, const uint64_t* r /* n*4 */,
                           const uint64_t* s /* n*4 */, const uint64_t* pk_xy /* n*8 */,
                           const uint8_t* pk_inf /* n or NULL */, uint8_t* status /* n */, size_t n);
+/* ok[i] = Curve::validate_point(&points[i]) for AffinePoint limbs xy (8 per element) and infinity flags (or NULL):
+ * Secp256k1 (secp256k1.rs:2722-2726) and P256 (p256.rs:2187-2191) override it with PointAffine::is_on_curve (an
+ * infinite point counts as on the curve); Ed25519 keeps the trait default (forge-ec-core/src/lib.rs:905-925):
+ * on the curve AND multiply(clear_cofactor(from_affine(p)), order()) is the identity, clear_cofactor being
+ * the default multiply by 8 (885-897) -- two variable-base multiplications per point.  Under the reference's
+ * arithmetic the generators of all three curves FAIL this check; that is reproduced. */
+int fec_batch_validate_point(fec_ctx* ctx, fec_curve curve, const uint64_t* xy /* n*8 */, const uint8_t* inf /* n or NULL */,
+                             uint8_t* ok /* n */, size_t n);
 /* KeyExchange::derive_shared_secret per element (forge-ec-curves/src/secp256k1.rs:1884-1904, p256.rs:2281-2302;
  * the pattern of forge-ec-examples/src/ecdh.rs:40-49), curve = FEC_SECP256K1 or FEC_P256 (Ed25519 implements no
  * KeyExchange: FEC_E_UNSUPPORTED).  secrets[i] = the 32 bytes of Ok(x.to_bytes()) of to_affine(multiply(
@@ -262,6 +271,8 @@ int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const
 int fec_ecdsa_verify_p256_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
                               const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
                               void* stream);
+int fec_batch_validate_point_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf, uint8_t* d_ok,
+                                 size_t n, void* stream);
 /* d_secrets 16-byte aligned; the caller owns (and clears) every buffer */
 int fec_batch_ecdh_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_private_keys, const uint64_t* d_pk_xy,
                        const uint8_t* d_pk_inf, uint8_t* d_secrets, uint8_t* d_status, size_t n, void* stream);

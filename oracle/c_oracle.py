@@ -76,6 +76,8 @@ def lib():
         L.fo_batch_p256_ecdsa_verify.restype = None
         L.fo_ecdsa_batch_verify.argtypes = [ctypes.c_int, p, p, p, p, p, p, ctypes.c_size_t, p]
         L.fo_ecdsa_batch_verify.restype = ctypes.c_int
+        L.fo_batch_validate_point.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_validate_point.restype = None
         L.fo_batch_ecdh.argtypes = [ctypes.c_int, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
         L.fo_batch_ecdh.restype = None
         L.fo_batch_ed25519_eddsa_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
@@ -261,6 +263,16 @@ def ecdsa_batch_verify(curve, digests, r, s, pk_xy, pk_inf, a):
     if rc < 0:
         raise ValueError("fo_ecdsa_batch_verify rc=%d" % rc)
     return rc, detail
+
+
+def batch_validate_point(curve, xy, inf=None, nthreads=1):
+    """Curve::validate_point per affine point: (n,) uint8, 1 valid / 0 not."""
+    xy = _u64(xy)
+    n = xy.size // 8
+    fl = np.ascontiguousarray(np.asarray(inf, dtype=np.uint8)) if inf is not None else None
+    ok = np.zeros(n, dtype=np.uint8)
+    lib().fo_batch_validate_point(curve, _ptr(xy), _ptr(fl) if fl is not None else None, _ptr(ok), n, nthreads)
+    return ok
 
 
 def batch_ecdh(curve, sk, pk_xy, pk_inf=None, nthreads=1):

@@ -1868,3 +1868,45 @@ void fo_batch_ecdh(int curve, const u64* sk, const u64* pk_xy, const uint8_t* pk
   }
   for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
 }
+
+/* ---- Curve::validate_point -----------------------------------------------------------------------------------
+ * Secp256k1 (secp256k1.rs:2722-2726) and P256 (p256.rs:2187-2191) override it with PointAffine::is_on_curve
+ * (978-1004 / 1636-1656; the infinity flag counts as on the curve).  Ed25519 keeps the trait default
+ * (forge-ec-core/src/lib.rs:905-925): is_on_curve (ed25519.rs:1719-1744) AND
+ * multiply(clear_cofactor(from_affine(p)), order()).is_identity(), with the default clear_cofactor (885-897) =
+ * multiply(p, Scalar::from(8)) and order() = L (ed25519.rs:75-80, 2099-2101). */
+int fo_validate_point(int curve, const u64 xy[8], int inf) {
+  fe x = ld(xy), y = ld(xy + 4);
+  if (curve == 0) return inf ? 1 : k_affine_new(x, y);
+  if (curve == 1) {
+    if (inf) return 1;
+    fe lhs = n_mul(y, y), rhs = n_rhs(x);
+    return lhs.v[0] == rhs.v[0] && lhs.v[1] == rhs.v[1] && lhs.v[2] == rhs.v[2] && lhs.v[3] == rhs.v[3];
+  }
+  if (curve != 2) return -1;
+  int on_curve = inf ? 1 : e_affine_new(x, y);
+  static const u64 eight[4] = {8, 0, 0, 0};
+  static const u64 order[4] = {0x5812631A5CF5D3EDULL, 0x14DEF9DEA2F79CD6ULL, 0, 0x1000000000000000ULL};
+  ept p = e_from_affine(xy, inf);
+  ept cleared = e_multiply(&p, eight);
+  ept sp = e_multiply(&cleared, order);
+  return on_curve & e_is_identity(&sp);
+}
+typedef struct { int curve; const u64* xy; const uint8_t* inf; uint8_t* ok; size_t lo, hi; } vp_t;
+static void* vpworker(void* arg) {
+  vp_t* j = (vp_t*)arg;
+  for (size_t i = j->lo; i < j->hi; ++i) j->ok[i] = (uint8_t)fo_validate_point(j->curve, j->xy + 8 * i, j->inf ? j->inf[i] : 0);
+  return NULL;
+}
+void fo_batch_validate_point(int curve, const u64* xy, const uint8_t* inf, uint8_t* ok, size_t n, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 64) nthreads = 64;
+  pthread_t th[64];
+  vp_t jobs[64];
+  for (int t = 0; t < nthreads; ++t) {
+    vp_t j = {curve, xy, inf, ok, n * t / nthreads, n * (t + 1) / nthreads};
+    jobs[t] = j;
+    pthread_create(&th[t], NULL, vpworker, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+}

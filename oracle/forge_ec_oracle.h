@@ -80,6 +80,11 @@ int fo_ecdsa_batch_verify(int curve, const unsigned char* digests, const uint64_
                           const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* a, size_t n,
                           uint64_t* detail);
 
+/* Curve::validate_point: is_on_curve for secp256k1 / P-256 (their overrides), the trait default for Ed25519
+ * (on the curve AND order * (8 * P) is the identity): 1 / 0 */
+int fo_validate_point(int curve, const uint64_t xy[8], int inf);
+void fo_batch_validate_point(int curve, const uint64_t* xy, const uint8_t* inf, uint8_t* ok, size_t n, int nthreads);
+
 /* KeyExchange::derive_shared_secret (secp256k1.rs:1884-1904, p256.rs:2281-2312): status 0 = Ok(out), 1 =
  * Err(InvalidPublicKey) (P-256 validation), 2 = Err for an identity result; -1 for a curve without KeyExchange */
 int fo_ecdh(int curve, const uint64_t sk[4], const uint64_t pk_xy[8], int pk_inf, unsigned char out[32]);

@@ -1256,3 +1256,20 @@ def ecdh(curve, sk, pk_xy, pk_inf=False):
         return 2, bytes(32)
     return 0, bytes(to_bytes_field(curve, ax))
 
+
+def validate_point(curve, xy, inf=False):
+    """Curve::validate_point: PointAffine::is_on_curve for Secp256k1 (secp256k1.rs:2722-2726 -> 978-1004) and P256
+    (p256.rs:2187-2191 -> 1636-1656); the trait default for Ed25519 (forge-ec-core/src/lib.rs:905-925): on the curve
+    and multiply(multiply(from_affine(p), 8), L) is the identity (default clear_cofactor 885-897)."""
+    x, y = list(xy[0:4]), list(xy[4:8])
+    if curve == SECP256K1:
+        return 1 if inf or _secp_on_curve(x, y) else 0
+    if curve == P256:
+        return 1 if inf or P256c.sqr(y) == _p256_rhs(x) else 0
+    x2, y2 = Ed.sqr(x), Ed.sqr(y)
+    on = inf or Ed.add(Ed.neg(x2), y2) == Ed.add([1, 0, 0, 0], Ed.mul(Ed.D, Ed.mul(x2, y2)))   # 1719-1744
+    p = Ed.identity() if inf else (x, y, [1, 0, 0, 0], Ed.mul(x, y))
+    order = [0x5812631A5CF5D3ED, 0x14DEF9DEA2F79CD6, 0, 0x1000000000000000]                      # L, 75-80
+    sp = Ed.multiply(Ed.multiply(p, [8, 0, 0, 0]), order)
+    return 1 if on and Ed.is_identity(sp) else 0
+

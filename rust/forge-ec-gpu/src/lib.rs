@@ -33,6 +33,8 @@ extern "C" {
     fn fec_batch_double_mul(ctx: *mut FecCtx, curve: c_int, u1: *const u64, u2: *const u64, q: *const u64, out: *mut u64, n: usize) -> c_int;
     fn fec_batch_to_affine(ctx: *mut FecCtx, curve: c_int, points: *const u64, xy: *mut u64, inf: *mut u8, n: usize) -> c_int;
     fn fec_multi_scalar_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
+    fn fec_batch_validate_point(ctx: *mut FecCtx, curve: c_int, xy: *const u64, inf: *const u8, ok: *mut u8, n: usize) -> c_int;
+    fn fec_batch_validate_point_dev(ctx: *mut FecCtx, curve: c_int, d_xy: *const u64, d_inf: *const u8, d_ok: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_ecdh(ctx: *mut FecCtx, curve: c_int, private_keys: *const u64, pk_xy: *const u64, pk_inf: *const u8, secrets: *mut u8, status: *mut u8, n: usize) -> c_int;
     fn fec_batch_ecdh_dev(ctx: *mut FecCtx, curve: c_int, d_private_keys: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_secrets: *mut u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_ecdsa_batch_verify(ctx: *mut FecCtx, curve: c_int, digests: *const u8, r: *const u64, s: *const u64, pk_xy: *const u64, pk_inf: *const u8, a: *const u64, n: usize, result: *mut u8, detail: *mut u64) -> c_int;
@@ -393,6 +395,21 @@ pub fn ecdsa_verify_batch_p256(ctx: &mut GpuContext, digests: &[[u8; 32]], r: &[
     Ok(status.iter().map(|&v| match v { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid }).collect())
 }
 
+/// `C::validate_point(&points[i])` per element (`secp256k1.rs:2722-2726`, `p256.rs:2187-2191`; the trait default
+/// `forge-ec-core/src/lib.rs:905-925` for Ed25519).
+pub fn batch_validate_point<C: GpuCurve>(ctx: &mut GpuContext, points: &[C::PointAffine]) -> Result<Vec<bool>> {
+    let n = points.len();
+    let (mut xy, mut inf, mut ok) = (vec![0u64; 8 * n], vec![0u8; n], vec![0u8; n]);
+    for (i, p) in points.iter().enumerate() {
+        let (l, f) = C::affine_limbs(p);
+        xy[8 * i..8 * i + 8].copy_from_slice(&l);
+        inf[i] = f as u8;
+    }
+    // SAFETY: every buffer holds n elements of the width the header states.
+    check(unsafe { fec_batch_validate_point(ctx.raw, C::ID, xy.as_ptr(), inf.as_ptr(), ok.as_mut_ptr(), n) })?;
+    Ok(ok.iter().map(|&v| v != 0).collect())
+}
+
 /// `KeyExchange::derive_shared_secret` per element (`secp256k1.rs:1884-1904`, `p256.rs:2281-2312`) for secp256k1 and
 /// P-256: `Ok(secret)` or the reference's error (`InvalidPublicKey` from P-256's validation; `InvalidEncoding` /
 /// `KeyExchangeError` when the product is the identity).  Reproduces reference behaviour; not a hardened ECDH.
@@ -553,6 +570,14 @@ pub mod dev {
     /// As [`batch_mul`].
     pub unsafe fn ecdsa_verify_secp256k1(ctx: &mut GpuContext, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
         check(fec_ecdsa_verify_secp256k1_dev(ctx.raw, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream))
+    }
+
+    /// `fec_batch_validate_point_dev`.
+    ///
+    /// # Safety
+    /// As [`batch_mul`].
+    pub unsafe fn batch_validate_point(ctx: &mut GpuContext, curve: c_int, d_xy: *const u64, d_inf: *const u8, d_ok: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_batch_validate_point_dev(ctx.raw, curve, d_xy, d_inf, d_ok, n, stream))
     }
 
     /// `fec_batch_ecdh_dev`.

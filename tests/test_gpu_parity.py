@@ -554,6 +554,35 @@ def test_batch_ecdh_matches_oracle(gpu_ctx, oracle, curve):
         gpu_ctx.batch_ecdh(2, sk, pk, inf)                    # Ed25519 implements no KeyExchange
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_batch_validate_point_matches_oracle(gpu_ctx, oracle, curve):
+    """Curve::validate_point per affine point: is_on_curve for secp256k1 / P-256 (their overrides), the trait
+    default -- on the curve and L * (8 * P) == identity, two multiplications -- for Ed25519."""
+    import torch
+    n = 1200 if curve != 2 else 700
+    xy = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 941), V.field_elements(n, curve, 942)], axis=1))
+    if curve == 1:
+        xy[:800] = _p256_true_points(800, 943)            # about half pass the reference's is_on_curve
+    if curve == 2:                                          # x = 0 columns: (0, 1) is on the curve and of order 1
+        xy[:40, :4] = 0
+        xy[:20, 4:] = np.array([1, 0, 0, 0], dtype=np.uint64)
+        g, _ = oracle.to_affine(2, oracle.generator(2))
+        xy[40] = g
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[5::53] = 1
+    want = oracle.batch_validate_point(curve, xy, inf, nthreads=16)
+    got = gpu_ctx.batch_validate_point(curve, xy, inf)
+    assert np.array_equal(got, want)
+    assert set(int(v) for v in np.unique(want)) == {0, 1} and int(want.sum()) > (300 if curve == 1 else 20)
+    assert np.array_equal(gpu_ctx.batch_validate_point(curve, xy, None), oracle.batch_validate_point(curve, xy, None, nthreads=16))
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev) for a in (xy, inf)]
+    ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    gpu_ctx.batch_validate_point_dev(curve, t[0].data_ptr(), t[1].data_ptr(), ok.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(ok.cpu().numpy(), want)
+
+
 def _p256_ecdsa_cases(oracle, n_random, n_valid):
     """As _ecdsa_cases for Ecdsa::<P256, D>::verify.  r or s >= n are NOT rejected by the reference (its
     ct_lt is the trait default, a top-byte <= comparison): those lanes run the whole computation."""

@@ -386,3 +386,23 @@ def test_ecdh_vectors(oracle):
         out, st = oracle.batch_ecdh(curve, [c["sk"] for c in cs], [c["pk"] for c in cs], [c["pk_inf"] for c in cs], nthreads=4)
         assert [int(v) for v in st] == [c["status"] for c in cs]
         assert [bytes(o).hex() for o in out] == [c["secret"] for c in cs]
+
+
+def test_validate_point_two_restatements_agree(oracle):
+    """Curve::validate_point: the C oracle against the Python model (secp256k1 / P-256: is_on_curve; Ed25519: the
+    trait default with its two multiplications), on inputs of every verdict."""
+    from oracle import py_model as M
+    for curve in (0, 1, 2):
+        n = 12 if curve != 2 else 6
+        xy = np.concatenate([V.field_elements(n, curve, 951), V.field_elements(n, curve, 952)], axis=1)
+        if curve == 2:
+            xy[0] = [0, 0, 0, 0, 1, 0, 0, 0]      # (0, 1): valid
+            xy[1] = [0, 0, 0, 0] + V.limbs_of(V.PRIME[2] - 1)
+        g, _ = oracle.to_affine(curve, oracle.generator(curve))
+        xy[2] = g                                  # the reference's own generator fails its check on every curve
+        inf = np.zeros(n, dtype=np.uint8)
+        inf[3] = 1
+        got = oracle.batch_validate_point(curve, xy, inf)
+        want = [M.validate_point(curve, [int(v) for v in xy[i]], bool(inf[i])) for i in range(n)]
+        assert [int(v) for v in got] == want
+        assert want[2] == 0 and want[3] == 1
