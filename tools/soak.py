@@ -1,0 +1,84 @@
+"""Whole-batch differential soak on the GPU box: every element of large random batches of the verification /
+key-exchange / validation pipelines against the C oracle (16 host threads).  Prints one JSON line per pipeline.
+
+  python tools/soak.py [log2-batch, default 19]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import forge_ec_amd as F  # noqa: E402
+import vectors as V  # noqa: E402
+from oracle import c_oracle as O  # noqa: E402
+
+
+def main():
+    n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 19)
+    ctx = F.Context(0)
+    rng = np.random.default_rng(20261004)
+
+    def report(name, got, want, t_gpu, t_cpu):
+        bad = int(np.count_nonzero(np.any(np.asarray(got).reshape(n, -1) != np.asarray(want).reshape(n, -1), axis=1)))
+        hist = {int(k): int(v) for k, v in zip(*np.unique(np.asarray(want).reshape(n, -1)[:, -1] if np.asarray(want).ndim > 1 else want, return_counts=True))} if np.asarray(want).ndim == 1 else None
+        print(json.dumps({"pipeline": name, "n": n, "mismatches": bad, "status_histogram": hist,
+                          "gpu_s": round(t_gpu, 3), "oracle_s": round(t_cpu, 1)}), flush=True)
+        return bad
+
+    total = 0
+    for curve, fn, ofn in ((0, ctx.ecdsa_verify_secp256k1, O.batch_secp256k1_ecdsa_verify), (1, ctx.ecdsa_verify_p256, O.batch_p256_ecdsa_verify)):
+        dg = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        dg[::3, 0] &= 0x7F
+        r, s = V.scalars(n, curve, 9001), V.scalars(n, curve, 9002)
+        pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 9003), V.field_elements(n, curve, 9004)], axis=1))
+        inf = (rng.integers(0, 64, size=n) == 0).astype(np.uint8)
+        t0 = time.perf_counter(); got = fn(dg, r, s, pk, inf); t1 = time.perf_counter()
+        want = ofn(dg, r, s, pk, inf, nthreads=16); t2 = time.perf_counter()
+        total += report("ecdsa_verify " + ("secp256k1" if curve == 0 else "p256"), got, want, t1 - t0, t2 - t1)
+    s, k = V.scalars(n, 2, 9011), V.scalars(n, 2, 9012)
+    pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 9013), V.field_elements(n, 2, 9014)], axis=1))
+    rr = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 9015), V.field_elements(n, 2, 9016)], axis=1))
+    pinf = (rng.integers(0, 16, size=n) == 0).astype(np.uint8)
+    rinf = (rng.integers(0, 64, size=n) == 0).astype(np.uint8)
+    t0 = time.perf_counter(); got = ctx.eddsa_verify_ed25519(rr, rinf, pk, pinf, s, k); t1 = time.perf_counter()
+    want = O.batch_ed25519_eddsa_verify(rr, rinf, pk, pinf, s, k, nthreads=16); t2 = time.perf_counter()
+    total += report("eddsa_verify ed25519", got, want, t1 - t0, t2 - t1)
+    for curve in (0, 1):
+        sk = V.scalars(n, curve, 9021)
+        pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 9022), V.field_elements(n, curve, 9023)], axis=1))
+        if curve == 1:  # true curve points for a quarter of the batch: the reference accepts about half of them
+            import random
+            pr, pb = V.PRIME[1], 0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B
+            rnd, rows = random.Random(77), []
+            while len(rows) < n // 4:
+                x = rnd.randrange(pr)
+                rhs = (x * x * x - 3 * x + pb) % pr
+                y = pow(rhs, (pr + 1) // 4, pr)
+                if y * y % pr == rhs:
+                    rows.append(V.limbs_of(x) + V.limbs_of(y))
+            pk[: n // 4] = np.array(rows, dtype=np.uint64)
+        inf = (rng.integers(0, 64, size=n) == 0).astype(np.uint8)
+        t0 = time.perf_counter(); sec, st = ctx.batch_ecdh(curve, sk, pk, inf); t1 = time.perf_counter()
+        wsec, wst = O.batch_ecdh(curve, sk, pk, inf, nthreads=16); t2 = time.perf_counter()
+        total += report("ecdh " + ("secp256k1" if curve == 0 else "p256") + " (Ok: %d)" % int((wst == 0).sum()),
+                        np.concatenate([sec, st[:, None]], axis=1), np.concatenate([wsec, wst[:, None]], axis=1), t1 - t0, t2 - t1)
+    m = n >> 2
+    xy = np.ascontiguousarray(np.concatenate([V.field_elements(m, 2, 9031), V.field_elements(m, 2, 9032)], axis=1))
+    xy[::7, :4] = 0
+    inf = (rng.integers(0, 16, size=m) == 0).astype(np.uint8)
+    t0 = time.perf_counter(); got = ctx.batch_validate_point(2, xy, inf); t1 = time.perf_counter()
+    want = O.batch_validate_point(2, xy, inf, nthreads=16); t2 = time.perf_counter()
+    bad = int(np.count_nonzero(got != want))
+    print(json.dumps({"pipeline": "validate_point ed25519", "n": m, "mismatches": bad, "valid": int(want.sum()),
+                      "gpu_s": round(t1 - t0, 3), "oracle_s": round(t2 - t1, 1)}), flush=True)
+    total += bad
+    print(json.dumps({"total_mismatches": total}))
+    sys.exit(1 if total else 0)
+
+
+main()
