@@ -28,7 +28,6 @@ namespace fecgpu {
 
 namespace {
 
-// (three wavefronts per SIMD -- asm blocks below v168 -- measured earlier in the round: 21-41 spilled VGPRs, no gain)
 enum { C_TICKET = 0, C_HEAD_D, C_TAIL_D, C_HEAD_A, C_TAIL_A, C_INFLIGHT, C_REMAIN, C_ERR, C_SERVING, C_WORDS };
 
 FEC_DEV p256::pt ld_pt(const u32* l, int stride) {
@@ -62,17 +61,101 @@ FEC_DEV p256::pt ld_base(const u32* points, size_t g) {
   return p;
 }
 
+// one coordinate (8 words) of a slot / of a base point
+FEC_DEV fe ld_coord(const u32* l, int stride, int c) {
+  fe a;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) a.w[i] = l[(8 * c + i) * stride];
+  return a;
+}
+FEC_DEV fe ld_base_coord(const u32* point, int c) {
+  const uint4* src = reinterpret_cast<const uint4*>(point + 8 * c);
+  const uint4 lo = src[0], hi = src[1];
+  fe a;
+  a.w[0] = lo.x; a.w[1] = lo.y; a.w[2] = lo.z; a.w[3] = lo.w;
+  a.w[4] = hi.x; a.w[5] = hi.y; a.w[6] = hi.z; a.w[7] = hi.w;
+  return a;
+}
+
+// p256::pdouble (1869-1912) on a slot, coordinates loaded where they are used (Y twice)
+FEC_DEV p256::pt pdouble_in_place(const u32* lp, int stride) {
+  using namespace p256;
+  const fe x = ld_coord(lp, stride, 0);
+  const fe xx = sqr(x);
+  const fe yy = sqr(ld_coord(lp, stride, 1));
+  const fe yyyy = sqr(yy);
+  const fe xy2 = sqr(add(x, yy));
+  const fe w = sub(sub(xy2, xx), yyyy);
+  const fe d = add(w, w);
+  const fe e = mul_small(xx, 3);
+  const fe ee = sqr(e);
+  pt r;
+  r.x = sub(sub(ee, d), d);
+  r.y = sub(mul(e, sub(d, r.x)), mul_small(yyyy, 8));
+  const fe y = ld_coord(lp, stride, 1), z = ld_coord(lp, stride, 2);
+  const fe z3 = add(y, y);
+  r.z = fe_select(mul(z3, z), z3, fe_eq(z, fe_small(1)));
+  return pt_select(r, identity(), fe_is_zero(z));
+}
+
+// p256::padd (1938-2007) with its operands left in memory: p in the slot (LDS), q in the caller's array.  Every
+// coordinate is loaded where it is first used and the early-outs (identity operands, equal or opposite points:
+// never on random inputs) re-read both points inside their rare branch, so that neither point is live across the
+// sixteen products -- the difference between 43 spilled registers and none at three wavefronts per SIMD.  The
+// products, their operands and their order are those of p256::padd_nodouble / padd.
+FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq) {
+  using namespace p256;
+  const fe z1 = ld_coord(lp, stride, 2), z2 = ld_base_coord(gq, 2);
+  const lmask idp = fe_is_zero(z1), idq = fe_is_zero(z2);
+  const fe z1z1 = sqr(z1), z2z2 = sqr(z2);
+  const fe zs = sub(sub(sqr(add(z1, z2)), z1z1), z2z2);
+  const fe s1 = mul(mul(ld_coord(lp, stride, 1), z2), z2z2);
+  __builtin_amdgcn_sched_barrier(0);  // keep the loads of q's coordinates where they are used (register budget)
+  const fe s2 = mul(mul(ld_base_coord(gq, 1), z1), z1z1);
+  const fe u1 = mul(ld_coord(lp, stride, 0), z2z2);
+  __builtin_amdgcn_sched_barrier(0);
+  const fe u2 = mul(ld_base_coord(gq, 0), z1z1);
+  const lmask ueq = fe_eq(u1, u2);
+  lmask same = 0, opposite = 0;
+  if (__builtin_expect(ueq != 0, 0)) {
+    same = ueq & fe_eq(s1, s2);
+    opposite = ueq & fe_eq(s1, neg(s2));
+  }
+  const fe h = sub(u2, u1);
+  const fe z3 = mul(zs, h);
+  const fe s21 = sub(s2, s1);
+  const fe r = add(s21, s21);
+  const fe i = sqr(add(h, h));
+  const fe j = mul(h, i);
+  const fe v = mul(u1, i);
+  pt o;
+  o.x = sub(sub(sub(sqr(r), j), v), v);
+  o.y = sub(mul(r, sub(v, o.x)), mul(add(s1, s1), j));
+  o.z = z3;
+  if (__builtin_expect((idp | idq | ueq) != 0, 0)) {
+    pt p, q;
+    p.x = ld_coord(lp, stride, 0); p.y = ld_coord(lp, stride, 1); p.z = ld_coord(lp, stride, 2);
+    q.x = ld_base_coord(gq, 0); q.y = ld_base_coord(gq, 1); q.z = ld_base_coord(gq, 2);
+    o = pt_select(o, identity(), uniform_mask(opposite));
+    o = pt_select(o, p, idq);
+    o = pt_select(o, q, idp);
+    const lmask nd = uniform_mask(same & ~idp & ~idq);
+    if (nd != 0) o = pt_select(o, pdouble(p), nd);
+  }
+  return o;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
-// Persistent workgroups (the shape of k_ed_mul_pers): one workgroup of EIGHT wavefronts per CU owns a contiguous
-// RANGE of elements and keeps QS = 1024 of them in LDS slots (point 96 B + scalar 32 B), refilling a slot
-// from the range the moment its element finishes -- no workgroup tail until the whole range is done.  (The
-// first form of this round -- 512 elements per workgroup, two workgroups per CU, each with its own tail --
-// ran 28.55 ms per 2^20 batch; this one 28.20 ms.)
+// Persistent workgroups (the shape of k_ed_mul_pers): one workgroup of TWELVE wavefronts per CU -- three per SIMD,
+// 168 VGPRs, the asm field blocks at v[122:167] -- owns a contiguous RANGE of elements and keeps QS = 1024 of them
+// in LDS slots (point 96 B + scalar 32 B), refilling a slot from the range the moment its element finishes: no
+// workgroup tail until the whole range is done.  History of this round per 2^20 batch: 512 elements per workgroup,
+// two workgroups of four wavefronts per CU 28.55 ms; persistent, eight wavefronts 28.2-28.4 ms; twelve wavefronts
+// with the operands of Add / double left in memory (padd_in_place, pdouble_in_place: no spills) 26.3 ms.
 // ---------------------------------------------------------------------------------------------------
 namespace {
-constexpr int QT = 512;      // threads per workgroup: 8 wavefronts, two per SIMD
+constexpr int QT = 768;      // threads per workgroup: 12 wavefronts, three per SIMD
 constexpr int QS = 1024;     // element slots per workgroup (8 x 64 in flight + 512 queued)
 constexpr int QRING = 2048;  // ring capacity (power of two >= QS)
 enum { P_NEXT = C_WORDS, P_WORDS };
@@ -142,7 +225,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     const int n_fin = __builtin_popcountll(__builtin_amdgcn_ballot_w64(nxt == 2));
     const lmask below = (1ull << lane) - 1;
     const int rank_d = __builtin_popcountll(m_d & below), rank_a = __builtin_popcountll(m_a & below);
-    const bool filling = fill < QS / QT;
+    const bool filling = fill < (QS + QT - 1) / QT;
     if (n_d + n_a + n_fin == 0 && !filling) {
       const int q_d = ctl[C_TAIL_D] - ctl[C_HEAD_D], q_a = ctl[C_TAIL_A] - ctl[C_HEAD_A];
       const int fl = ctl[C_INFLIGHT], rem = ctl[C_REMAIN];
@@ -211,20 +294,18 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     if (filling) {  // next part of the initial fill
       ++fill;
       e = fill * QT + tid;
-      if (fill < QS / QT && e < range) nxt = claim(e);
+      if (e < QS && e < range) nxt = claim(e);
       continue;
     }
     if (kind < 0) continue;
     spins = 0;
     const bool active = lane < count;
     e = active ? lds_q[kind][(start + lane) & (QRING - 1)] : 0;
-    p256::pt p = p256::identity();
-    if (active) p = ld_pt(lds_st + e, QS);
     int step = active ? lds_step[e] : 0;
     bool fin = false;
     p256::pt res = p256::identity();
     if (kind == 0) {
-      res = p256::pdouble(p);
+      res = pdouble_in_place(lds_st + e, QS);
       if (active) {
         const int b = 255 - step;
         const u32 bit = (lds_k[(b >> 5) * QS + e] >> (b & 31)) & 1u;
@@ -239,13 +320,8 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
         if (!fin) st_pt(lds_st + e, QS, res);
       }
     } else {
-      p256::pt q = FIXED ? ld_pt(points, 1) : (active ? ld_base(points, lo + lds_gid[e]) : p256::identity());
-      lmask nd;
-      res = p256::padd_nodouble(p, q, nd);
-      if (__builtin_expect(nd != 0, 0)) {
-        p256::pt d2 = p256::pdouble(p);
-        res = p256::pt_select(res, d2, nd);
-      }
+      // inactive lanes add slot 0 and element 0 of the range: harmless, never stored
+      res = padd_in_place(lds_st + e, QS, FIXED ? points : points + (lo + (active ? lds_gid[e] : 0u)) * 24);
       if (active) {
         ++step;
         lds_step[e] = (unsigned short)step;

@@ -511,7 +511,7 @@ HEADER = """// field_asm.inc -- GENERATED by tools/gen_field_asm.py; do not edit
 
 
 SECP_TOP = 168
-P256_TOP = int(os.environ.get("FEC_P256_TOP", "256"))
+P256_TOP = int(os.environ.get("FEC_P256_TOP", "168"))  # the P-256 scheduler runs three wavefronts per SIMD (168 VGPRs)
 
 
 def main():
