@@ -94,20 +94,96 @@ __global__ __launch_bounds__(64) void k_ed_build_table(const u32* __restrict__ b
   }
 }
 
+// ed::padd (1864-1928) with the addend left in the LDS table: its coordinates are loaded where they are used and the
+// early-outs (identity operands, opposite points) re-read it inside their rare branch, so that the addend is not live
+// across the nine products -- what lets the fixed-base kernel run at three wavefronts per SIMD (168 VGPRs).  Same
+// products, operands and order as ed::padd.
+FEC_DEV fe ld_tab(const u32* e, int c) {
+  fe a;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) a.w[i] = e[8 * c + i];
+  return a;
+}
+FEC_DEV ed::pt padd_table(const ed::pt& p, const u32* e) {
+  using namespace ed;
+  lmask opposite, idq;
+  fe a, b, d;
+  {
+    const fe qx = ld_tab(e, 0), qy = ld_tab(e, 1);
+    {
+      const fe qz = ld_tab(e, 2);
+      idq = fe_is_zero(qx) & fe_eq(qy, qz);                      // is_identity (1785-1791), t below
+      d = mul(p.z, qz);
+    }
+    opposite = fe_eq(p.x, neg(qx)) & fe_eq(p.y, qy);            // 1878, raw coordinates
+    a = mul(sub(p.y, p.x), sub(qy, qx));
+    b = mul(add(p.y, p.x), add(qy, qx));
+  }
+  __builtin_amdgcn_sched_barrier(0);  // keep the load of q.t below the first three products (register budget)
+  fe c;
+  {
+    const fe qt = ld_tab(e, 3);
+    idq &= fe_is_zero(qt);
+    c = mul(mul(p.t, qt), D_());
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const lmask idp = is_identity(p);
+  const fe ee = sub(b, a), f = sub(d, c), g = add(d, c), h = add(b, a);
+  pt o;
+  o.x = mul(ee, f);
+  o.y = mul(g, h);
+  o.t = mul(ee, h);
+  o.z = mul(f, g);
+  if (__builtin_expect((opposite | idp | idq) != 0, 0)) {  // improbable after a lane's first addition (acc = identity)
+    pt q;
+    q.x = ld_tab(e, 0); q.y = ld_tab(e, 1); q.z = ld_tab(e, 2); q.t = ld_tab(e, 3);
+    o = pt_select(o, identity(), uniform_mask(opposite));
+    o = pt_select(o, p, uniform_mask(idq));
+    o = pt_select(o, q, idp);
+  }
+  return o;
+}
+
+// ed::multiply_fixed with the addend read in place (see padd_table)
+FEC_DEV ed::pt multiply_fixed_in_place(const ed::pt& base, const u32* tab, const u32* kw) {
+  using namespace ed;
+  u32 any = 0;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kw[i * KSTRIDE];
+  const lmask early = is_identity(base) | lanes_where(any == 0);
+  pt result = identity();
+  int wi = 0;
+  u32 cur = kw[0];
+#pragma unroll 1
+  for (;;) {
+    while (cur == 0 && wi < 7) {  // advance to this lane's next non-zero scalar word
+      ++wi;
+      cur = kw[wi * KSTRIDE];
+    }
+    const bool have = cur != 0;
+    const lmask active = lanes_where(have);
+    if (active == 0) break;  // every lane of the wavefront has consumed its set bits
+    const u32 bpos = have ? (u32)__builtin_ctz(cur) : 0u;
+    cur &= cur - 1;
+    const pt sum = padd_table(result, tab + (have ? (u32)wi * 32u + bpos : 0u) * ED_TSTRIDE);
+    result = pt_select(result, sum, active);
+  }
+  return pt_select(result, identity(), early);
+}
+
 // Ed25519 fixed-base: out[i] = multiply(base, scalars[i]) from the LDS addend table.
 // A lane performs one addition per set bit of its scalar, so a wavefront runs for the largest
 // popcount among its 64 lanes.  The workgroup therefore bins its 256 scalars by popcount (counting
 // sort through LDS) and hands each wavefront one quartile -- rotated by workgroup so that no SIMD
 // always gets the heavy quartile: the four wavefronts then run about 123 + 128 + 134 + 150
 // iterations instead of 4 x 148.  Only the lane -> element assignment changes; every element sees
-// exactly the additions the reference performs, in the reference's order.
-__global__ __launch_bounds__(TPB) void k_ed_fixed_base(const u32* __restrict__ scalars,
+// exactly the additions the reference performs, in the reference's order.  Three workgroups per CU
+// (three wavefronts per SIMD): 168 VGPRs without a spill (padd_table) and 43 KiB of LDS -- the results
+// are staged out through the table's own LDS region once every lane is done.
+__global__ __launch_bounds__(TPB, 3) void k_ed_fixed_base(const u32* __restrict__ scalars,
                                                        const u32* __restrict__ base,
                                                        const u32* __restrict__ table,
                                                        u32* __restrict__ out, size_t n) {
   __shared__ u32 lds_k[8 * TPB];
-  __shared__ u32 lds_t[256 * ed::ED_TSTRIDE];
-  __shared__ u32 lds_o[32 * TPB];
+  __shared__ u32 lds_t[256 * ed::ED_TSTRIDE];   // the addend table; reused to stage the results out once every lane is done
   __shared__ int lds_bin[260];
   __shared__ unsigned short lds_perm[TPB];
   const int valid = block_valid(n);
@@ -155,13 +231,16 @@ __global__ __launch_bounds__(TPB) void k_ed_fixed_base(const u32* __restrict__ s
   // wavefront w of workgroup b takes quartile (w + b) mod 4 of the sorted list
   const int slot = ((((e >> 6) + (int)blockIdx.x) & 3) << 6) | (e & 63);
   const int src = lds_perm[slot];
+  ed::pt r = ed::identity();
   if (src < valid) {
     ed::pt b = ld_words(base);
-    ed::pt r = ed::multiply_fixed(b, lds_t, lds_k + src);
-    st_lds(lds_o + src, TPB, r);
+    r = multiply_fixed_in_place(b, lds_t, lds_k + src);
   }
+  __syncthreads();                      // every lane has read its last table entry
+  static_assert(256 * ed::ED_TSTRIDE >= 32 * TPB, "the table region holds the staged results");
+  if (src < valid) st_lds(lds_t + src, TPB, r);
   __syncthreads();
-  stage_out<32>(out + first * 32, lds_o, valid);
+  stage_out<32>(out + first * 32, lds_t, valid);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -512,6 +512,7 @@ HEADER = """// field_asm.inc -- GENERATED by tools/gen_field_asm.py; do not edit
 
 SECP_TOP = 168
 P256_TOP = int(os.environ.get("FEC_P256_TOP", "168"))  # the P-256 scheduler runs three wavefronts per SIMD (168 VGPRs)
+ED_TOP = int(os.environ.get("FEC_ED_TOP", "168"))    # the Ed25519 fixed-base kernel runs three wavefronts per SIMD
 
 
 def main():
@@ -519,7 +520,7 @@ def main():
     report = []
 
     def add(name, blk, regs):
-        assert regs[-1] in (255, SECP_TOP - 1, P256_TOP - 1) and regs[0] % 2 == 0, (name, regs[0], regs[-1])
+        assert regs[-1] in (255, SECP_TOP - 1, P256_TOP - 1, ED_TOP - 1) and regs[0] % 2 == 0, (name, regs[0], regs[-1])
         parts.append("#define FEC_%s_ASM \\\n" % name + blk.text().replace("\n", " \\\n") + "\n")
         parts.append("#define FEC_%s_CLOBBERS \"vcc\", " % name + clobbers(regs) + "\n")
         parts.append("// FEC_%s_ASM: %d instructions, fixed block v[%d:%d]\n" % (name, len(blk.lines), regs[0], regs[-1]))
@@ -534,8 +535,8 @@ def main():
     add("P256_SQR", *p256_sqr(P256_TOP - 46))
     add("P256_MUL3", *p256_mul_small(P256_TOP - 24, 3))
     add("P256_MUL8", *p256_mul_small(P256_TOP - 24, 8))
-    add("ED_MUL", *ed_mul(256 - 32))
-    add("ED_SQR", *ed_sqr(256 - 46))
+    add("ED_MUL", *ed_mul(ED_TOP - 32))
+    add("ED_SQR", *ed_sqr(ED_TOP - 46))
     with open(OUT, "w") as f:
         f.write("\n".join(parts))
     print("wrote %s (%s)" % (OUT, ", ".join(report)))
