@@ -41,6 +41,13 @@ WORKLOADS = {
     "secp256k1-fixed": ("secp256k1", "fixed", 693248, 128, "north_star fixed-base target"),
 }
 CURVE_ID = {"secp256k1": 0, "p256": 1, "ed25519": 2}
+# where the PMC traffic is far above the algorithmic bytes ON PURPOSE
+TRAFFIC_NOTES = {
+    "ed25519-var": "the running result of every in-flight element lives in its slot of the output array and is read and "
+                   "rewritten by ~128 additions per element (L2 / Infinity Cache working set, 1.4 TB/s): LDS holds the "
+                   "addends of 1152 elements per CU instead, which is what lets the kernel run three wavefronts per SIMD "
+                   "(20.8 ms); with both in LDS (592 slots, two wavefronts per SIMD) it moved 305 MB and took 22.4 ms",
+}
 # guide-derived integer-VALU peak: 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per
 # v_mad_u64_u32 wave-instruction (MI355X_MICROARCH.md chip parameters; issue cost measured,
 # profiles/valu_rates2_r01.txt) = 39.3e12 MAD32/s
@@ -287,6 +294,7 @@ def main():
                 "bound": "int-valu", "achieved": achieved / 1e12, "peak": PEAK_MAD32_FORMULA / 1e12,
                 "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_FORMULA, "traffic": pmc["traffic"],
                 "traffic_source": pmc["source"],
+                "traffic_note": TRAFFIC_NOTES.get(workload),
                 "kernel": kname, "kernel_ms": kernel_ms,
                 "algorithmic_mad32_per_unit": alg, "units_per_launch": n,
                 "peak_measured": peak_measured / 1e12, "frac_of_measured_peak": achieved / peak_measured,

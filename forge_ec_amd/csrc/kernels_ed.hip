@@ -243,27 +243,130 @@ __global__ __launch_bounds__(TPB, 3) void k_ed_fixed_base(const u32* __restrict_
   stage_out<32>(out + first * 32, lds_t, valid);
 }
 
+// ---- Add / double with their operands left in memory (register budget of three wavefronts per SIMD) ----
+// the running result sits in the element's slot of the OUTPUT array (32 consecutive words), the addend in its LDS
+// slot (word w at l[w * stride]).  Coordinates are loaded where they are used; the early-outs (identity operands,
+// opposite points: improbable after an element's first addition) re-read both points inside their rare branch.
+// Same products, operands and order as ed::padd / ed::pdbl.
+namespace {
+FEC_DEV fe ld_gcoord(const u32* g, int c) {
+  const uint4* s4 = reinterpret_cast<const uint4*>(g + 8 * c);
+  const uint4 lo = s4[0], hi = s4[1];
+  fe a;
+  a.w[0] = lo.x; a.w[1] = lo.y; a.w[2] = lo.z; a.w[3] = lo.w;
+  a.w[4] = hi.x; a.w[5] = hi.y; a.w[6] = hi.z; a.w[7] = hi.w;
+  return a;
+}
+FEC_DEV fe ld_lcoord(const u32* l, int stride, int c) {
+  fe a;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) a.w[i] = l[(8 * c + i) * stride];
+  return a;
+}
+// result (global) + addend (LDS)
+FEC_DEV ed::pt padd_mem(const u32* gr, const u32* la, int stride) {
+  using namespace ed;
+  lmask opposite, idp, idq;
+  fe a, b, d;
+  {
+    const fe px = ld_gcoord(gr, 0), py = ld_gcoord(gr, 1), qx = ld_lcoord(la, stride, 0), qy = ld_lcoord(la, stride, 1);
+    {
+      const fe pz = ld_gcoord(gr, 2), qz = ld_lcoord(la, stride, 2);
+      idp = fe_is_zero(px) & fe_eq(py, pz);                    // is_identity (1785-1791), t below
+      idq = fe_is_zero(qx) & fe_eq(qy, qz);
+      d = mul(pz, qz);
+    }
+    opposite = fe_eq(px, neg(qx)) & fe_eq(py, qy);             // 1878, raw coordinates
+    a = mul(sub(py, px), sub(qy, qx));
+    b = mul(add(py, px), add(qy, qx));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  fe c;
+  {
+    const fe pt_ = ld_gcoord(gr, 3), qt = ld_lcoord(la, stride, 3);
+    idp &= fe_is_zero(pt_);
+    idq &= fe_is_zero(qt);
+    c = mul(mul(pt_, qt), D_());
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const fe ee = sub(b, a), f = sub(d, c), g = add(d, c), h = add(b, a);
+  pt o;
+  o.x = mul(ee, f);
+  o.y = mul(g, h);
+  o.t = mul(ee, h);
+  o.z = mul(f, g);
+  if (__builtin_expect((opposite | idp | idq) != 0, 0)) {
+    pt p, q;
+    p.x = ld_gcoord(gr, 0); p.y = ld_gcoord(gr, 1); p.z = ld_gcoord(gr, 2); p.t = ld_gcoord(gr, 3);
+    q.x = ld_lcoord(la, stride, 0); q.y = ld_lcoord(la, stride, 1); q.z = ld_lcoord(la, stride, 2); q.t = ld_lcoord(la, stride, 3);
+    o = pt_select(o, identity(), uniform_mask(opposite));
+    o = pt_select(o, p, uniform_mask(idq));
+    o = pt_select(o, q, uniform_mask(idp));
+  }
+  return o;
+}
+// addend.double() = addend + addend (1828-1832), addend in LDS
+FEC_DEV ed::pt pdbl_mem(const u32* la, int stride) {
+  using namespace ed;
+  lmask opposite, idp;
+  fe a, b, d;
+  {
+    const fe x = ld_lcoord(la, stride, 0), y = ld_lcoord(la, stride, 1);
+    {
+      const fe z = ld_lcoord(la, stride, 2);
+      idp = fe_is_zero(x) & fe_eq(y, z);
+      d = sqr_exact(z);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    opposite = fe_eq(x, neg(x));                               // Add's test with q = p: x == -x
+    a = sqr_exact(sub(y, x));
+    b = sqr_exact(add(y, x));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  fe c;
+  {
+    const fe t = ld_lcoord(la, stride, 3);
+    idp &= fe_is_zero(t);
+    c = mul(sqr_exact(t), D_());
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const fe ee = sub(b, a), f = sub(d, c), g = add(d, c), h = add(b, a);
+  pt o;
+  o.x = mul(ee, f);
+  o.y = mul(g, h);
+  o.t = mul(ee, h);
+  o.z = mul(f, g);
+  if (__builtin_expect((opposite | idp) != 0, 0)) {
+    pt p;
+    p.x = ld_lcoord(la, stride, 0); p.y = ld_lcoord(la, stride, 1); p.z = ld_lcoord(la, stride, 2); p.t = ld_lcoord(la, stride, 3);
+    o = pt_select(o, identity(), uniform_mask(opposite));
+    o = pt_select(o, p, uniform_mask(idp));
+  }
+  return o;
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------------
-// One workgroup of EIGHT wavefronts per CU owns a contiguous RANGE of elements and keeps PS = 592 of them
-// in flight in LDS slots -- addend AND running result (256 B per slot, 148 KiB) -- refilling a slot from
-// the range the moment its element finishes: no workgroup tail until the whole range is done (elements of
-// different generations share the queues), and HBM sees each point once in and once out.  (The first form
-// of this round, 512 elements per workgroup with the running result in the OUTPUT array, moved 30.5 GB
-// through the fabric per 2^20 batch against 0.3 GB algorithmic -- every one of ~128 additions per element
-// read and rewrote 128 B -- at 22.9 ms; this form: 22.5 ms.)  Each element still sees exactly the
-// reference's operation sequence.
+// One workgroup of TWELVE wavefronts per CU (three per SIMD, 168 VGPRs) owns a contiguous RANGE of elements and
+// keeps PS = 1152 of them in slots -- the addend in LDS (128 B per slot, 144 KiB), the running result in the
+// element's slot of the OUTPUT array (read and rewritten by ~128 additions per element; L2 / Infinity Cache
+// traffic) -- refilling a slot from the range the moment its element finishes: no
+// workgroup tail until the whole range is done.  Add and double read their operands from memory where they are
+// used (padd_mem, pdbl_mem).  History of this round per 2^20 batch: 512 elements per workgroup, four wavefronts,
+// result in the output array 22.9 ms; persistent, eight wavefronts, addend AND result in LDS (592 slots fill the
+// 160 KiB, so three wavefronts per SIMD could not fit) 22.4 ms; this form, see the measurement in DESIGN.md.
+// Each element still sees exactly the reference's operation sequence.
 // ---------------------------------------------------------------------------------------------------
 namespace {
-constexpr int PT = 512;     // threads per workgroup: 8 wavefronts, two per SIMD
-constexpr int PS = 592;     // element slots per workgroup (8 x 64 in flight + 80 queued)
-constexpr int PRING = 1024;  // ring capacity (power of two >= PS)
+constexpr int PT = 768;     // threads per workgroup: 12 wavefronts, three per SIMD
+constexpr int PS = 1152;    // element slots per workgroup (12 x 64 in flight + 384 queued)
+constexpr int PRING = 2048;  // ring capacity (power of two >= PS)
 enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace
 
 __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ scalars, const u32* __restrict__ points,
                                                     u32* __restrict__ out, size_t n, unsigned per_wg) {
-  __shared__ u32 lds_ad[32 * PS];              // addend of slot e: word w at lds_ad[w * PS + e]
-  __shared__ u32 lds_rs[32 * PS];              // running result of slot e
+  __shared__ u32 lds_ad[32 * PS];              // addend of slot e: word w at lds_ad[w * PS + e]; the running result
+                                               // lives in the element's slot of `out`
   __shared__ u32 lds_gid[PS];                  // element of slot e, relative to the workgroup's range
   __shared__ unsigned short lds_step[PS];      // current step i of slot e (A_i / D_i pending)
   __shared__ unsigned short lds_q[2][PRING];   // ready rings: [0] needs the doubling D_i, [1] needs the addition A_i
@@ -271,7 +374,11 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
   const size_t lo = (size_t)blockIdx.x * per_wg;
   const int range = (n - lo) < (size_t)per_wg ? (int)(n - lo) : (int)per_wg;
   const int tid = threadIdx.x, lane = tid & 63;
-  volatile int* ctl = lds_ctl;
+  // one opaque base register for the control words: otherwise every word's (link-time constant, > 64 KiB) LDS
+  // address is hoisted into a VGPR of its own -- ten registers the three-wavefront budget does not have
+  int* ctl_base = lds_ctl;
+  asm volatile("" : "+v"(ctl_base));
+  volatile int* ctl = ctl_base;
   if (tid == 0) {
     FEC_UNROLL for (int w = 0; w < P_WORDS; ++w) lds_ctl[w] = 0;
     lds_ctl[C_REMAIN] = range < PS ? range : PS;   // live slots
@@ -284,7 +391,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
   // (1 = A_0 if bit 0 is set, else 0 = D_0), or 2 when the range is used up (the slot dies).
   auto claim = [&](int e) -> int {
     for (;;) {
-      const int rel = atomicAdd(&lds_ctl[P_NEXT], 1);
+      const int rel = atomicAdd(&ctl_base[P_NEXT], 1);
       if (rel >= range) return 2;
       const size_t g = lo + rel;
       const ed::pt base = ld_glb(points + g * 32);
@@ -295,7 +402,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
         continue;
       }
       st_lds(lds_ad + e, PS, base);
-      st_lds(lds_rs + e, PS, ed::identity());
+      st_glb(out + g * 32, ed::identity());
       lds_gid[e] = (u32)rel;
       lds_step[e] = 0;
       return (scalars[g * 8] & 1u) ? 1 : 0;
@@ -333,7 +440,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
     }
     // ---- critical section (FIFO ticket lock, lane 0) ----
     if (lane == 0) {
-      const int my = atomicAdd(&lds_ctl[C_TICKET], 1);
+      const int my = atomicAdd(&ctl_base[C_TICKET], 1);
       while (ctl[C_SERVING] != my) __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -383,7 +490,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
     kind = pick;
     nxt = 3;
     if (finished) break;
-    if (first_fill) {  // second half of the initial fill: slots PT..PS-1
+    if (first_fill) {  // second part of the initial fill: slots PT..PS-1
       first_fill = false;
       e = PT + tid;
       if (e < PS && e < range) nxt = claim(e);
@@ -392,22 +499,20 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
     if (kind < 0) continue;
     spins = 0;
     const bool active = lane < count;
-    e = active ? lds_q[kind][(start + lane) & (PRING - 1)] : 0;
-    ed::pt ad = ed::identity();
-    if (active) ad = ld_lds(lds_ad + e, PS);
+    e = active ? lds_q[kind][(start + lane) & (PRING - 1)] : 0;   // inactive lanes compute on slot 0: never stored
     int step = active ? lds_step[e] : 0;
     bool fin = false;
-    ed::pt res = ed::identity();
-    if (kind == 1) {  // A_i: result = result + addend  (2083-2086, bit i set)
-      ed::pt r = active ? ld_lds(lds_rs + e, PS) : ed::identity();
-      res = ed::padd(r, ad);
+    if (kind == 1) {  // A_i: result = result + addend  (2083-2086, bit i set); the result stays in its output slot
+      // inactive lanes read element 0 of the range (always present) and slot 0: computed, never stored
+      u32* slot = out + (lo + (active ? lds_gid[e] : 0u)) * 32;
+      const ed::pt res = padd_mem(slot, lds_ad + e, PS);
       if (active) {
+        st_glb(slot, res);
         fin = step == 255;  // the last doubling is never used
-        if (!fin) st_lds(lds_rs + e, PS, res);
         nxt = 0;            // then D_i
       }
     } else {  // D_i: addend = addend.double()  (2089), then step i + 1
-      ed::pt d = ed::pdbl(ad);
+      const ed::pt d = pdbl_mem(lds_ad + e, PS);
       if (active) {
         st_lds(lds_ad + e, PS, d);
         ++step;
@@ -415,15 +520,13 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
         const u32 bit = scalar_bit(scalars, lo + lds_gid[e], step);
         fin = !bit && step == 255;
         nxt = bit ? 1 : 0;
-        if (fin) res = ld_lds(lds_rs + e, PS);
       }
     }
-    if (fin) {  // the element is done: its result goes out, the slot takes the next element of the range
-      st_glb(out + (lo + lds_gid[e]) * 32, res);
-      nxt = claim(e);
-    }
-    // slots are lane-private between the pop and the push; the workgroup-scope release fence inside the
-    // critical section orders this batch's LDS stores before the queue entries that hand the slots on
+    if (fin) nxt = claim(e);  // the element is done (its result is in place): the slot takes the next element
+    // slots (LDS addend, output-array result) are lane-private between the pop and the push; every access to an
+    // element's output slot comes from THIS workgroup (one CU, one vector L1), and the workgroup-scope release
+    // fence inside the critical section (s_waitcnt vmcnt(0) lgkmcnt(0)) orders this batch's stores before the
+    // queue entries that hand the slots on
   }
   __syncthreads();
   if (lds_ctl[C_ERR] != 0) {  // watchdog fired (cannot happen): all-zero results fail every parity check loudly
