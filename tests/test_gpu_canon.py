@@ -611,4 +611,5 @@ def test_eddsa_sign_rfc8032(gpu_ctx):
         hl = dev.scalar_muladd(_arr([h >> 256]), two256, _arr([h & (2**256 - 1)]))
         S = dev.eddsa_sign_finish(hl, _arr([a]), rl)
         sig = Renc + M.unlimbs(S[0]).to_bytes(32, "little")
-        assert sig.hex() == sighex
+        assert sig.hex() == sighex, "r mod l = %x (want %x), R status %s, xy %s" % (
+            M.unlimbs(rl[0]), r % E.N, st, [hex(int(v)) for v in xy[0]])
