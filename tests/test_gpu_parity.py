@@ -235,6 +235,20 @@ def test_ragged_sizes_config1(gpu_ctx, oracle, n):
         _assert_same(got, want, "secp256k1 n=%d" % n)
 
 
+@pytest.mark.parametrize("curve", [1, 2])
+def test_scheduler_kernels_at_slot_and_wavefront_boundaries(gpu_ctx, oracle, curve):
+    """The persistent schedulers (P-256, Ed25519 variable base: 768 threads, 1024 / 1152 slots per workgroup, ranges
+    of at least 64 elements per workgroup) and the Ed25519 table kernel at batch sizes around every boundary of
+    that geometry, with zero scalars and identity points sprinkled in (elements answered at claim time)."""
+    g = oracle.generator(curve)
+    for n in (1, 2, 63, 64, 65, 127, 129, 767, 768, 769, 1023, 1025, 1151, 1153, 4097, 16385 + 7):
+        k, p = V.scalars(n, curve, 7000 + n), V.points(n, curve, 7100 + n)
+        k[::11] = 0
+        p[5::13] = oracle.identity(curve)
+        assert np.array_equal(gpu_ctx.batch_mul(curve, k, p), oracle.batch_mul(curve, k, p, nthreads=16)), (curve, n)
+        assert np.array_equal(gpu_ctx.batch_mul_fixed(curve, k, g), oracle.batch_mul_fixed(curve, k, g, nthreads=16)), (curve, n)
+
+
 def test_host_pipeline_chunking_is_invisible(gpu_ctx, oracle):
     """The host-pointer path pipelines chunks over two streams; results must not depend on the
     chunk size (1 chunk, many chunks, ragged last chunk, odd and even chunk counts)."""
