@@ -67,3 +67,18 @@ def test_product_code_never_touches_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", os.path.join(pkg, "libfecgpu.so")], capture_output=True, text=True).stdout
     assert "forge_ec_oracle" not in out
+
+
+def test_generated_field_asm_is_current(tmp_path):
+    """forge_ec_amd/csrc/field_asm.inc is the output of tools/gen_field_asm.py with its default register blocks
+    (all three curves below v168: every multiplication kernel runs three wavefronts per SIMD)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_field_asm", os.path.join(root, "tools", "gen_field_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gen.OUT = str(tmp_path / "field_asm.inc")
+    gen.main()
+    assert open(gen.OUT).read() == open(os.path.join(root, "forge_ec_amd", "csrc", "field_asm.inc")).read()
+    assert gen.SECP_TOP == gen.P256_TOP == gen.ED_TOP == 168
