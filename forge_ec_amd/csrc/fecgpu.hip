@@ -341,64 +341,43 @@ __global__ __launch_bounds__(TPB) void k_to_affine(const u32* __restrict__ point
 // terms of the two folds at 262-281, challenges e_i and weights a_i supplied by the caller:
 //   A_i = multiply(G, s_i * a_i)                                           (266-268)
 //   B_i = multiply(from_affine(R_i) + multiply(from_affine(P_i), e_i), a_i) (273-280)
-// One lane per signature; the three ladders share one instance of the ladder code.
-__global__ __launch_bounds__(TPB, 2) void k_schnorr_terms_secp(const u32* __restrict__ pk_xy,
-                                                            const u32* __restrict__ r_xy,
-                                                            const u32* __restrict__ ss, const u32* __restrict__ as,
-                                                            const u32* __restrict__ es, const u32* __restrict__ gen,
-                                                            u32* __restrict__ out_a, u32* __restrict__ out_b,
-                                                            size_t n) {
-  __shared__ u32 lds_k[3][8 * TPB];   // s (then s*a), e, a
-  __shared__ u32 lds_p[16 * TPB];     // public key x, y; then the A / B results (12 words)
-  __shared__ u32 lds_r[16 * TPB];     // signature point x, y
+// as a pipeline over the ladder kernel (kernels_secp.hip): k_schnorr_pre (s_i * a_i, from_affine(P_i)),
+// the fixed-base and one variable-base launch side by side in time, k_schnorr_mid (R_i + e_i P_i), the
+// second variable-base launch.  (Round 1 ran the three ladders one after the other in one lane of one
+// kernel: 58 spilled VGPRs, 8.5 ms at n = 4096 where two ladder latencies are 4.6 ms.)
+__global__ __launch_bounds__(TPB) void k_schnorr_pre(const u32* __restrict__ pk_xy, const u32* __restrict__ ss,
+                                                     const u32* __restrict__ as, u32* __restrict__ sa,
+                                                     u32* __restrict__ p_out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  fe s, a;
+  FEC_UNROLL for (int w = 0; w < 8; ++w) { s.w[w] = ss[i * 8 + w]; a.w[w] = as[i * 8 + w]; }
+  const fe prod = secp::sc_mul(s, a);                         // impl Mul for Scalar
+  FEC_UNROLL for (int w = 0; w < 8; ++w) sa[i * 8 + w] = prod.w[w];
+  // from_affine (1365-1373): the caller has rejected identities
+  FEC_UNROLL for (int w = 0; w < 16; ++w) p_out[i * 24 + w] = pk_xy[i * 16 + w];
+  FEC_UNROLL for (int w = 0; w < 8; ++w) p_out[i * 24 + 16 + w] = w == 0 ? 1u : 0u;
+}
+// q_i = from_affine(R_i) + ep_i   (277-279)
+__global__ __launch_bounds__(TPB) void k_schnorr_mid(const u32* __restrict__ r_xy, const u32* __restrict__ ep,
+                                                     u32* __restrict__ q_out, size_t n) {
+  __shared__ u32 lds_p[Secp::PW * TPB];
+  __shared__ u32 lds_r[16 * TPB];
   const int valid = block_valid(n);
   const size_t first = (size_t)blockIdx.x * TPB;
-  stage_in<8>(lds_k[0], ss + first * 8, valid);
-  stage_in<8>(lds_k[1], es + first * 8, valid);
-  stage_in<8>(lds_k[2], as + first * 8, valid);
-  stage_in<16>(lds_p, pk_xy + first * 16, valid);
+  stage_in<Secp::PW>(lds_p, ep + first * Secp::PW, valid);
   stage_in<16>(lds_r, r_xy + first * 16, valid);
   __syncthreads();
   const int e = threadIdx.x;
-  secp::pt ta = secp::identity(), tb = secp::identity();
   if (e < valid) {
-    fe sa = secp::sc_mul(load_fe(lds_k[0] + e, TPB), load_fe(lds_k[2] + e, TPB));   // impl Mul for Scalar
-    store_fe(lds_k[0] + e, TPB, sa);
-    secp::pt t = secp::identity();
-#pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {
-      secp::pt base;
-      if (pass == 0) {
-        base = Secp::load(gen, 1);
-      } else if (pass == 1) {  // from_affine (1365-1373): the caller has rejected identities
-        base.x = load_fe(lds_p + e, TPB);
-        base.y = load_fe(lds_p + 8 * TPB + e, TPB);
-        base.z = fe_small(1);
-      } else {
-        base = t;
-      }
-      secp::pt m = secp::multiply(base, lds_k[pass] + e);
-      if (pass == 0) {
-        ta = m;
-      } else if (pass == 1) {
-        secp::pt r;
-        r.x = load_fe(lds_r + e, TPB);
-        r.y = load_fe(lds_r + 8 * TPB + e, TPB);
-        r.z = fe_small(1);
-        t = secp::padd(r, m);
-      } else {
-        tb = m;
-      }
-    }
+    secp::pt r;
+    r.x = load_fe(lds_r + e, TPB);
+    r.y = load_fe(lds_r + 8 * TPB + e, TPB);
+    r.z = fe_small(1);
+    Secp::store(lds_p + e, TPB, secp::padd(r, Secp::load(lds_p + e, TPB)));
   }
   __syncthreads();
-  if (e < valid) Secp::store(lds_p + e, TPB, ta);
-  __syncthreads();
-  stage_out<Secp::PW>(out_a + first * Secp::PW, lds_p, valid);
-  __syncthreads();
-  if (e < valid) Secp::store(lds_p + e, TPB, tb);
-  __syncthreads();
-  stage_out<Secp::PW>(out_b + first * Secp::PW, lds_p, valid);
+  stage_out<Secp::PW>(q_out + first * Secp::PW, lds_p, valid);
 }
 
 // The two strictly sequential folds (s_g += ..., r_e_p += ...: 268, 281) and the comparison at 286:
@@ -1410,12 +1389,38 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
   unsigned int* d_done = (unsigned int*)(tail + 2 * pb + 128 + 8);
   if (hipMemsetAsync(tail + 2 * pb + 128, 0, 16, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
   {
-    Launch L(ctx, nullptr, "k_schnorr_terms_secp");
-    hipLaunchKernelGGL(k_schnorr_terms_secp, dim3(grid_for(n)), dim3(TPB), 0, L.s, (const u32*)ctx->d_buf[0],
-                       (const u32*)ctx->d_buf[1], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3],
-                       (const u32*)ctx->d_buf[4], reinterpret_cast<const u32*>(ctx->d_gen[FEC_SECP256K1]),
-                       (u32*)ctx->d_buf[5], (u32*)ctx->d_buf[6], n);
+    // work area: s*a (32 n), from_affine(P) (96 n), e*P (96 n), R + e*P (96 n)
+    char* work = static_cast<char*>(scratch_for(ctx, ctx->stream, n * 320));
+    if (!work) return FEC_E_OOM;
+    u32* sa = reinterpret_cast<u32*>(work);
+    u32* pp = reinterpret_cast<u32*>(work + n * 32);
+    u32* ep = reinterpret_cast<u32*>(work + n * 128);
+    u32* qq = reinterpret_cast<u32*>(work + n * 224);
+    const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[FEC_SECP256K1]);
+    Launch L(ctx, nullptr, "k_schnorr_pre + k_secp_mul x3 + k_schnorr_mid");
+    const dim3 g(grid_for(n)), b(TPB);
+    hipLaunchKernelGGL(k_schnorr_pre, g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2],
+                       (const u32*)ctx->d_buf[3], sa, pp, n);
+    // the A terms do not depend on the B chain: they run on the ctx's second stream beside it (at the moderate n
+    // this entry point is meant for, a launch fills a fraction of the chip and is bound by one ladder's latency)
+    hipEvent_t ev_pre = nullptr, ev_a = nullptr;
+    const bool side = ctx->stream2 != nullptr && hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev_a, hipEventDisableTiming) == hipSuccess;
+    hipStream_t sa_stream = L.s;
+    if (side) {
+      (void)hipEventRecord(ev_pre, L.s);
+      (void)hipStreamWaitEvent(ctx->stream2, ev_pre, 0);
+      sa_stream = ctx->stream2;
+    }
+    secp_launch_mul(true, sa, gen, (u32*)ctx->d_buf[5], n, sa_stream);                  // A_i (266-268)
+    if (side) (void)hipEventRecord(ev_a, ctx->stream2);
+    secp_launch_mul(false, (const u32*)ctx->d_buf[4], pp, ep, n, L.s);                 // e_i P_i (276)
+    hipLaunchKernelGGL(k_schnorr_mid, g, b, 0, L.s, (const u32*)ctx->d_buf[1], (const u32*)ep, qq, n);
+    secp_launch_mul(false, (const u32*)ctx->d_buf[3], qq, (u32*)ctx->d_buf[6], n, L.s); // B_i (282)
+    if (side) (void)hipStreamWaitEvent(L.s, ev_a, 0);
     rc = L.done();
+    if (ev_pre) (void)hipEventDestroy(ev_pre);
+    if (ev_a) (void)hipEventDestroy(ev_a);
     if (rc != FEC_OK) return rc;
   }
   hipLaunchKernelGGL(k_schnorr_fold_compare_secp, dim3(2), dim3(64), 0, ctx->stream, (const u32*)ctx->d_buf[5],
