@@ -1191,7 +1191,7 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
   {
     Launch L(ctx, nullptr, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op + k_fold_sum + k_ecdsa_batch_finish"
                                                   : "k_p256_mul_sched x2 + k_point_op + k_fold_sum + k_ecdsa_batch_finish");
-    ecdsa_batch_mul_launch(curve, reinterpret_cast<const u32*>(ctx->d_gen[curve]), work, n, L.s);
+    ecdsa_batch_mul_launch(curve, reinterpret_cast<const u32*>(ctx->d_gen[curve]), work, n, L.s, ctx->stream2);
     const dim3 g(grid_for(n)), b(TPB);
     if (curve == FEC_SECP256K1) {  // r_i = r1 + r2 (355), then r_sum += r_i in index order (358)
       hipLaunchKernelGGL((k_point_op<Secp>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, ta, n);

@@ -39,7 +39,7 @@ void ecdsa_launch(int curve, const unsigned char* digests, const u32* r, const u
 size_t ecdsa_batch_work_bytes(size_t n);
 void ecdsa_batch_pre_launch(int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
                             const unsigned char* pk_inf, const u32* weights, void* work, size_t n, hipStream_t s);
-void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hipStream_t s);
+void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hipStream_t s, hipStream_t side);
 void ecdsa_batch_finish_launch(int curve, const u32* r_sum, const void* work, size_t n, unsigned char* result, u32* detail,
                                hipStream_t s);
 

@@ -409,15 +409,33 @@ void ecdsa_batch_pre_launch(int curve, const unsigned char* digests, const u32* 
   else hipLaunchKernelGGL((k_ecdsa_pre<EP256>), g, b, 0, s, digests, r, s_, pk, pk_inf, weights, u1, u2, q, flags, ar, n);
 }
 // second half: ta = multiply(G, a*u1), tb = multiply(Q, a*u2)
-void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hipStream_t s) {
+// `side` (may be null): a second stream for the fixed-base launch -- at the moderate n batch_verify is meant for, one
+// launch fills a fraction of the chip and is bound by the latency of one multiplication, so the two overlap
+void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hipStream_t s, hipStream_t side) {
   char* w = static_cast<char*>(work);
   const u32* u1 = reinterpret_cast<const u32*>(w);
   const u32* u2 = reinterpret_cast<const u32*>(w + n * 32);
   const u32* q = reinterpret_cast<const u32*>(w + n * 64);
   u32* ta = reinterpret_cast<u32*>(w + n * 160);
   u32* tb = reinterpret_cast<u32*>(w + n * 256);
-  if (curve == FEC_SECP256K1) { ESecp::launch_mul(true, u1, gen, ta, n, s); ESecp::launch_mul(false, u2, q, tb, n, s); }
-  else { EP256::launch_mul(true, u1, gen, ta, n, s); EP256::launch_mul(false, u2, q, tb, n, s); }
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  const bool two = side != nullptr && side != s && n < ((size_t)1 << 16) &&
+                   hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) == hipSuccess;
+  hipStream_t sf = s;
+  if (two) {
+    (void)hipEventRecord(ev_in, s);
+    (void)hipStreamWaitEvent(side, ev_in, 0);
+    sf = side;
+  }
+  if (curve == FEC_SECP256K1) ESecp::launch_mul(true, u1, gen, ta, n, sf);
+  else EP256::launch_mul(true, u1, gen, ta, n, sf);
+  if (two) (void)hipEventRecord(ev_out, side);
+  if (curve == FEC_SECP256K1) ESecp::launch_mul(false, u2, q, tb, n, s);
+  else EP256::launch_mul(false, u2, q, tb, n, s);
+  if (two) (void)hipStreamWaitEvent(s, ev_out, 0);
+  if (ev_in) (void)hipEventDestroy(ev_in);
+  if (ev_out) (void)hipEventDestroy(ev_out);
 }
 void ecdsa_batch_finish_launch(int curve, const u32* r_sum, const void* work, size_t n, unsigned char* result, u32* detail,
                                hipStream_t s) {
