@@ -256,7 +256,8 @@ int fec_point_op(fec_ctx* ctx, fec_curve curve, fec_point_opcode op, const uint6
  * Ed25519 double-mul, the canonical-mode work areas), so a launch that goes to another stream than
  * the ctx's previous launch is ordered after it with an event (no host blocking) -- launches of
  * one ctx therefore execute in call order whatever streams they name.  Use one ctx per stream for
- * concurrent streams. ---- */
+ * concurrent streams.  A stream handed to a *_dev call must stay alive until the next call on the same ctx has
+ * returned (or the ctx is destroyed): that call records an event on it to order itself after it. ---- */
 int fec_batch_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars,
                       const uint64_t* d_points, uint64_t* d_out, size_t n, void* stream);
 int fec_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars,
