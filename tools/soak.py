@@ -31,6 +31,18 @@ def main():
         return bad
 
     total = 0
+    for curve in (0, 1, 2):   # whole-batch fixed-base and variable-base multiplications
+        g = O.generator(curve)
+        k = V.scalars(n, curve, 8001 + curve)
+        k[::1001] = 0
+        t0 = time.perf_counter(); got = ctx.batch_mul_fixed(curve, k, g); t1 = time.perf_counter()
+        want = O.batch_mul_fixed(curve, k, g, nthreads=16); t2 = time.perf_counter()
+        total += report("multiply fixed-base curve %d" % curve, got, want, t1 - t0, t2 - t1)
+        p = V.points(n, curve, 8011 + curve)
+        p[7::997] = O.identity(curve)
+        t0 = time.perf_counter(); got = ctx.batch_mul(curve, k, p); t1 = time.perf_counter()
+        want = O.batch_mul(curve, k, p, nthreads=16); t2 = time.perf_counter()
+        total += report("multiply variable-base curve %d" % curve, got, want, t1 - t0, t2 - t1)
     for curve, fn, ofn in ((0, ctx.ecdsa_verify_secp256k1, O.batch_secp256k1_ecdsa_verify), (1, ctx.ecdsa_verify_p256, O.batch_p256_ecdsa_verify)):
         dg = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
         dg[::3, 0] &= 0x7F
