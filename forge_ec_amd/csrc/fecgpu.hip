@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <system_error>
 #include <thread>
@@ -1175,8 +1176,9 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
     if (rc != FEC_OK) return rc;
   }
   // the loop returns at the first signature that fails a check (317-342): nothing after it is computed
-  std::vector<unsigned char> flags(n);
-  if (hipMemcpyAsync(flags.data(), work + n * 352, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  std::unique_ptr<unsigned char[]> flags(new (std::nothrow) unsigned char[n]);  // no exception may cross the C ABI
+  if (!flags) return FEC_E_OOM;
+  if (hipMemcpyAsync(flags.get(), work + n * 352, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
     (void)hipGetLastError();
     return FEC_E_LAUNCH;
