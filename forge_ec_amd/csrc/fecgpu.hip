@@ -1661,15 +1661,21 @@ int fec_ctx_wipe(fec_ctx* ctx) {
   if (ctx->device < 0 || !ctx->stream) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   (void)hipDeviceSynchronize();
+  // hipMemset is asynchronous with respect to the host and runs on the NULL stream, which the ctx's non-blocking
+  // stream does not synchronise with: a launch issued right after the wipe could run before the tail of the
+  // memsets and have its work area zeroed under it (seen as an intermittent "point at infinity" from the canonical
+  // mul_base that followed a signing helper).  The wipe therefore goes to the ctx stream and is waited for.
+  hipStream_t st = ctx->stream;
   bool ok = true;
   for (int i = 0; i < 8; ++i)
-    if (ctx->d_buf[i]) ok = ok && hipMemset(ctx->d_buf[i], 0, ctx->d_cap[i]) == hipSuccess;
+    if (ctx->d_buf[i]) ok = ok && hipMemsetAsync(ctx->d_buf[i], 0, ctx->d_cap[i], st) == hipSuccess;
   for (auto& e : ctx->stream_scratch)
-    if (e.buf) ok = ok && hipMemset(e.buf, 0, e.cap) == hipSuccess;
-  if (ctx->d_win_scratch) ok = ok && hipMemset(ctx->d_win_scratch, 0, ctx->win_scratch_cap) == hipSuccess;
-  if (ctx->d_zbuf) ok = ok && hipMemset(ctx->d_zbuf, 0, ctx->zbuf_cap) == hipSuccess;
-  if (ctx->d_tbuf) ok = ok && hipMemset(ctx->d_tbuf, 0, ctx->tbuf_cap) == hipSuccess;
-  if (ctx->d_verify) ok = ok && hipMemset(ctx->d_verify, 0, ctx->verify_cap) == hipSuccess;
+    if (e.buf) ok = ok && hipMemsetAsync(e.buf, 0, e.cap, st) == hipSuccess;
+  if (ctx->d_win_scratch) ok = ok && hipMemsetAsync(ctx->d_win_scratch, 0, ctx->win_scratch_cap, st) == hipSuccess;
+  if (ctx->d_zbuf) ok = ok && hipMemsetAsync(ctx->d_zbuf, 0, ctx->zbuf_cap, st) == hipSuccess;
+  if (ctx->d_tbuf) ok = ok && hipMemsetAsync(ctx->d_tbuf, 0, ctx->tbuf_cap, st) == hipSuccess;
+  if (ctx->d_verify) ok = ok && hipMemsetAsync(ctx->d_verify, 0, ctx->verify_cap, st) == hipSuccess;
+  ok = ok && hipStreamSynchronize(st) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
     return FEC_E_DEVICE;

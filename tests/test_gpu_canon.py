@@ -613,3 +613,22 @@ def test_eddsa_sign_rfc8032(gpu_ctx):
         sig = Renc + M.unlimbs(S[0]).to_bytes(32, "little")
         assert sig.hex() == sighex, "r mod l = %x (want %x), R status %s, xy %s" % (
             M.unlimbs(rl[0]), r % E.N, st, [hex(int(v)) for v in xy[0]])
+
+
+def test_wipe_is_ordered_before_the_next_call(gpu_ctx):
+    """fec_ctx_wipe zeroes the ctx's device work areas; it must be complete when it returns.  (It once used
+    hipMemset on the NULL stream -- asynchronous to the host, not ordered with the ctx's non-blocking stream -- and
+    a call that followed a signing helper intermittently had its Z buffer zeroed between two of its kernels:
+    "point at infinity" out of a plain k*B.)"""
+    from forge_ec_amd.canon import CanonEd25519, CanonSecp256k1
+    for cls in (CanonEd25519, CanonSecp256k1):
+        dev = cls(gpu_ctx)
+        k = _arr([0x8332edb9e5d3ac8522a07b5a1857169a67e6509ab59af23ccdb039970ffbf8f, 5, 2**200 + 12345])
+        want_xy, want_st = dev.mul_base(k)
+        assert not want_st.any()
+        big = V.scalars(1 << 16, 0, 9100)          # make the work areas large enough for the wipe to take a while
+        dev.mul_base(big)
+        for _ in range(25):
+            gpu_ctx.wipe()
+            xy, st = dev.mul_base(k)
+            assert np.array_equal(st, want_st) and np.array_equal(xy, want_xy)
