@@ -858,12 +858,13 @@ int fec_ctx_create(fec_ctx** out, int device) {
     }
   }
   {
+    // every copy goes to the ctx stream: it is non-blocking, i.e. NOT ordered with NULL-stream work
     bool ok = ensure(ctx, 0, 64) == FEC_OK && ensure(ctx, 1, 64) == FEC_OK;
-    ok = ok && hipMemcpy(ctx->d_buf[0], SECP_GXY, 64, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(ctx->d_buf[1], SECP_R2X2, 64, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(ctx->d_gen[0] + 8, FE_ONE, 32, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(ctx->d_gen[1], GEN_P256, 96, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(ctx->d_gen[2], GEN_ED, 128, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpyAsync(ctx->d_buf[0], SECP_GXY, 64, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(ctx->d_buf[1], SECP_R2X2, 64, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(ctx->d_gen[0] + 8, FE_ONE, 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(ctx->d_gen[1], GEN_P256, 96, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(ctx->d_gen[2], GEN_ED, 128, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
     // secp256k1: (gx, gy) * R_SQUARED;  Ed25519: t = x * y
     ok = ok && launch_field(ctx, FEC_SECP256K1, FEC_F_MUL, (const u64*)ctx->d_buf[0],
                             (const u64*)ctx->d_buf[1], ctx->d_gen[0], 2) == FEC_OK;
