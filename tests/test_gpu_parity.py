@@ -191,6 +191,32 @@ def test_p256_ladder_takes_the_equal_points_branch(gpu_ctx, oracle):
                  "p256 fixed-base on a self-doubling base")
 
 
+def test_ed25519_scheduler_takes_the_rare_branches(gpu_ctx, oracle):
+    """Ed25519 Add's early-outs inside the scheduler kernel (padd_mem / pdbl_mem re-read both operands in a rare
+    branch): points with x = 0 satisfy x == -x, so their doubling takes the "opposite points" exit and yields the
+    identity, after which every addition meets an identity addend; y == z with x = 0 but t != 0 is NOT the identity.
+    Such lanes are mixed with ordinary ones so that wavefronts hold both kinds."""
+    n = 900
+    k, p = V.scalars(n, 2, 397), V.points(n, 2, 398)
+    rng = np.random.default_rng(4)
+    special = rng.choice(n, size=120, replace=False)
+    ys = V.field_elements(len(special), 2, 399)
+    for j, i in enumerate(special):
+        pt = np.zeros(16, dtype=np.uint64)
+        pt[4:8] = ys[j]                       # y
+        pt[8:12] = ys[j] if j % 3 == 0 else np.array([1, 0, 0, 0], dtype=np.uint64)   # z == y for a third of them
+        if j % 2:
+            pt[12:16] = V.limbs_of(7 + j)     # t != 0: never the identity
+        p[i] = pt
+        if j % 4 == 0:
+            k[i] = V.limbs_of(1 + 2 * j)      # small scalars: few steps before the high zero bits
+    got = gpu_ctx.batch_mul(2, k, p)
+    want = oracle.batch_mul(2, k, p, nthreads=8)
+    _assert_same(got, want, "ed25519 scheduler with x = 0 lanes")
+    dm = gpu_ctx.batch_double_mul(2, k[:300], k[300:600], p[:300])
+    _assert_same(dm, oracle.batch_double_mul(2, k[:300], k[300:600], p[:300], nthreads=8), "ed25519 double-mul with x = 0 lanes")
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_batch_mul_fixed_matches_oracle(gpu_ctx, oracle, curve):
     n = 1000
