@@ -215,6 +215,11 @@ def test_ed25519_scheduler_takes_the_rare_branches(gpu_ctx, oracle):
     _assert_same(got, want, "ed25519 scheduler with x = 0 lanes")
     dm = gpu_ctx.batch_double_mul(2, k[:300], k[300:600], p[:300])
     _assert_same(dm, oracle.batch_double_mul(2, k[:300], k[300:600], p[:300], nthreads=8), "ed25519 double-mul with x = 0 lanes")
+    # the table kernel (padd_table) on bases whose addend table degenerates: identity entries, opposite points
+    for i in special[:4]:
+        base = np.ascontiguousarray(p[i])
+        _assert_same(gpu_ctx.batch_mul_fixed(2, k[:300], base), oracle.batch_mul_fixed(2, k[:300], base, nthreads=8),
+                     "ed25519 fixed-base on an x = 0 base")
 
 
 @pytest.mark.parametrize("curve", CURVES)
