@@ -1,7 +1,7 @@
 """Whole-batch differential soak on the GPU box: every element of large random batches of the verification /
 key-exchange / validation pipelines against the C oracle (16 host threads).  Prints one JSON line per pipeline.
 
-  python tools/soak.py [log2-batch, default 19]
+  python tests/soak.py [log2-batch, default 19]
 """
 import json
 import os
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ is one of the places allowed to call the oracle
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import forge_ec_amd as F  # noqa: E402
