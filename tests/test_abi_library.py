@@ -82,3 +82,21 @@ def test_generated_field_asm_is_current(tmp_path):
     gen.main()
     assert open(gen.OUT).read() == open(os.path.join(root, "forge_ec_amd", "csrc", "field_asm.inc")).read()
     assert gen.SECP_TOP == gen.P256_TOP == gen.ED_TOP == 168
+
+
+def test_only_the_allowed_places_call_the_oracle():
+    """oracle/ is test infrastructure: besides tests/, only __graft_entry__.smoke() and bench.py's cpu_baseline leg
+    may import it -- no script under tools/, rust/, examples/ or the package does."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b|from\s+\.+oracle\b)|libforge_ec_oracle", re.M)
+    for top in ("tools", "forge_ec_amd", "rust", "examples", "include"):
+        for dirpath, _, files in os.walk(os.path.join(root, top)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".cpp", ".hip", ".hpp", ".h", ".c", ".rs")):
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert not pat.search(text), os.path.join(dirpath, f)
+    bench = open(os.path.join(root, "bench.py")).read()
+    assert len(re.findall(r"^\s*from oracle|^\s*import oracle", bench, flags=re.M)) == 1   # inside cpu_baseline()
+    assert "def cpu_baseline" in bench and bench.index("def cpu_baseline") < bench.index("from oracle")
