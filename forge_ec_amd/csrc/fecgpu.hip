@@ -556,6 +556,35 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
   return L.done();
 }
 
+// A launch forked onto the ctx's second stream and joined back (events; no host blocking).  Inactive -- `s` is the
+// main stream and fork_done / join do nothing -- for large batches, when the ctx has no second stream, or when the
+// main stream IS the second stream.
+struct SideStream {
+  // two launches of n elements each fit side by side: 256 CUs x 768 lanes / 2
+  static constexpr size_t kSideStreamMax = 98304;
+  hipStream_t main, s;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  bool active = false;
+  SideStream(fec_ctx* ctx, hipStream_t main_, size_t n, size_t limit = kSideStreamMax) : main(main_), s(main_) {
+    if (n > limit || !ctx->stream2 || ctx->stream2 == main_) return;
+    if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    (void)hipEventRecord(ev_in, main);
+    (void)hipStreamWaitEvent(ctx->stream2, ev_in, 0);
+    s = ctx->stream2;
+    active = true;
+  }
+  void fork_done() { if (active) (void)hipEventRecord(ev_out, s); }
+  void join() { if (active) (void)hipStreamWaitEvent(main, ev_out, 0); }
+  ~SideStream() {
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+  }
+};
+
 // out[i] = multiply(G, u1[i]) + multiply(q[i], u2[i])   (ecdsa.rs:254-256).
 // Composed from the single-multiplication kernels: u1*G and u2*Q into per-stream scratch (secp256k1: the
 // 3-waves-per-SIMD ladder, fixed then variable base; P-256: the task scheduler twice; Ed25519: the LDS
@@ -582,17 +611,28 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
   }
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op"
                         : (curve == FEC_P256 ? "k_p256_mul_sched x2 + k_point_op" : "k_ed_fixed_base + k_ed_mul_pers + k_point_op"));
+  // Up to 98304 elements one launch fills at most half of the chip's lanes and is bound by the latency of one
+  // multiplication: the fixed-base product then runs on the ctx's second stream beside the variable-base one (the
+  // persistent kernels, one workgroup per CU, each on half of the CUs).
+  // (Ed25519: the table kernel is short and not capped to half of the CUs; side by side pays up to 2^15 elements)
+  SideStream side(ctx, L.s, n, curve == FEC_ED25519 ? (size_t)1 << 15 : SideStream::kSideStreamMax);
   if (curve == FEC_SECP256K1) {  // the 3-waves-per-SIMD ladder twice (fixed G, then Q) beats the fused 2-wave kernel
-    secp_launch_mul(true, a, gen, ta, n, L.s);
+    secp_launch_mul(true, a, gen, ta, n, side.s);
+    side.fork_done();
     secp_launch_mul(false, b2, q, tb, n, L.s);
+    side.join();
     hipLaunchKernelGGL((k_point_op<Secp>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   } else if (curve == FEC_P256) {
-    p256_launch_mul(true, a, gen, ta, n, L.s);
-    p256_launch_mul(false, b2, q, tb, n, L.s);
+    p256_launch_mul(true, a, gen, ta, n, side.s, side.active ? 2 : 1);
+    side.fork_done();
+    p256_launch_mul(false, b2, q, tb, n, L.s, side.active ? 2 : 1);
+    side.join();
     hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   } else {
-    ed_fixed_launch(a, gen, ctx->d_ed_table, ta, n, L.s);
-    ed_launch_mul(b2, q, tb, n, L.s);
+    ed_fixed_launch(a, gen, ctx->d_ed_table, ta, n, side.s);
+    side.fork_done();
+    ed_launch_mul(b2, q, tb, n, L.s, side.active ? 2 : 1);
+    side.join();
     hipLaunchKernelGGL((k_point_op<Ed>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   }
   return L.done();

@@ -7,11 +7,13 @@
 namespace fecgpu {
 
 // kernels_p256.hip: P-256 Curve::multiply, workgroup task scheduler.  out[i] = multiply(fixed ? points[0] : points[i], scalars[i])
-void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
+// `cu_divisor` > 1: the launch takes at most that fraction of the CUs (a second launch on another stream runs beside it).
+void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,
+                     unsigned cu_divisor = 1);
 
 // kernels_ed.hip: Ed25519 variable-base Curve::multiply, persistent workgroup task scheduler (one workgroup
 // per CU, element state in LDS, slots refilled from the workgroup's range).
-void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
+void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s, unsigned cu_divisor = 1);
 // kernels_ed.hip: Ed25519 fixed-base multiply from the 256-entry addend table of `base` (table[j] = 2^j * base by
 // the reference's own doubling chain, built once per base by ed_build_table_launch; 256 * 32 words).
 void ed_build_table_launch(const u32* base, u32* table, hipStream_t s);

@@ -66,7 +66,7 @@ struct ESecp {
   FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return secp::to_affine(p, x, y); }
   FEC_DEV static fe wmul(const fe& a, const fe& b) { return secp::sc_mul(a, b); }   // impl Mul for Scalar
   FEC_DEV static fe wadd(const fe& a, const fe& b) { return secp::sc_add(a, b); }   // impl Add for Scalar
-  static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s) {
+  static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s, unsigned = 1) {
     secp_launch_mul(fixed, k, p, o, n, s);
   }
 };
@@ -105,8 +105,8 @@ struct EP256 {
   FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return p256::to_affine(p, x, y); }
   FEC_DEV static fe wmul(const fe& a, const fe& b) { return p256::sc_mul32(a, b); }
   FEC_DEV static fe wadd(const fe& a, const fe& b) { return p256::sc_fe(p256::sc_add(p256::sc_of(a), p256::sc_of(b))); }
-  static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s) {
-    p256_launch_mul(fixed, k, p, o, n, s);
+  static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s, unsigned cu_divisor = 1) {
+    p256_launch_mul(fixed, k, p, o, n, s, cu_divisor);
   }
 };
 
@@ -419,7 +419,7 @@ void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hip
   u32* ta = reinterpret_cast<u32*>(w + n * 160);
   u32* tb = reinterpret_cast<u32*>(w + n * 256);
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
-  const bool two = side != nullptr && side != s && n < ((size_t)1 << 16) &&
+  const bool two = side != nullptr && side != s && n <= 98304 &&  // two launches side by side, half of the CUs each
                    hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess &&
                    hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) == hipSuccess;
   hipStream_t sf = s;
@@ -429,10 +429,10 @@ void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hip
     sf = side;
   }
   if (curve == FEC_SECP256K1) ESecp::launch_mul(true, u1, gen, ta, n, sf);
-  else EP256::launch_mul(true, u1, gen, ta, n, sf);
+  else EP256::launch_mul(true, u1, gen, ta, n, sf, two ? 2 : 1);
   if (two) (void)hipEventRecord(ev_out, side);
   if (curve == FEC_SECP256K1) ESecp::launch_mul(false, u2, q, tb, n, s);
-  else EP256::launch_mul(false, u2, q, tb, n, s);
+  else EP256::launch_mul(false, u2, q, tb, n, s, two ? 2 : 1);
   if (two) (void)hipStreamWaitEvent(s, ev_out, 0);
   if (ev_in) (void)hipEventDestroy(ev_in);
   if (ev_out) (void)hipEventDestroy(ev_out);

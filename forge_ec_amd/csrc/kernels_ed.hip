@@ -94,57 +94,48 @@ __global__ __launch_bounds__(64) void k_ed_build_table(const u32* __restrict__ b
   }
 }
 
-// ed::padd (1864-1928) with the addend left in the LDS table: its coordinates are loaded where they are used and the
-// early-outs (identity operands, opposite points) re-read it inside their rare branch, so that the addend is not live
-// across the nine products -- what lets the fixed-base kernel run at three wavefronts per SIMD (168 VGPRs).  Same
-// products, operands and order as ed::padd.
+// ed::padd (1864-1928) against an entry of the fixed-base LDS table.  What Add computes from the addend alone --
+// rhs.y - rhs.x and rhs.y + rhs.x (1897-1898) -- is a function of the table entry, so it is computed once per entry
+// when the table is staged (same Sub / Add, same operands): an LDS entry holds y - x, y + x, z, t and word 0 of x and
+// of y (FT_STRIDE words).  The coordinates are loaded where they are used, so that the addend is not live across the
+// nine products (three wavefronts per SIMD, 168 VGPRs).  The early-outs (1869-1880) sit behind one-word tests every
+// lane taking one must pass -- is_identity needs x == 0, the negation test needs p.y == q.y -- and evaluate the exact
+// masks on the plain entry (x, y, z, t: `g`, the table in global memory) inside the rare branch.
+constexpr int FT_STRIDE = 35;   // odd: lanes reading different entries spread over the LDS banks
 FEC_DEV fe ld_tab(const u32* e, int c) {
   fe a;
   FEC_UNROLL for (int i = 0; i < 8; ++i) a.w[i] = e[8 * c + i];
   return a;
 }
-FEC_DEV ed::pt padd_table(const ed::pt& p, const u32* e) {
+FEC_DEV ed::pt padd_table(const ed::pt& p, const u32* e, const u32* g) {
   using namespace ed;
-  lmask opposite, idq;
+  const lmask maybe = lanes_where(p.x.w[0] == 0u || e[32] == 0u || p.y.w[0] == e[33]);
   fe a, b, d;
-  {
-    const fe qx = ld_tab(e, 0), qy = ld_tab(e, 1);
-    {
-      const fe qz = ld_tab(e, 2);
-      idq = fe_is_zero(qx) & fe_eq(qy, qz);                      // is_identity (1785-1791), t below
-      d = mul(p.z, qz);
-    }
-    opposite = fe_eq(p.x, neg(qx)) & fe_eq(p.y, qy);            // 1878, raw coordinates
-    a = mul(sub(p.y, p.x), sub(qy, qx));
-    b = mul(add(p.y, p.x), add(qy, qx));
-  }
+  d = mul(p.z, ld_tab(e, 2));
+  a = mul(sub(p.y, p.x), ld_tab(e, 0));
+  b = mul(add(p.y, p.x), ld_tab(e, 1));
   __builtin_amdgcn_sched_barrier(0);  // keep the load of q.t below the first three products (register budget)
-  fe c;
-  {
-    const fe qt = ld_tab(e, 3);
-    idq &= fe_is_zero(qt);
-    c = mul(mul(p.t, qt), D_());
-  }
+  fe c = mul(mul(p.t, ld_tab(e, 3)), D_());
   __builtin_amdgcn_sched_barrier(0);
-  const lmask idp = is_identity(p);
-  const fe ee = sub(b, a), f = sub(d, c), g = add(d, c), h = add(b, a);
+  const fe ee = sub(b, a), f = sub(d, c), gg = add(d, c), h = add(b, a);
   pt o;
   o.x = mul(ee, f);
-  o.y = mul(g, h);
+  o.y = mul(gg, h);
   o.t = mul(ee, h);
-  o.z = mul(f, g);
-  if (__builtin_expect((opposite | idp | idq) != 0, 0)) {  // improbable after a lane's first addition (acc = identity)
-    pt q;
-    q.x = ld_tab(e, 0); q.y = ld_tab(e, 1); q.z = ld_tab(e, 2); q.t = ld_tab(e, 3);
+  o.z = mul(f, gg);
+  if (__builtin_expect(maybe != 0, 0)) {  // improbable: a lane's first addition is a copy (multiply_fixed_in_place)
+    const pt q = ld_words(g);
+    const lmask opposite = fe_eq(p.x, neg(q.x)) & fe_eq(p.y, q.y);  // 1878, raw coordinates
+    const lmask idp = is_identity(p), idq = is_identity(q);
     o = pt_select(o, identity(), uniform_mask(opposite));
     o = pt_select(o, p, uniform_mask(idq));
-    o = pt_select(o, q, idp);
+    o = pt_select(o, q, uniform_mask(idp));
   }
   return o;
 }
 
 // ed::multiply_fixed with the addend read in place (see padd_table)
-FEC_DEV ed::pt multiply_fixed_in_place(const ed::pt& base, const u32* tab, const u32* kw) {
+FEC_DEV ed::pt multiply_fixed_in_place(const ed::pt& base, const u32* tab, const u32* gtab, const u32* kw) {
   using namespace ed;
   u32 any = 0;
   FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kw[i * KSTRIDE];
@@ -152,6 +143,18 @@ FEC_DEV ed::pt multiply_fixed_in_place(const ed::pt& base, const u32* tab, const
   pt result = identity();
   int wi = 0;
   u32 cur = kw[0];
+  {
+    // The lane's FIRST addition is identity() + addend, which Add answers with the addend through its first
+    // early-out (1869-1871): a copy of the table entry instead of nine products.
+    while (cur == 0 && wi < 7) {
+      ++wi;
+      cur = kw[wi * KSTRIDE];
+    }
+    const bool have = cur != 0;
+    const pt q = ld_words(gtab + (have ? (u32)wi * 32u + (u32)__builtin_ctz(cur) : 0u) * 32u);
+    cur &= cur - 1;  // (0 stays 0)
+    result = pt_select(result, q, lanes_where(have));
+  }
 #pragma unroll 1
   for (;;) {
     while (cur == 0 && wi < 7) {  // advance to this lane's next non-zero scalar word
@@ -163,7 +166,8 @@ FEC_DEV ed::pt multiply_fixed_in_place(const ed::pt& base, const u32* tab, const
     if (active == 0) break;  // every lane of the wavefront has consumed its set bits
     const u32 bpos = have ? (u32)__builtin_ctz(cur) : 0u;
     cur &= cur - 1;
-    const pt sum = padd_table(result, tab + (have ? (u32)wi * 32u + bpos : 0u) * ED_TSTRIDE);
+    const u32 j = have ? (u32)wi * 32u + bpos : 0u;
+    const pt sum = padd_table(result, tab + j * FT_STRIDE, gtab + j * 32u);
     result = pt_select(result, sum, active);
   }
   return pt_select(result, identity(), early);
@@ -183,18 +187,26 @@ __global__ __launch_bounds__(TPB, 3) void k_ed_fixed_base(const u32* __restrict_
                                                        const u32* __restrict__ table,
                                                        u32* __restrict__ out, size_t n) {
   __shared__ u32 lds_k[8 * TPB];
-  __shared__ u32 lds_t[256 * ed::ED_TSTRIDE];   // the addend table; reused to stage the results out once every lane is done
+  __shared__ u32 lds_t[256 * FT_STRIDE];   // the addend table (see padd_table); reused to stage the results out once every lane is done
   __shared__ int lds_bin[260];
   __shared__ unsigned short lds_perm[TPB];
   const int valid = block_valid(n);
   const size_t first = (size_t)blockIdx.x * TPB;
   const int e = threadIdx.x;
   stage_in<8>(lds_k, scalars + first * 8, valid);
-  for (int v = threadIdx.x; v < 256 * 32 / 4; v += TPB) {  // 32 KiB table, 16-byte loads (L2-resident)
-    uint4 x = *reinterpret_cast<const uint4*>(table + (size_t)v * 4);
-    int j = (v * 4) / 32, w = (v * 4) % 32;
-    u32* d = lds_t + j * ed::ED_TSTRIDE + w;
-    d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+  static_assert(TPB == 256, "one thread stages one table entry");
+  {  // entry e of the 32 KiB table (L2-resident): y - x, y + x, z, t, x.w[0], y.w[0]
+    const ed::pt q = ld_words(table + (size_t)e * 32);
+    const fe ymx = ed::sub(q.y, q.x), ypx = ed::add(q.y, q.x);
+    u32* d = lds_t + e * FT_STRIDE;
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      d[i] = ymx.w[i];
+      d[8 + i] = ypx.w[i];
+      d[16 + i] = q.z.w[i];
+      d[24 + i] = q.t.w[i];
+    }
+    d[32] = q.x.w[0];
+    d[33] = q.y.w[0];
   }
   for (int v = e; v < 260; v += TPB) lds_bin[v] = 0;
   __syncthreads();
@@ -234,10 +246,10 @@ __global__ __launch_bounds__(TPB, 3) void k_ed_fixed_base(const u32* __restrict_
   ed::pt r = ed::identity();
   if (src < valid) {
     ed::pt b = ld_words(base);
-    r = multiply_fixed_in_place(b, lds_t, lds_k + src);
+    r = multiply_fixed_in_place(b, lds_t, table, lds_k + src);
   }
   __syncthreads();                      // every lane has read its last table entry
-  static_assert(256 * ed::ED_TSTRIDE >= 32 * TPB, "the table region holds the staged results");
+  static_assert(256 * FT_STRIDE >= 32 * TPB, "the table region holds the staged results");
   if (src < valid) st_lds(lds_t + src, TPB, r);
   __syncthreads();
   stage_out<32>(out + first * 32, lds_t, valid);
@@ -265,17 +277,17 @@ FEC_DEV fe ld_lcoord(const u32* l, int stride, int c) {
 // result (global) + addend (LDS)
 FEC_DEV ed::pt padd_mem(const u32* gr, const u32* la, int stride) {
   using namespace ed;
-  lmask opposite, idp, idq;
+  // the early-outs sit behind one-word tests every lane taking one must pass (is_identity: x == 0; negation test:
+  // p.y == q.y); the exact masks are evaluated inside the rare branch
+  lmask maybe;
   fe a, b, d;
   {
     const fe px = ld_gcoord(gr, 0), py = ld_gcoord(gr, 1), qx = ld_lcoord(la, stride, 0), qy = ld_lcoord(la, stride, 1);
     {
       const fe pz = ld_gcoord(gr, 2), qz = ld_lcoord(la, stride, 2);
-      idp = fe_is_zero(px) & fe_eq(py, pz);                    // is_identity (1785-1791), t below
-      idq = fe_is_zero(qx) & fe_eq(qy, qz);
       d = mul(pz, qz);
     }
-    opposite = fe_eq(px, neg(qx)) & fe_eq(py, qy);             // 1878, raw coordinates
+    maybe = lanes_where(px.w[0] == 0u || qx.w[0] == 0u || py.w[0] == qy.w[0]);
     a = mul(sub(py, px), sub(qy, qx));
     b = mul(add(py, px), add(qy, qx));
   }
@@ -283,8 +295,6 @@ FEC_DEV ed::pt padd_mem(const u32* gr, const u32* la, int stride) {
   fe c;
   {
     const fe pt_ = ld_gcoord(gr, 3), qt = ld_lcoord(la, stride, 3);
-    idp &= fe_is_zero(pt_);
-    idq &= fe_is_zero(qt);
     c = mul(mul(pt_, qt), D_());
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -294,10 +304,12 @@ FEC_DEV ed::pt padd_mem(const u32* gr, const u32* la, int stride) {
   o.y = mul(g, h);
   o.t = mul(ee, h);
   o.z = mul(f, g);
-  if (__builtin_expect((opposite | idp | idq) != 0, 0)) {
+  if (__builtin_expect(maybe != 0, 0)) {  // an element's first addition (result = identity); improbable afterwards
     pt p, q;
     p.x = ld_gcoord(gr, 0); p.y = ld_gcoord(gr, 1); p.z = ld_gcoord(gr, 2); p.t = ld_gcoord(gr, 3);
     q.x = ld_lcoord(la, stride, 0); q.y = ld_lcoord(la, stride, 1); q.z = ld_lcoord(la, stride, 2); q.t = ld_lcoord(la, stride, 3);
+    const lmask opposite = fe_eq(p.x, neg(q.x)) & fe_eq(p.y, q.y);  // 1878, raw coordinates
+    const lmask idp = is_identity(p), idq = is_identity(q);       // 1785-1791
     o = pt_select(o, identity(), uniform_mask(opposite));
     o = pt_select(o, p, uniform_mask(idq));
     o = pt_select(o, q, uniform_mask(idp));
@@ -307,17 +319,18 @@ FEC_DEV ed::pt padd_mem(const u32* gr, const u32* la, int stride) {
 // addend.double() = addend + addend (1828-1832), addend in LDS
 FEC_DEV ed::pt pdbl_mem(const u32* la, int stride) {
   using namespace ed;
-  lmask opposite, idp;
+  // Add's early-outs with q = p: is_identity needs x == 0; the negation test x == -x needs word 0 of x to equal
+  // word 0 of neg(x), which is 0 for x == 0 and 0xFFFFFFED - x.w[0] otherwise (547-570)
+  lmask maybe;
   fe a, b, d;
   {
     const fe x = ld_lcoord(la, stride, 0), y = ld_lcoord(la, stride, 1);
     {
       const fe z = ld_lcoord(la, stride, 2);
-      idp = fe_is_zero(x) & fe_eq(y, z);
       d = sqr_exact(z);
     }
     __builtin_amdgcn_sched_barrier(0);
-    opposite = fe_eq(x, neg(x));                               // Add's test with q = p: x == -x
+    maybe = lanes_where(x.w[0] == 0u || x.w[0] == 0xFFFFFFEDu - x.w[0]);
     a = sqr_exact(sub(y, x));
     b = sqr_exact(add(y, x));
   }
@@ -325,7 +338,6 @@ FEC_DEV ed::pt pdbl_mem(const u32* la, int stride) {
   fe c;
   {
     const fe t = ld_lcoord(la, stride, 3);
-    idp &= fe_is_zero(t);
     c = mul(sqr_exact(t), D_());
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -335,9 +347,11 @@ FEC_DEV ed::pt pdbl_mem(const u32* la, int stride) {
   o.y = mul(g, h);
   o.t = mul(ee, h);
   o.z = mul(f, g);
-  if (__builtin_expect((opposite | idp) != 0, 0)) {
+  if (__builtin_expect(maybe != 0, 0)) {
     pt p;
     p.x = ld_lcoord(la, stride, 0); p.y = ld_lcoord(la, stride, 1); p.z = ld_lcoord(la, stride, 2); p.t = ld_lcoord(la, stride, 3);
+    const lmask opposite = fe_eq(p.x, neg(p.x));                 // Add's test with q = p: x == -x
+    const lmask idp = is_identity(p);
     o = pt_select(o, identity(), uniform_mask(opposite));
     o = pt_select(o, p, uniform_mask(idp));
   }
@@ -402,8 +416,8 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
         continue;
       }
       st_lds(lds_ad + e, PS, base);
-      st_glb(out + g * 32, ed::identity());
       lds_gid[e] = (u32)rel;
+      st_glb(out + g * 32, ed::identity());
       lds_step[e] = 0;
       return (scalars[g * 8] & 1u) ? 1 : 0;
     }
@@ -516,8 +530,8 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
       if (active) {
         st_lds(lds_ad + e, PS, d);
         ++step;
-        lds_step[e] = (unsigned short)step;
         const u32 bit = scalar_bit(scalars, lo + lds_gid[e], step);
+        lds_step[e] = (unsigned short)step;
         fin = !bit && step == 255;
         nxt = bit ? 1 : 0;
       }
@@ -543,15 +557,16 @@ void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32*
   hipLaunchKernelGGL(k_ed_fixed_base, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, scalars, base, table, out, n);
 }
 
-void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s) {
-  // one workgroup per CU, each with a contiguous range of at least 64 elements
+void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s, unsigned cu_divisor) {
+  // one workgroup per CU (or per cu_divisor-th CU), each with a contiguous range of at least 64 elements
   static const unsigned cus = [] {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     return (unsigned)v;
   }();
   size_t grid = (n + 63) / 64;
-  if (grid > cus) grid = cus;
+  const unsigned cap = cu_divisor > 1 && cus >= cu_divisor ? cus / cu_divisor : cus;
+  if (grid > cap) grid = cap;
   const unsigned per_wg = (unsigned)((n + grid - 1) / grid);
   grid = (n + per_wg - 1) / per_wg;
   hipLaunchKernelGGL(k_ed_mul_pers, dim3((unsigned)grid), dim3(PT), 0, s, scalars, points, out, n, per_wg);

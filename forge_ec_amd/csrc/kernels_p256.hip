@@ -349,15 +349,16 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   }
 }
 
-void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s) {
-  // one workgroup per CU, each with a contiguous range of at least 64 elements
+void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s, unsigned cu_divisor) {
+  // one workgroup per CU (or per cu_divisor-th CU), each with a contiguous range of at least 64 elements
   static const unsigned cus = [] {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     return (unsigned)v;
   }();
   size_t grid = (n + 63) / 64;
-  if (grid > cus) grid = cus;
+  const unsigned cap = cu_divisor > 1 && cus >= cu_divisor ? cus / cu_divisor : cus;
+  if (grid > cap) grid = cap;
   const unsigned per_wg = (unsigned)((n + grid - 1) / grid);
   grid = (n + per_wg - 1) / per_wg;
   if (fixed) hipLaunchKernelGGL((k_p256_mul_sched<true>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);

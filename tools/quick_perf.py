@@ -1,9 +1,13 @@
-"""Quick single-GPU timing probe: kernel ms (HIP events inside the library) per curve/config."""
+"""Quick single-GPU timing probe: kernel ms (HIP events inside the library) per curve/config.
+FEC_AB_LIB=<path> times another build of the library (same-box A/B comparisons)."""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
+from forge_ec_amd import _lib
+if os.environ.get("FEC_AB_LIB"):
+    _lib.SO_PATH = os.path.abspath(os.environ["FEC_AB_LIB"])
 import forge_ec_amd as F
 import vectors as V
 
