@@ -93,8 +93,14 @@ FEC_DEV p256::pt pdouble_in_place(const u32* lp, int stride) {
   r.y = sub(mul(e, sub(d, r.x)), mul_small(yyyy, 8));
   const fe y = ld_coord(lp, stride, 1), z = ld_coord(lp, stride, 2);
   const fe z3 = add(y, y);
-  r.z = fe_select(mul(z3, z), z3, fe_eq(z, fe_small(1)));
-  return pt_select(r, identity(), fe_is_zero(z));
+  r.z = mul(z3, z);
+  // z.is_one() (1909: once per element, on the first doubling after the result became the base point) and the
+  // identity early-out (1870) behind one-word tests every lane taking one must pass
+  if (__builtin_expect(lanes_where(z.w[0] <= 1u) != 0, 0)) {
+    r.z = fe_select(r.z, z3, fe_eq(z, fe_small(1)));
+    r = pt_select(r, identity(), fe_is_zero(z));
+  }
+  return r;
 }
 
 // p256::padd (1938-2007) with its operands left in memory: p in the slot (LDS), q in the caller's array.  Every
