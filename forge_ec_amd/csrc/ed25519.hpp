@@ -24,16 +24,15 @@ FEC_DEV fe D_() {  // 86-91
 // reduce (214-247): clear bit 255 and add 19 if it was set (no carry out is possible); then
 // subtract p if the value is >= p, i.e. if value + 19 reaches 2^255.
 FEC_DEV fe reduce(const fe& a) {
-  u32 top = a.w[7] >> 31;
-  fe v0 = a, v;
-  v0.w[7] &= 0x7FFFFFFFu;
-  add_word256(v, v0, top * 19u);
+  fe v = a;
+  const u32 top = a.w[7] >> 31;
+  v.w[7] &= 0x7FFFFFFFu;
+  const lmask cy = add_short1(v, top * 19u);          // leaves word 0 with probability 19 / 2^32
+  if (__builtin_expect(cy != 0, 0)) carry_from<1>(v, cy);
   // v < 2^255 + 19.  v >= p = 2^255 - 19 needs either bit 255 set again or words 1..6 all ones with
-  // w7 == 0x7FFFFFFF: ~2^-224 on random data, so the exact comparison sits behind a wave-uniform
-  // branch.
-  u32 ones = v.w[1] & v.w[2] & v.w[3] & v.w[4] & v.w[5] & v.w[6] & (v.w[7] | 0x80000000u);
-  lmask maybe = lanes_where(ones == 0xFFFFFFFFu || (v.w[7] >> 31) != 0);
-  if (maybe != 0) {
+  // w7 == 0x7FFFFFFF, either way a top word >= 0x7FFFFFFF: ~2^-31 per lane, so the exact comparison sits behind a
+  // wave-uniform branch.
+  if (__builtin_expect(lanes_where(v.w[7] >= 0x7FFFFFFFu) != 0, 0)) {
     fe u;
     lmask t;
     FEC_ADDK256(u, v, t, 19, 0, 0, 0, 0, 0, 0, 0);  // u = v + 19 < 2^256
@@ -45,21 +44,38 @@ FEC_DEV fe reduce(const fe& a) {
   return v;
 }
 
-// Add (458-488): a + b; if it carried out of 2^256, add 19 (wrapping); then reduce().
+// Add (458-488): a + b; if it carried out of 2^256, add 19 (wrapping); then reduce().  Canonical operands
+// (< 2^255) never carry: the + 19 sits behind a wave-uniform branch.
 FEC_DEV fe add(const fe& a, const fe& b) {
-  fe s, s2;
-  lmask carry = add256(s, a, b);
-  add_word256(s2, s, word_select(0u, 19u, carry));
-  return reduce(s2);
+  fe s;
+  const lmask carry = add256(s, a, b);
+  if (__builtin_expect(carry != 0, 0)) {
+    fe s2;
+    add_word256(s2, s, word_select(0u, 19u, carry));
+    s = s2;
+  }
+  return reduce(s);
 }
 
-// Sub (490-520): a - b; add p (wrapping) if it borrowed.  No reduce.
+// Sub (490-520): a - b; add p (wrapping) if it borrowed.  No reduce.  d + p = d - 19 + 2^255 (mod 2^256).
 FEC_DEV fe sub(const fe& a, const fe& b) {
-  fe d, w;
-  lmask borrow = sub256(d, a, b);
-  sub_word256(w, d, word_select(0u, 19u, borrow));   // d + p = d - 19 + 2^255
-  w.w[7] ^= word_select(0u, 0x80000000u, borrow);
-  return w;
+  fe d;
+  const lmask borrow = sub256(d, a, b);
+  lmask bw;  // the borrow of the - 19 leaves word 0 with probability 19 / 2^32
+#ifdef FEC_HOST_EMUL
+  bw = sub_short1(d, word_select(0u, 19u, borrow));
+  d.w[7] ^= word_select(0u, 0x80000000u, borrow);
+#else
+  u32 t;
+  asm("v_cndmask_b32_e64 %3, 0, 19, %4\n\t"
+      "v_sub_co_u32_e32 %0, vcc, %0, %3\n\t"
+      "v_cndmask_b32_e64 %3, 0, 1, %4\n\t"
+      "v_lshl_add_u32 %1, %3, 31, %1\n\t"     // toggling bit 255 = adding 2^31 to the top word
+      "s_mov_b64 %2, vcc"                      // last: %2 may share its registers with %4
+      : "+v"(d.w[0]), "+v"(d.w[7]), "=s"(bw), "=&v"(t) : "s"(borrow) : "vcc");
+#endif
+  if (__builtin_expect(bw != 0, 0)) borrow_from<1>(d, bw);  // commutes with the toggle (both are additions mod 2^32 on word 7)
+  return d;
 }
 
 // Neg (547-570): p - a (wrapping), 0 -> 0.

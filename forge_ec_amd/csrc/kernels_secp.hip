@@ -5,11 +5,12 @@
 // Held entirely in registers it needs 214-256 VGPRs (2 waves per SIMD).  The measured issue cost of
 // the v_mad_u64_u32 / v_addc pairs that make up most of the kernel drops from 5.3 to 5.0 cycles per
 // instruction with a third wavefront on the SIMD (profiles/valu_latency_r02.txt), so this kernel is
-// built for 168 VGPRs: both ladder points are PARKED in LDS at the top of a step (48 words per lane),
-// the addition consumes its register copies, the doubling's operand is re-read from LDS afterwards,
-// the field multiplications' fixed register block sits at v[132:167] (tools/gen_field_asm.py), and the
-// scalar is read from HBM one word per 32 steps instead of being staged in LDS.  LDS: 48 KiB per
-// workgroup, three workgroups per CU.
+// built for 168 VGPRs: both ladder points LIVE in LDS (48 words per lane) -- a step loads them for the
+// addition, re-reads the doubling's operand, and stores sum and doubling to the slots the scalar bit
+// selects (an address select instead of 72 register selects per step) -- the field multiplications'
+// fixed register block sits at v[132:167] (tools/gen_field_asm.py), and the scalar is read from HBM
+// one word per 32 steps instead of being staged in LDS.  LDS: 48 KiB per workgroup, three workgroups
+// per CU.
 #include <hip/hip_runtime.h>
 
 #include "../../include/fecgpu.h"
@@ -56,35 +57,36 @@ __global__ __launch_bounds__(TPB, 3) void k_secp_mul(const u32* __restrict__ sca
     u32 any = 0;
     FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kg[i];
     const lmask early = secp::is_identity(r1) | lanes_where(any == 0);
-    secp::pt r0 = secp::identity();
+    // The two ladder points LIVE in LDS: slot 0 (words 0..23) holds r0, slot 1 (words 24..47) r1.  A step reads both,
+    // adds them, re-reads the one the reference's kept doubling takes, and writes the sum and the doubling back to
+    // the slots the bit selects -- one address select per access instead of a register select per word.
+    u32* const slot0 = lds + e;
+    st3(slot0, TPB, secp::identity());
+    st3(slot0 + 24 * TPB, TPB, r1);
     u32 kword = 0;
 #pragma unroll 1
     for (int i = 0; i < 256; ++i) {
       if ((i & 31) == 0) kword = kg[i >> 5];
       // bit i of the ladder (2655-2659): byte i/8 of the little-endian bytes, MSB first in the byte
       const int sh = (((i >> 3) & 3) << 3) + 7 - (i & 7);
-      const lmask bit = lanes_where(((kword >> sh) & 1u) != 0);
-      st3(lds + e, TPB, r0);
-      st3(lds + 24 * TPB + e, TPB, r1);
+      const u32 b = (kword >> sh) & 1u;
       lmask nd;
-      secp::pt s = secp::padd_nodouble(r0, r1, nd);
+      secp::pt s = secp::padd_nodouble(ld3(slot0, TPB), ld3(slot0 + 24 * TPB, TPB), nd);
       if (__builtin_expect(nd != 0, 0)) {  // Add (1469-1473) returns self.double(): never on random inputs
-        secp::pt d0 = secp::pdouble(ld3(lds + e, TPB));
+        secp::pt d0 = secp::pdouble(ld3(slot0, TPB));
         s = secp::pt_select(s, d0, nd);
       }
-      // only the doubling the reference keeps (2669-2684): double(bit ? r1 : r0), operand re-read from LDS
-      secp::pt din;
-      FEC_UNROLL for (int w = 0; w < 8; ++w) {
-        din.x.w[w] = word_select(lds[w * TPB + e], lds[(24 + w) * TPB + e], bit);
-        din.y.w[w] = word_select(lds[(8 + w) * TPB + e], lds[(32 + w) * TPB + e], bit);
-        din.z.w[w] = word_select(lds[(16 + w) * TPB + e], lds[(40 + w) * TPB + e], bit);
-      }
-      secp::pt d = secp::pdouble(din);
-      r0 = secp::pt_select(d, s, bit);
-      r1 = secp::pt_select(s, d, bit);
+      // (r0, r1) = bit ? (s, d) : (d, s) with d = double(bit ? r1 : r0), the only doubling the reference keeps
+      // (2669-2684): the doubling's operand sits in slot `b`, which the doubling then overwrites; the sum goes to
+      // the other slot, whose point is dead once the addition has read it
+      u32* const slot_d = slot0 + b * (24u * TPB);
+      u32* const slot_s = slot0 + (b ^ 1u) * (24u * TPB);
+      const secp::pt din = ld3(slot_d, TPB);
+      st3(slot_s, TPB, s);
+      st3(slot_d, TPB, secp::pdouble(din));
     }
-    r0 = secp::pt_select(r0, secp::identity(), early);
-    st3(lds + e, TPB, r0);
+    const secp::pt r0 = secp::pt_select(ld3(slot0, TPB), secp::identity(), early);
+    st3(slot0, TPB, r0);
   }
   __syncthreads();
   stage_out<24>(out + first * 24, lds, valid);

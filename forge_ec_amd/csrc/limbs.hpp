@@ -391,6 +391,152 @@ FEC_DEV lmask uniform_mask(lmask m) {
 // and the "s" operands of the asm selects above would then be handed VGPRs.
 FEC_DEV bool lane_of(lmask m) { return word_select(0u, 1u, uniform_mask(m)) != 0; }
 
+// ---- short carry chains -------------------------------------------------------------------------------------
+// Adding or subtracting a one- or two-word constant on the lanes of a mask touches words 0..1; the carry (borrow)
+// leaves them only when the word it enters is all ones (zero): ~2^-32 per lane.  The chain therefore stops after the
+// constant's words and hands the outgoing carry back as a lane mask; the caller continues it through the remaining
+// words behind a wave-uniform branch (carry_from / borrow_from).  Exact for every operand.
+#ifdef FEC_HOST_EMUL
+// x.w[0..1] += m ? (1:k0) : 0; returns the carry out of word 1
+FEC_DEV lmask add_short2(fe& x, lmask m, u32 k0) {
+  if (!m) return 0;
+  u64 s = (u64)x.w[0] + k0;
+  x.w[0] = (u32)s;
+  s = (u64)x.w[1] + 1u + (s >> 32);
+  x.w[1] = (u32)s;
+  return (s >> 32) ? ~0ull : 0ull;
+}
+// x.w[0..1] -= m ? (1:k0) : 0; returns the borrow out of word 1
+FEC_DEV lmask sub_short2(fe& x, lmask m, u32 k0) {
+  if (!m) return 0;
+  u64 d = (u64)x.w[0] - k0;
+  x.w[0] = (u32)d;
+  d = (u64)x.w[1] - 1u - ((d >> 32) & 1);
+  x.w[1] = (u32)d;
+  return ((d >> 32) & 1) ? ~0ull : 0ull;
+}
+#define FEC_ADD_SHORT2(x, m, cy, k0) cy = add_short2(x, m, (u32)(k0))
+#define FEC_SUB_SHORT2(x, m, bw, k0) bw = sub_short2(x, m, (u32)(k0))
+// x.w[0] += k (a per-lane word); returns the carry out of word 0
+FEC_DEV lmask add_short1(fe& x, u32 k) {
+  u64 s = (u64)x.w[0] + k;
+  x.w[0] = (u32)s;
+  return (s >> 32) ? ~0ull : 0ull;
+}
+// x.w[0] -= k (a per-lane word); returns the borrow out of word 0
+FEC_DEV lmask sub_short1(fe& x, u32 k) {
+  u64 d = (u64)x.w[0] - k;
+  x.w[0] = (u32)d;
+  return ((d >> 32) & 1) ? ~0ull : 0ull;
+}
+// x += 2^(32 F) on the lanes of m, wrapping at 2^256;  x -= 2^(32 F) likewise
+template <int F>
+FEC_DEV void carry_from(fe& x, lmask m) {
+  u64 c = m ? 1 : 0;
+  for (int i = F; i < 8; ++i) {
+    u64 s = (u64)x.w[i] + c;
+    x.w[i] = (u32)s;
+    c = s >> 32;
+  }
+}
+template <int F>
+FEC_DEV void borrow_from(fe& x, lmask m) {
+  u64 b = m ? 1 : 0;
+  for (int i = F; i < 8; ++i) {
+    u64 d = (u64)x.w[i] - b;
+    x.w[i] = (u32)d;
+    b = (d >> 32) & 1;
+  }
+}
+#else
+// k0: any 32-bit literal (it rides in a VOP2 literal slot); the constant's word 1 is 1
+#define FEC_ADD_SHORT2(x, m, cy, k0) \
+  do { \
+    u32 fec_t0_, fec_t1_; \
+    asm("v_cndmask_b32_e64 %3, 0, 1, %5\n\t" \
+        "v_mul_u32_u24_e32 %4, " #k0 ", %3\n\t" \
+        "v_add_co_u32_e32 %0, vcc, %0, %4\n\t" \
+        "v_addc_co_u32_e32 %1, vcc, %1, %3, vcc\n\t" \
+        "s_mov_b64 %2, vcc" \
+        : "+v"((x).w[0]), "+v"((x).w[1]), "=s"(cy), "=&v"(fec_t1_), "=&v"(fec_t0_) : "s"(m) : "vcc"); \
+  } while (0)
+#define FEC_SUB_SHORT2(x, m, bw, k0) \
+  do { \
+    u32 fec_t0_, fec_t1_; \
+    asm("v_cndmask_b32_e64 %3, 0, 1, %5\n\t" \
+        "v_mul_u32_u24_e32 %4, " #k0 ", %3\n\t" \
+        "v_sub_co_u32_e32 %0, vcc, %0, %4\n\t" \
+        "v_subb_co_u32_e32 %1, vcc, %1, %3, vcc\n\t" \
+        "s_mov_b64 %2, vcc" \
+        : "+v"((x).w[0]), "+v"((x).w[1]), "=s"(bw), "=&v"(fec_t1_), "=&v"(fec_t0_) : "s"(m) : "vcc"); \
+  } while (0)
+FEC_DEV lmask add_short1(fe& x, u32 k) {
+  lmask c;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %2\n\t"
+      "s_mov_b64 %1, vcc"
+      : "+v"(x.w[0]), "=s"(c) : "v"(k) : "vcc");
+  return c;
+}
+FEC_DEV lmask sub_short1(fe& x, u32 k) {
+  lmask c;
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
+      "s_mov_b64 %1, vcc"
+      : "+v"(x.w[0]), "=s"(c) : "v"(k) : "vcc");
+  return c;
+}
+// the continuation as ONE statement (VCC must not be touched between the chain's instructions)
+template <int F>
+FEC_DEV void carry_from(fe& x, lmask m) {
+  static_assert(F == 1 || F == 2, "continuations start at word 1 or word 2");
+  if (F == 1)
+    asm("s_mov_b64 vcc, %7\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+        "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+        "v_addc_co_u32_e32 %6, vcc, 0, %6, vcc"
+        : "+v"(x.w[1]), "+v"(x.w[2]), "+v"(x.w[3]), "+v"(x.w[4]), "+v"(x.w[5]), "+v"(x.w[6]), "+v"(x.w[7])
+        : "s"(m) : "vcc");
+  else
+    asm("s_mov_b64 vcc, %6\n\t"
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+        "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc"
+        : "+v"(x.w[2]), "+v"(x.w[3]), "+v"(x.w[4]), "+v"(x.w[5]), "+v"(x.w[6]), "+v"(x.w[7])
+        : "s"(m) : "vcc");
+}
+template <int F>
+FEC_DEV void borrow_from(fe& x, lmask m) {
+  static_assert(F == 1 || F == 2, "continuations start at word 1 or word 2");
+  if (F == 1)
+    asm("s_mov_b64 vcc, %7\n\t"
+        "v_subbrev_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_subbrev_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+        "v_subbrev_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+        "v_subbrev_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+        "v_subbrev_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+        "v_subbrev_co_u32_e32 %6, vcc, 0, %6, vcc"
+        : "+v"(x.w[1]), "+v"(x.w[2]), "+v"(x.w[3]), "+v"(x.w[4]), "+v"(x.w[5]), "+v"(x.w[6]), "+v"(x.w[7])
+        : "s"(m) : "vcc");
+  else
+    asm("s_mov_b64 vcc, %6\n\t"
+        "v_subbrev_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_subbrev_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+        "v_subbrev_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+        "v_subbrev_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+        "v_subbrev_co_u32_e32 %5, vcc, 0, %5, vcc"
+        : "+v"(x.w[2]), "+v"(x.w[3]), "+v"(x.w[4]), "+v"(x.w[5]), "+v"(x.w[6]), "+v"(x.w[7])
+        : "s"(m) : "vcc");
+}
+#endif
+
 // one level of indirection so that a constant list passed as a single macro (FEC_SECP_C, ...)
 // is expanded before it is split into k0..k7
 #define FEC_ADDK256(r, a, c, ...) FEC_ADDK256_(r, a, c, __VA_ARGS__)

@@ -43,21 +43,32 @@ FEC_DEV fe csub_p_unlikely(const fe& v) {
   return v;
 }
 
-// Add (353-393): s = a + b mod 2^256; subtract p once if the add carried or s >= p.
+// Add (353-393): s = a + b mod 2^256; subtract p once -- i.e. add c = 2^32 + 977 mod 2^256 -- if the add carried or
+// s >= p.  s >= p needs a top word of all ones (2^-32 per lane): such wavefronts take the literal form.  Otherwise
+// the condition is the carry alone, and c touches words 0..1 (short chain, limbs.hpp).
 FEC_DEV fe add(const fe& a, const fe& b) {
-  fe s, w;
-  lmask carry = add256(s, a, b);
-  lmask ov;
-  FEC_ADDK256(w, s, ov, FEC_SECP_C);  // w = s - p mod 2^256
-  return fe_select(s, w, carry | ov);
+  fe s;
+  const lmask carry = add256(s, a, b);
+  if (__builtin_expect(lanes_where(s.w[7] == 0xFFFFFFFFu) != 0, 0)) {
+    fe w;
+    lmask ov;
+    FEC_ADDK256(w, s, ov, FEC_SECP_C);  // w = s - p mod 2^256
+    return fe_select(s, w, carry | ov);
+  }
+  lmask cy;
+  FEC_ADD_SHORT2(s, carry, cy, 0x3d1);
+  if (__builtin_expect(cy != 0, 0)) carry_from<2>(s, cy);
+  return s;
 }
 
 // Sub (395-440): d = a - b mod 2^256; add p (wrapping), i.e. subtract c, if it borrowed.
 FEC_DEV fe sub(const fe& a, const fe& b) {
-  fe d, r;
-  lmask borrow = sub256(d, a, b);
-  sub_lohi256(r, d, word_select(0u, 0x3D1u, borrow), word_select(0u, 1u, borrow));
-  return r;
+  fe d;
+  const lmask borrow = sub256(d, a, b);
+  lmask bw;
+  FEC_SUB_SHORT2(d, borrow, bw, 0x3d1);
+  if (__builtin_expect(bw != 0, 0)) borrow_from<2>(d, bw);
+  return d;
 }
 
 // Neg (509-539): p - a (wrapping), 0 -> 0.

@@ -121,5 +121,9 @@ def edge_field_values(curve):
             (1 << 255) - 1, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, 1 << 192, 1 << 224, (1 << 256) - p,
             (1 << 256) - p - 1, (1 << 256) - 2, 0xFFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000,
             0xFFFFFFFFFFFFFFFF0000000000000000FFFFFFFFFFFFFFFF0000000000000000,
-            0x00000000FFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000FFFFFFFF]
+            0x00000000FFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000FFFFFFFF,
+            # operands whose sums / differences send the carry of the short chains (+- c on words 0..1, +- 19 on
+            # word 0: limbs.hpp) through the remaining words
+            12, (1 << 255) + 5, (1 << 255) + 7, (1 << 64) - 2, (1 << 32) - 19, (1 << 32) - 3, (1 << 255) - 20,
+            (1 << 256) - (1 << 64), (1 << 256) - (1 << 32) - 5]
     return [v for v in vals if 0 <= v < (1 << 256)]
