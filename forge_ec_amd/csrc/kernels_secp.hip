@@ -39,6 +39,68 @@ FEC_DEV void st3(u32* l, int stride, const secp::pt& p) {
   }
 }
 
+// one coordinate (c = 0, 1, 2: X, Y, Z) of a ladder point in its LDS slot
+FEC_DEV fe ldc(const u32* l, int c) {
+  fe a;
+  FEC_UNROLL for (int i = 0; i < 8; ++i) a.w[i] = l[(8 * c + i) * TPB];
+  return a;
+}
+
+// secp::padd_nodouble (Add, 1444-1498) with both operands left in their LDS slots: every coordinate is loaded where
+// it is first used (Z twice), so that neither point is live across the sixteen products, and the early-outs
+// (identity operands: Z == 0; u1 == u2) sit behind one-word tests every lane taking one must pass, their exact masks
+// evaluated on the re-read points inside the rare branch.  The same products on the same operands as
+// padd_nodouble(); independent products are merely issued in another order.
+FEC_DEV secp::pt padd_slots(const u32* lp, const u32* lq, lmask& need_double) {
+  using namespace secp;
+  fe z1s, z1c, z2s, z2c;
+  lmask maybe;
+  {
+    const fe z1 = ldc(lp, 2);
+    maybe = lanes_where(z1.w[0] == 0u);
+    z1s = sqr(z1);
+    z1c = mul(z1s, z1);
+  }
+  __builtin_amdgcn_sched_barrier(0);  // keep the loads where they are used (register budget of three waves per SIMD)
+  {
+    const fe z2 = ldc(lq, 2);
+    maybe |= lanes_where(z2.w[0] == 0u);
+    z2s = sqr(z2);
+    z2c = mul(z2s, z2);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const fe u1 = mul(ldc(lp, 0), z2s);
+  const fe u2 = mul(ldc(lq, 0), z1s);
+  __builtin_amdgcn_sched_barrier(0);
+  const fe s1 = mul(ldc(lp, 1), z2c);
+  const fe s2 = mul(ldc(lq, 1), z1c);
+  __builtin_amdgcn_sched_barrier(0);
+  lmask ueq = 0, seq = 0;
+  if (__builtin_expect(lanes_where(u1.w[0] == u2.w[0]) != 0, 0)) {
+    ueq = fe_eq(u1, u2);
+    seq = fe_eq(s1, s2);
+  }
+  const fe h = sub(u2, u1);
+  const fe r = sub(s2, s1);
+  const fe h2 = sqr(h);
+  const fe h3 = mul(h2, h);
+  const fe u1h2 = mul(u1, h2);
+  pt o;
+  o.x = sub(sub(sub(sqr(r), h3), u1h2), u1h2);
+  o.y = sub(mul(r, sub(u1h2, o.x)), mul(s1, h3));
+  o.z = mul(mul(h, ldc(lp, 2)), ldc(lq, 2));
+  need_double = 0;
+  if (__builtin_expect((maybe | ueq) != 0, 0)) {  // early-outs: only the ladder's first steps
+    const pt p = ld3(lp, TPB), q = ld3(lq, TPB);
+    const lmask idp = is_identity(p), idq = is_identity(q);
+    o = pt_select(o, identity(), ueq & ~seq);
+    o = pt_select(o, p, idq);
+    o = pt_select(o, q, idp);
+    need_double = ueq & seq & ~idp & ~idq;
+  }
+  return o;
+}
+
 }  // namespace
 
 template <bool FIXED>
@@ -71,7 +133,7 @@ __global__ __launch_bounds__(TPB, 3) void k_secp_mul(const u32* __restrict__ sca
       const int sh = (((i >> 3) & 3) << 3) + 7 - (i & 7);
       const u32 b = (kword >> sh) & 1u;
       lmask nd;
-      secp::pt s = secp::padd_nodouble(ld3(slot0, TPB), ld3(slot0 + 24 * TPB, TPB), nd);
+      secp::pt s = padd_slots(slot0, slot0 + 24 * TPB, nd);
       if (__builtin_expect(nd != 0, 0)) {  // Add (1469-1473) returns self.double(): never on random inputs
         secp::pt d0 = secp::pdouble(ld3(slot0, TPB));
         s = secp::pt_select(s, d0, nd);
