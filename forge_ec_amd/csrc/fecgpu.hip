@@ -531,9 +531,11 @@ int launch_ed_fixed(fec_ctx* ctx, const u64* ds, const u64* dbase, const u64* ho
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int rc = ensure_ed_table(ctx, dbase, host_base, s);
   if (rc != FEC_OK) return rc;
+  void* work = nullptr;  // the batch-wide popcount sort of large batches: per-stream scratch
+  if (ed_fixed_work_bytes(n) != 0 && !(work = scratch_for(ctx, s, ed_fixed_work_bytes(n)))) return FEC_E_OOM;
   Launch L(ctx, stream, "k_ed_fixed_base");
   ed_fixed_launch(reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(dbase), ctx->d_ed_table,
-                  reinterpret_cast<u32*>(dout), n, L.s);
+                  reinterpret_cast<u32*>(dout), n, work, L.s);
   return L.done();
 }
 
@@ -601,7 +603,8 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
   dim3 g(grid_for(n)), b(TPB);
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   const size_t pb = (size_t)plimbs(curve) * 8;
-  char* scratch = static_cast<char*>(scratch_for(ctx, st, 2 * n * pb));
+  const size_t ed_work = curve == FEC_ED25519 ? ed_fixed_work_bytes(n) : 0;
+  char* scratch = static_cast<char*>(scratch_for(ctx, st, 2 * n * pb + ed_work));
   if (!scratch) return FEC_E_OOM;
   u32* ta = reinterpret_cast<u32*>(scratch);
   u32* tb = reinterpret_cast<u32*>(scratch + n * pb);
@@ -629,7 +632,7 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
     side.join();
     hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   } else {
-    ed_fixed_launch(a, gen, ctx->d_ed_table, ta, n, side.s);
+    ed_fixed_launch(a, gen, ctx->d_ed_table, ta, n, ed_work ? scratch + 2 * n * pb : nullptr, side.s);  // (ed_work != 0 only where the side stream is off)
     side.fork_done();
     ed_launch_mul(b2, q, tb, n, L.s, side.active ? 2 : 1);
     side.join();
@@ -689,7 +692,8 @@ int launch_eddsa_verify(fec_ctx* ctx, const u64* dr, const unsigned char* drinf,
                         const u64* ds, const u64* dk, unsigned char* dstatus, size_t n, void* stream) {
   if (n == 0) return FEC_OK;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-  char* work = static_cast<char*>(scratch_for(ctx, st, n * 384));
+  const size_t ed_work = ed_fixed_work_bytes(n);
+  char* work = static_cast<char*>(scratch_for(ctx, st, n * 384 + ed_work));
   if (!work) return FEC_E_OOM;
   u32* a = reinterpret_cast<u32*>(work);
   u32* sg = reinterpret_cast<u32*>(work + n * 128);
@@ -699,7 +703,7 @@ int launch_eddsa_verify(fec_ctx* ctx, const u64* dr, const unsigned char* drinf,
   Launch L(ctx, stream, "k_eddsa_pre + k_ed_fixed_base + k_ed_mul_pers + k_eddsa_finish");
   eddsa_pre_launch(reinterpret_cast<const u32*>(dpk), dpinf, a, n, L.s);
   ed_fixed_launch(reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(ctx->d_gen[FEC_ED25519]),
-                  ctx->d_ed_table, sg, n, L.s);
+                  ctx->d_ed_table, sg, n, ed_work ? work + n * 384 : nullptr, L.s);
   ed_launch_mul(reinterpret_cast<const u32*>(dk), a, ka, n, L.s);
   eddsa_finish_launch(sg, ka, reinterpret_cast<const u32*>(dr), drinf, dstatus, n, L.s);
   return L.done();

@@ -17,7 +17,10 @@ void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hi
 // kernels_ed.hip: Ed25519 fixed-base multiply from the 256-entry addend table of `base` (table[j] = 2^j * base by
 // the reference's own doubling chain, built once per base by ed_build_table_launch; 256 * 32 words).
 void ed_build_table_launch(const u32* base, u32* table, hipStream_t s);
-void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, hipStream_t s);
+// `work`: ed_fixed_work_bytes(n) bytes of device scratch owned by the launch's stream (0 bytes / null for small
+// batches: the batch-wide popcount sort pays from 2^16 elements on).
+size_t ed_fixed_work_bytes(size_t n);
+void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, void* work, hipStream_t s);
 
 // kernels_secp.hip: secp256k1 Curve::multiply, lane-per-element ladder at three wavefronts per SIMD.
 void secp_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);

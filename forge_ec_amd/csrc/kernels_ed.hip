@@ -255,6 +255,116 @@ __global__ __launch_bounds__(TPB, 3) void k_ed_fixed_base(const u32* __restrict_
   stage_out<32>(out + first * 32, lds_t, valid);
 }
 
+// ---- the same kernel for large batches: elements sorted by popcount over the WHOLE batch -------------------------
+// With the in-kernel sort a wavefront's 64 lanes come from one quartile of 256 elements and run for that quartile's
+// largest popcount: 134 iterations on average against 128 additions per element.  For batches of 2^16 elements and
+// more three small kernels first sort the element INDICES of the whole batch by descending popcount (counting sort:
+// histogram, 257-bin scan, scatter; workgroups of 1024 threads x 4 elements with LDS histograms, so that the global
+// atomics are one per non-empty bin per workgroup), and the table kernel walks that permutation: every wavefront's
+// lanes then have (almost always) the same popcount, no lane idles, and the workgroups come heaviest first.  Only
+// the lane -> element assignment changes; results go straight to the elements' own output slots.
+namespace {
+constexpr int SORT_T = 1024, SORT_E = 4;   // threads per sorting workgroup, elements per thread
+constexpr size_t ED_SORT_MIN = (size_t)1 << 16;
+constexpr int ED_BINS = 257;               // popcount 0 .. 256
+constexpr size_t ED_PERM_OFFSET = 2048;    // bytes: 2 x 257 counters in front of the permutation
+
+FEC_DEV int scalar_popcount(const u32* scalars, size_t g) {
+  const uint4* k = reinterpret_cast<const uint4*>(scalars + g * 8);
+  const uint4 a = k[0], b = k[1];
+  return __builtin_popcount(a.x) + __builtin_popcount(a.y) + __builtin_popcount(a.z) + __builtin_popcount(a.w) +
+         __builtin_popcount(b.x) + __builtin_popcount(b.y) + __builtin_popcount(b.z) + __builtin_popcount(b.w);
+}
+}  // namespace
+
+// hist[b] += number of elements with popcount b (hist zeroed by the launcher)
+__global__ __launch_bounds__(SORT_T) void k_ed_pc_hist(const u32* __restrict__ scalars, size_t n, int* __restrict__ hist) {
+  __shared__ int lh[ED_BINS];
+  for (int v = threadIdx.x; v < ED_BINS; v += SORT_T) lh[v] = 0;
+  __syncthreads();
+  const size_t first = (size_t)blockIdx.x * SORT_T * SORT_E;
+  FEC_UNROLL for (int k = 0; k < SORT_E; ++k) {
+    const size_t g = first + (size_t)k * SORT_T + threadIdx.x;
+    if (g < n) atomicAdd(&lh[scalar_popcount(scalars, g)], 1);
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < ED_BINS; v += SORT_T)
+    if (lh[v]) atomicAdd(&hist[v], lh[v]);
+}
+// cursor[b] = number of elements with popcount > b: the first position of bin b in descending order
+__global__ __launch_bounds__(64) void k_ed_pc_scan(const int* __restrict__ hist, int* __restrict__ cursor) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int run = 0;
+  for (int b = ED_BINS - 1; b >= 0; --b) {
+    cursor[b] = run;
+    run += hist[b];
+  }
+}
+// perm[position] = element index, positions handed out bin by bin (order inside a bin is immaterial)
+__global__ __launch_bounds__(SORT_T) void k_ed_pc_scatter(const u32* __restrict__ scalars, size_t n, int* __restrict__ cursor,
+                                                        u32* __restrict__ perm) {
+  __shared__ int lh[ED_BINS];
+  __shared__ int lbase[ED_BINS];
+  for (int v = threadIdx.x; v < ED_BINS; v += SORT_T) lh[v] = 0;
+  __syncthreads();
+  const size_t first = (size_t)blockIdx.x * SORT_T * SORT_E;
+  int pc[SORT_E], rank[SORT_E];
+  FEC_UNROLL for (int k = 0; k < SORT_E; ++k) {
+    const size_t g = first + (size_t)k * SORT_T + threadIdx.x;
+    pc[k] = -1;
+    rank[k] = 0;
+    if (g < n) {
+      pc[k] = scalar_popcount(scalars, g);
+      rank[k] = atomicAdd(&lh[pc[k]], 1);
+    }
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < ED_BINS; v += SORT_T) lbase[v] = lh[v] ? atomicAdd(&cursor[v], lh[v]) : 0;
+  __syncthreads();
+  FEC_UNROLL for (int k = 0; k < SORT_E; ++k) {
+    const size_t g = first + (size_t)k * SORT_T + threadIdx.x;
+    if (pc[k] >= 0) perm[lbase[pc[k]] + rank[k]] = (u32)g;
+  }
+}
+
+// k_ed_fixed_base over the permutation: lane e of workgroup b computes element perm[b * TPB + e]
+__global__ __launch_bounds__(TPB, 3) void k_ed_fixed_sorted(const u32* __restrict__ scalars,
+                                                         const u32* __restrict__ base,
+                                                         const u32* __restrict__ table,
+                                                         const u32* __restrict__ perm,
+                                                         u32* __restrict__ out, size_t n) {
+  __shared__ u32 lds_k[8 * TPB];
+  __shared__ u32 lds_t[256 * FT_STRIDE];
+  const int valid = block_valid(n);
+  const int e = threadIdx.x;
+  const size_t g = e < valid ? (size_t)perm[(size_t)blockIdx.x * TPB + e] : 0;
+  if (e < valid) {
+    const uint4* k = reinterpret_cast<const uint4*>(scalars + g * 8);
+    const uint4 a = k[0], b = k[1];
+    lds_k[0 * TPB + e] = a.x; lds_k[1 * TPB + e] = a.y; lds_k[2 * TPB + e] = a.z; lds_k[3 * TPB + e] = a.w;
+    lds_k[4 * TPB + e] = b.x; lds_k[5 * TPB + e] = b.y; lds_k[6 * TPB + e] = b.z; lds_k[7 * TPB + e] = b.w;
+  }
+  static_assert(TPB == 256 && KSTRIDE == TPB, "one thread stages one table entry; scalar columns at stride TPB");
+  {  // entry e of the table: y - x, y + x, z, t, x.w[0], y.w[0] (see padd_table)
+    const ed::pt q = ld_words(table + (size_t)e * 32);
+    const fe ymx = ed::sub(q.y, q.x), ypx = ed::add(q.y, q.x);
+    u32* d = lds_t + e * FT_STRIDE;
+    FEC_UNROLL for (int i = 0; i < 8; ++i) {
+      d[i] = ymx.w[i];
+      d[8 + i] = ypx.w[i];
+      d[16 + i] = q.z.w[i];
+      d[24 + i] = q.t.w[i];
+    }
+    d[32] = q.x.w[0];
+    d[33] = q.y.w[0];
+  }
+  __syncthreads();
+  if (e < valid) {
+    const ed::pt b = ld_words(base);
+    st_glb(out + g * 32, multiply_fixed_in_place(b, lds_t, table, lds_k + e));
+  }
+}
+
 // ---- Add / double with their operands left in memory (register budget of three wavefronts per SIMD) ----
 // the running result sits in the element's slot of the OUTPUT array (32 consecutive words), the addend in its LDS
 // slot (word w at l[w * stride]).  Coordinates are loaded where they are used; the early-outs (identity operands,
@@ -553,8 +663,22 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
 void ed_build_table_launch(const u32* base, u32* table, hipStream_t s) {
   hipLaunchKernelGGL(k_ed_build_table, dim3(1), dim3(64), 0, s, base, table);
 }
-void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_ed_fixed_base, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, scalars, base, table, out, n);
+size_t ed_fixed_work_bytes(size_t n) { return n >= ED_SORT_MIN ? ED_PERM_OFFSET + n * sizeof(u32) : 0; }
+void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, void* work, hipStream_t s) {
+  const unsigned grid = (unsigned)((n + TPB - 1) / TPB);
+  if (n < ED_SORT_MIN || work == nullptr) {  // small batch (or no work area): quartiles of each workgroup's own 256 elements
+    hipLaunchKernelGGL(k_ed_fixed_base, dim3(grid), dim3(TPB), 0, s, scalars, base, table, out, n);
+    return;
+  }
+  int* hist = static_cast<int*>(work);
+  int* cursor = hist + 260;
+  u32* perm = reinterpret_cast<u32*>(static_cast<char*>(work) + ED_PERM_OFFSET);
+  const unsigned sgrid = (unsigned)((n + (size_t)SORT_T * SORT_E - 1) / ((size_t)SORT_T * SORT_E));
+  (void)hipMemsetAsync(hist, 0, ED_PERM_OFFSET, s);
+  hipLaunchKernelGGL(k_ed_pc_hist, dim3(sgrid), dim3(SORT_T), 0, s, scalars, n, hist);
+  hipLaunchKernelGGL(k_ed_pc_scan, dim3(1), dim3(64), 0, s, (const int*)hist, cursor);
+  hipLaunchKernelGGL(k_ed_pc_scatter, dim3(sgrid), dim3(SORT_T), 0, s, scalars, n, cursor, perm);
+  hipLaunchKernelGGL(k_ed_fixed_sorted, dim3(grid), dim3(TPB), 0, s, scalars, base, table, (const u32*)perm, out, n);
 }
 
 void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s, unsigned cu_divisor) {

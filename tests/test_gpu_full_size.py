@@ -64,6 +64,31 @@ def test_config2_secp256k1_variable_base_2p20(gpu_ctx, oracle):
     assert _digest(out) == _digest(_run_dev(gpu_ctx, "var", curve, [k, p], n))
 
 
+def test_ed25519_fixed_base_batch_wide_popcount_sort(gpu_ctx, oracle):
+    """From 2^16 elements on the table kernel walks a permutation of the whole batch sorted by popcount
+    (kernels_ed.hip: k_ed_pc_hist / _scan / _scatter, k_ed_fixed_sorted).  A ragged batch just above the threshold
+    with zero scalars, single-bit scalars, all-ones scalars and long runs of equal popcount, every element
+    compared with the oracle; and the same rows through the small-batch kernel (in-kernel quartile sort)."""
+    n, curve = (1 << 16) + 37, 2
+    k = V.scalars(n, curve, 2301)
+    k[5] = 0                                   # multiply's zero-scalar early-out (popcount 0: sorts last)
+    k[n - 1] = 0
+    k[100:164] = np.uint64(0xFFFFFFFFFFFFFFFF)  # popcount 256, consumed as is (no reduction mod l)
+    for i in range(256):
+        k[1000 + i] = 0
+        k[1000 + i, i // 64] = np.uint64(1) << np.uint64(i % 64)   # a single addend each: results are table entries
+    k[3000:9000, 1:] = 0                       # low popcounts
+    k[20000:30000] = k[20000]                  # one popcount bin with 10^4 elements
+    dev_out = _run_dev(gpu_ctx, "fixed", curve, [k], n)
+    g = oracle.generator(curve)
+    want = oracle.batch_mul_fixed(curve, k, g, nthreads=16)
+    assert np.array_equal(dev_out, want)
+    for lo, cnt in ((0, 300), (900, 400), (n - 300, 300)):
+        assert np.array_equal(gpu_ctx.batch_mul_fixed(curve, k[lo:lo + cnt], g), want[lo:lo + cnt])
+    # run-to-run determinism although positions inside a popcount bin are handed out by atomics
+    assert _digest(dev_out) == _digest(_run_dev(gpu_ctx, "fixed", curve, [k], n))
+
+
 def test_config3_ed25519_fixed_base_2p20(gpu_ctx, oracle):
     n, curve = 1 << 20, 2
     k = V.scalars(n, curve, 2003)
