@@ -533,7 +533,7 @@ int launch_ed_fixed(fec_ctx* ctx, const u64* ds, const u64* dbase, const u64* ho
   if (rc != FEC_OK) return rc;
   void* work = nullptr;  // the batch-wide popcount sort of large batches: per-stream scratch
   if (ed_fixed_work_bytes(n) != 0 && !(work = scratch_for(ctx, s, ed_fixed_work_bytes(n)))) return FEC_E_OOM;
-  Launch L(ctx, stream, "k_ed_fixed_base");
+  Launch L(ctx, stream, work ? "k_ed_fixed_sorted (+ k_ed_pc_hist, k_ed_pc_scan, k_ed_pc_scatter)" : "k_ed_fixed_base");
   ed_fixed_launch(reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(dbase), ctx->d_ed_table,
                   reinterpret_cast<u32*>(dout), n, work, L.s);
   return L.done();
