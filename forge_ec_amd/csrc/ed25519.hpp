@@ -133,7 +133,8 @@ FEC_DEV fe mul(const fe& a, const fe& b) {
         "=v"(r.w[7]), "=&s"(sink), "=&s"(exc)
       : FEC_V8(a), FEC_V8(b)
       : FEC_ED_MUL_CLOBBERS);
-  if (__builtin_expect(exc != 0, 0)) return mul_cxx(a, b);
+  if (__builtin_expect(exc != 0, 0)) r = fe_select(r, mul_cxx(a, b), ~(lmask)0);
+  // (the rare leg is selected INTO r: a leg that returned its own registers would cost the common leg eight v_mov at the join)
   return r;
 }
 FEC_DEV fe sqr_exact(const fe& a) {
@@ -144,7 +145,7 @@ FEC_DEV fe sqr_exact(const fe& a) {
         "=v"(r.w[7]), "=&s"(sink), "=&s"(exc)
       : FEC_V8(a)
       : FEC_ED_SQR_CLOBBERS);
-  if (__builtin_expect(exc != 0, 0)) return sqr_cxx(a);
+  if (__builtin_expect(exc != 0, 0)) r = fe_select(r, sqr_cxx(a), ~(lmask)0);
   return r;
 }
 #endif

@@ -28,7 +28,43 @@ namespace fecgpu {
 
 namespace {
 
-enum { C_TICKET = 0, C_HEAD_D, C_TAIL_D, C_HEAD_A, C_TAIL_A, C_INFLIGHT, C_REMAIN, C_ERR, C_SERVING, C_WORDS };
+// words 0..5 are rewritten in every critical section (one ds_write_b128 + one ds_write_b64); 0..7 are read with two
+// ds_read_b128
+enum { C_HEAD_D = 0, C_TAIL_D, C_HEAD_A, C_TAIL_A, C_INFLIGHT, C_REMAIN, C_ERR, C_TICKET, C_SERVING, C_WORDS };
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+// the eight control words in two LDS reads, each broadcast from lane 0 into SGPRs (they are wave-uniform: the queue
+// arithmetic that follows then runs on the scalar unit, not as 64-lane VALU instructions)
+struct CtlWords {
+  int head_d, tail_d, head_a, tail_a, inflight, remain, err;
+};
+FEC_DEV CtlWords ctl_read(unsigned lds_addr) {
+  v4i_t a, b;
+  asm volatile("ds_read_b128 %0, %2\n\t"
+               "ds_read_b128 %1, %2 offset:16\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b) : "v"(lds_addr) : "memory");
+  CtlWords c;
+  c.head_d = __builtin_amdgcn_readfirstlane(a.x);
+  c.tail_d = __builtin_amdgcn_readfirstlane(a.y);
+  c.head_a = __builtin_amdgcn_readfirstlane(a.z);
+  c.tail_a = __builtin_amdgcn_readfirstlane(a.w);
+  c.inflight = __builtin_amdgcn_readfirstlane(b.x);
+  c.remain = __builtin_amdgcn_readfirstlane(b.y);
+  c.err = __builtin_amdgcn_readfirstlane(b.z);
+  return c;
+}
+// words 0..5 written back (the caller runs this on lane 0 only)
+FEC_DEV void ctl_write(unsigned lds_addr, int head_d, int tail_d, int head_a, int tail_a, int inflight, int remain) {
+  v4i_t a;
+  a.x = head_d; a.y = tail_d; a.z = head_a; a.w = tail_a;
+  v2i_t b;
+  b.x = inflight; b.y = remain;
+  asm volatile("ds_write_b128 %0, %1\n\t"
+               "ds_write_b64 %0, %2 offset:16\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : : "v"(lds_addr), "v"(a), "v"(b) : "memory");
+}
 
 FEC_DEV p256::pt ld_pt(const u32* l, int stride) {
   p256::pt p;
@@ -85,14 +121,14 @@ FEC_DEV p256::pt pdouble_in_place(const u32* lp, int stride) {
   const fe yyyy = sqr(yy);
   const fe xy2 = sqr(add(x, yy));
   const fe w = sub(sub(xy2, xx), yyyy);
-  const fe d = add(w, w);
+  const fe d = dbl(w);
   const fe e = mul_small(xx, 3);
   const fe ee = sqr(e);
   pt r;
   r.x = sub(sub(ee, d), d);
   r.y = sub(mul(e, sub(d, r.x)), mul_small(yyyy, 8));
   const fe y = ld_coord(lp, stride, 1), z = ld_coord(lp, stride, 2);
-  const fe z3 = add(y, y);
+  const fe z3 = dbl(y);
   r.z = mul(z3, z);
   // z.is_one() (1909: once per element, on the first doubling after the result became the base point) and the
   // identity early-out (1870) behind one-word tests every lane taking one must pass
@@ -129,13 +165,13 @@ FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq) {
   const fe h = sub(u2, u1);
   const fe z3 = mul(zs, h);
   const fe s21 = sub(s2, s1);
-  const fe r = add(s21, s21);
-  const fe i = sqr(add(h, h));
+  const fe r = dbl(s21);
+  const fe i = sqr(dbl(h));
   const fe j = mul(h, i);
   const fe v = mul(u1, i);
   pt o;
   o.x = sub(sub(sub(sqr(r), j), v), v);
-  o.y = sub(mul(r, sub(v, o.x)), mul(add(s1, s1), j));
+  o.y = sub(mul(r, sub(v, o.x)), mul(dbl(s1), j));
   o.z = z3;
   if (__builtin_expect((idp | idq | ueq) != 0, 0)) {
     pt p, q;
@@ -175,11 +211,17 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   __shared__ u32 lds_gid[QS];                   // element of slot e, relative to the workgroup's range
   __shared__ unsigned short lds_step[QS];
   __shared__ unsigned short lds_q[2][QRING];
-  __shared__ int lds_ctl[P_WORDS];
+  __shared__ __attribute__((aligned(16))) int lds_ctl[P_WORDS];
   const size_t lo = (size_t)blockIdx.x * per_wg;
   const int range = (n - lo) < (size_t)per_wg ? (int)(n - lo) : (int)per_wg;
   const int tid = threadIdx.x, lane = tid & 63;
-  volatile int* ctl = lds_ctl;
+  // The control words are read and written through an LDS-address-space pointer: a volatile access through a generic
+  // pointer is left as a FLAT access by the compiler (64-bit address, sc0 sc1, a VMEM round trip each), and the
+  // critical section is a chain of a dozen of them.  One opaque base register, immediate offsets.
+  typedef volatile __attribute__((address_space(3))) int* lds_int_ptr;
+  lds_int_ptr ctl = (lds_int_ptr)lds_ctl;
+  asm volatile("" : "+v"(ctl));
+  const unsigned ctl_addr = (unsigned)(size_t)ctl;  // LDS byte address of the control block
   if (tid == 0) {
     FEC_UNROLL for (int w = 0; w < P_WORDS; ++w) lds_ctl[w] = 0;
     lds_ctl[C_REMAIN] = range < QS ? range : QS;   // live slots
@@ -252,16 +294,17 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       while (ctl[C_SERVING] != my) __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    int t_d = ctl[C_TAIL_D], t_a = ctl[C_TAIL_A];
+    const CtlWords cw = ctl_read(ctl_addr);
+    int t_d = cw.tail_d, t_a = cw.tail_a;
     if (nxt == 0) lds_q[0][(t_d + rank_d) & (QRING - 1)] = (unsigned short)e;
     if (nxt == 1) lds_q[1][(t_a + rank_a) & (QRING - 1)] = (unsigned short)e;
     t_d += n_d;
     t_a += n_a;
-    int inflight = ctl[C_INFLIGHT] - count;
-    const int remain = ctl[C_REMAIN] - n_fin;
-    int h_d = ctl[C_HEAD_D], h_a = ctl[C_HEAD_A];
+    int inflight = cw.inflight - count;
+    const int remain = cw.remain - n_fin;
+    int h_d = cw.head_d, h_a = cw.head_a;
     const int av_d = t_d - h_d, av_a = t_a - h_a;
-    const int err = ctl[C_ERR];
+    const int err = cw.err;
     int th = remain >> 3;
     th = th < 1 ? 1 : (th > 64 ? 64 : th);
     int pick = -1;
@@ -284,14 +327,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     }
     inflight += count;
     const bool finished = (!filling && remain == 0 && inflight == 0) || err != 0;
-    if (lane == 0) {
-      ctl[C_TAIL_D] = t_d;
-      ctl[C_TAIL_A] = t_a;
-      ctl[C_HEAD_D] = h_d;
-      ctl[C_HEAD_A] = h_a;
-      ctl[C_INFLIGHT] = inflight;
-      ctl[C_REMAIN] = remain;
-    }
+    if (lane == 0) ctl_write(ctl_addr, h_d, t_d, h_a, t_a, inflight, remain);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) ctl[C_SERVING] = ctl[C_SERVING] + 1;
     kind = pick;

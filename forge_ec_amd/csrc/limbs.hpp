@@ -106,6 +106,8 @@ FEC_DEV lmask sub256(fe& r, const fe& a, const fe& b) {
   }
   return bo ? ~0ull : 0ull;
 }
+// r = a + a mod 2^256; returns the carry-out lane mask
+FEC_DEV lmask dbl256(fe& r, const fe& a) { return add256(r, a, a); }
 FEC_DEV lmask add256_cin(fe& r, const fe& a, const fe& b, lmask cin) {
   u64 c = cin ? 1 : 0;
   for (int i = 0; i < 8; ++i) {
@@ -165,6 +167,26 @@ FEC_DEV lmask add256(fe& r, const fe& a, const fe& b) {
       "s_mov_b64 %8, vcc"
       : FEC_RW8(x), "=s"(c)
       : FEC_V8(b)
+      : "vcc");
+  r = x;
+  return c;
+}
+// r = a + a mod 2^256; returns the carry-out lane mask.  One operand list: with add256(r, a, a) the tied copy of a
+// and a itself (still an input) have to sit in different registers, eight v_mov.
+FEC_DEV lmask dbl256(fe& r, const fe& a) {
+  lmask c;
+  fe x = a;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, %3, %3, vcc\n\t"
+      "v_addc_co_u32_e32 %4, vcc, %4, %4, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, %5, %5, vcc\n\t"
+      "v_addc_co_u32_e32 %6, vcc, %6, %6, vcc\n\t"
+      "v_addc_co_u32_e32 %7, vcc, %7, %7, vcc\n\t"
+      "s_mov_b64 %8, vcc"
+      : FEC_RW8(x), "=s"(c)
+      :
       : "vcc");
   r = x;
   return c;

@@ -25,13 +25,13 @@ FEC_DEV fe csub_p(const fe& v) {
   return fe_select(v, w, ~borrow);
 }
 
-// Add (416-468), literal for arbitrary 256-bit operands.  carry <= 1 after the limb loop.
+// Add (416-468), literal for arbitrary 256-bit operands, from the limb loop's sum s and carry on (the loops that follow
+// depend on a and b only through them).  carry <= 1 after the limb loop.
 // `while carry > 0` (436-452): the first trip adds 2^256-p; it carries again only if
 // (a+b-2^256) >= p, and then the second trip cannot (s' < 2^256-p, so s' + (2^256-p) < 2^256): at
-// most two trips; then reduce() (one trip).
-FEC_DEV fe add_general(const fe& a, const fe& b) {
-  fe s, s1;
-  lmask carry = add256(s, a, b);
+// most two trips; then reduce() (one trip).  Works IN PLACE on s: every step is a select into s.
+FEC_DEV void add_tail_general(fe& s, lmask carry) {
+  fe s1;
   lmask ac;
   FEC_ADDK256(s1, s, ac, FEC_P256_RED);
   s = fe_select(s, s1, carry);
@@ -43,37 +43,88 @@ FEC_DEV fe add_general(const fe& a, const fe& b) {
     (void)t;
     s = fe_select(s, s2, again);
   }
-  return csub_p(s);
-}
-
-// Add for the common case.  For canonical operands (a, b < p) the loops above collapse to
-// (a + b) mod p: with a carry, s + (2^256-p) = a+b-p < p and nothing else fires; without one the
-// result is s - p if s >= p.  Both are w = s - p (mod 2^256), selected on carry | (s >= p).
-// A non-canonical operand (possible after the reference's Sub, ~2^-32 per subtraction) needs a
-// top word of 0xFFFFFFFF; such wavefronts take the literal routine.
-FEC_DEV fe add(const fe& a, const fe& b) {
-  lmask noncanon = lanes_where(a.w[7] == 0xFFFFFFFFu || b.w[7] == 0xFFFFFFFFu);
-  if (__builtin_expect(noncanon != 0, 0)) return add_general(a, b);
-  fe s, w;
-  lmask carry = add256(s, a, b);
+  fe w;
   lmask borrow;
   FEC_SUBK256(w, s, borrow, FEC_P256_P);
-  return fe_select(s, w, carry | ~borrow);
+  s = fe_select(s, w, ~borrow);
+}
+FEC_DEV fe add_general(const fe& a, const fe& b) {
+  fe s;
+  lmask carry = add256(s, a, b);
+  add_tail_general(s, carry);
+  return s;
+}
+
+// 2^256 - p = {1, 0, 0, -1, -1, -1, -2, 0} added IN PLACE on the lanes of m
+#ifdef FEC_HOST_EMUL
+FEC_DEV void add_red_masked(fe& s, lmask m) {
+  if (!m) return;
+  fe w;
+  lmask t;
+  FEC_ADDK256(w, s, t, FEC_P256_RED);
+  (void)t;
+  s = w;
+}
+#else
+FEC_DEV void add_red_masked(fe& s, lmask m) {
+  u32 t1, tm, t2;
+  asm("v_cndmask_b32_e64 %8, 0, 1, %11\n\t"
+      "v_cndmask_b32_e64 %9, 0, -1, %11\n\t"
+      "v_cndmask_b32_e64 %10, 0, -2, %11\n\t"
+      "v_add_co_u32_e32 %0, vcc, %0, %8\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, %3, %9, vcc\n\t"
+      "v_addc_co_u32_e32 %4, vcc, %4, %9, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, %5, %9, vcc\n\t"
+      "v_addc_co_u32_e32 %6, vcc, %6, %10, vcc\n\t"
+      "v_addc_co_u32_e32 %7, vcc, 0, %7, vcc"
+      : FEC_RW8(s), "=&v"(t1), "=&v"(tm), "=&v"(t2) : "s"(m) : "vcc");
+}
+#endif
+
+// Add for the common case.  For canonical operands (a, b < p) the loops of the literal form collapse to
+// (a + b) mod p: with a carry, s + (2^256-p) = a+b-p < p and nothing else fires; without one the
+// result is s - p if s >= p, which needs a top word of all ones in s (2^-32 per lane).  A non-canonical operand
+// (possible after the reference's Sub, ~2^-32 per subtraction) needs a top word of 0xFFFFFFFF too.  Wavefronts with
+// any of the three take the literal tail; everywhere else the condition is the carry alone and 2^256 - p is added
+// under the carry mask.  Both legs work IN PLACE on the sum: a rare leg that produced its result elsewhere would
+// cost the common leg eight v_mov at the join.
+FEC_DEV fe add(const fe& a, const fe& b) {
+  const lmask noncanon = lanes_where(a.w[7] == 0xFFFFFFFFu || b.w[7] == 0xFFFFFFFFu);
+  fe s;
+  const lmask carry = add256(s, a, b);
+  if (__builtin_expect((noncanon | lanes_where(s.w[7] == 0xFFFFFFFFu)) != 0, 0)) add_tail_general(s, carry);
+  else add_red_masked(s, carry);
+  return s;
+}
+// a + a through Add (the doublings of the point formulas), with one operand list (dbl256)
+FEC_DEV fe dbl(const fe& a) {
+  const lmask noncanon = lanes_where(a.w[7] == 0xFFFFFFFFu);
+  fe s;
+  const lmask carry = dbl256(s, a);
+  if (__builtin_expect((noncanon | lanes_where(s.w[7] == 0xFFFFFFFFu)) != 0, 0)) add_tail_general(s, carry);
+  else add_red_masked(s, carry);
+  return s;
 }
 
 // Sub (470-496): if a < b { a = a + P  (Add reduces that back to canon(a)) }; then a wrapping
-// 256-bit subtraction.  For a < p the `+= P` is a no-op; for p <= a < b it subtracts p.
+// 256-bit subtraction.  For a < p the `+= P` is a no-op; for p <= a < b it subtracts p: the result is
+// (a - b) - p = (a - b) + (2^256 - p) mod 2^256 on the lanes where a >= p and the subtraction borrowed.
+// a >= p needs a.w[7] == 0xFFFFFFFF (2^-32 per lane): the exact test runs BEFORE the subtraction and leaves only a
+// lane mask, and the correction is applied IN PLACE, so that the common path neither keeps a copy of a nor pays
+// moves at a join.
 FEC_DEV fe sub(const fe& a, const fe& b) {
-  fe d;
-  lmask borrow = sub256(d, a, b);
-  // a >= p needs a.w[7] == 0xFFFFFFFF; only then can canon(a) differ from a
-  lmask maybe = borrow & lanes_where(a.w[7] == 0xFFFFFFFFu);
-  if (maybe != 0) {
-    fe ac = csub_p(a);
-    fe d2;
-    sub256(d2, ac, b);
-    d = fe_select(d, d2, maybe);
+  lmask ge = 0;
+  if (__builtin_expect(lanes_where(a.w[7] == 0xFFFFFFFFu) != 0, 0)) {
+    fe t;
+    lmask bo;
+    FEC_SUBK256(t, a, bo, FEC_P256_P);
+    ge = ~bo;  // a >= p, exactly
   }
+  fe d;
+  const lmask borrow = sub256(d, a, b);
+  if (__builtin_expect((ge & borrow) != 0, 0)) add_red_masked(d, uniform_mask(ge & borrow));
   return d;
 }
 
@@ -183,7 +234,7 @@ FEC_DEV fe mul_small_k(const fe& a) {
         : FEC_V8(a)
         : FEC_P256_MUL8_CLOBBERS);
   }
-  if (__builtin_expect(exc != 0, 0)) return mul_small_cxx(a, K);  // the sum carried out of 2^256
+  if (__builtin_expect(exc != 0, 0)) r = fe_select(r, mul_small_cxx(a, K), ~(lmask)0);  // the sum carried out of 2^256
   return csub_p_top(r);
 }
 FEC_DEV fe sqr(const fe& a) {

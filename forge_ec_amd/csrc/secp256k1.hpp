@@ -61,6 +61,22 @@ FEC_DEV fe add(const fe& a, const fe& b) {
   return s;
 }
 
+// a + a through Add (353-393) -- FieldElement::double (105-109) is `s + s` -- with one operand list (dbl256)
+FEC_DEV fe dbl(const fe& a) {
+  fe s;
+  const lmask carry = dbl256(s, a);
+  if (__builtin_expect(lanes_where(s.w[7] == 0xFFFFFFFFu) != 0, 0)) {
+    fe w;
+    lmask ov;
+    FEC_ADDK256(w, s, ov, FEC_SECP_C);  // w = s - p mod 2^256
+    return fe_select(s, w, carry | ov);
+  }
+  lmask cy;
+  FEC_ADD_SHORT2(s, carry, cy, 0x3d1);
+  if (__builtin_expect(cy != 0, 0)) carry_from<2>(s, cy);
+  return s;
+}
+
 // Sub (395-440): d = a - b mod 2^256; add p (wrapping), i.e. subtract c, if it borrowed.
 FEC_DEV fe sub(const fe& a, const fe& b) {
   fe d;
@@ -177,8 +193,10 @@ FEC_DEV fe mul_small_k(const fe& a) {
         : FEC_V8(a), "s"(0xD2253531u), "s"(977u)
         : FEC_SECP_MUL8_CLOBBERS);
   }
-  if (__builtin_expect(exc != 0, 0)) return mul_small_cxx(a, K);  // m0 + t8 carried out of word 0
-  if (__builtin_expect(bw != 0, 0)) r = borrow_from_word2(r, bw);
+  // the rare legs are selected INTO r: a leg that returned its own registers would cost the common leg eight v_mov at
+  // the join
+  if (__builtin_expect(exc != 0, 0)) r = fe_select(r, mul_small_cxx(a, K), ~(lmask)0);  // m0 + t8 carried out of word 0
+  else if (__builtin_expect(bw != 0, 0)) r = borrow_from_word2(r, bw);
   return csub_p_top(r);
 }
 #endif
@@ -358,7 +376,8 @@ FEC_DEV fe sqr(const fe& a) {
         "=&v"(r.w[7]), "=&s"(tmp), "=&s"(exc)
       : FEC_V8(a), "s"(977u)
       : FEC_SECP_SQR_CLOBBERS);
-  if (__builtin_expect(exc != 0, 0)) return sqr_cxx(a);
+  if (__builtin_expect(exc != 0, 0)) r = fe_select(r, sqr_cxx(a), ~(lmask)0);
+  // (the rare leg is selected INTO r: a leg that returned its own registers would cost the common leg eight v_mov at the join)
   return csub_p_top(r);
 }
 #endif
@@ -391,14 +410,14 @@ FEC_DEV pt pdouble(const pt& p) {
   fe c = sqr(b);
   fe xpb2 = sqr(add(p.x, b));
   fe dd = sub(sub(xpb2, a), c);
-  fe d = add(dd, dd);
+  fe d = dbl(dd);
   fe e = mul_small(a, 3);
   fe f = sqr(e);
   pt r;
-  r.x = sub(f, add(d, d));
+  r.x = sub(f, dbl(d));
   r.y = sub(mul(e, sub(d, r.x)), mul_small(c, 8));
   fe yz = mul(p.y, p.z);
-  r.z = add(yz, yz);
+  r.z = dbl(yz);
   lmask idp = is_identity(p);
   if (__builtin_expect(idp != 0, 0)) r = pt_select(r, identity(), idp);
   return r;
