@@ -17,12 +17,12 @@
 #include "ed25519.hpp"
 #include "staging.hpp"
 #include "kernels.hpp"
+#include "sched_ctl.hpp"
 
 namespace fecgpu {
 
 namespace {
 
-enum { C_TICKET = 0, C_HEAD_D, C_TAIL_D, C_HEAD_A, C_TAIL_A, C_INFLIGHT, C_REMAIN, C_ERR, C_SERVING, C_WORDS };
 
 FEC_DEV ed::pt ld_lds(const u32* l, int stride) {
   ed::pt p;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
   __shared__ u32 lds_gid[PS];                  // element of slot e, relative to the workgroup's range
   __shared__ unsigned short lds_step[PS];      // current step i of slot e (A_i / D_i pending)
   __shared__ unsigned short lds_q[2][PRING];   // ready rings: [0] needs the doubling D_i, [1] needs the addition A_i
-  __shared__ int lds_ctl[P_WORDS];
+  __shared__ __attribute__((aligned(16))) int lds_ctl[P_WORDS];
   const size_t lo = (size_t)blockIdx.x * per_wg;
   const int range = (n - lo) < (size_t)per_wg ? (int)(n - lo) : (int)per_wg;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -502,7 +502,9 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
   // address is hoisted into a VGPR of its own -- ten registers the three-wavefront budget does not have
   int* ctl_base = lds_ctl;
   asm volatile("" : "+v"(ctl_base));
-  volatile int* ctl = ctl_base;
+  lds_int_ptr ctl = (lds_int_ptr)lds_ctl;   // LDS-address-space accesses (sched_ctl.hpp)
+  asm volatile("" : "+v"(ctl));
+  const unsigned ctl_addr = (unsigned)(size_t)ctl;
   if (tid == 0) {
     FEC_UNROLL for (int w = 0; w < P_WORDS; ++w) lds_ctl[w] = 0;
     lds_ctl[C_REMAIN] = range < PS ? range : PS;   // live slots
@@ -568,16 +570,17 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
       while (ctl[C_SERVING] != my) __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    int t_d = ctl[C_TAIL_D], t_a = ctl[C_TAIL_A];
+    const CtlWords cw = ctl_read(ctl_addr);
+    int t_d = cw.tail_d, t_a = cw.tail_a;
     if (nxt == 0) lds_q[0][(t_d + rank_d) & (PRING - 1)] = (unsigned short)e;
     if (nxt == 1) lds_q[1][(t_a + rank_a) & (PRING - 1)] = (unsigned short)e;
     t_d += n_d;
     t_a += n_a;
-    int inflight = ctl[C_INFLIGHT] - count;
-    const int remain = ctl[C_REMAIN] - n_fin;
-    int h_d = ctl[C_HEAD_D], h_a = ctl[C_HEAD_A];
+    int inflight = cw.inflight - count;
+    const int remain = cw.remain - n_fin;
+    int h_d = cw.head_d, h_a = cw.head_a;
     const int av_d = t_d - h_d, av_a = t_a - h_a;
-    const int err = ctl[C_ERR];
+    const int err = cw.err;
     int th = remain >> 3;
     th = th < 1 ? 1 : (th > 64 ? 64 : th);
     int pick = -1;
@@ -600,14 +603,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
     }
     inflight += count;
     const bool finished = (!first_fill && remain == 0 && inflight == 0) || err != 0;
-    if (lane == 0) {
-      ctl[C_TAIL_D] = t_d;
-      ctl[C_TAIL_A] = t_a;
-      ctl[C_HEAD_D] = h_d;
-      ctl[C_HEAD_A] = h_a;
-      ctl[C_INFLIGHT] = inflight;
-      ctl[C_REMAIN] = remain;
-    }
+    if (lane == 0) ctl_write(ctl_addr, h_d, t_d, h_a, t_a, inflight, remain);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) ctl[C_SERVING] = ctl[C_SERVING] + 1;
     // ---- end of critical section ----
