@@ -107,11 +107,14 @@ FEC_DEV p256::pt pdouble_in_place(const u32* lp, int stride) {
 // never on random inputs) re-read both points inside their rare branch, so that neither point is live across the
 // sixteen products -- the difference between 43 spilled registers and none at three wavefronts per SIMD.  The
 // products, their operands and their order are those of p256::padd_nodouble / padd.
-FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq) {
+// `gzz` (when not null): z2z2 = q.z * q.z of this addend, computed once per element (or per launch for a fixed base)
+// by the same sqr() -- the addend of an element never changes, and its square is one of the sixteen products of every
+// addition.
+FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u32* gzz) {
   using namespace p256;
   const fe z1 = ld_coord(lp, stride, 2), z2 = ld_base_coord(gq, 2);
   const lmask idp = fe_is_zero(z1), idq = fe_is_zero(z2);
-  const fe z1z1 = sqr(z1), z2z2 = sqr(z2);
+  const fe z1z1 = sqr(z1), z2z2 = gzz ? ld_base_coord(gzz, 0) : sqr(z2);
   const fe zs = sub(sub(sqr(add(z1, z2)), z1z1), z2z2);
   const fe s1 = mul(mul(ld_coord(lp, stride, 1), z2), z2z2);
   __builtin_amdgcn_sched_barrier(0);  // keep the loads of q's coordinates where they are used (register budget)
@@ -166,7 +169,11 @@ constexpr int QRING = 2048;  // ring capacity (power of two >= QS)
 enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace
 
-template <bool FIXED>
+// HOIST: z2z2 of an element's base point is read instead of recomputed by every addition.  Variable base: a pre-pass
+// (k_p256_z2z2) leaves it in the first eight words of the element's OUTPUT slot, which nothing else uses until the
+// element's result is stored (the launcher falls back to HOIST = false when `out` overlaps `points`).  Fixed base:
+// computed once per workgroup into LDS.
+template <bool FIXED, bool HOIST>
 __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict__ scalars, const u32* __restrict__ points,
                                                       u32* __restrict__ out, size_t n, unsigned per_wg) {
   __shared__ u32 lds_st[24 * QS];               // X, Y, Z of slot e: word w at lds_st[w * QS + e]
@@ -175,6 +182,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   __shared__ unsigned short lds_step[QS];
   __shared__ unsigned short lds_q[2][QRING];
   __shared__ __attribute__((aligned(16))) int lds_ctl[P_WORDS];
+  __shared__ __attribute__((aligned(16))) u32 lds_zz[8];   // FIXED && HOIST: base.z * base.z
   const size_t lo = (size_t)blockIdx.x * per_wg;
   const int range = (n - lo) < (size_t)per_wg ? (int)(n - lo) : (int)per_wg;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -182,6 +190,12 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   lds_int_ptr ctl = (lds_int_ptr)lds_ctl;
   asm volatile("" : "+v"(ctl));
   const unsigned ctl_addr = (unsigned)(size_t)ctl;  // LDS byte address of the control block
+  if (FIXED && HOIST) {  // every lane computes the same square; one stores it
+    const fe zz = p256::sqr(ld_base_coord(points, 2));
+    if (tid == 0) {
+      FEC_UNROLL for (int w = 0; w < 8; ++w) lds_zz[w] = zz.w[w];
+    }
+  }
   if (tid == 0) {
     FEC_UNROLL for (int w = 0; w < P_WORDS; ++w) lds_ctl[w] = 0;
     lds_ctl[C_REMAIN] = range < QS ? range : QS;   // live slots
@@ -323,7 +337,9 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       }
     } else {
       // inactive lanes add slot 0 and element 0 of the range: harmless, never stored
-      res = padd_in_place(lds_st + e, QS, FIXED ? points : points + (lo + (active ? lds_gid[e] : 0u)) * 24);
+      const size_t g_el = lo + (active ? lds_gid[e] : 0u);
+      res = padd_in_place(lds_st + e, QS, FIXED ? points : points + g_el * 24,
+                          !HOIST ? nullptr : (FIXED ? lds_zz : out + g_el * 24));
       if (active) {
         ++step;
         lds_step[e] = (unsigned short)step;
@@ -351,6 +367,16 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   }
 }
 
+// out[g * 24 + 0..7] = points[g].z * points[g].z (the reference's square() = self * self, 772-776)
+__global__ __launch_bounds__(TPB) void k_p256_z2z2(const u32* __restrict__ points, u32* __restrict__ out, size_t n) {
+  const size_t g = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= n) return;
+  const fe zz = p256::sqr(ld_base_coord(points + g * 24, 2));
+  uint4* o = reinterpret_cast<uint4*>(out + g * 24);
+  o[0] = make_uint4(zz.w[0], zz.w[1], zz.w[2], zz.w[3]);
+  o[1] = make_uint4(zz.w[4], zz.w[5], zz.w[6], zz.w[7]);
+}
+
 void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s, unsigned cu_divisor) {
   // one workgroup per CU (or per cu_divisor-th CU), each with a contiguous range of at least 64 elements
   static const unsigned cus = [] {
@@ -363,8 +389,18 @@ void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out
   if (grid > cap) grid = cap;
   const unsigned per_wg = (unsigned)((n + grid - 1) / grid);
   grid = (n + per_wg - 1) / per_wg;
-  if (fixed) hipLaunchKernelGGL((k_p256_mul_sched<true>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
-  else hipLaunchKernelGGL((k_p256_mul_sched<false>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
+  if (fixed) {
+    hipLaunchKernelGGL((k_p256_mul_sched<true, true>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
+    return;
+  }
+  // the pre-pass parks z2z2 in the output slots: not when the caller's output array overlaps its points
+  const uintptr_t p0 = (uintptr_t)points, p1 = p0 + n * 96, o0 = (uintptr_t)out, o1 = o0 + n * 96;
+  if (p0 < o1 && o0 < p1) {
+    hipLaunchKernelGGL((k_p256_mul_sched<false, false>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
+    return;
+  }
+  hipLaunchKernelGGL(k_p256_z2z2, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, points, out, n);
+  hipLaunchKernelGGL((k_p256_mul_sched<false, true>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
 }
 
 }  // namespace fecgpu

@@ -729,6 +729,31 @@ def test_device_pointer_path_with_torch(gpu_ctx, oracle):
     _assert_same(got, want, "secp256k1 batch_mul_dev")
 
 
+@pytest.mark.parametrize("curve", [0, 1, 2])
+def test_batch_mul_in_place_output(gpu_ctx, oracle, curve):
+    """`out` may be the `points` array itself (an element's point is not read after its result is stored).  The
+    P-256 kernel parks z2z2 of every base point in its output slot and must notice the overlap (kernels_p256.hip:
+    it then recomputes the square in every addition instead); also a partial overlap, shifted by 5 elements."""
+    import torch
+    n = 1500
+    k = V.scalars(n, curve, 351)
+    p = V.points(n, curve, 352)
+    want = oracle.batch_mul(curve, k, p, nthreads=8)
+    dk = torch.from_numpy(k.view(np.int64)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    dp = torch.from_numpy(p.view(np.int64)).cuda()
+    gpu_ctx.batch_mul_dev(curve, dk.data_ptr(), dp.data_ptr(), dp.data_ptr(), n, stream)
+    torch.cuda.synchronize()
+    _assert_same(dp.cpu().numpy().view(np.uint64), want, "in-place batch_mul_dev")
+    if curve == 1:  # output 5 elements above the points inside one allocation: no element's output slot is its own point's
+        limbs = V.POINT_LIMBS[curve]
+        buf = torch.zeros((n + 5, limbs), dtype=torch.int64, device="cuda")
+        buf[:n] = torch.from_numpy(p.view(np.int64)).cuda()
+        gpu_ctx.batch_mul_dev(curve, dk.data_ptr(), buf.data_ptr(), buf[5:].data_ptr(), 5, stream)  # reads rows 0..4, writes 5..9
+        torch.cuda.synchronize()
+        _assert_same(buf[5:10].cpu().numpy().view(np.uint64), want[:5], "adjacent ranges")
+
+
 def test_schnorr_batch_verify_secp256k1_matches_oracle(gpu_ctx, oracle):
     """schnorr::batch_verify::<Secp256k1, D> (schnorr.rs:194-290) through the C ABI: the boolean and the
     two affine sums the reference compares, bit-exact with the oracle, over several batch sizes
