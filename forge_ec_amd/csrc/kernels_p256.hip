@@ -169,10 +169,7 @@ constexpr int QRING = 2048;  // ring capacity (power of two >= QS)
 enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace
 
-// HOIST: z2z2 of an element's base point is read instead of recomputed by every addition.  Variable base: a pre-pass
-// (k_p256_z2z2) leaves it in the first eight words of the element's OUTPUT slot, which nothing else uses until the
-// element's result is stored (the launcher falls back to HOIST = false when `out` overlaps `points`).  Fixed base:
-// computed once per workgroup into LDS.
+// HOIST (fixed base): z2z2 of the base point is computed once per workgroup into LDS instead of by every addition.
 template <bool FIXED, bool HOIST>
 __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict__ scalars, const u32* __restrict__ points,
                                                       u32* __restrict__ out, size_t n, unsigned per_wg) {
@@ -339,7 +336,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       // inactive lanes add slot 0 and element 0 of the range: harmless, never stored
       const size_t g_el = lo + (active ? lds_gid[e] : 0u);
       res = padd_in_place(lds_st + e, QS, FIXED ? points : points + g_el * 24,
-                          !HOIST ? nullptr : (FIXED ? lds_zz : out + g_el * 24));
+                          (FIXED && HOIST) ? lds_zz : nullptr);
       if (active) {
         ++step;
         lds_step[e] = (unsigned short)step;
@@ -367,16 +364,6 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   }
 }
 
-// out[g * 24 + 0..7] = points[g].z * points[g].z (the reference's square() = self * self, 772-776)
-__global__ __launch_bounds__(TPB) void k_p256_z2z2(const u32* __restrict__ points, u32* __restrict__ out, size_t n) {
-  const size_t g = (size_t)blockIdx.x * TPB + threadIdx.x;
-  if (g >= n) return;
-  const fe zz = p256::sqr(ld_base_coord(points + g * 24, 2));
-  uint4* o = reinterpret_cast<uint4*>(out + g * 24);
-  o[0] = make_uint4(zz.w[0], zz.w[1], zz.w[2], zz.w[3]);
-  o[1] = make_uint4(zz.w[4], zz.w[5], zz.w[6], zz.w[7]);
-}
-
 void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s, unsigned cu_divisor) {
   // one workgroup per CU (or per cu_divisor-th CU), each with a contiguous range of at least 64 elements
   static const unsigned cus = [] {
@@ -393,14 +380,10 @@ void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out
     hipLaunchKernelGGL((k_p256_mul_sched<true, true>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
     return;
   }
-  // the pre-pass parks z2z2 in the output slots: not when the caller's output array overlaps its points
-  const uintptr_t p0 = (uintptr_t)points, p1 = p0 + n * 96, o0 = (uintptr_t)out, o1 = o0 + n * 96;
-  if (p0 < o1 && o0 < p1) {
-    hipLaunchKernelGGL((k_p256_mul_sched<false, false>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
-    return;
-  }
-  hipLaunchKernelGGL(k_p256_z2z2, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, points, out, n);
-  hipLaunchKernelGGL((k_p256_mul_sched<false, true>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
+  // Variable base: z2z2 is recomputed by every addition.  Parking it in the element's (still unused) output slot was
+  // 2.6 % faster (25.0 -> 24.4 ms) but pushed a workgroup's working set out of its XCD's L2 -- 23 GB of L2-side
+  // fetches per launch instead of 0.44 (profiles/pmc_r02br_p256_hoist.json) -- and broke in-place calls; not kept.
+  hipLaunchKernelGGL((k_p256_mul_sched<false, false>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
 }
 
 }  // namespace fecgpu

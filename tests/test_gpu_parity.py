@@ -731,9 +731,8 @@ def test_device_pointer_path_with_torch(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("curve", [0, 1, 2])
 def test_batch_mul_in_place_output(gpu_ctx, oracle, curve):
-    """`out` may be the `points` array itself (an element's point is not read after its result is stored).  The
-    P-256 kernel parks z2z2 of every base point in its output slot and must notice the overlap (kernels_p256.hip:
-    it then recomputes the square in every addition instead); also a partial overlap, shifted by 5 elements."""
+    """`out` may be the `points` array itself (an element's point is not read after its result is stored); also
+    adjacent input / output ranges inside one allocation."""
     import torch
     n = 1500
     k = V.scalars(n, curve, 351)
