@@ -48,8 +48,8 @@ TRAFFIC_NOTES = {
                      "over the 160 MB algorithmic); the kernel moves 47 GB/s, the sort is worth 6 % of its time",
     "ed25519-var": "the running result of every in-flight element lives in its slot of the output array and is read and "
                    "rewritten by ~128 additions per element (L2 / Infinity Cache working set, 1.4 TB/s): LDS holds the "
-                   "addends of 1152 elements per CU instead, which is what lets the kernel run three wavefronts per SIMD "
-                   "(20.8 ms); with both in LDS (592 slots, two wavefronts per SIMD) it moved 305 MB and took 22.4 ms",
+                   "addends of 1024 elements per CU instead, which is what lets the kernel run three wavefronts per SIMD; "
+                   "with both in LDS (592 slots, two wavefronts per SIMD) it moved 305 MB and took 22.4 ms against 19.5",
 }
 # guide-derived integer-VALU peak: 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per
 # v_mad_u64_u32 wave-instruction (MI355X_MICROARCH.md chip parameters; issue cost measured,

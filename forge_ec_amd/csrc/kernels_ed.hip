@@ -471,7 +471,7 @@ FEC_DEV ed::pt pdbl_mem(const u32* la, int stride) {
 
 // ---------------------------------------------------------------------------------------------------
 // One workgroup of TWELVE wavefronts per CU (three per SIMD, 168 VGPRs) owns a contiguous RANGE of elements and
-// keeps PS = 1152 of them in slots -- the addend in LDS (128 B per slot, 144 KiB), the running result in the
+// keeps PS = 1024 of them in slots -- the addend in LDS (128 B per slot, 128 KiB), the running result in the
 // element's slot of the OUTPUT array (read and rewritten by ~128 additions per element; L2 / Infinity Cache
 // traffic) -- refilling a slot from the range the moment its element finishes: no
 // workgroup tail until the whole range is done.  Add and double read their operands from memory where they are
@@ -482,7 +482,7 @@ FEC_DEV ed::pt pdbl_mem(const u32* la, int stride) {
 // ---------------------------------------------------------------------------------------------------
 namespace {
 constexpr int PT = 768;     // threads per workgroup: 12 wavefronts, three per SIMD
-constexpr int PS = 1152;    // element slots per workgroup (12 x 64 in flight + 384 queued)
+constexpr int PS = 1024;    // element slots per workgroup (12 x 64 in flight + 256 queued); swept: 896 -> 18.6 ms, 960 -> 19.1, 1024 -> 17.6, 1088 -> 17.8, 1152 -> 18.0 (same box)
 constexpr int PRING = 2048;  // ring capacity (power of two >= PS)
 enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace
