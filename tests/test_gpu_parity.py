@@ -268,7 +268,7 @@ def test_ragged_sizes_config1(gpu_ctx, oracle, n):
 
 @pytest.mark.parametrize("curve", [1, 2])
 def test_scheduler_kernels_at_slot_and_wavefront_boundaries(gpu_ctx, oracle, curve):
-    """The persistent schedulers (P-256, Ed25519 variable base: 768 threads, 1024 / 1152 slots per workgroup, ranges
+    """The persistent schedulers (P-256, Ed25519 variable base: 768 threads, 1024 slots per workgroup, ranges
     of at least 64 elements per workgroup) and the Ed25519 table kernel at batch sizes around every boundary of
     that geometry, with zero scalars and identity points sprinkled in (elements answered at claim time)."""
     g = oracle.generator(curve)
