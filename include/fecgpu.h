@@ -64,6 +64,10 @@
  * GPU is the intended use (multi-GPU = one process per GPU).
  *
  * Errors: 0 on success, negative fec_status otherwise; never aborts, never throws across the ABI.
+ *
+ * Aliasing: the output array of fec_batch_mul / fec_batch_mul_dev may be the `points` array itself (an
+ * element's point is not read after its result is stored; tests/test_gpu_parity.py:
+ * test_batch_mul_in_place_output); any other overlap of an output with an input is undefined.
  */
 #ifndef FECGPU_H
 #define FECGPU_H
