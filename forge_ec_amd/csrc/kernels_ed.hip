@@ -498,11 +498,10 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
   const size_t lo = (size_t)blockIdx.x * per_wg;
   const int range = (n - lo) < (size_t)per_wg ? (int)(n - lo) : (int)per_wg;
   const int tid = threadIdx.x, lane = tid & 63;
-  // one opaque base register for the control words: otherwise every word's (link-time constant, > 64 KiB) LDS
-  // address is hoisted into a VGPR of its own -- ten registers the three-wavefront budget does not have
-  int* ctl_base = lds_ctl;
-  asm volatile("" : "+v"(ctl_base));
-  lds_int_ptr ctl = (lds_int_ptr)lds_ctl;   // LDS-address-space accesses (sched_ctl.hpp)
+  // control words through an LDS-address-space pointer (sched_ctl.hpp) in ONE opaque base register: otherwise every
+  // word's (link-time constant, > 64 KiB) LDS address is hoisted into a VGPR of its own -- ten registers the
+  // three-wavefront budget does not have
+  lds_int_ptr ctl = (lds_int_ptr)lds_ctl;
   asm volatile("" : "+v"(ctl));
   const unsigned ctl_addr = (unsigned)(size_t)ctl;
   if (tid == 0) {
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
   // (1 = A_0 if bit 0 is set, else 0 = D_0), or 2 when the range is used up (the slot dies).
   auto claim = [&](int e) -> int {
     for (;;) {
-      const int rel = atomicAdd(&ctl_base[P_NEXT], 1);
+      const int rel = lds_fetch_add(ctl, P_NEXT, 1);
       if (rel >= range) return 2;
       const size_t g = lo + rel;
       const ed::pt base = ld_glb(points + g * 32);
@@ -566,7 +565,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
     }
     // ---- critical section (FIFO ticket lock, lane 0) ----
     if (lane == 0) {
-      const int my = atomicAdd(&ctl_base[C_TICKET], 1);
+      const int my = lds_fetch_add(ctl, C_TICKET, 1);
       while (ctl[C_SERVING] != my) __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -49,6 +49,11 @@ FEC_DEV void ctl_write(unsigned lds_addr, int head_d, int tail_d, int head_a, in
 }
 
 typedef volatile __attribute__((address_space(3))) int* lds_int_ptr;
+// atomic fetch-and-add on control word `w` (ds_add_rtn_u32; atomicAdd() on a generic pointer would be a FLAT atomic)
+FEC_DEV int lds_fetch_add(lds_int_ptr ctl, int w, int v) {
+  return __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(ctl + w), v, __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 }  // namespace
 }  // namespace fecgpu
