@@ -215,17 +215,17 @@ extern "C" {
 
 // ---- canonical-math mode (include/fecgpu_canon.h): NOT reference parity ----------------------
 int fec_canon_mul_base_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, uint64_t* d_out_xy,
-                           uint8_t* d_status, size_t n, void* stream) {
+                           uint8_t* d_status, size_t n, void* stream) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_scalars || !d_out_xy || !d_status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (!aligned16(d_scalars) || !aligned16(d_out_xy)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_canon_mul_base(ctx, curve, d_scalars, d_out_xy, d_status, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_mul_base(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, uint64_t* out_xy, uint8_t* status,
-                       size_t n) {
+                       size_t n) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!scalars || !out_xy || !status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
@@ -237,20 +237,20 @@ int fec_canon_mul_base(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, u
   return host_chunked(ctx, n, in, in_stride, out, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
     return launch_canon_mul_base(ctx, curve, (const u64*)d[0], (u64*)o[0], (unsigned char*)o[1], cnt, nullptr);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_scalars, const uint64_t* d_points_xy,
-                      uint64_t* d_out_xy, uint8_t* d_status, size_t n, void* stream) {
+                      uint64_t* d_out_xy, uint8_t* d_status, size_t n, void* stream) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_scalars || !d_points_xy || !d_out_xy || !d_status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (!aligned16(d_scalars) || !aligned16(d_points_xy) || !aligned16(d_out_xy)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_canon_mul(ctx, curve, d_scalars, d_points_xy, d_out_xy, d_status, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points_xy,
-                  uint64_t* out_xy, uint8_t* status, size_t n) {
+                  uint64_t* out_xy, uint8_t* status, size_t n) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!scalars || !points_xy || !out_xy || !status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
@@ -262,11 +262,11 @@ int fec_canon_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const 
   return host_chunked(ctx, n, in, in_stride, out, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
     return launch_canon_mul(ctx, curve, (const u64*)d[0], (const u64*)d[1], (u64*)o[0], (unsigned char*)o[1], cnt, nullptr);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1, const uint64_t* d_u2,
                              const uint64_t* d_points_xy, uint64_t* d_out_xy, uint8_t* d_status, size_t n,
-                             void* stream) {
+                             void* stream) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_u1 || !d_u2 || !d_points_xy || !d_out_xy || !d_status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return FEC_E_ARG;
@@ -275,10 +275,10 @@ int fec_canon_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_u1
   int rc = launch_canon_mul_base(ctx, curve, d_u1, d_out_xy, d_status, n, stream, false);
   if (rc != FEC_OK) return rc;
   return launch_canon_mul(ctx, curve, d_u2, d_points_xy, d_out_xy, d_status, n, stream, true);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, const uint64_t* u2,
-                         const uint64_t* points_xy, uint64_t* out_xy, uint8_t* status, size_t n) {
+                         const uint64_t* points_xy, uint64_t* out_xy, uint8_t* status, size_t n) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!u1 || !u2 || !points_xy || !out_xy || !status))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return FEC_E_ARG;
@@ -293,21 +293,21 @@ int fec_canon_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
     return launch_canon_mul(ctx, curve, (const u64*)d[1], (const u64*)d[2], (u64*)o[0], (unsigned char*)o[1], cnt, nullptr,
                             true);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_ecdsa_verify_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_z, const uint64_t* d_r,
                                const uint64_t* d_s, const uint64_t* d_pk_xy, uint8_t* d_result, size_t n,
-                               void* stream) {
+                               void* stream) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_z || !d_r || !d_s || !d_pk_xy || !d_result))) return FEC_E_ARG;
   if (curve != FEC_SECP256K1 && curve != FEC_P256) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
   if (!aligned16(d_z) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_pk_xy)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_canon_ecdsa_verify(ctx, curve, d_z, d_r, d_s, d_pk_xy, d_result, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_ecdsa_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* z, const uint64_t* r, const uint64_t* s,
-                           const uint64_t* pk_xy, uint8_t* result, size_t n) {
+                           const uint64_t* pk_xy, uint8_t* result, size_t n) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!z || !r || !s || !pk_xy || !result))) return FEC_E_ARG;
   if (curve != FEC_SECP256K1 && curve != FEC_P256) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
@@ -320,19 +320,19 @@ int fec_canon_ecdsa_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* z, con
     return launch_canon_ecdsa_verify(ctx, curve, (const u64*)d[0], (const u64*)d[1], (const u64*)d[2], (const u64*)d[3],
                                      (unsigned char*)o[0], cnt, nullptr);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_bip340_verify_dev(fec_ctx* ctx, const uint64_t* d_pk_x, const uint64_t* d_r, const uint64_t* d_s,
-                                const uint64_t* d_e, uint8_t* d_result, size_t n, void* stream) {
+                                const uint64_t* d_e, uint8_t* d_result, size_t n, void* stream) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_pk_x || !d_r || !d_s || !d_e || !d_result))) return FEC_E_ARG;
   if (!aligned16(d_pk_x) || !aligned16(d_r) || !aligned16(d_s) || !aligned16(d_e)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_canon_sig_verify(ctx, FEC_SECP256K1, d_pk_x, d_r, d_s, d_e, d_result, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_bip340_verify(fec_ctx* ctx, const uint64_t* pk_x, const uint64_t* r, const uint64_t* s,
-                            const uint64_t* e, uint8_t* result, size_t n) {
+                            const uint64_t* e, uint8_t* result, size_t n) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!pk_x || !r || !s || !e || !result))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
@@ -344,19 +344,19 @@ int fec_canon_bip340_verify(fec_ctx* ctx, const uint64_t* pk_x, const uint64_t* 
     return launch_canon_sig_verify(ctx, FEC_SECP256K1, (const u64*)d[0], (const u64*)d[1], (const u64*)d[2], (const u64*)d[3],
                                    (unsigned char*)o[0], cnt, nullptr);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_eddsa_verify_dev(fec_ctx* ctx, const uint64_t* d_a_enc, const uint64_t* d_r_enc, const uint64_t* d_s,
-                               const uint64_t* d_h, uint8_t* d_result, size_t n, void* stream) {
+                               const uint64_t* d_h, uint8_t* d_result, size_t n, void* stream) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!d_a_enc || !d_r_enc || !d_s || !d_h || !d_result))) return FEC_E_ARG;
   if (!aligned16(d_a_enc) || !aligned16(d_r_enc) || !aligned16(d_s) || !aligned16(d_h)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_canon_sig_verify(ctx, FEC_ED25519, d_a_enc, d_r_enc, d_s, d_h, d_result, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_eddsa_verify(fec_ctx* ctx, const uint64_t* a_enc, const uint64_t* r_enc, const uint64_t* s,
-                           const uint64_t* h, uint8_t* result, size_t n) {
+                           const uint64_t* h, uint8_t* result, size_t n) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || (n && (!a_enc || !r_enc || !s || !h || !result))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
@@ -368,10 +368,10 @@ int fec_canon_eddsa_verify(fec_ctx* ctx, const uint64_t* a_enc, const uint64_t* 
     return launch_canon_sig_verify(ctx, FEC_ED25519, (const u64*)d[0], (const u64*)d[1], (const u64*)d[2], (const u64*)d[3],
                                    (unsigned char*)o[0], cnt, nullptr);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_scalar_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b,
-                        const uint64_t* c, uint64_t* out, size_t n) {
+                        const uint64_t* c, uint64_t* out, size_t n) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || !canon_curve_ok(curve) || op < 0 || op > 1 || (n && (!a || !out))) return FEC_E_ARG;
   if (op == 0 && n && (!b || !c)) return FEC_E_ARG;
@@ -389,10 +389,10 @@ int fec_canon_scalar_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a
     else hipLaunchKernelGGL((k_canon_scalar_op<canon::NEd>), g, blk, 0, L.s, op, x, y, z, (u32*)o[0], cnt);
     return L.done();
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
-                       size_t n) {
+                       size_t n) try {
   FEC_FIRST_DEVICE(ctx);  // canonical mode is not sharded: a multi-device ctx runs it on devices[0]
   if (!ctx || op < FEC_F_ADD || op > FEC_F_INV || (n && (!a || !out))) return FEC_E_ARG;
   if (!canon_curve_ok(curve)) return curve_ok(curve) ? FEC_E_UNSUPPORTED : FEC_E_ARG;
@@ -412,6 +412,6 @@ int fec_canon_field_op(fec_ctx* ctx, fec_curve curve, int op, const uint64_t* a,
     else hipLaunchKernelGGL((k_canon_field_op<ced>), dim3(grid_for(n)), dim3(TPB), 0, L.s, op, (const u32*)x, (const u32*)y, (u32*)o, n);
     return L.done();
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 }  // extern "C"

@@ -552,8 +552,8 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
   Launch L(ctx, stream, name);
   switch (curve) {
     case FEC_SECP256K1: secp_launch_mul(fixed, s, p, o, n, L.s); break;
-    case FEC_P256: p256_launch_mul(fixed, s, p, o, n, L.s); break;
-    default: ed_launch_mul(s, p, o, n, L.s); break;
+    case FEC_P256: p256_launch_mul(sched_env(ctx), fixed, s, p, o, n, L.s); break;
+    default: ed_launch_mul(sched_env(ctx), s, p, o, n, L.s); break;
   }
   return L.done();
 }
@@ -626,15 +626,15 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
     side.join();
     hipLaunchKernelGGL((k_point_op<Secp>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   } else if (curve == FEC_P256) {
-    p256_launch_mul(true, a, gen, ta, n, side.s, side.active ? 2 : 1);
+    p256_launch_mul(sched_env(ctx), true, a, gen, ta, n, side.s, side.active ? 2 : 1);
     side.fork_done();
-    p256_launch_mul(false, b2, q, tb, n, L.s, side.active ? 2 : 1);
+    p256_launch_mul(sched_env(ctx), false, b2, q, tb, n, L.s, side.active ? 2 : 1);
     side.join();
     hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   } else {
     ed_fixed_launch(a, gen, ctx->d_ed_table, ta, n, ed_work ? scratch + 2 * n * pb : nullptr, side.s);  // (ed_work != 0 only where the side stream is off)
     side.fork_done();
-    ed_launch_mul(b2, q, tb, n, L.s, side.active ? 2 : 1);
+    ed_launch_mul(sched_env(ctx), b2, q, tb, n, L.s, side.active ? 2 : 1);
     side.join();
     hipLaunchKernelGGL((k_point_op<Ed>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   }
@@ -679,7 +679,7 @@ int launch_ecdsa_verify(fec_ctx* ctx, int curve, const unsigned char* dd, const 
   if (!work) return FEC_E_OOM;
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_ecdsa_pre + k_secp_mul x2 + k_ecdsa_finish"
                                                : "k_ecdsa_pre + k_p256_mul_sched x2 + k_ecdsa_finish");
-  ecdsa_launch(curve, dd, reinterpret_cast<const u32*>(dr), reinterpret_cast<const u32*>(ds),
+  ecdsa_launch(sched_env(ctx), curve, dd, reinterpret_cast<const u32*>(dr), reinterpret_cast<const u32*>(ds),
                reinterpret_cast<const u32*>(dpk), dinf, reinterpret_cast<const u32*>(ctx->d_gen[curve]), dstatus, work, n,
                L.s);
   return L.done();
@@ -704,7 +704,7 @@ int launch_eddsa_verify(fec_ctx* ctx, const u64* dr, const unsigned char* drinf,
   eddsa_pre_launch(reinterpret_cast<const u32*>(dpk), dpinf, a, n, L.s);
   ed_fixed_launch(reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(ctx->d_gen[FEC_ED25519]),
                   ctx->d_ed_table, sg, n, ed_work ? work + n * 384 : nullptr, L.s);
-  ed_launch_mul(reinterpret_cast<const u32*>(dk), a, ka, n, L.s);
+  ed_launch_mul(sched_env(ctx), reinterpret_cast<const u32*>(dk), a, ka, n, L.s);
   eddsa_finish_launch(sg, ka, reinterpret_cast<const u32*>(dr), drinf, dstatus, n, L.s);
   return L.done();
 }
@@ -719,7 +719,7 @@ int launch_validate(fec_ctx* ctx, int curve, const u64* dxy, const unsigned char
     if (!work) return FEC_E_OOM;
   }
   Launch L(ctx, stream, curve == FEC_ED25519 ? "k_ed_validate_pre + k_ed_mul_pers x2 + k_ed_validate_finish" : "k_validate_weierstrass");
-  validate_launch(curve, reinterpret_cast<const u32*>(dxy), dinf, dok, work, n, L.s);
+  validate_launch(sched_env(ctx), curve, reinterpret_cast<const u32*>(dxy), dinf, dok, work, n, L.s);
   return L.done();
 }
 
@@ -731,7 +731,7 @@ int launch_ecdh(fec_ctx* ctx, int curve, const u64* dsk, const u64* dpk, const u
   void* work = scratch_for(ctx, st, ecdh_work_bytes(n));
   if (!work) return FEC_E_OOM;
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_ecdh_pre + k_secp_mul + k_ecdh_finish" : "k_ecdh_pre + k_p256_mul_sched + k_ecdh_finish");
-  ecdh_launch(curve, reinterpret_cast<const u32*>(dsk), reinterpret_cast<const u32*>(dpk), dinf, reinterpret_cast<u32*>(dout),
+  ecdh_launch(sched_env(ctx), curve, reinterpret_cast<const u32*>(dsk), reinterpret_cast<const u32*>(dpk), dinf, reinterpret_cast<u32*>(dout),
               dstatus, work, n, L.s);
   return L.done();
 }
@@ -818,32 +818,41 @@ int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, siz
   }
   int rc = copy_back(nchunks - 1);
   if (rc != FEC_OK) return rc;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream2) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
-  return FEC_OK;
+  return sync_and_check(ctx, ctx->stream, ctx->stream2);
 }
 
 // Multi-device ctx: contiguous shards [g*n/N, (g+1)*n/N), one host thread per shard worker, each
 // calling the single-device entry point on its child ctx with offset pointers.  Returns the first
 // failure in shard order.
+constexpr size_t kMaxShards = 16;  // fec_ctx_create_multi's limit
 template <class F>
 int multi_shard(fec_ctx* ctx, size_t n, F call) {
   const size_t N = ctx->children.size();
-  std::vector<int> rc(N, FEC_OK);
-  std::vector<std::thread> workers;
-  workers.reserve(N);
+  if (N == 0 || N > kMaxShards) return FEC_E_ARG;
+  // fixed-size state: nothing here allocates, so the only thing that can throw is the creation of a thread, and
+  // an exception inside a worker is caught inside the worker (it would otherwise terminate the process)
+  int rc[kMaxShards];
+  std::thread workers[kMaxShards];
+  for (size_t g = 0; g < N; ++g) rc[g] = FEC_OK;
   for (size_t g = 0; g < N; ++g) {
     const size_t lo = n / N * g + (n % N) * g / N, hi = n / N * (g + 1) + (n % N) * (g + 1) / N;
     if (hi == lo) continue;
     try {
-      workers.emplace_back([&rc, &call, ctx, g, lo, hi] { rc[g] = call(ctx->children[g], lo, hi - lo); });
-    } catch (const std::system_error&) {
+      workers[g] = std::thread([&rc, &call, ctx, g, lo, hi] {
+        try {
+          rc[g] = call(ctx->children[g], lo, hi - lo);
+        } catch (const std::bad_alloc&) {
+          rc[g] = FEC_E_OOM;
+        } catch (...) {
+          rc[g] = FEC_E_DEVICE;
+        }
+      });
+    } catch (...) {  // std::system_error: the thread could not be started
       rc[g] = FEC_E_COMM;
     }
   }
-  for (auto& w : workers) w.join();
+  for (size_t g = 0; g < N; ++g)
+    if (workers[g].joinable()) workers[g].join();
   for (size_t g = 0; g < N; ++g)
     if (rc[g] != FEC_OK) return rc[g];
   return FEC_OK;
@@ -856,7 +865,7 @@ extern "C" {
 
 int fec_point_limbs(fec_curve curve) { return curve_ok(curve) ? plimbs(curve) : 0; }
 
-const char* fec_strerror(int status) {
+const char* fec_strerror(int status) try {
   switch (status) {
     case FEC_OK: return "ok";
     case FEC_E_ARG: return "invalid argument";
@@ -867,9 +876,9 @@ const char* fec_strerror(int status) {
     case FEC_E_COMM: return "multi-device ctx: a shard worker could not be started";
     default: return "unknown fecgpu status";
   }
-}
+} FEC_ABI_CATCH_NULL
 
-int fec_ctx_create(fec_ctx** out, int device) {
+int fec_ctx_create(fec_ctx** out, int device) try {
   if (!out) return FEC_E_ARG;
   *out = nullptr;
   int count = 0;
@@ -897,9 +906,23 @@ int fec_ctx_create(fec_ctx** out, int device) {
   }
   for (int c = 0; c < 3; ++c) {
     if (hipMalloc(&ctx->d_gen[c], (size_t)plimbs(c) * 8) != hipSuccess) {
+      (void)hipGetLastError();
       fec_ctx_destroy(ctx);
       return FEC_E_OOM;
     }
+  }
+  {  // the device error word: pinned host memory the kernels can write (kernels.hpp: SchedEnv)
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (h) (void)hipHostFree(h);
+      fec_ctx_destroy(ctx);
+      return FEC_E_OOM;
+    }
+    std::memset(h, 0, 64);
+    ctx->h_err = static_cast<unsigned*>(h);
+    ctx->d_err = static_cast<unsigned*>(d);
   }
   {
     // every copy goes to the ctx stream: it is non-blocking, i.e. NOT ordered with NULL-stream work
@@ -924,9 +947,9 @@ int fec_ctx_create(fec_ctx** out, int device) {
   }
   *out = ctx;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
-int fec_ctx_create_multi(fec_ctx** out, const int* devices, int n_devices) {
+int fec_ctx_create_multi(fec_ctx** out, const int* devices, int n_devices) try {
   if (!out) return FEC_E_ARG;
   *out = nullptr;
   if (n_devices < 1 || n_devices > 16) return FEC_E_ARG;
@@ -939,16 +962,22 @@ int fec_ctx_create_multi(fec_ctx** out, const int* devices, int n_devices) {
       fec_ctx_destroy(parent);
       return rc;
     }
-    parent->children.push_back(child);
+    try {
+      parent->children.push_back(child);
+    } catch (...) {
+      fec_ctx_destroy(child);
+      fec_ctx_destroy(parent);
+      return FEC_E_OOM;
+    }
   }
   parent->device = parent->children[0]->device;
   *out = parent;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_ctx_device_count(fec_ctx* ctx) { return !ctx ? 0 : (ctx->children.empty() ? 1 : (int)ctx->children.size()); }
 
-void fec_ctx_destroy(fec_ctx* ctx) {
+void fec_ctx_destroy(fec_ctx* ctx) try {
   if (!ctx) return;
   if (!ctx->children.empty()) {
     for (fec_ctx* c : ctx->children) fec_ctx_destroy(c);
@@ -956,12 +985,24 @@ void fec_ctx_destroy(fec_ctx* ctx) {
     return;
   }
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
-  for (int i = 0; i < 8; ++i)
+  // Wipe BEFORE anything is freed: nothing a caller passed in outlives the ctx in device memory, and no memset is ever
+  // issued on an address that has gone back to the allocator (round 2 freed the staging buffers first and wiped
+  // afterwards: the wipe then either failed on the first freed pointer and skipped everything else, or zeroed
+  // memory that another ctx had been handed in the meantime).
+  (void)fec_ctx_wipe(ctx);
+  for (int i = 0; i < 8; ++i) {
     if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
+    ctx->d_buf[i] = nullptr;
+    ctx->d_cap[i] = 0;
+  }
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-  for (int i = 0; i < 3; ++i)
+  ctx->stream2 = nullptr;
+  for (int i = 0; i < 3; ++i) {
     if (ctx->d_gen[i]) (void)hipFree(ctx->d_gen[i]);
-  (void)fec_ctx_wipe(ctx);  // nothing a caller passed in outlives the ctx in device memory
+    ctx->d_gen[i] = nullptr;
+  }
+  if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+  ctx->h_err = ctx->d_err = nullptr;
   if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
   for (auto& e : ctx->stream_scratch)
     if (e.buf) (void)hipFree(e.buf);
@@ -978,19 +1019,19 @@ void fec_ctx_destroy(fec_ctx* ctx) {
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
-}
+} FEC_ABI_CATCH_VOID
 
 int fec_batch_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* ds, const uint64_t* dp, uint64_t* dout,
-                      size_t n, void* stream) {
+                      size_t n, void* stream) try {
   if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!ds || !dp || !dout))) return FEC_E_ARG;
   if (!aligned16(ds) || !aligned16(dp) || !aligned16(dout)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_mul(ctx, curve, false, ds, dp, dout, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* ds, const uint64_t* dbase,
-                            uint64_t* dout, size_t n, void* stream) {
+                            uint64_t* dout, size_t n, void* stream) try {
   if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!ds || !dbase || !dout))) return FEC_E_ARG;
   if (!aligned16(ds) || !aligned16(dbase) || !aligned16(dout)) return FEC_E_ARG;
@@ -1001,19 +1042,19 @@ int fec_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* ds, c
     return launch_ed_fixed(ctx, ds, dbase, host_base, dout, n, stream);
   }
   return launch_mul(ctx, curve, true, ds, dbase, dout, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d1, const uint64_t* d2,
-                             const uint64_t* dq, uint64_t* dout, size_t n, void* stream) {
+                             const uint64_t* dq, uint64_t* dout, size_t n, void* stream) try {
   if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!d1 || !d2 || !dq || !dout))) return FEC_E_ARG;
   if (!aligned16(d1) || !aligned16(d2) || !aligned16(dq) || !aligned16(dout)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_double_mul(ctx, curve, d1, d2, dq, dout, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points,
-                  uint64_t* out, size_t n) {
+                  uint64_t* out, size_t n) try {
   if (is_multi(ctx)) {
     if (!curve_ok(curve) || (n && (!scalars || !points || !out))) return FEC_E_ARG;
     const size_t pl = (size_t)plimbs(curve);
@@ -1028,10 +1069,10 @@ int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const 
   return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void*, void* o, size_t cnt, void* s) {
     return launch_mul(ctx, curve, false, (const u64*)a, (const u64*)b, (u64*)o, cnt, s);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* base,
-                        uint64_t* out, size_t n) {
+                        uint64_t* out, size_t n) try {
   if (is_multi(ctx)) {
     if (!curve_ok(curve) || !base || (n && (!scalars || !out))) return FEC_E_ARG;
     const size_t pl = (size_t)plimbs(curve);
@@ -1057,10 +1098,10 @@ int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, 
     if (curve == FEC_ED25519) return launch_ed_fixed(ctx, (const u64*)a, (const u64*)b, base, (u64*)o, cnt, s);
     return launch_mul(ctx, curve, true, (const u64*)a, (const u64*)b, (u64*)o, cnt, s);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, const uint64_t* u2,
-                         const uint64_t* q, uint64_t* out, size_t n) {
+                         const uint64_t* q, uint64_t* out, size_t n) try {
   if (is_multi(ctx)) {
     if (!curve_ok(curve) || (n && (!u1 || !u2 || !q || !out))) return FEC_E_ARG;
     const size_t pl = (size_t)plimbs(curve);
@@ -1075,10 +1116,10 @@ int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
   return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void* c, void* o, size_t cnt, void* s) {
     return launch_double_mul(ctx, curve, (const u64*)a, (const u64*)b, (const u64*)c, (u64*)o, cnt, s);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points,
-                         uint64_t* out, size_t n) {
+                         uint64_t* out, size_t n) try {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx || !curve_ok(curve) || !out || (n && (!scalars || !points))) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1111,12 +1152,9 @@ int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars,
     if (rc != FEC_OK) return rc;
   }
   if (hipMemcpyAsync(out, ctx->d_buf[7], pb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
+  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
 namespace {
 int ecdsa_verify_dev(fec_ctx* ctx, int curve, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
@@ -1157,32 +1195,29 @@ int ecdsa_verify_host(fec_ctx* ctx, int curve, const uint8_t* digests, const uin
                            pk_inf ? (const unsigned char*)ctx->d_buf[5] : nullptr, (unsigned char*)ctx->d_buf[3], n, nullptr);
   if (rc != FEC_OK) return rc;
   if (hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
+  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   return FEC_OK;
 }
 }  // namespace
 
 int fec_ecdsa_verify_secp256k1_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
                                    const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
-                                   void* stream) {
+                                   void* stream) try {
   return ecdsa_verify_dev(ctx, FEC_SECP256K1, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 int fec_ecdsa_verify_secp256k1(fec_ctx* ctx, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
-                               const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) {
+                               const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) try {
   return ecdsa_verify_host(ctx, FEC_SECP256K1, digests, r, s, pk_xy, pk_inf, status, n);
-}
+} FEC_ABI_CATCH_STATUS
 int fec_ecdsa_verify_p256_dev(fec_ctx* ctx, const uint8_t* d_digests, const uint64_t* d_r, const uint64_t* d_s,
                               const uint64_t* d_pk_xy, const uint8_t* d_pk_inf, uint8_t* d_status, size_t n,
-                              void* stream) {
+                              void* stream) try {
   return ecdsa_verify_dev(ctx, FEC_P256, d_digests, d_r, d_s, d_pk_xy, d_pk_inf, d_status, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 int fec_ecdsa_verify_p256(fec_ctx* ctx, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
-                          const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) {
+                          const uint64_t* pk_xy, const uint8_t* pk_inf, uint8_t* status, size_t n) try {
   return ecdsa_verify_host(ctx, FEC_P256, digests, r, s, pk_xy, pk_inf, status, n);
-}
+} FEC_ABI_CATCH_STATUS
 
 // Ecdsa::<C, D>::batch_verify (forge-ec-signature/src/ecdsa.rs:287-391), C = Secp256k1 / P256, with the digests
 // and the weights a_i (302-306) supplied.  The per-signature scalars and the 2n multiplications run in
@@ -1190,7 +1225,7 @@ int fec_ecdsa_verify_p256(fec_ctx* ctx, const uint8_t* digests, const uint64_t* 
 // r_sum += r_i (358) and the ordered scalar sum (368-372) are reproduced exactly.
 int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests, const uint64_t* r, const uint64_t* s,
                            const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* a, size_t n, uint8_t* result,
-                           uint64_t* detail) {
+                           uint64_t* detail) try {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx || !result || (n && (!digests || !r || !s || !pk_xy || !a))) return FEC_E_ARG;
   if (curve != FEC_SECP256K1 && curve != FEC_P256) return FEC_E_UNSUPPORTED;
@@ -1224,10 +1259,7 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
   std::unique_ptr<unsigned char[]> flags(new (std::nothrow) unsigned char[n]);  // no exception may cross the C ABI
   if (!flags) return FEC_E_OOM;
   if (hipMemcpyAsync(flags.get(), work + n * 352, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
+  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   for (size_t i = 0; i < n; ++i)
     if (flags[i] != 0) {
       *result = flags[i] == 2 ? 2 : 0;
@@ -1238,7 +1270,7 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
   {
     Launch L(ctx, nullptr, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op + k_fold_sum + k_ecdsa_batch_finish"
                                                   : "k_p256_mul_sched x2 + k_point_op + k_fold_sum + k_ecdsa_batch_finish");
-    ecdsa_batch_mul_launch(curve, reinterpret_cast<const u32*>(ctx->d_gen[curve]), work, n, L.s, ctx->stream2);
+    ecdsa_batch_mul_launch(sched_env(ctx), curve, reinterpret_cast<const u32*>(ctx->d_gen[curve]), work, n, L.s, ctx->stream2);
     const dim3 g(grid_for(n)), b(TPB);
     if (curve == FEC_SECP256K1) {  // r_i = r1 + r2 (355), then r_sum += r_i in index order (358)
       hipLaunchKernelGGL((k_point_op<Secp>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, ta, n);
@@ -1256,25 +1288,22 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
   if (hipMemcpyAsync(&res, tail + 96 + 128, 1, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipMemcpyAsync(det, tail + 96, 128, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
     return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
+  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   *result = res;
   if (detail) std::memcpy(detail, det, 128);
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_validate_point_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf, uint8_t* d_ok,
-                                 size_t n, void* stream) {
+                                 size_t n, void* stream) try {
   if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!d_xy || !d_ok))) return FEC_E_ARG;
   if (!aligned16(d_xy)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_validate(ctx, curve, d_xy, d_inf, d_ok, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
-int fec_batch_validate_point(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* ok, size_t n) {
+int fec_batch_validate_point(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* ok, size_t n) try {
   if (!curve_ok(curve)) return FEC_E_ARG;
   if (is_multi(ctx)) {
     if (n && (!xy || !ok)) return FEC_E_ARG;
@@ -1295,25 +1324,22 @@ int fec_batch_validate_point(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, 
                        (unsigned char*)ctx->d_buf[2], n, nullptr);
   if (rc != FEC_OK) return rc;
   if (hipMemcpyAsync(ok, ctx->d_buf[2], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
+  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_ecdh_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_private_keys, const uint64_t* d_pk_xy,
-                       const uint8_t* d_pk_inf, uint8_t* d_secrets, uint8_t* d_status, size_t n, void* stream) {
+                       const uint8_t* d_pk_inf, uint8_t* d_secrets, uint8_t* d_status, size_t n, void* stream) try {
   if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || (n && (!d_private_keys || !d_pk_xy || !d_secrets || !d_status))) return FEC_E_ARG;
   if (curve != FEC_SECP256K1 && curve != FEC_P256) return FEC_E_UNSUPPORTED;   // Ed25519 has no KeyExchange impl
   if (!aligned16(d_private_keys) || !aligned16(d_pk_xy) || !aligned16(d_secrets)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_ecdh(ctx, curve, d_private_keys, d_pk_xy, d_pk_inf, d_secrets, d_status, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_ecdh(fec_ctx* ctx, fec_curve curve, const uint64_t* private_keys, const uint64_t* pk_xy, const uint8_t* pk_inf,
-                   uint8_t* secrets, uint8_t* status, size_t n) {
+                   uint8_t* secrets, uint8_t* status, size_t n) try {
   if (curve != FEC_SECP256K1 && curve != FEC_P256) return FEC_E_UNSUPPORTED;
   if (is_multi(ctx)) {
     if (n && (!private_keys || !pk_xy || !secrets || !status)) return FEC_E_ARG;
@@ -1325,49 +1351,42 @@ int fec_batch_ecdh(fec_ctx* ctx, fec_curve curve, const uint64_t* private_keys, 
   if (!ctx || (n && (!private_keys || !pk_xy || !secrets || !status))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  // slots: 0 private keys, 1 public keys, 2 infinity flags, 3 status, 4 secrets
-  const void* hin[3] = {private_keys, pk_xy, pk_inf};
-  const size_t bytes[3] = {n * 32, n * 64, n};
-  for (int i = 0; i < 3; ++i) {
-    if (!hin[i]) continue;
-    int rc = ensure(ctx, i, bytes[i]);
-    if (rc != FEC_OK) return rc;
-    if (hipMemcpyAsync(ctx->d_buf[i], hin[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  }
-  int rc = ensure(ctx, 3, n);
-  if (rc == FEC_OK) rc = ensure(ctx, 4, n * 32);
-  if (rc != FEC_OK) return rc;
-  rc = launch_ecdh(ctx, curve, (const u64*)ctx->d_buf[0], (const u64*)ctx->d_buf[1],
-                   pk_inf ? (const unsigned char*)ctx->d_buf[2] : nullptr, (unsigned char*)ctx->d_buf[4],
-                   (unsigned char*)ctx->d_buf[3], n, nullptr);
-  if (rc != FEC_OK) return rc;
-  if (hipMemcpyAsync(secrets, ctx->d_buf[4], n * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-      hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-    return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
-  // the private keys, the shared points and the secrets were staged in ctx-owned device memory: clear it
-  (void)hipMemsetAsync(ctx->d_buf[0], 0, n * 32, ctx->stream);
-  (void)hipMemsetAsync(ctx->d_buf[4], 0, n * 32, ctx->stream);
-  if (void* work = scratch_for(ctx, ctx->stream, ecdh_work_bytes(n))) (void)hipMemsetAsync(work, 0, ecdh_work_bytes(n), ctx->stream);
-  (void)hipStreamSynchronize(ctx->stream);
-  return FEC_OK;
-}
+  // Chunked like the other element-wise calls (device staging bounded by one chunk).  The private keys (slot 0), the
+  // secrets (slot 4) and the shared points (the stream's scratch) sit in ctx-owned device memory while the call runs:
+  // they are cleared on EVERY way out of it, error returns included.
+  struct Wipe {
+    fec_ctx* c;
+    ~Wipe() {
+      if (c->d_buf[0]) (void)hipMemsetAsync(c->d_buf[0], 0, c->d_cap[0], c->stream);
+      if (c->d_buf[4]) (void)hipMemsetAsync(c->d_buf[4], 0, c->d_cap[4], c->stream);
+      for (auto& e : c->stream_scratch)
+        if (e.stream == c->stream && e.buf) (void)hipMemsetAsync(e.buf, 0, e.cap, c->stream);
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipGetLastError();
+    }
+  } wipe{ctx};
+  const void* const in[4] = {private_keys, pk_xy, pk_inf, nullptr};
+  const size_t in_stride[4] = {32, 64, 1, 0};
+  void* const outs[2] = {secrets, status};
+  const size_t out_stride[2] = {32, 1};
+  return host_chunked(ctx, n, in, in_stride, outs, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
+    return launch_ecdh(ctx, curve, (const u64*)d[0], (const u64*)d[1], (const unsigned char*)d[2], (unsigned char*)o[0],
+                       (unsigned char*)o[1], cnt, nullptr);
+  });
+} FEC_ABI_CATCH_STATUS
 
 int fec_eddsa_verify_ed25519_dev(fec_ctx* ctx, const uint64_t* d_r_xy, const uint8_t* d_r_inf, const uint64_t* d_pk_xy,
                                  const uint8_t* d_pk_inf, const uint64_t* d_s, const uint64_t* d_k, uint8_t* d_status,
-                                 size_t n, void* stream) {
+                                 size_t n, void* stream) try {
   if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || (n && (!d_r_xy || !d_pk_xy || !d_s || !d_k || !d_status))) return FEC_E_ARG;
   if (!aligned16(d_r_xy) || !aligned16(d_pk_xy) || !aligned16(d_s) || !aligned16(d_k)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_eddsa_verify(ctx, d_r_xy, d_r_inf, d_pk_xy, d_pk_inf, d_s, d_k, d_status, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_eddsa_verify_ed25519(fec_ctx* ctx, const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* pk_xy,
-                             const uint8_t* pk_inf, const uint64_t* s, const uint64_t* k, uint8_t* status, size_t n) {
+                             const uint8_t* pk_inf, const uint64_t* s, const uint64_t* k, uint8_t* status, size_t n) try {
   if (is_multi(ctx)) {
     if (n && (!r_xy || !pk_xy || !s || !k || !status)) return FEC_E_ARG;
     return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
@@ -1395,18 +1414,15 @@ int fec_eddsa_verify_ed25519(fec_ctx* ctx, const uint64_t* r_xy, const uint8_t* 
                            (const u64*)ctx->d_buf[2], (const u64*)ctx->d_buf[4], (unsigned char*)ctx->d_buf[3], n, nullptr);
   if (rc != FEC_OK) return rc;
   if (hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
+  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
 // schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290)
 int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, const uint8_t* pk_inf,
                                        const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s,
                                        const uint64_t* a, const uint64_t* e, size_t n, uint8_t* result,
-                                       uint64_t* sides_xy, uint8_t* sides_inf) {
+                                       uint64_t* sides_xy, uint8_t* sides_inf) try {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx || !result || (n && (!pk_xy || !r_xy || !s || !a || !e))) return FEC_E_ARG;
   *result = 0;
@@ -1478,27 +1494,24 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
   if (hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipMemcpyAsync(sides, d_sides, 128, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
     return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
+  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   *result = flags[0];
   if (sides_xy) std::memcpy(sides_xy, sides, 128);
   if (sides_inf) { sides_inf[0] = flags[1]; sides_inf[1] = flags[2]; }
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf,
-                           uint8_t* d_out, size_t n, void* stream) {
+                           uint8_t* d_out, size_t n, void* stream) try {
   if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!d_xy || !d_out))) return FEC_E_ARG;
   if (!aligned16(d_xy) || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_compress(ctx, curve, d_xy, d_inf, d_out, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* out,
-                       size_t n) {
+                       size_t n) try {
   if (is_multi(ctx)) {
     if (!curve_ok(curve) || (n && (!xy || !out))) return FEC_E_ARG;
     return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
@@ -1514,7 +1527,7 @@ int fec_batch_compress(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const 
   return host_chunked(ctx, n, in, in_stride, outs, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
     return launch_compress(ctx, curve, (const u64*)d[0], (const unsigned char*)d[1], (unsigned char*)o[0], cnt, nullptr);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 // decode entry points: in -> (xy, inf, ok).  The device writes inf and ok into one staging area
 // (inf at [0, cnt), ok at [chunk, chunk + cnt)), so host_chunked's two output slots suffice.
@@ -1541,16 +1554,14 @@ static int decode_host(fec_ctx* ctx, int op, fec_curve curve, const uint8_t* in,
         hipMemcpyAsync(inf + lo, flags, cnt, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipMemcpyAsync(ok + lo, flags + chunk, cnt, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
       return FEC_E_DEVICE;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-      (void)hipGetLastError();
-      return FEC_E_LAUNCH;
-    }
+    rc = sync_and_check(ctx, ctx->stream);
+    if (rc != FEC_OK) return rc;
   }
   return FEC_OK;
 }
 
 int fec_batch_decompress(fec_ctx* ctx, fec_curve curve, const uint8_t* in, uint64_t* xy, uint8_t* inf, uint8_t* ok,
-                         size_t n) {
+                         size_t n) try {
   if (is_multi(ctx)) {
     if (!curve_ok(curve) || (n && (!in || !xy || !inf || !ok))) return FEC_E_ARG;
     return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
@@ -1560,10 +1571,10 @@ int fec_batch_decompress(fec_ctx* ctx, fec_curve curve, const uint8_t* in, uint6
   if (!ctx || !curve_ok(curve) || (n && (!in || !xy || !inf || !ok))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   return decode_host(ctx, 0, curve, in, 33, xy, inf, ok, n);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_decode_uncompressed(fec_ctx* ctx, fec_curve curve, const uint8_t* in, uint64_t* xy, uint8_t* inf,
-                                  uint8_t* ok, size_t n) {
+                                  uint8_t* ok, size_t n) try {
   if (is_multi(ctx)) {
     if (!curve_ok(curve) || (n && (!in || !xy || !inf || !ok))) return FEC_E_ARG;
     return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
@@ -1573,10 +1584,10 @@ int fec_batch_decode_uncompressed(fec_ctx* ctx, fec_curve curve, const uint8_t* 
   if (!ctx || !curve_ok(curve) || (n && (!in || !xy || !inf || !ok))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   return decode_host(ctx, 1, curve, in, 65, xy, inf, ok, n);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_encode_uncompressed(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, const uint8_t* inf, uint8_t* out,
-                                  size_t n) {
+                                  size_t n) try {
   if (is_multi(ctx)) {
     if (!curve_ok(curve) || (n && (!xy || !out))) return FEC_E_ARG;
     return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
@@ -1594,19 +1605,19 @@ int fec_batch_encode_uncompressed(fec_ctx* ctx, fec_curve curve, const uint64_t*
     codec_launch(2, curve, d[0], d[1], o[0], nullptr, nullptr, cnt, L.s);
     return L.done();
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
-                            uint8_t* d_inf, size_t n, void* stream) {
+                            uint8_t* d_inf, size_t n, void* stream) try {
   if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
   if (!ctx || !curve_ok(curve) || (n && (!d_points || !d_xy || !d_inf))) return FEC_E_ARG;
   if (!aligned16(d_points) || !aligned16(d_xy)) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   return launch_to_affine(ctx, curve, d_points, d_xy, d_inf, n, stream);
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points, uint64_t* xy, uint8_t* inf,
-                        size_t n) {
+                        size_t n) try {
   if (is_multi(ctx)) {
     if (!curve_ok(curve) || (n && (!points || !xy || !inf))) return FEC_E_ARG;
     const size_t pl = (size_t)plimbs(curve);
@@ -1630,15 +1641,12 @@ int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points, u
   if (hipMemcpyAsync(xy, ctx->d_buf[3], n * 64, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipMemcpyAsync(inf, ctx->d_buf[1], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
     return FEC_E_DEVICE;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return FEC_E_LAUNCH;
-  }
+  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a, const uint64_t* b,
-                 uint64_t* out, size_t n) {
+                 uint64_t* out, size_t n) try {
   if (is_multi(ctx)) {
     if (!curve_ok(curve) || (n && (!a || !out))) return FEC_E_ARG;
     return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
@@ -1653,10 +1661,10 @@ int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint6
   return host_pipeline(ctx, n, in, out, 32, [&](void* x, void* y, void*, void* o, size_t cnt, void* s) {
     return launch_field(ctx, curve, op, (const u64*)x, (const u64*)y, (u64*)o, cnt, s);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
 int fec_point_op(fec_ctx* ctx, fec_curve curve, fec_point_opcode op, const uint64_t* p, const uint64_t* q,
-                 uint64_t* out, size_t n) {
+                 uint64_t* out, size_t n) try {
   if (is_multi(ctx)) {
     if (!curve_ok(curve) || (n && (!p || !out))) return FEC_E_ARG;
     const size_t pl = (size_t)plimbs(curve);
@@ -1674,9 +1682,9 @@ int fec_point_op(fec_ctx* ctx, fec_curve curve, fec_point_opcode op, const uint6
   return host_pipeline(ctx, n, in, out, pb, [&](void* x, void* y, void*, void* o, size_t cnt, void* s) {
     return launch_point(ctx, curve, op, (const u64*)x, (const u64*)y, (u64*)o, cnt, s);
   });
-}
+} FEC_ABI_CATCH_STATUS
 
-int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out) {
+int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out) try {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx || !curve_ok(curve) || !out) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1685,15 +1693,15 @@ int fec_generator(fec_ctx* ctx, fec_curve curve, uint64_t* out) {
     return FEC_E_DEVICE;
   }
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
-const uint64_t* fec_generator_dev(fec_ctx* ctx, fec_curve curve) {
+const uint64_t* fec_generator_dev(fec_ctx* ctx, fec_curve curve) try {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx || !curve_ok(curve)) return nullptr;
   return ctx->d_gen[curve];
-}
+} FEC_ABI_CATCH_NULL
 
-int fec_ctx_wipe(fec_ctx* ctx) {
+int fec_ctx_wipe(fec_ctx* ctx) try {
   if (!ctx) return FEC_E_ARG;
   if (is_multi(ctx)) {
     int rc = FEC_OK;
@@ -1711,24 +1719,65 @@ int fec_ctx_wipe(fec_ctx* ctx) {
   // memsets and have its work area zeroed under it (seen as an intermittent "point at infinity" from the canonical
   // mul_base that followed a signing helper).  The wipe therefore goes to the ctx stream and is waited for.
   hipStream_t st = ctx->stream;
-  bool ok = true;
-  for (int i = 0; i < 8; ++i)
-    if (ctx->d_buf[i]) ok = ok && hipMemsetAsync(ctx->d_buf[i], 0, ctx->d_cap[i], st) == hipSuccess;
-  for (auto& e : ctx->stream_scratch)
-    if (e.buf) ok = ok && hipMemsetAsync(e.buf, 0, e.cap, st) == hipSuccess;
-  if (ctx->d_win_scratch) ok = ok && hipMemsetAsync(ctx->d_win_scratch, 0, ctx->win_scratch_cap, st) == hipSuccess;
-  if (ctx->d_zbuf) ok = ok && hipMemsetAsync(ctx->d_zbuf, 0, ctx->zbuf_cap, st) == hipSuccess;
-  if (ctx->d_tbuf) ok = ok && hipMemsetAsync(ctx->d_tbuf, 0, ctx->tbuf_cap, st) == hipSuccess;
-  if (ctx->d_verify) ok = ok && hipMemsetAsync(ctx->d_verify, 0, ctx->verify_cap, st) == hipSuccess;
-  ok = ok && hipStreamSynchronize(st) == hipSuccess;
-  if (!ok) {
+  // every buffer is attempted whatever happened to the ones before it (no short-circuit: a failure must not leave
+  // the remaining buffers -- u1/u2, ECDH work areas, signing nonces -- uncleared)
+  int failed = 0;
+  auto zero = [&](void* p, size_t bytes) {
+    if (p && bytes && hipMemsetAsync(p, 0, bytes, st) != hipSuccess) {
+      (void)hipGetLastError();
+      ++failed;
+    }
+  };
+  for (int i = 0; i < 8; ++i) zero(ctx->d_buf[i], ctx->d_cap[i]);
+  for (auto& e : ctx->stream_scratch) zero(e.buf, e.cap);
+  zero(ctx->d_win_scratch, ctx->win_scratch_cap);
+  zero(ctx->d_zbuf, ctx->zbuf_cap);
+  zero(ctx->d_tbuf, ctx->tbuf_cap);
+  zero(ctx->d_verify, ctx->verify_cap);
+  if (hipStreamSynchronize(st) != hipSuccess) {
     (void)hipGetLastError();
-    return FEC_E_DEVICE;
+    ++failed;
   }
-  return FEC_OK;
-}
+  return failed ? FEC_E_DEVICE : FEC_OK;
+} FEC_ABI_CATCH_STATUS
 
-int fec_ctx_set_chunk(fec_ctx* ctx, size_t elements) {
+// The sticky device error state of the ctx (see kernels.hpp: SchedEnv), for callers of the *_dev entry points: those
+// return as soon as the work is enqueued, so a fault a kernel reports can only be seen afterwards.  Synchronises the
+// ctx's device, then returns FEC_E_LAUNCH if any kernel launched through this ctx since the last check reported a
+// fault (its outputs must not be used), FEC_OK otherwise; reading clears the state.
+int fec_ctx_check(fec_ctx* ctx) try {
+  if (!ctx) return FEC_E_ARG;
+  if (is_multi(ctx)) {
+    int rc = FEC_OK;
+    for (fec_ctx* c : ctx->children) {
+      const int r = fec_ctx_check(c);
+      if (rc == FEC_OK) rc = r;
+    }
+    return rc;
+  }
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  if (hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    (void)take_device_error(ctx);
+    return FEC_E_LAUNCH;
+  }
+  return take_device_error(ctx);
+} FEC_ABI_CATCH_STATUS
+
+// Debug hook: while enabled, every launch of a scheduler kernel (P-256, Ed25519 variable base -- also inside the
+// composed entry points) raises its fault word at once, exactly as the watchdog would.  Lets a test assert that a
+// scheduler fault comes back as FEC_E_LAUNCH.
+int fec_ctx_debug_force_fault(fec_ctx* ctx, int enabled) try {
+  if (!ctx) return FEC_E_ARG;
+  if (is_multi(ctx)) {
+    for (fec_ctx* c : ctx->children) c->debug_force_fault = enabled ? 1u : 0u;
+    return FEC_OK;
+  }
+  ctx->debug_force_fault = enabled ? 1u : 0u;
+  return FEC_OK;
+} FEC_ABI_CATCH_STATUS
+
+int fec_ctx_set_chunk(fec_ctx* ctx, size_t elements) try {
   if (is_multi(ctx)) {
     for (fec_ctx* c : ctx->children) c->chunk = elements ? elements : c->chunk;
     return elements ? FEC_OK : FEC_E_ARG;
@@ -1736,17 +1785,17 @@ int fec_ctx_set_chunk(fec_ctx* ctx, size_t elements) {
   if (!ctx || elements == 0) return FEC_E_ARG;
   ctx->chunk = elements;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
-int fec_ctx_set_timing(fec_ctx* ctx, int enabled) {
+int fec_ctx_set_timing(fec_ctx* ctx, int enabled) try {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx) return FEC_E_ARG;
   ctx->timing = enabled != 0;
   ctx->timed = false;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
-int fec_ctx_last_kernel_ms(fec_ctx* ctx, float* ms, const char** kernel_name) {
+int fec_ctx_last_kernel_ms(fec_ctx* ctx, float* ms, const char** kernel_name) try {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx || !ms) return FEC_E_ARG;
   if (!ctx->timed) return FEC_E_ARG;
@@ -1757,9 +1806,9 @@ int fec_ctx_last_kernel_ms(fec_ctx* ctx, float* ms, const char** kernel_name) {
   }
   if (kernel_name) *kernel_name = ctx->last_kernel;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
-int fec_measure_peak_mad32(fec_ctx* ctx, double* mad32_per_sec) {
+int fec_measure_peak_mad32(fec_ctx* ctx, double* mad32_per_sec) try {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx || !mad32_per_sec) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
@@ -1780,9 +1829,9 @@ int fec_measure_peak_mad32(fec_ctx* ctx, double* mad32_per_sec) {
   }
   *mad32_per_sec = best;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
-int fec_ctx_device_info(fec_ctx* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz) {
+int fec_ctx_device_info(fec_ctx* ctx, char* name, size_t name_len, int* compute_units, int* clock_khz) try {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx) return FEC_E_ARG;
   if (name && name_len) {
@@ -1791,6 +1840,6 @@ int fec_ctx_device_info(fec_ctx* ctx, char* name, size_t name_len, int* compute_
   if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
   if (clock_khz) *clock_khz = ctx->prop.clockRate;
   return FEC_OK;
-}
+} FEC_ABI_CATCH_STATUS
 
 }  // extern "C"

@@ -5,9 +5,11 @@
 
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../../include/fecgpu.h"
+#include "kernels.hpp"
 #include "staging.hpp"
 
 struct fec_ctx {
@@ -58,7 +60,28 @@ struct fec_ctx {
   // staging): a launch on a stream other than the previous launch's stream first waits for that one
   hipStream_t last_stream = nullptr;
   hipEvent_t ev_order = nullptr;
+  // Device error word (kernels.hpp: SchedEnv): one word of pinned host memory mapped into the device.  A scheduler
+  // kernel whose watchdog / index guard fires stores a FEC_DEVERR_* code here; the host reads it after synchronising
+  // (sync_and_check, fec_ctx_check).  Sticky until read.
+  unsigned* h_err = nullptr;       // host view
+  unsigned* d_err = nullptr;       // device view of the same word
+  unsigned debug_force_fault = 0;  // fec_ctx_debug_force_fault
 };
+
+// No exception may cross the C ABI: every extern "C" definition in fecgpu.hip and canon.hip is a function-try-block
+// closed by one of these (tests/test_abi_library.py checks that none is missing).
+#define FEC_ABI_CATCH_STATUS            \
+  catch (const std::bad_alloc&) {       \
+    return FEC_E_OOM;                   \
+  }                                     \
+  catch (...) {                         \
+    return FEC_E_DEVICE;                \
+  }
+#define FEC_ABI_CATCH_VOID catch (...) {}
+#define FEC_ABI_CATCH_NULL \
+  catch (...) {            \
+    return nullptr;        \
+  }
 
 // a multi-device ctx runs everything that is not sharded on its first shard worker
 #define FEC_FIRST_DEVICE(ctx)                                      \
@@ -75,7 +98,12 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 inline int ensure(fec_ctx* ctx, int slot, size_t bytes) {
   if (ctx->d_cap[slot] >= bytes) return FEC_OK;
-  if (ctx->d_buf[slot]) (void)hipFree(ctx->d_buf[slot]);
+  if (ctx->d_buf[slot]) {
+    // a staging buffer may hold a caller's keys: it is cleared before it goes back to the allocator (hipFree waits
+    // for the device, so the memset has run by the time the memory is released)
+    (void)hipMemsetAsync(ctx->d_buf[slot], 0, ctx->d_cap[slot], ctx->stream);
+    (void)hipFree(ctx->d_buf[slot]);
+  }
   ctx->d_buf[slot] = nullptr;
   ctx->d_cap[slot] = 0;
   size_t cap = bytes + (bytes >> 2) + 4096;
@@ -92,6 +120,7 @@ inline void* scratch_for(fec_ctx* ctx, hipStream_t stream, size_t bytes) {
   for (auto& e : ctx->stream_scratch) {
     if (e.stream != stream) continue;
     if (e.cap >= bytes) return e.buf;
+    (void)hipMemsetAsync(e.buf, 0, e.cap, stream);  // cleared before it is released (it may hold u1/u2, shared points)
     (void)hipStreamSynchronize(stream);
     (void)hipFree(e.buf);
     e.buf = nullptr;
@@ -109,7 +138,12 @@ inline void* scratch_for(fec_ctx* ctx, hipStream_t stream, size_t bytes) {
     return nullptr;
   }
   e.cap = bytes + (bytes >> 2);
-  ctx->stream_scratch.push_back(e);
+  try {
+    ctx->stream_scratch.push_back(e);
+  } catch (...) {  // no exception may cross the C ABI
+    (void)hipFree(e.buf);
+    return nullptr;
+  }
   return e.buf;
 }
 
@@ -148,6 +182,37 @@ struct Launch {
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 
+inline SchedEnv sched_env(const fec_ctx* ctx) {
+  SchedEnv e;
+  e.err = ctx->d_err;
+  e.cus = ctx->prop.multiProcessorCount > 0 ? (unsigned)ctx->prop.multiProcessorCount : 256u;
+  e.force_fault = ctx->debug_force_fault;
+  return e;
+}
+
+// Reads and clears the ctx's device error word.  Only meaningful once the launches in question have completed
+// (the callers synchronise first).  FEC_E_LAUNCH when a kernel reported a fault: its outputs must not be used.
+inline int take_device_error(fec_ctx* ctx) {
+  if (!ctx->h_err) return FEC_OK;
+  const unsigned code = *reinterpret_cast<volatile unsigned*>(ctx->h_err);
+  if (code == 0) return FEC_OK;
+  *reinterpret_cast<volatile unsigned*>(ctx->h_err) = 0;
+  return FEC_E_LAUNCH;
+}
+
+// The end of every host-pointer entry point: wait for the stream(s), turn a HIP failure into FEC_E_LAUNCH, then
+// look at the device error word.
+inline int sync_and_check(fec_ctx* ctx, hipStream_t a, hipStream_t b = nullptr) {
+  bool ok = hipStreamSynchronize(a) == hipSuccess;
+  if (b) ok = (hipStreamSynchronize(b) == hipSuccess) && ok;
+  if (!ok) {
+    (void)hipGetLastError();
+    (void)take_device_error(ctx);
+    return FEC_E_LAUNCH;
+  }
+  return take_device_error(ctx);
+}
+
 // Host-pointer call over chunks of ctx->chunk elements with up to four per-element inputs (slots 0-3)
 // and two per-element outputs (slots 4-5): H2D, body(d_in[4], d_out[2], count), D2H per chunk on the
 // ctx stream.  Device staging and any per-element scratch the body allocates stay bounded by one
@@ -184,10 +249,8 @@ inline int host_chunked(fec_ctx* ctx, size_t n, const void* const in[4], const s
                          ctx->stream) != hipSuccess)
         return FEC_E_DEVICE;
     }
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-      (void)hipGetLastError();
-      return FEC_E_LAUNCH;
-    }
+    rc = sync_and_check(ctx, ctx->stream);
+    if (rc != FEC_OK) return rc;
   }
   return FEC_OK;
 }

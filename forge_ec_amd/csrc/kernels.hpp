@@ -6,14 +6,30 @@
 
 namespace fecgpu {
 
+// What a launch of one of the persistent scheduler kernels needs from the ctx it runs for.
+//   err         the ctx's device-visible error word (pinned host memory mapped into the device): a scheduler whose
+//               watchdog fires ORs FEC_DEVERR_* into it besides zero-filling its outputs, and every host-pointer entry
+//               point reads it after its final synchronisation (fec_ctx_check for the *_dev callers) -- a scheduler
+//               fault therefore surfaces as FEC_E_LAUNCH, never as FEC_OK with zeroed points.
+//   cus         CU count of the ctx's OWN device (one persistent workgroup per CU)
+//   force_fault debug hook (fec_ctx_debug_force_fault): the kernels raise their C_ERR word at once, so that the
+//               whole error path can be exercised by a test
+struct SchedEnv {
+  unsigned* err = nullptr;
+  unsigned cus = 256;
+  unsigned force_fault = 0;
+};
+enum : unsigned { FEC_DEVERR_SCHED_WATCHDOG = 1u, FEC_DEVERR_SCHED_INDEX = 2u, FEC_DEVERR_FORCED = 4u };
+
 // kernels_p256.hip: P-256 Curve::multiply, workgroup task scheduler.  out[i] = multiply(fixed ? points[0] : points[i], scalars[i])
 // `cu_divisor` > 1: the launch takes at most that fraction of the CUs (a second launch on another stream runs beside it).
-void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,
+void p256_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,
                      unsigned cu_divisor = 1);
 
 // kernels_ed.hip: Ed25519 variable-base Curve::multiply, persistent workgroup task scheduler (one workgroup
 // per CU, element state in LDS, slots refilled from the workgroup's range).
-void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s, unsigned cu_divisor = 1);
+void ed_launch_mul(const SchedEnv& env, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,
+                   unsigned cu_divisor = 1);
 // kernels_ed.hip: Ed25519 fixed-base multiply from the 256-entry addend table of `base` (table[j] = 2^j * base by
 // the reference's own doubling chain, built once per base by ed_build_table_launch; 256 * 32 words).
 void ed_build_table_launch(const u32* base, u32* table, hipStream_t s);
@@ -34,7 +50,7 @@ void codec_launch(int op, int curve, const void* in, const void* in2, void* out,
 // kernels_ecdsa.hip: Ecdsa::<C, D>::verify for C = Secp256k1 / P256 (ecdsa.rs:213-281): scalar pre-pass, the two
 // multiplications through the launchers above, finishing pass.  `work` holds ecdsa_work_bytes(n) bytes.
 size_t ecdsa_work_bytes(size_t n);
-void ecdsa_launch(int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
+void ecdsa_launch(const SchedEnv& env, int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
                   const unsigned char* pk_inf, const u32* gen, unsigned char* status, void* work, size_t n,
                   hipStream_t s);
 
@@ -44,19 +60,19 @@ void ecdsa_launch(int curve, const unsigned char* digests, const u32* r, const u
 size_t ecdsa_batch_work_bytes(size_t n);
 void ecdsa_batch_pre_launch(int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
                             const unsigned char* pk_inf, const u32* weights, void* work, size_t n, hipStream_t s);
-void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hipStream_t s, hipStream_t side);
+void ecdsa_batch_mul_launch(const SchedEnv& env, int curve, const u32* gen, void* work, size_t n, hipStream_t s, hipStream_t side);
 void ecdsa_batch_finish_launch(int curve, const u32* r_sum, const void* work, size_t n, unsigned char* result, u32* detail,
                                hipStream_t s);
 
 // kernels_ecdsa.hip: Curve::validate_point per affine point (secp256k1 / P-256: is_on_curve; Ed25519: the trait default
 // with its two multiplications).  `work` holds validate_work_bytes(curve, n) bytes (0 for the Weierstrass curves).
 size_t validate_work_bytes(int curve, size_t n);
-void validate_launch(int curve, const u32* xy, const unsigned char* inf, unsigned char* ok, void* work, size_t n, hipStream_t s);
+void validate_launch(const SchedEnv& env, int curve, const u32* xy, const unsigned char* inf, unsigned char* ok, void* work, size_t n, hipStream_t s);
 
 // kernels_ecdsa.hip: KeyExchange::derive_shared_secret for secp256k1 / P-256 (secp256k1.rs:1884-1904, p256.rs:2281-2312):
 // validation + from_affine, the variable-base multiplication, to_affine + x.to_bytes().  out: 8 words (32 bytes) per element.
 size_t ecdh_work_bytes(size_t n);
-void ecdh_launch(int curve, const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* out, unsigned char* status,
+void ecdh_launch(const SchedEnv& env, int curve, const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* out, unsigned char* status,
                  void* work, size_t n, hipStream_t s);
 
 // kernels_ecdsa.hip: Eddsa verify around the Ed25519 multiplications (eddsa.rs:174-211, 430-447).

@@ -66,7 +66,7 @@ struct ESecp {
   FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return secp::to_affine(p, x, y); }
   FEC_DEV static fe wmul(const fe& a, const fe& b) { return secp::sc_mul(a, b); }   // impl Mul for Scalar
   FEC_DEV static fe wadd(const fe& a, const fe& b) { return secp::sc_add(a, b); }   // impl Add for Scalar
-  static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s, unsigned = 1) {
+  static void launch_mul(const SchedEnv&, bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s, unsigned = 1) {
     secp_launch_mul(fixed, k, p, o, n, s);
   }
 };
@@ -105,8 +105,9 @@ struct EP256 {
   FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return p256::to_affine(p, x, y); }
   FEC_DEV static fe wmul(const fe& a, const fe& b) { return p256::sc_mul32(a, b); }
   FEC_DEV static fe wadd(const fe& a, const fe& b) { return p256::sc_fe(p256::sc_add(p256::sc_of(a), p256::sc_of(b))); }
-  static void launch_mul(bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s, unsigned cu_divisor = 1) {
-    p256_launch_mul(fixed, k, p, o, n, s, cu_divisor);
+  static void launch_mul(const SchedEnv& env, bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s,
+                         unsigned cu_divisor = 1) {
+    p256_launch_mul(env, fixed, k, p, o, n, s, cu_divisor);
   }
 };
 
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(TPB) void k_ecdsa_finish(const u32* __restrict__ ta
 }
 
 template <class E>
-void run(const unsigned char* dd, const u32* dr, const u32* ds, const u32* dpk, const unsigned char* dinf, const u32* gen,
+void run(const SchedEnv& env, const unsigned char* dd, const u32* dr, const u32* ds, const u32* dpk, const unsigned char* dinf, const u32* gen,
          unsigned char* dstatus, void* work, size_t n, hipStream_t s) {
   char* w = static_cast<char*>(work);
   u32* u1 = reinterpret_cast<u32*>(w);
@@ -170,8 +171,8 @@ void run(const unsigned char* dd, const u32* dr, const u32* ds, const u32* dpk, 
   const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
   hipLaunchKernelGGL((k_ecdsa_pre<E>), g, b, 0, s, dd, dr, ds, dpk, dinf, (const u32*)nullptr, u1, u2, q, flags,
                      (u32*)nullptr, n);
-  E::launch_mul(true, u1, gen, ta, n, s);
-  E::launch_mul(false, u2, q, tb, n, s);
+  E::launch_mul(env, true, u1, gen, ta, n, s);
+  E::launch_mul(env, false, u2, q, tb, n, s);
   hipLaunchKernelGGL((k_ecdsa_finish<E>), g, b, 0, s, (const u32*)ta, (const u32*)tb, dr, (const unsigned char*)flags, dstatus, n);
 }
 
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(TPB) void k_ecdh_finish(const u32* __restrict__ t, 
   status[i] = st;
 }
 template <class E>
-void run_ecdh(const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* out, unsigned char* status, void* work, size_t n,
+void run_ecdh(const SchedEnv& env, const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* out, unsigned char* status, void* work, size_t n,
               hipStream_t s) {
   char* w = static_cast<char*>(work);
   u32* q = reinterpret_cast<u32*>(w);
@@ -252,7 +253,7 @@ void run_ecdh(const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* ou
   unsigned char* flags = reinterpret_cast<unsigned char*>(w + n * 192);
   const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
   hipLaunchKernelGGL((k_ecdh_pre<E>), g, b, 0, s, pk, pk_inf, q, flags, n);
-  E::launch_mul(false, sk, q, t, n, s);
+  E::launch_mul(env, false, sk, q, t, n, s);
   hipLaunchKernelGGL((k_ecdh_finish<E>), g, b, 0, s, (const u32*)t, (const unsigned char*)flags, out, status, n);
 }
 
@@ -364,7 +365,7 @@ size_t ecdsa_work_bytes(size_t n) { return n * 353; }
 
 // Curve::validate_point.  Work (Ed25519 only): point A (128 n), scalars (32 n), products T1, T2 (128 n each), flags (n).
 size_t validate_work_bytes(int curve, size_t n) { return curve == FEC_ED25519 ? n * 417 : 0; }
-void validate_launch(int curve, const u32* xy, const unsigned char* inf, unsigned char* ok, void* work, size_t n, hipStream_t s) {
+void validate_launch(const SchedEnv& env, int curve, const u32* xy, const unsigned char* inf, unsigned char* ok, void* work, size_t n, hipStream_t s) {
   const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
   if (curve == FEC_SECP256K1) {
     hipLaunchKernelGGL((k_validate_weierstrass<FEC_SECP256K1>), g, b, 0, s, xy, inf, ok, n);
@@ -379,19 +380,19 @@ void validate_launch(int curve, const u32* xy, const unsigned char* inf, unsigne
     unsigned char* flags = reinterpret_cast<unsigned char*>(w + n * 416);
     hipLaunchKernelGGL(k_ed_validate_pre, g, b, 0, s, xy, inf, a, flags, n);
     hipLaunchKernelGGL(k_fill_scalar, g, b, 0, s, k, make_uint4(8, 0, 0, 0), make_uint4(0, 0, 0, 0), n);          // Scalar::from(8)
-    ed_launch_mul(k, a, t1, n, s);                                                                            // clear_cofactor
+    ed_launch_mul(env, k, a, t1, n, s);                                                                            // clear_cofactor
     hipLaunchKernelGGL(k_fill_scalar, g, b, 0, s, k, make_uint4(0x5CF5D3EDu, 0x5812631Au, 0xA2F79CD6u, 0x14DEF9DEu),
                        make_uint4(0, 0, 0, 0x10000000u), n);                                                  // order() = L
-    ed_launch_mul(k, t1, t2, n, s);
+    ed_launch_mul(env, k, t1, t2, n, s);
     hipLaunchKernelGGL(k_ed_validate_finish, g, b, 0, s, (const u32*)t2, (const unsigned char*)flags, ok, n);
   }
 }
 
 size_t ecdh_work_bytes(size_t n) { return n * 193; }
-void ecdh_launch(int curve, const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* out, unsigned char* status,
-                 void* work, size_t n, hipStream_t s) {
-  if (curve == FEC_SECP256K1) run_ecdh<ESecp>(sk, pk, pk_inf, out, status, work, n, s);
-  else run_ecdh<EP256>(sk, pk, pk_inf, out, status, work, n, s);
+void ecdh_launch(const SchedEnv& env, int curve, const u32* sk, const u32* pk, const unsigned char* pk_inf, u32* out,
+                 unsigned char* status, void* work, size_t n, hipStream_t s) {
+  if (curve == FEC_SECP256K1) run_ecdh<ESecp>(env, sk, pk, pk_inf, out, status, work, n, s);
+  else run_ecdh<EP256>(env, sk, pk, pk_inf, out, status, work, n, s);
 }
 
 // batch_verify, first half: work area as ecdsa_launch plus ar at +n*353 rounded up to 16 (n * 32 bytes).
@@ -411,7 +412,7 @@ void ecdsa_batch_pre_launch(int curve, const unsigned char* digests, const u32* 
 // second half: ta = multiply(G, a*u1), tb = multiply(Q, a*u2)
 // `side` (may be null): a second stream for the fixed-base launch -- at the moderate n batch_verify is meant for, one
 // launch fills a fraction of the chip and is bound by the latency of one multiplication, so the two overlap
-void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hipStream_t s, hipStream_t side) {
+void ecdsa_batch_mul_launch(const SchedEnv& env, int curve, const u32* gen, void* work, size_t n, hipStream_t s, hipStream_t side) {
   char* w = static_cast<char*>(work);
   const u32* u1 = reinterpret_cast<const u32*>(w);
   const u32* u2 = reinterpret_cast<const u32*>(w + n * 32);
@@ -428,11 +429,11 @@ void ecdsa_batch_mul_launch(int curve, const u32* gen, void* work, size_t n, hip
     (void)hipStreamWaitEvent(side, ev_in, 0);
     sf = side;
   }
-  if (curve == FEC_SECP256K1) ESecp::launch_mul(true, u1, gen, ta, n, sf);
-  else EP256::launch_mul(true, u1, gen, ta, n, sf, two ? 2 : 1);
+  if (curve == FEC_SECP256K1) ESecp::launch_mul(env, true, u1, gen, ta, n, sf);
+  else EP256::launch_mul(env, true, u1, gen, ta, n, sf, two ? 2 : 1);
   if (two) (void)hipEventRecord(ev_out, side);
-  if (curve == FEC_SECP256K1) ESecp::launch_mul(false, u2, q, tb, n, s);
-  else EP256::launch_mul(false, u2, q, tb, n, s, two ? 2 : 1);
+  if (curve == FEC_SECP256K1) ESecp::launch_mul(env, false, u2, q, tb, n, s);
+  else EP256::launch_mul(env, false, u2, q, tb, n, s, two ? 2 : 1);
   if (two) (void)hipStreamWaitEvent(s, ev_out, 0);
   if (ev_in) (void)hipEventDestroy(ev_in);
   if (ev_out) (void)hipEventDestroy(ev_out);
@@ -444,11 +445,11 @@ void ecdsa_batch_finish_launch(int curve, const u32* r_sum, const void* work, si
   else hipLaunchKernelGGL((k_ecdsa_batch_finish<EP256>), dim3(1), dim3(64), 0, s, r_sum, ar, n, result, detail);
 }
 
-void ecdsa_launch(int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
+void ecdsa_launch(const SchedEnv& env, int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
                   const unsigned char* pk_inf, const u32* gen, unsigned char* status, void* work, size_t n,
                   hipStream_t s) {
-  if (curve == FEC_SECP256K1) run<ESecp>(digests, r, s_, pk, pk_inf, gen, status, work, n, s);
-  else run<EP256>(digests, r, s_, pk, pk_inf, gen, status, work, n, s);
+  if (curve == FEC_SECP256K1) run<ESecp>(env, digests, r, s_, pk, pk_inf, gen, status, work, n, s);
+  else run<EP256>(env, digests, r, s_, pk, pk_inf, gen, status, work, n, s);
 }
 
 }  // namespace fecgpu

@@ -267,7 +267,13 @@ namespace {
 constexpr int SORT_T = 1024, SORT_E = 4;   // threads per sorting workgroup, elements per thread
 constexpr size_t ED_SORT_MIN = (size_t)1 << 16;
 constexpr int ED_BINS = 257;               // popcount 0 .. 256
-constexpr size_t ED_PERM_OFFSET = 2048;    // bytes: 2 x 257 counters in front of the permutation
+// Work-area header in front of the permutation: hist[ED_BINS] at int 0, cursor[ED_BINS] at int ED_CURSOR_AT.
+// (Round 2 had cursor at int 260 and the permutation at byte 2048: cursor[252..256] shared their words with
+// perm[0..4], so a batch with scalars of popcount >= 252 in two sort blocks scattered through clobbered cursors.)
+constexpr int ED_CURSOR_AT = 264;
+constexpr size_t ED_PERM_OFFSET = 4096;    // bytes
+static_assert(ED_CURSOR_AT >= ED_BINS && (size_t)(ED_CURSOR_AT + ED_BINS) * sizeof(int) <= ED_PERM_OFFSET,
+              "hist, cursor and the permutation must not overlap");
 
 FEC_DEV int scalar_popcount(const u32* scalars, size_t g) {
   const uint4* k = reinterpret_cast<const uint4*>(scalars + g * 8);
@@ -323,7 +329,10 @@ __global__ __launch_bounds__(SORT_T) void k_ed_pc_scatter(const u32* __restrict_
   __syncthreads();
   FEC_UNROLL for (int k = 0; k < SORT_E; ++k) {
     const size_t g = first + (size_t)k * SORT_T + threadIdx.x;
-    if (pc[k] >= 0) perm[lbase[pc[k]] + rank[k]] = (u32)g;
+    if (pc[k] >= 0) {
+      const size_t pos = (size_t)lbase[pc[k]] + (size_t)rank[k];
+      if (pos < n) perm[pos] = (u32)g;  // (always true: the cursors partition [0, n))
+    }
   }
 }
 
@@ -488,7 +497,8 @@ enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace
 
 __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ scalars, const u32* __restrict__ points,
-                                                    u32* __restrict__ out, size_t n, unsigned per_wg) {
+                                                    u32* __restrict__ out, size_t n, unsigned per_wg,
+                                                    unsigned* __restrict__ err, unsigned force_fault) {
   __shared__ u32 lds_ad[32 * PS];              // addend of slot e: word w at lds_ad[w * PS + e]; the running result
                                                // lives in the element's slot of `out`
   __shared__ u32 lds_gid[PS];                  // element of slot e, relative to the workgroup's range
@@ -507,6 +517,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
   if (tid == 0) {
     FEC_UNROLL for (int w = 0; w < P_WORDS; ++w) lds_ctl[w] = 0;
     lds_ctl[C_REMAIN] = range < PS ? range : PS;   // live slots
+    if (force_fault) lds_ctl[C_ERR] = (int)FEC_DEVERR_FORCED;   // debug hook: every wavefront leaves at its first critical section
   }
   __syncthreads();
 
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
       if (!go) {
         __builtin_amdgcn_s_sleep(64);
         if (++spins > (1u << 22)) {  // watchdog (~10 s): cannot happen unless the queue logic is broken
-          if (lane == 0) ctl[C_ERR] = 1;
+          if (lane == 0) ctl[C_ERR] = (int)FEC_DEVERR_SCHED_WATCHDOG;
           break;
         }
         continue;
@@ -620,38 +631,55 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
     const bool active = lane < count;
     e = active ? lds_q[kind][(start + lane) & (PRING - 1)] : 0;   // inactive lanes compute on slot 0: never stored
     int step = active ? lds_step[e] : 0;
+    // Every global address below is formed from this index.  It is written by claim() and always < range; the test
+    // keeps a broken queue (which the design excludes and the watchdog would report) from ever addressing memory
+    // outside the workgroup's own range: such a lane works on element 0 of the range, stores nothing, and raises C_ERR.
+    u32 gid = active ? lds_gid[e] : 0u;
+    const bool oob = gid >= (u32)range;
+    gid = oob ? 0u : gid;
+    const bool live = active && !oob;
     bool fin = false;
     if (kind == 1) {  // A_i: result = result + addend  (2083-2086, bit i set); the result stays in its output slot
       // inactive lanes read element 0 of the range (always present) and slot 0: computed, never stored
-      u32* slot = out + (lo + (active ? lds_gid[e] : 0u)) * 32;
+      u32* slot = out + (lo + gid) * 32;
       const ed::pt res = padd_mem(slot, lds_ad + e, PS);
-      if (active) {
+      if (live) {
         st_glb(slot, res);
         fin = step == 255;  // the last doubling is never used
         nxt = 0;            // then D_i
       }
     } else {  // D_i: addend = addend.double()  (2089), then step i + 1
       const ed::pt d = pdbl_mem(lds_ad + e, PS);
-      if (active) {
+      if (live) {
         st_lds(lds_ad + e, PS, d);
         ++step;
-        const u32 bit = scalar_bit(scalars, lo + lds_gid[e], step);
+        const u32 bit = scalar_bit(scalars, lo + gid, step);
         lds_step[e] = (unsigned short)step;
         fin = !bit && step == 255;
         nxt = bit ? 1 : 0;
       }
     }
     if (fin) nxt = claim(e);  // the element is done (its result is in place): the slot takes the next element
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(oob) != 0, 0)) {
+      if (oob) ctl[C_ERR] = (int)FEC_DEVERR_SCHED_INDEX;
+    }
     // slots (LDS addend, output-array result) are lane-private between the pop and the push; every access to an
     // element's output slot comes from THIS workgroup (one CU, one vector L1), and the workgroup-scope release
     // fence inside the critical section (s_waitcnt vmcnt(0) lgkmcnt(0)) orders this batch's stores before the
     // queue entries that hand the slots on
   }
   __syncthreads();
-  if (lds_ctl[C_ERR] != 0) {  // watchdog fired (cannot happen): all-zero results fail every parity check loudly
+  if (const int ec = lds_ctl[C_ERR]) {
+    // Scheduler fault (watchdog, index guard, or the debug hook): the workgroup's results are not trustworthy.  They are
+    // zero-filled AND the ctx's error word is set, which the host reads after its synchronisation: the call returns
+    // FEC_E_LAUNCH (fecgpu.hip: sync_and_check, fec_ctx_check) instead of FEC_OK with plausible-looking points.
     ed::pt z;
     z.x = z.y = z.z = z.t = fe_zero();
     for (int el = tid; el < range; el += PT) st_glb(out + (lo + el) * 32, z);
+    if (tid == 0 && err != nullptr) {  // plain store into pinned host memory (no PCIe atomic needed: any non-zero value is the signal)
+      *reinterpret_cast<volatile unsigned*>(err) = (unsigned)ec;
+      __threadfence_system();
+    }
   }
 }
 
@@ -666,7 +694,7 @@ void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32*
     return;
   }
   int* hist = static_cast<int*>(work);
-  int* cursor = hist + 260;
+  int* cursor = hist + ED_CURSOR_AT;
   u32* perm = reinterpret_cast<u32*>(static_cast<char*>(work) + ED_PERM_OFFSET);
   const unsigned sgrid = (unsigned)((n + (size_t)SORT_T * SORT_E - 1) / ((size_t)SORT_T * SORT_E));
   (void)hipMemsetAsync(hist, 0, ED_PERM_OFFSET, s);
@@ -676,19 +704,18 @@ void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32*
   hipLaunchKernelGGL(k_ed_fixed_sorted, dim3(grid), dim3(TPB), 0, s, scalars, base, table, (const u32*)perm, out, n);
 }
 
-void ed_launch_mul(const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s, unsigned cu_divisor) {
-  // one workgroup per CU (or per cu_divisor-th CU), each with a contiguous range of at least 64 elements
-  static const unsigned cus = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    return (unsigned)v;
-  }();
+void ed_launch_mul(const SchedEnv& env, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,
+                   unsigned cu_divisor) {
+  // one workgroup per CU (or per cu_divisor-th CU) of the ctx's own device, each with a contiguous range of at least
+  // 64 elements
+  const unsigned cus = env.cus ? env.cus : 256u;
   size_t grid = (n + 63) / 64;
   const unsigned cap = cu_divisor > 1 && cus >= cu_divisor ? cus / cu_divisor : cus;
   if (grid > cap) grid = cap;
   const unsigned per_wg = (unsigned)((n + grid - 1) / grid);
   grid = (n + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(k_ed_mul_pers, dim3((unsigned)grid), dim3(PT), 0, s, scalars, points, out, n, per_wg);
+  hipLaunchKernelGGL(k_ed_mul_pers, dim3((unsigned)grid), dim3(PT), 0, s, scalars, points, out, n, per_wg, env.err,
+                     env.force_fault);
 }
 
 }  // namespace fecgpu

@@ -172,7 +172,8 @@ enum { P_NEXT = C_WORDS, P_WORDS };
 // HOIST (fixed base): z2z2 of the base point is computed once per workgroup into LDS instead of by every addition.
 template <bool FIXED, bool HOIST>
 __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict__ scalars, const u32* __restrict__ points,
-                                                      u32* __restrict__ out, size_t n, unsigned per_wg) {
+                                                      u32* __restrict__ out, size_t n, unsigned per_wg,
+                                                      unsigned* __restrict__ err, unsigned force_fault) {
   __shared__ u32 lds_st[24 * QS];               // X, Y, Z of slot e: word w at lds_st[w * QS + e]
   __shared__ u32 lds_k[8 * QS];                 // scalar of slot e
   __shared__ u32 lds_gid[QS];                   // element of slot e, relative to the workgroup's range
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   if (tid == 0) {
     FEC_UNROLL for (int w = 0; w < P_WORDS; ++w) lds_ctl[w] = 0;
     lds_ctl[C_REMAIN] = range < QS ? range : QS;   // live slots
+    if (force_fault) lds_ctl[C_ERR] = (int)FEC_DEVERR_FORCED;   // debug hook: every wavefront leaves at its first critical section
   }
   __syncthreads();
 
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       if (!go) {
         __builtin_amdgcn_s_sleep(64);
         if (++spins > (1u << 22)) {
-          if (lane == 0) ctl[C_ERR] = 1;
+          if (lane == 0) ctl[C_ERR] = (int)FEC_DEVERR_SCHED_WATCHDOG;
           break;
         }
         continue;
@@ -315,11 +317,17 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     const bool active = lane < count;
     e = active ? lds_q[kind][(start + lane) & (QRING - 1)] : 0;
     int step = active ? lds_step[e] : 0;
+    // Every global address below is formed from this index (written by claim(), always < range): a broken queue must
+    // never address memory outside the workgroup's own range -- such a lane works on element 0, stores nothing, raises C_ERR.
+    u32 gid = active ? lds_gid[e] : 0u;
+    const bool oob = gid >= (u32)range;
+    gid = oob ? 0u : gid;
+    const bool live = active && !oob;
     bool fin = false;
     p256::pt res = p256::identity();
     if (kind == 0) {
       res = pdouble_in_place(lds_st + e, QS);
-      if (active) {
+      if (live) {
         const int b = 255 - step;
         const u32 bit = (lds_k[(b >> 5) * QS + e] >> (b & 31)) & 1u;
         if (bit) {
@@ -334,10 +342,10 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       }
     } else {
       // inactive lanes add slot 0 and element 0 of the range: harmless, never stored
-      const size_t g_el = lo + (active ? lds_gid[e] : 0u);
+      const size_t g_el = lo + gid;
       res = padd_in_place(lds_st + e, QS, FIXED ? points : points + g_el * 24,
                           (FIXED && HOIST) ? lds_zz : nullptr);
-      if (active) {
+      if (live) {
         ++step;
         lds_step[e] = (unsigned short)step;
         nxt = 0;
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       }
     }
     if (fin) {  // the element is done: its result goes out (16-byte stores), the slot takes the next element
-      uint4* o = reinterpret_cast<uint4*>(out + (lo + lds_gid[e]) * 24);
+      uint4* o = reinterpret_cast<uint4*>(out + (lo + gid) * 24);
       FEC_UNROLL for (int w = 0; w < 2; ++w) {
         o[w] = make_uint4(res.x.w[4 * w], res.x.w[4 * w + 1], res.x.w[4 * w + 2], res.x.w[4 * w + 3]);
         o[2 + w] = make_uint4(res.y.w[4 * w], res.y.w[4 * w + 1], res.y.w[4 * w + 2], res.y.w[4 * w + 3]);
@@ -354,36 +362,45 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       }
       nxt = claim(e);
     }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(oob) != 0, 0)) {
+      if (oob) ctl[C_ERR] = (int)FEC_DEVERR_SCHED_INDEX;
+    }
   }
   __syncthreads();
-  if (lds_ctl[C_ERR] != 0) {  // watchdog fired (cannot happen): all-zero results fail every parity check loudly
+  if (const int ec = lds_ctl[C_ERR]) {
+    // Scheduler fault (watchdog, index guard, or the debug hook): zero-fill the workgroup's results AND set the ctx's
+    // error word, which the host reads after its synchronisation -- the call returns FEC_E_LAUNCH (see kernels_ed.hip).
     for (int el = tid; el < range; el += QT) {
       uint4* o = reinterpret_cast<uint4*>(out + (lo + el) * 24);
       FEC_UNROLL for (int w = 0; w < 6; ++w) o[w] = make_uint4(0, 0, 0, 0);
     }
+    if (tid == 0 && err != nullptr) {
+      *reinterpret_cast<volatile unsigned*>(err) = (unsigned)ec;
+      __threadfence_system();
+    }
   }
 }
 
-void p256_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s, unsigned cu_divisor) {
-  // one workgroup per CU (or per cu_divisor-th CU), each with a contiguous range of at least 64 elements
-  static const unsigned cus = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    return (unsigned)v;
-  }();
+void p256_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,
+                     unsigned cu_divisor) {
+  // one workgroup per CU (or per cu_divisor-th CU) of the ctx's own device, each with a contiguous range of at least
+  // 64 elements
+  const unsigned cus = env.cus ? env.cus : 256u;
   size_t grid = (n + 63) / 64;
   const unsigned cap = cu_divisor > 1 && cus >= cu_divisor ? cus / cu_divisor : cus;
   if (grid > cap) grid = cap;
   const unsigned per_wg = (unsigned)((n + grid - 1) / grid);
   grid = (n + per_wg - 1) / per_wg;
   if (fixed) {
-    hipLaunchKernelGGL((k_p256_mul_sched<true, true>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
+    hipLaunchKernelGGL((k_p256_mul_sched<true, true>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg,
+                       env.err, env.force_fault);
     return;
   }
   // Variable base: z2z2 is recomputed by every addition.  Parking it in the element's (still unused) output slot was
   // 2.6 % faster (25.0 -> 24.4 ms) but pushed a workgroup's working set out of its XCD's L2 -- 23 GB of L2-side
   // fetches per launch instead of 0.44 (profiles/pmc_r02br_p256_hoist.json) -- and broke in-place calls; not kept.
-  hipLaunchKernelGGL((k_p256_mul_sched<false, false>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg);
+  hipLaunchKernelGGL((k_p256_mul_sched<false, false>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg,
+                     env.err, env.force_fault);
 }
 
 }  // namespace fecgpu

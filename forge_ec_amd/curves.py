@@ -58,6 +58,16 @@ class Context:
         """fec_ctx_wipe: zero every ctx-owned device buffer that can hold copies of caller data."""
         _check(self._lib.fec_ctx_wipe(self._h), "fec_ctx_wipe")
 
+    def check(self):
+        """fec_ctx_check: synchronise, then raise FecError(FEC_E_LAUNCH) if a kernel launched through this ctx since
+        the last check reported a fault (the outputs of those launches must not be used).  For the *_dev callers;
+        the host-pointer calls check by themselves."""
+        _check(self._lib.fec_ctx_check(self._h), "fec_ctx_check")
+
+    def debug_force_fault(self, enabled):
+        """fec_ctx_debug_force_fault: test hook -- scheduler kernels raise their fault word at once."""
+        _check(self._lib.fec_ctx_debug_force_fault(self._h, 1 if enabled else 0), "fec_ctx_debug_force_fault")
+
     def device_count(self):
         return int(self._lib.fec_ctx_device_count(self._h))
 

@@ -59,11 +59,20 @@
  * Results are bit-exact with the reference's CPU arithmetic, including its quirks.  There is NO
  * CPU fallback: every entry point runs hand-written HIP kernels on the ctx's GPU or fails.
  *
- * Threading: a fec_ctx owns one HIP device, one stream and its staging buffers; calls on one ctx
- * must be serialised by the caller, different ctxs are independent.  One ctx per process per
- * GPU is the intended use (multi-GPU = one process per GPU).
+ * Threading: a fec_ctx made by fec_ctx_create owns one HIP device, two streams and its staging
+ * buffers; calls on one ctx must be serialised by the caller, different ctxs are independent.
+ * Multi-GPU comes in two forms: fec_ctx_create_multi -- ONE ctx whose
+ * element-wise host-pointer calls are sharded over several devices inside the library (what a Rust
+ * caller binds) -- or one process per GPU, each with its own single-device ctx and the *_dev entry
+ * points (what bench.py does under torch.distributed).
  *
- * Errors: 0 on success, negative fec_status otherwise; never aborts, never throws across the ABI.
+ * Errors: 0 on success, negative fec_status otherwise.  The library itself never calls abort() and no
+ * C++ exception leaves it (every entry point is a function-try-block).  A fault that a KERNEL reports
+ * -- the watchdog or the index guard of a scheduler kernel -- is carried to the host in a per-ctx
+ * device error word: host-pointer calls return FEC_E_LAUNCH (never FEC_OK with unusable outputs), callers
+ * of the *_dev entry points ask fec_ctx_check().  What the library cannot promise is what the HIP runtime
+ * underneath does on a GPU memory fault or queue exception: by default it aborts the process; a host that
+ * prefers an error code sets HIP_SKIP_ABORT_ON_GPU_ERROR=1 before its first HIP call.
  *
  * Aliasing: the output array of fec_batch_mul / fec_batch_mul_dev may be the `points` array itself (an
  * element's point is not read after its result is stored; tests/test_gpu_parity.py:
@@ -86,7 +95,7 @@ typedef enum {
   FEC_E_ARG = -1,         /* null pointer, unknown curve/op, misaligned device pointer */
   FEC_E_DEVICE = -2,      /* no such GPU / HIP runtime failure */
   FEC_E_OOM = -3,         /* device or pinned-host allocation failed */
-  FEC_E_LAUNCH = -4,      /* kernel launch or execution failed */
+  FEC_E_LAUNCH = -4,      /* kernel launch or execution failed, or a kernel reported a fault (outputs unusable) */
   FEC_E_UNSUPPORTED = -5, /* op not defined for this curve / for a multi-device ctx */
   FEC_E_COMM = -6         /* multi-device ctx: a shard worker could not be started */
 } fec_status;
@@ -111,13 +120,18 @@ int fec_ctx_create(fec_ctx** out, int device);
  * forge-ec-signature/src/ecdsa.rs:313-361, schnorr.rs:268-284).  devices[0..n_devices) are HIP
  * ordinals, 1 <= n_devices <= 16; an ordinal may appear more than once (several shard workers on
  * one GPU).  The element-wise host-pointer entry points -- fec_batch_mul, fec_batch_mul_fixed,
- * fec_batch_double_mul, fec_batch_to_affine, fec_batch_compress, fec_ecdsa_verify_secp256k1,
- * fec_field_op, fec_point_op -- then split the batch into n_devices contiguous shards
+ * fec_batch_double_mul, fec_batch_to_affine, fec_batch_compress, fec_batch_decompress,
+ * fec_batch_encode_uncompressed, fec_batch_decode_uncompressed, fec_ecdsa_verify_secp256k1,
+ * fec_ecdsa_verify_p256, fec_eddsa_verify_ed25519, fec_batch_ecdh, fec_batch_validate_point,
+ * fec_field_op, fec_point_op (tests/test_gpu_multi_ctx.py runs every one of them sharded) -- then
+ * split the batch into n_devices contiguous shards
  * [g*n/N, (g+1)*n/N), run each shard on its device from its own host thread with that device's
  * chunked copy/compute pipeline, and write results straight into the caller's output array: the
  * "gather" is the D2H copy of each shard, there is no device-to-device exchange.  Results are
  * identical to a single-device ctx.  Entry points that are not element-wise (fec_multi_scalar_mul,
- * fec_schnorr_batch_verify_secp256k1, fec_generator*, the measurement hooks) run on devices[0];
+ * fec_ecdsa_batch_verify, fec_schnorr_batch_verify_secp256k1, fec_generator*, the measurement hooks)
+ * run on devices[0]; fec_ctx_wipe, fec_ctx_check, fec_ctx_set_chunk and fec_ctx_debug_force_fault apply
+ * to every shard worker;
  * the *_dev entry points take device pointers of ONE device and return FEC_E_UNSUPPORTED.
  * devices == NULL means ordinals 0..n_devices-1. */
 int fec_ctx_create_multi(fec_ctx** out, const int* devices, int n_devices);
@@ -294,6 +308,17 @@ int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_poi
  * per-stream scratch of composed launches, the canonical-mode work areas).  Synchronises the device.
  * fec_ctx_destroy calls it; call it yourself after a batch whose inputs were sensitive. */
 int fec_ctx_wipe(fec_ctx* ctx);
+
+/* The sticky device error state of the ctx, for callers of the *_dev entry points (those return once the work
+ * is enqueued, so a fault reported by a kernel can only be seen afterwards; the host-pointer entry points do this
+ * check themselves).  Synchronises the ctx's device(s); FEC_E_LAUNCH if a kernel launched through this ctx since
+ * the last check reported a fault -- the outputs of those launches must not be used -- else FEC_OK.  Reading
+ * clears the state. */
+int fec_ctx_check(fec_ctx* ctx);
+/* Debug / test hook: while enabled, every scheduler-kernel launch of this ctx (P-256 and Ed25519 variable-base
+ * multiplication, also inside the composed entry points) raises its fault word at once, exactly as its watchdog
+ * would: outputs are zero-filled and the call (or fec_ctx_check) returns FEC_E_LAUNCH. */
+int fec_ctx_debug_force_fault(fec_ctx* ctx, int enabled);
 
 /* Host-pointer batches are processed as a two-lane pipeline of `elements`-sized chunks (default
  * 2^18): copies of one chunk overlap the kernel of the other, and device staging memory is bounded

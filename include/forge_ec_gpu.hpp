@@ -40,6 +40,12 @@ class GpuContext {
   GpuContext(const GpuContext&) = delete;
   GpuContext& operator=(const GpuContext&) = delete;
   fec_ctx* raw() const { return ctx_; }
+  // fec_ctx_check: for callers of the *_dev entry points -- throws Error(FEC_E_LAUNCH) if a kernel launched through
+  // this ctx since the last check reported a fault (the host-pointer calls check by themselves)
+  void check_device() {
+    int rc = fec_ctx_check(ctx_);
+    if (rc != FEC_OK) throw Error(rc);
+  }
   static GpuContext& global() {  // process-wide default context on device 0
     static GpuContext g(0);
     return g;

@@ -26,6 +26,8 @@ extern "C" {
     fn fec_ctx_device_count(ctx: *mut FecCtx) -> c_int;
     fn fec_ctx_destroy(ctx: *mut FecCtx);
     fn fec_ctx_wipe(ctx: *mut FecCtx) -> c_int;
+    fn fec_ctx_check(ctx: *mut FecCtx) -> c_int;
+    fn fec_ctx_debug_force_fault(ctx: *mut FecCtx, enabled: c_int) -> c_int;
     fn fec_generator(ctx: *mut FecCtx, curve: c_int, out: *mut u64) -> c_int;
     fn fec_generator_dev(ctx: *mut FecCtx, curve: c_int) -> *const u64;
     fn fec_batch_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
@@ -116,6 +118,20 @@ impl GpuContext {
     pub fn wipe(&mut self) -> Result<()> {
         // SAFETY: self.raw is a live ctx.
         check(unsafe { fec_ctx_wipe(self.raw) })
+    }
+
+    /// `fec_ctx_check`: synchronise, then `Err` if a kernel launched through this ctx since the last check reported
+    /// a fault (the outputs of those launches must not be used).  The host-pointer calls check by themselves; this
+    /// is for callers of the `*_dev` entry points.
+    pub fn check(&mut self) -> Result<()> {
+        // SAFETY: self.raw is a live ctx.
+        check(unsafe { fec_ctx_check(self.raw) })
+    }
+
+    /// Test hook (`fec_ctx_debug_force_fault`): scheduler kernels raise their fault word at once.
+    pub fn debug_force_fault(&mut self, enabled: bool) -> Result<()> {
+        // SAFETY: self.raw is a live ctx.
+        check(unsafe { fec_ctx_debug_force_fault(self.raw, enabled as c_int) })
     }
 
     /// Elements per pipeline chunk of the host-pointer calls (tuning knob; results do not depend on it).

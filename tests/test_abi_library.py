@@ -100,3 +100,58 @@ def test_only_the_allowed_places_call_the_oracle():
     bench = open(os.path.join(root, "bench.py")).read()
     assert len(re.findall(r"^\s*from oracle|^\s*import oracle", bench, flags=re.M)) == 1   # inside cpu_baseline()
     assert "def cpu_baseline" in bench and bench.index("def cpu_baseline") < bench.index("from oracle")
+
+
+def _extern_c_definitions(path):
+    """(name, text-after-signature) of every function DEFINED at namespace level inside the extern "C" block."""
+    text = open(path).read()
+    body = text[text.index('extern "C" {'):text.index('}  // extern "C"')]
+    out = []
+    for m in re.finditer(r"^(?:int|void|const char\*|const uint64_t\*) (fec_\w+)\(", body, flags=re.M):
+        rest = body[m.end():]
+        depth, i = 1, 0
+        while depth:  # end of the parameter list
+            depth += {"(": 1, ")": -1}.get(rest[i], 0)
+            i += 1
+        out.append((m.group(1), rest[i:i + 200]))
+    return out
+
+
+def test_no_exception_can_cross_the_c_abi():
+    """Every extern "C" definition is a function-try-block closed by an FEC_ABI_CATCH_* macro (one-line bodies that
+    touch nothing that can throw are listed), and a shard worker thread catches inside the thread."""
+    trivial = {"fec_point_limbs", "fec_ctx_device_count"}
+    seen = 0
+    for src in ("fecgpu.hip", "canon.hip"):
+        path = os.path.join(ROOT, "forge_ec_amd", "csrc", src)
+        for name, after in _extern_c_definitions(path):
+            seen += 1
+            if name in trivial:
+                continue
+            assert after.lstrip().startswith("try {"), "%s in %s is not a function-try-block" % (name, src)
+        text = open(path).read()
+        assert text.count(") try {") == text.count("} FEC_ABI_CATCH_")
+    from forge_ec_amd import _lib
+    assert seen == len(_lib.ABI_SYMBOLS) + len(_lib.CANON_ABI_SYMBOLS)
+    fec = open(os.path.join(ROOT, "forge_ec_amd", "csrc", "fecgpu.hip")).read()
+    worker = fec[fec.index("workers[g] = std::thread("):]
+    assert worker.index("try {") < worker.index("call(ctx->children[g]") < worker.index("catch (...)")
+
+
+def test_ed25519_sort_header_layout():
+    """The popcount sort's work-area header: hist, cursor and the permutation do not overlap (round 2 had
+    cursor[252..256] on top of perm[0..4]); the layout is also a static_assert in the source."""
+    text = open(os.path.join(ROOT, "forge_ec_amd", "csrc", "kernels_ed.hip")).read()
+    bins = int(re.search(r"constexpr int ED_BINS = (\d+);", text).group(1))
+    cursor_at = int(re.search(r"constexpr int ED_CURSOR_AT = (\d+);", text).group(1))
+    perm_off = int(re.search(r"constexpr size_t ED_PERM_OFFSET = (\d+);", text).group(1))
+    assert bins == 257 and cursor_at >= bins and (cursor_at + bins) * 4 <= perm_off
+    assert "hist + ED_CURSOR_AT" in text and "hipMemsetAsync(hist, 0, ED_PERM_OFFSET" in text
+    assert "static_assert(ED_CURSOR_AT >= ED_BINS" in text
+
+
+def test_destroy_wipes_before_it_frees():
+    fec = open(os.path.join(ROOT, "forge_ec_amd", "csrc", "fecgpu.hip")).read()
+    d = fec[fec.index("void fec_ctx_destroy("):]
+    d = d[:d.index("FEC_ABI_CATCH_VOID")]
+    assert d.index("fec_ctx_wipe(ctx)") < d.index("hipFree("), "the wipe must come before the first hipFree"
