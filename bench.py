@@ -8,10 +8,16 @@ bench.py -- headline benchmark of the batched scalar-multiplication hot path on 
 
 Default workload (BASELINE.json configs[1], the headline): 2^20 secp256k1 variable-base scalar
 multiplications per GPU (--workload selects the other BASELINE configurations) on synthetic seeded inputs (forge_ec_amd/synth.py), inputs resident in HBM before the timed
-region.  One "step" = one pass of the hot path over one 2^20 batch.  With N > 1 ranks every rank
-runs its own 2^20 shard (weak scaling, no collective on the compute path) and the result shards
-are gathered to rank 0 over RCCL/xGMI (--gather rank0, the default; all / none for comparison),
-overlapped with the next step's kernel.
+region.  One "step" = one pass of the hot path over one batch.
+
+N > 1: no collective on the compute path; the result shards are gathered to rank 0 over RCCL/xGMI, overlapped
+with the next step's kernel.  --scaling weak (default): every rank runs its own 2^--log2-batch shard.
+--scaling strong --log2-global-batch G: ONE global batch of 2^G elements split into contiguous shards
+(forge_ec_amd.dist.shard_range) -- how BASELINE.json quotes its two 8-GPU configurations:
+    --workload p256-var --scaling strong --log2-global-batch 22          configs[3]
+    --workload secp256k1-double --scaling strong --log2-global-batch 20  configs[4]
+--gather both (the default when N > 1) times the K steps twice, with the gather to rank 0 (`value`) and without it
+(`gather.none`), so that the gather's cost is visible in one line.
 
 Prints ONE JSON line on rank 0: metric/value (whole-job scalar-muls/s), roofline (integer-VALU:
 algorithmic 32x32 multiply-adds per second against the chip's peak; kernel time from HIP events
@@ -64,11 +70,17 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="secp256k1-var", choices=list(WORKLOADS),
                     help="default = the headline (BASELINE.json configs[1])")
-    ap.add_argument("--log2-batch", type=int, default=20, help="scalar-muls per GPU per step = 2^this")
-    ap.add_argument("--gather", default="rank0", choices=["rank0", "all", "none"],
-                    help="N>1: gather the result shards to rank 0 over RCCL (overlapped with the next step), "
-                         "all-gather them to every rank, or leave them in place")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    ap.add_argument("--log2-batch", type=int, default=20, help="weak scaling: scalar-muls per GPU per step = 2^this")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: 2^--log2-batch per GPU; strong: 2^--log2-global-batch in all, split into contiguous shards")
+    ap.add_argument("--log2-global-batch", type=int, default=None,
+                    help="strong scaling: scalar-muls per step over ALL GPUs = 2^this (default: the size BASELINE.json "
+                         "quotes for the workload, else 20)")
+    ap.add_argument("--gather", default=None, choices=["both", "rank0", "all", "none"],
+                    help="N>1: `both` (default) = time the K steps with the gather of the result shards to rank 0 over RCCL "
+                         "(overlapped with the next step; this is `value`) and again without it (`gather.none`); or one of "
+                         "rank0 / all (all-gather to every rank) / none only")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (all legs together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -87,38 +99,48 @@ def host_cores():
 
 
 def cpu_baseline(workload, inputs, gpu_out, target_s):
-    """Time the C oracle (the reference's full work, discarded doublings included) on this box's
-    cores over a bounded prefix of the same inputs; compare with the GPU output (parity sample)."""
+    """Time the C oracle (the reference's full work, discarded doublings included) on this box's host cores over a
+    bounded prefix of the same inputs -- on ONE thread and on all granted cores (SURVEY.md section 8d asks for both) --
+    and compare the all-core leg's output with the GPU output (the parity sample).  The timed library is the oracle's
+    source rebuilt on this box with -O3 -march=native when gcc is here (c_oracle.native_lib), else the shipped
+    x86-64-v2 build; `build` says which."""
     from oracle import c_oracle
     curve_name, kind = WORKLOADS[workload][0], WORKLOADS[workload][1]
     cid = CURVE_ID[curve_name]
     cores = host_cores()
+    L, build = c_oracle.native_lib()
 
-    def run(m):
+    def run(m, threads):
         if kind == "var":
-            return c_oracle.batch_mul(cid, inputs[0][:m], inputs[1][:m], nthreads=cores)
+            return c_oracle.batch_mul(cid, inputs[0][:m], inputs[1][:m], nthreads=threads, L=L)
         if kind == "fixed":
-            return c_oracle.batch_mul_fixed(cid, inputs[0][:m], c_oracle.generator(cid), nthreads=cores)
-        return c_oracle.batch_double_mul(cid, inputs[0][:m], inputs[1][:m], inputs[2][:m], nthreads=cores)
+            return c_oracle.batch_mul_fixed(cid, inputs[0][:m], c_oracle.generator(cid), nthreads=threads, L=L)
+        return c_oracle.batch_double_mul(cid, inputs[0][:m], inputs[1][:m], inputs[2][:m], nthreads=threads, L=L)
 
-    probe = 64 * cores
-    t0 = time.perf_counter()
-    run(probe)
-    dt = time.perf_counter() - t0
-    rate = probe / max(dt, 1e-9)
-    n = int(min(inputs[0].shape[0], max(probe, rate * target_s)))
-    t0 = time.perf_counter()
-    ref = run(n)
-    dt = time.perf_counter() - t0
-    ok = bool(np.array_equal(ref, gpu_out[:n]))
+    def leg(threads, seconds):
+        probe = 64 * threads
+        t0 = time.perf_counter()
+        run(probe, threads)
+        rate = probe / max(time.perf_counter() - t0, 1e-9)
+        m = int(min(inputs[0].shape[0], max(probe, rate * seconds)))
+        t0 = time.perf_counter()
+        ref = run(m, threads)
+        return m, time.perf_counter() - t0, ref
+
+    n1, dt1, ref1 = leg(1, target_s / 3.0)
+    n, dt, ref = leg(cores, target_s * 2.0 / 3.0) if cores > 1 else (n1, dt1, ref1)
+    ok = bool(np.array_equal(ref, gpu_out[:n])) and bool(np.array_equal(ref1, gpu_out[:n1]))
     return {"value": n / dt, "unit": "scalar-muls/s", "cores": cores, "kind": "port",
-            "sample": "first %d of the rank-0 batch (%s), C oracle oracle/forge_ec_oracle.c, "
-                      "%d threads, %.1f s" % (n, workload, cores, dt),
+            "single_thread": {"value": n1 / dt1, "unit": "scalar-muls/s", "cores": 1,
+                              "sample": "first %d of the rank-0 batch, %.1f s" % (n1, dt1)},
+            "cpu_model": c_oracle.cpu_model(), "build": build,
+            "sample": "first %d of the rank-0 batch (%s), C oracle oracle/forge_ec_oracle.c (a restatement of the "
+                      "reference's Rust, not rustc output), %d threads, %.1f s" % (n, workload, cores, dt),
             "parity_sample_bit_exact": ok}
 
 
 def committed_pmc(workload, n):
-    """HBM bytes per launch and VALUBusy from a committed rocprofv3 PMC pass (bench.py cannot collect
+    """HBM bytes per launch and the VALU issue interval from a committed rocprofv3 PMC pass (bench.py cannot collect
     PMC itself).  Only a pass taken on THIS build counts: tools/pmc_summarize.py records the library's
     source hash beside the counters, and a pass whose hash differs from the loaded library's is
     ignored -- the fields are then null and say why."""
@@ -140,11 +162,35 @@ def committed_pmc(workload, n):
             continue
         d = t.get("derived", {})
         return {"traffic": d.get("hbm_bytes_per_launch"),
-                "valu_busy_pct": t.get("counters", {}).get("VALUBusy", {}).get("per_launch"),
+                "valu_issue_cycles": valu_issue_cycles(t),
                 "source": "%s: committed rocprofv3 PMC pass of this kernel's sources (%s + includes, hash %s), not measured by this run"
                           % (rel, tu, here[:12])}
     why = ("only a stale PMC pass exists (%s, other source hash)" % stale) if stale else "no committed PMC pass for this workload"
-    return {"traffic": None, "valu_busy_pct": None, "source": why}
+    return {"traffic": None, "valu_issue_cycles": None, "source": why}
+
+
+# Multiply instructions the kernels EXECUTE per unit (v_mad_u64_u32 + v_mul_lo_u32 on the hot path, static count from
+# tools/isa_mix.py: profiles/r02_isa_mix_k_secp_mul.txt, profiles/r03_isa_mix_sched_kernels.txt) next to the ALGORITHMIC
+# MAD32 of the reference's op sequence that `roofline.achieved` is priced with: the kernels need fewer multiplies than the
+# reference performs (closed-form Montgomery recurrence, exact squarings, z2z2 computed once per element), so `frac` is
+# NOT the share of issue slots spent multiplying -- carries outnumber multiplies in every one of them.
+EXECUTED_MULS = {
+    "secp256k1-var": 256 * 1600, "secp256k1-fixed": 256 * 1600, "secp256k1-double": 2 * 256 * 1600 + 1600,
+    "p256-var": 256 * 324 + 128 * 848, "ed25519-var": 255 * 536 + 128 * 648, "ed25519-fixed": 128 * 648,
+}
+# the size BASELINE.json quotes for a workload's configuration (strong scaling default)
+BASELINE_LOG2_GLOBAL = {"p256-var": 22, "secp256k1-double": 20}
+
+
+def valu_issue_cycles(pmc_json):
+    """Cycles per VALU wave-instruction per SIMD from a committed PMC pass: (GRBM_GUI_ACTIVE / 8 XCDs) / (SQ_INSTS_VALU /
+    1024 SIMDs).  This -- not the derived VALUBusy counter, which reads 102-104 % on these kernels -- is the statement
+    "the kernel is VALU-issue bound": a 64-lane instruction occupies its SIMD for about four cycles."""
+    c = pmc_json.get("counters", {})
+    try:
+        return (c["GRBM_GUI_ACTIVE"]["per_launch"] / 8.0) / (c["SQ_INSTS_VALU"]["per_launch"] / 1024.0)
+    except (KeyError, ZeroDivisionError):
+        return None
 
 
 def main():
@@ -152,6 +198,7 @@ def main():
     import torch
     import forge_ec_amd as F
     from forge_ec_amd import synth
+    from forge_ec_amd.dist import shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,17 +219,34 @@ def main():
     workload = args.workload
     curve, kind, alg, hbm_bytes, cfg = WORKLOADS[workload]
     cid = CURVE_ID[curve]
-    n = 1 << args.log2_batch
     limbs = F.POINT_LIMBS[cid]
     ctx = F.Context(local_rank)
+    strong = args.scaling == "strong"
+    if strong:
+        log2_global = args.log2_global_batch if args.log2_global_batch is not None else BASELINE_LOG2_GLOBAL.get(workload, 20)
+        n_global = 1 << log2_global
+        lo, hi = shard_range(n_global, rank, world)
+        n = hi - lo
+        if n == 0:
+            raise SystemExit("a rank has an empty shard")
+    else:
+        n = 1 << args.log2_batch
+        n_global, lo = n * world, None
 
-    # synthetic seeded inputs, one stream pair per rank; resident in HBM before timing
-    k = synth.scalars(n, cid, 1000 + 3 * rank)
-    inputs = [k]
-    if kind in ("var", "double"):
-        inputs.append(synth.points(n, cid, 1001 + 3 * rank) if kind == "var" else synth.scalars(n, cid, 1001 + 3 * rank))
-    if kind == "double":
-        inputs.append(synth.points(n, cid, 1002 + 3 * rank))
+    # synthetic seeded inputs, resident in HBM before timing.  Weak scaling: one stream set per rank.  Strong scaling:
+    # ONE global batch (the same data whatever N is), every rank generates it and keeps its contiguous shard.
+    def gen(count, seed_off):
+        k = synth.scalars(count, cid, 1000 + seed_off)
+        arrs = [k]
+        if kind in ("var", "double"):
+            arrs.append(synth.points(count, cid, 1001 + seed_off) if kind == "var" else synth.scalars(count, cid, 1001 + seed_off))
+        if kind == "double":
+            arrs.append(synth.points(count, cid, 1002 + seed_off))
+        return arrs
+    if strong:
+        inputs = [np.ascontiguousarray(a[lo:lo + n]) for a in gen(n_global, 0)]
+    else:
+        inputs = gen(n, 3 * rank)
     d_in = [torch.from_numpy(a.view(np.int64)).cuda() for a in inputs]
     d_out = [torch.empty((n, limbs), dtype=torch.int64, device="cuda") for _ in range(2)]
     # All launches and collectives are ordered on ONE explicit (non-default) torch stream: the library
@@ -195,13 +259,21 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
 
-    gather = None
-    if dist is not None and args.gather != "none":
+    gather_arg = args.gather if args.gather is not None else ("both" if dist is not None else "none")
+    if dist is None:
+        gather_arg = "none"
+    modes = ["rank0", "none"] if gather_arg == "both" else [gather_arg]   # the first mode's time is `value`
+    gathers = {}
+    if dist is not None:
         from forge_ec_amd.dist import ResultGather
-        gather = [ResultGather(n * world, limbs, torch.device("cuda", local_rank),
-                               dst=0 if args.gather == "rank0" else None) for _ in range(2)]
+        for m in modes:
+            if m != "none":
+                gathers[m] = [ResultGather(n_global, limbs, torch.device("cuda", local_rank),
+                                           dst=0 if m == "rank0" else None) for _ in range(2)]
 
-    def step(i, timed):
+    launched = {"name": None}  # the kernel(s) the library reports for the timed launch
+
+    def step(i, timed, gather):
         buf = i & 1
         if gather is not None:
             gather[buf].finish()  # the collective that last read d_out[buf] has completed
@@ -219,55 +291,63 @@ def main():
             gather[buf].start(d_out[buf])
         return ms
 
-    launched = {"name": None}  # the kernel(s) the library reports for the timed launch
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctx.set_timing(False)
-    for i in range(args.warmup):
-        step(i, False)
-    if gather is not None:
-        for g in gather:
-            g.finish()
-    barrier()
-    # timed region: exactly K steps, barrier + synchronize on both sides
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, False)
-    if gather is not None:
-        for g in gather:
-            g.finish()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(mode):
+        """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
+        gather = gathers.get(mode)
+        ctx.set_timing(False)
+        for i in range(args.warmup):
+            step(i, False, gather)
+        if gather is not None:
+            for g in gather:
+                g.finish()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, False, gather)
+        if gather is not None:
+            for g in gather:
+                g.finish()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    elapsed_by_mode = {m: timed_region(m) for m in modes}
+    elapsed = elapsed_by_mode[modes[0]]
+    # the *_dev launches only enqueue: a fault a kernel reported is visible now (the host-pointer calls check themselves)
+    ctx.check()
 
     # kernel duration from HIP events on the launch stream (separate passes, not in `value`)
+    gather0 = gathers.get(modes[0])
     ctx.set_timing(True)
-    kms = [step(i, True) for i in range(min(args.steps, 5))]
-    if gather is not None:
-        for g in gather:
+    kms = [step(i, True, gather0) for i in range(min(args.steps, 5))]
+    if gather0 is not None:
+        for g in gather0:
             g.finish()
     ctx.set_timing(False)
     torch.cuda.synchronize()
-    if gather is not None and os.environ.get("FEC_BENCH_CHECK_GATHER") == "1":
+    if gather0 is not None and os.environ.get("FEC_BENCH_CHECK_GATHER") == "1":
         # rehearsal aid: the gathered block of this rank must equal the shard the kernel just produced
-        step(0, False)
-        full = gather[0].finish()
+        step(0, False, gather0)
+        full = gather0[0].finish()
         torch.cuda.synchronize()
-        if full is not None and not torch.equal(full[rank * n:(rank + 1) * n], d_out[0]):
+        off = lo if strong else rank * n
+        if full is not None and not torch.equal(full[off:off + n], d_out[0]):
             raise SystemExit("gathered shard differs from the kernel output")
     kernel_ms = float(np.mean(kms))
     peak_measured = ctx.measure_peak_mad32()
     info = ctx.device_info()
 
     if rank == 0:
-        total = n * world * args.steps
+        total = n_global * args.steps
         value = total / elapsed
         achieved = n * alg / (kernel_ms * 1e-3)
         kname = launched["name"]  # as the library names the launch (the rocprofv3 kernel-stats row has the same stem)
@@ -281,17 +361,24 @@ def main():
                 print(json.dumps({"error": "GPU output differs from the CPU oracle on the parity sample",
                                   "workload": workload, "cpu_baseline": cpu}), flush=True)
                 raise SystemExit(3)
+        base_cfgs = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+        if strong:
+            quoted = {"p256-var": base_cfgs[3], "secp256k1-double": base_cfgs[4]}.get(workload)
+            wl = ("%s -- run as ONE global batch of 2^%d split into %d contiguous shard(s) of %d"
+                  % (quoted if quoted and n_global == 1 << BASELINE_LOG2_GLOBAL[workload] else
+                     "2^%d %s scalar-muls (global)" % (n_global.bit_length() - 1, workload), n_global.bit_length() - 1, world, n))
+        else:
+            wl = "2^%d %s scalar-muls per GPU per step (BASELINE.json %s)" % (args.log2_batch, workload, cfg)
         out = {
             "metric": "%s scalar-muls/sec (batched, %s)" % (
                 workload, "bit-exact vs CPU oracle on the parity sample" if cpu else "parity check not run in this invocation"),
             "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "2^%d %s scalar-muls per GPU per step (BASELINE.json %s)"
-                                   % (args.log2_batch, workload, cfg),
-                       "curve": curve, "kind": kind, "batch_per_gpu": n, "global_batch": n * world,
-                       "result_gather": (args.gather if dist is not None else "n/a"),
+            "config": {"workload": wl,
+                       "curve": curve, "kind": kind, "batch_per_gpu": n, "global_batch": n_global,
+                       "result_gather": (modes[0] if dist is not None else "n/a"),
                        "device": info["name"], "compute_units": info["compute_units"]},
             "roofline": {
                 "bound": "int-valu", "achieved": achieved / 1e12, "peak": PEAK_MAD32_FORMULA / 1e12,
@@ -299,13 +386,19 @@ def main():
                 "traffic_source": pmc["source"],
                 "traffic_note": TRAFFIC_NOTES.get(workload),
                 "kernel": kname, "kernel_ms": kernel_ms,
-                "algorithmic_mad32_per_unit": alg, "units_per_launch": n,
+                "algorithmic_mad32_per_unit": alg, "executed_mul_insts_per_unit": EXECUTED_MULS.get(workload),
+                "units_per_launch": n,
                 "peak_measured": peak_measured / 1e12, "frac_of_measured_peak": achieved / peak_measured,
-                "valu_busy_pct": pmc["valu_busy_pct"],
+                "valu_issue_cycles_per_inst_per_simd": pmc["valu_issue_cycles"],
                 "hbm": {"achieved_GBps": n * hbm_bytes / (kernel_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
                         "algorithmic_bytes_per_unit": hbm_bytes},
             },
         }
+        if dist is not None:
+            # the gather's cost, both ways in one line: throughput with the result shards gathered
+            # to rank 0 (overlapped with the next step's kernel) and with the shards left where they are
+            out["gather"] = {m: {"value": total / elapsed_by_mode[m], "ms_per_step": elapsed_by_mode[m] / args.steps * 1e3}
+                             for m in modes}
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

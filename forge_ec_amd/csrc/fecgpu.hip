@@ -562,13 +562,17 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
 // main stream and fork_done / join do nothing -- for large batches, when the ctx has no second stream, or when the
 // main stream IS the second stream.
 struct SideStream {
-  // two launches of n elements each fit side by side: 256 CUs x 768 lanes / 2
-  static constexpr size_t kSideStreamMax = 98304;
+  // Round 2 forked only up to 98304 elements (two launches side by side fill the chip: 256 CUs x 768 lanes / 2).  Measured
+  // in round 3 (profiles/double_mul_side_stream_r03.jsonl): forking wins at EVERY size for the two Weierstrass curves --
+  // the tail of one launch overlaps the head of the other, and below 2^18 elements a lone persistent kernel cannot fill
+  // its 1024 slots per CU -- 2^17: secp256k1 8.68 -> 7.85 ms, P-256 8.80 -> 6.38 ms; 2^20: 57.56 -> 56.83, 48.65 -> 48.10.
+  static constexpr size_t kSideStreamMax = (size_t)-1;
   hipStream_t main, s;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   bool active = false;
   SideStream(fec_ctx* ctx, hipStream_t main_, size_t n, size_t limit = kSideStreamMax) : main(main_), s(main_) {
-    if (n > limit || !ctx->stream2 || ctx->stream2 == main_) return;
+    // (not inside a multi-chunk host pipeline: its second lane IS the side stream and is busy with the other chunk)
+    if (n > limit || !ctx->stream2 || ctx->stream2 == main_ || ctx->in_multi_chunk_pipeline) return;
     if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
@@ -614,11 +618,15 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
   }
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op"
                         : (curve == FEC_P256 ? "k_p256_mul_sched x2 + k_point_op" : "k_ed_fixed_base + k_ed_mul_pers + k_point_op"));
-  // Up to 98304 elements one launch fills at most half of the chip's lanes and is bound by the latency of one
-  // multiplication: the fixed-base product then runs on the ctx's second stream beside the variable-base one (the
-  // persistent kernels, one workgroup per CU, each on half of the CUs).
+  // The fixed-base product runs on the ctx's second stream beside the variable-base one (the persistent kernels, one
+  // workgroup per CU, each on half of the CUs): see SideStream.
   // (Ed25519: the table kernel is short and not capped to half of the CUs; side by side pays up to 2^15 elements)
-  SideStream side(ctx, L.s, n, curve == FEC_ED25519 ? (size_t)1 << 15 : SideStream::kSideStreamMax);
+  // FEC_SIDE_STREAM_MAX (elements; measurement knob of tools/double_mul_small_perf.py) overrides the limit
+  static const size_t side_max = [] {
+    const char* e = std::getenv("FEC_SIDE_STREAM_MAX");
+    return e && *e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)SideStream::kSideStreamMax;
+  }();
+  SideStream side(ctx, L.s, n, curve == FEC_ED25519 ? (size_t)1 << 15 : side_max);
   if (curve == FEC_SECP256K1) {  // the 3-waves-per-SIMD ladder twice (fixed G, then Q) beats the fused 2-wave kernel
     secp_launch_mul(true, a, gen, ta, n, side.s);
     side.fork_done();
@@ -681,7 +689,7 @@ int launch_ecdsa_verify(fec_ctx* ctx, int curve, const unsigned char* dd, const 
                                                : "k_ecdsa_pre + k_p256_mul_sched x2 + k_ecdsa_finish");
   ecdsa_launch(sched_env(ctx), curve, dd, reinterpret_cast<const u32*>(dr), reinterpret_cast<const u32*>(ds),
                reinterpret_cast<const u32*>(dpk), dinf, reinterpret_cast<const u32*>(ctx->d_gen[curve]), dstatus, work, n,
-               L.s);
+               L.s, ctx->stream2 != L.s ? ctx->stream2 : nullptr);
   return L.done();
 }
 
@@ -783,6 +791,11 @@ int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, siz
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   const size_t chunk = ctx->chunk;
   const size_t nchunks = (n + chunk - 1) / chunk;
+  struct InPipeline {  // (SideStream: a multi-chunk pipeline keeps both streams busy by itself)
+    fec_ctx* c;
+    ~InPipeline() { c->in_multi_chunk_pipeline = false; }
+  } in_pipeline{ctx};
+  ctx->in_multi_chunk_pipeline = nchunks > 1;
   hipStream_t lanes[2] = {ctx->stream, ctx->stream2};
   auto copy_back = [&](size_t c) -> int {
     const int lane = (int)(c & 1);

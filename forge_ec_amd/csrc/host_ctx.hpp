@@ -66,6 +66,7 @@ struct fec_ctx {
   unsigned* h_err = nullptr;       // host view
   unsigned* d_err = nullptr;       // device view of the same word
   unsigned debug_force_fault = 0;  // fec_ctx_debug_force_fault
+  bool in_multi_chunk_pipeline = false;  // set by host_pipeline while it runs more than one chunk (fecgpu.hip: SideStream)
 };
 
 // No exception may cross the C ABI: every extern "C" definition in fecgpu.hip and canon.hip is a function-try-block

@@ -52,7 +52,7 @@ void codec_launch(int op, int curve, const void* in, const void* in2, void* out,
 size_t ecdsa_work_bytes(size_t n);
 void ecdsa_launch(const SchedEnv& env, int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
                   const unsigned char* pk_inf, const u32* gen, unsigned char* status, void* work, size_t n,
-                  hipStream_t s);
+                  hipStream_t s, hipStream_t side = nullptr);   // side: a second stream for the fixed-base launch, or null
 
 // kernels_ecdsa.hip: Ecdsa::<C, D>::batch_verify (ecdsa.rs:287-391) in three parts around the point fold that
 // fecgpu.hip owns.  Work area (ecdsa_batch_work_bytes): u1 +0, u2 +32n, Q +64n, ta +160n, tb +256n, flags +352n

@@ -158,9 +158,39 @@ __global__ __launch_bounds__(TPB) void k_ecdsa_finish(const u32* __restrict__ ta
   status[i] = f == F_FALSE ? 0 : (f == F_PANIC ? 2 : st);
 }
 
+// The fixed-base multiplication of a pair (multiply(G, u1), multiply(Q, u2)) forked onto a second stream and joined back
+// with events (no host blocking): the two launches overlap, each persistent kernel on half of the CUs.  Wins at every
+// batch size (fecgpu.hip: SideStream).  Inactive -- `s` is the main stream -- without a distinct second stream.
+struct Fork {
+  hipStream_t main, s;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  bool active = false;
+  Fork(hipStream_t main_, hipStream_t side) : main(main_), s(main_) {
+    if (side == nullptr || side == main_) return;
+    if (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    (void)hipEventRecord(ev_in, main);
+    (void)hipStreamWaitEvent(side, ev_in, 0);
+    s = side;
+    active = true;
+  }
+  void join() {
+    if (!active) return;
+    (void)hipEventRecord(ev_out, s);
+    (void)hipStreamWaitEvent(main, ev_out, 0);
+  }
+  ~Fork() {
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+  }
+};
+
 template <class E>
 void run(const SchedEnv& env, const unsigned char* dd, const u32* dr, const u32* ds, const u32* dpk, const unsigned char* dinf, const u32* gen,
-         unsigned char* dstatus, void* work, size_t n, hipStream_t s) {
+         unsigned char* dstatus, void* work, size_t n, hipStream_t s, hipStream_t side) {
   char* w = static_cast<char*>(work);
   u32* u1 = reinterpret_cast<u32*>(w);
   u32* u2 = reinterpret_cast<u32*>(w + n * 32);
@@ -171,8 +201,12 @@ void run(const SchedEnv& env, const unsigned char* dd, const u32* dr, const u32*
   const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
   hipLaunchKernelGGL((k_ecdsa_pre<E>), g, b, 0, s, dd, dr, ds, dpk, dinf, (const u32*)nullptr, u1, u2, q, flags,
                      (u32*)nullptr, n);
-  E::launch_mul(env, true, u1, gen, ta, n, s);
-  E::launch_mul(env, false, u2, q, tb, n, s);
+  {
+    Fork fork(s, side);
+    E::launch_mul(env, true, u1, gen, ta, n, fork.s, fork.active ? 2 : 1);
+    E::launch_mul(env, false, u2, q, tb, n, s, fork.active ? 2 : 1);
+    fork.join();
+  }
   hipLaunchKernelGGL((k_ecdsa_finish<E>), g, b, 0, s, (const u32*)ta, (const u32*)tb, dr, (const unsigned char*)flags, dstatus, n);
 }
 
@@ -419,24 +453,13 @@ void ecdsa_batch_mul_launch(const SchedEnv& env, int curve, const u32* gen, void
   const u32* q = reinterpret_cast<const u32*>(w + n * 64);
   u32* ta = reinterpret_cast<u32*>(w + n * 160);
   u32* tb = reinterpret_cast<u32*>(w + n * 256);
-  hipEvent_t ev_in = nullptr, ev_out = nullptr;
-  const bool two = side != nullptr && side != s && n <= 98304 &&  // two launches side by side, half of the CUs each
-                   hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) == hipSuccess;
-  hipStream_t sf = s;
-  if (two) {
-    (void)hipEventRecord(ev_in, s);
-    (void)hipStreamWaitEvent(side, ev_in, 0);
-    sf = side;
-  }
-  if (curve == FEC_SECP256K1) ESecp::launch_mul(env, true, u1, gen, ta, n, sf);
-  else EP256::launch_mul(env, true, u1, gen, ta, n, sf, two ? 2 : 1);
-  if (two) (void)hipEventRecord(ev_out, side);
+  Fork fork(s, side);
+  const bool two = fork.active;
+  if (curve == FEC_SECP256K1) ESecp::launch_mul(env, true, u1, gen, ta, n, fork.s);
+  else EP256::launch_mul(env, true, u1, gen, ta, n, fork.s, two ? 2 : 1);
   if (curve == FEC_SECP256K1) ESecp::launch_mul(env, false, u2, q, tb, n, s);
   else EP256::launch_mul(env, false, u2, q, tb, n, s, two ? 2 : 1);
-  if (two) (void)hipStreamWaitEvent(s, ev_out, 0);
-  if (ev_in) (void)hipEventDestroy(ev_in);
-  if (ev_out) (void)hipEventDestroy(ev_out);
+  fork.join();
 }
 void ecdsa_batch_finish_launch(int curve, const u32* r_sum, const void* work, size_t n, unsigned char* result, u32* detail,
                                hipStream_t s) {
@@ -447,9 +470,9 @@ void ecdsa_batch_finish_launch(int curve, const u32* r_sum, const void* work, si
 
 void ecdsa_launch(const SchedEnv& env, int curve, const unsigned char* digests, const u32* r, const u32* s_, const u32* pk,
                   const unsigned char* pk_inf, const u32* gen, unsigned char* status, void* work, size_t n,
-                  hipStream_t s) {
-  if (curve == FEC_SECP256K1) run<ESecp>(env, digests, r, s_, pk, pk_inf, gen, status, work, n, s);
-  else run<EP256>(env, digests, r, s_, pk, pk_inf, gen, status, work, n, s);
+                  hipStream_t s, hipStream_t side) {
+  if (curve == FEC_SECP256K1) run<ESecp>(env, digests, r, s_, pk, pk_inf, gen, status, work, n, s, side);
+  else run<EP256>(env, digests, r, s_, pk, pk_inf, gen, status, work, n, s, side);
 }
 
 }  // namespace fecgpu

@@ -642,14 +642,18 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
     if (kind == 1) {  // A_i: result = result + addend  (2083-2086, bit i set); the result stays in its output slot
       // inactive lanes read element 0 of the range (always present) and slot 0: computed, never stored
       u32* slot = out + (lo + gid) * 32;
+      FEC_MARK("task_add_begin");
       const ed::pt res = padd_mem(slot, lds_ad + e, PS);
+      FEC_MARK("task_add_end");
       if (live) {
         st_glb(slot, res);
         fin = step == 255;  // the last doubling is never used
         nxt = 0;            // then D_i
       }
     } else {  // D_i: addend = addend.double()  (2089), then step i + 1
+      FEC_MARK("task_double_begin");
       const ed::pt d = pdbl_mem(lds_ad + e, PS);
+      FEC_MARK("task_double_end");
       if (live) {
         st_lds(lds_ad + e, PS, d);
         ++step;

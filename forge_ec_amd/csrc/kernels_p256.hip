@@ -27,6 +27,32 @@
 
 namespace fecgpu {
 
+// Scheduler statistics for tools/microbench/sched_stats.hip (compiled in only with -DFEC_SCHED_STATS; the shipped
+// library has none of it): [0] doubling batches, [1] lanes in them, [2] addition batches, [3] lanes in them,
+// [4] doubling batches that took the rare leg, [5] addition batches that took the rare leg, [6] polls of waiting wavefronts
+// (wave-local counters, flushed with one atomic per counter per wavefront when the kernel ends: counting with an atomic
+// per event slowed the kernel 2000-fold and measured the atomics)
+#ifdef FEC_SCHED_STATS
+__device__ unsigned long long g_sched_stats[8];
+#define FEC_STAT_DECL unsigned fec_st[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define FEC_STAT(i, v) fec_st[i] += (unsigned)(v)
+#define FEC_STAT_FLUSH                                                                             \
+  do {                                                                                             \
+    if ((threadIdx.x & 63) == 0)                                                                   \
+      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_sched_stats[i_], (unsigned long long)fec_st[i_]); \
+  } while (0)
+#else
+#define FEC_STAT_DECL \
+  do {                \
+  } while (0)
+#define FEC_STAT(i, v) \
+  do {                 \
+  } while (0)
+#define FEC_STAT_FLUSH \
+  do {                 \
+  } while (0)
+#endif
+
 namespace {
 
 FEC_DEV p256::pt ld_pt(const u32* l, int stride) {
@@ -58,6 +84,22 @@ FEC_DEV p256::pt ld_base(const u32* points, size_t g) {
     p.z.w[4 * i] = v[4 + i].x; p.z.w[4 * i + 1] = v[4 + i].y; p.z.w[4 * i + 2] = v[4 + i].z; p.z.w[4 * i + 3] = v[4 + i].w;
   }
   return p;
+}
+
+// Streaming accesses (a result is written once, a scalar is read eight words in 256 steps) carry the non-temporal
+// hint so that they do not push the base points -- re-read by every addition -- out of the XCD's L2.
+typedef u32 v4u_t __attribute__((ext_vector_type(4)));
+typedef u32 v2u_t __attribute__((ext_vector_type(2)));
+FEC_DEV void st_stream(u32* g, u32 a, u32 b, u32 c, u32 d) {
+  v4u_t v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4u_t*>(g));
+}
+FEC_DEV void st_out(u32* o, const p256::pt& r) {  // 24 words, 16-byte stores
+  FEC_UNROLL for (int w = 0; w < 2; ++w) {
+    st_stream(o + 4 * w, r.x.w[4 * w], r.x.w[4 * w + 1], r.x.w[4 * w + 2], r.x.w[4 * w + 3]);
+    st_stream(o + 8 + 4 * w, r.y.w[4 * w], r.y.w[4 * w + 1], r.y.w[4 * w + 2], r.y.w[4 * w + 3]);
+    st_stream(o + 16 + 4 * w, r.z.w[4 * w], r.z.w[4 * w + 1], r.z.w[4 * w + 2], r.z.w[4 * w + 3]);
+  }
 }
 
 // one coordinate (8 words) of a slot / of a base point
@@ -107,14 +149,14 @@ FEC_DEV p256::pt pdouble_in_place(const u32* lp, int stride) {
 // never on random inputs) re-read both points inside their rare branch, so that neither point is live across the
 // sixteen products -- the difference between 43 spilled registers and none at three wavefronts per SIMD.  The
 // products, their operands and their order are those of p256::padd_nodouble / padd.
-// `gzz` (when not null): z2z2 = q.z * q.z of this addend, computed once per element (or per launch for a fixed base)
-// by the same sqr() -- the addend of an element never changes, and its square is one of the sixteen products of every
-// addition.
-FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u32* gzz) {
+// `lzz` (when not null): z2z2 = q.z * q.z of this addend in LDS (word w at lzz[w * zstride]), computed once per element
+// (or per launch for a fixed base) by the same sqr() -- the addend of an element never changes, and its square is one of
+// the sixteen products of every addition.
+FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u32* lzz, int zstride) {
   using namespace p256;
   const fe z1 = ld_coord(lp, stride, 2), z2 = ld_base_coord(gq, 2);
   const lmask idp = fe_is_zero(z1), idq = fe_is_zero(z2);
-  const fe z1z1 = sqr(z1), z2z2 = gzz ? ld_base_coord(gzz, 0) : sqr(z2);
+  const fe z1z1 = sqr(z1), z2z2 = lzz ? ld_coord(lzz, zstride, 0) : sqr(z2);
   const fe zs = sub(sub(sqr(add(z1, z2)), z1z1), z2z2);
   const fe s1 = mul(mul(ld_coord(lp, stride, 1), z2), z2z2);
   __builtin_amdgcn_sched_barrier(0);  // keep the loads of q's coordinates where they are used (register budget)
@@ -175,12 +217,18 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
                                                       u32* __restrict__ out, size_t n, unsigned per_wg,
                                                       unsigned* __restrict__ err, unsigned force_fault) {
   __shared__ u32 lds_st[24 * QS];               // X, Y, Z of slot e: word w at lds_st[w * QS + e]
-  __shared__ u32 lds_k[8 * QS];                 // scalar of slot e
+  // z2z2 = base.z * base.z of slot e's element (variable base): one of the sixteen products of EVERY addition of an
+  // element depends on its base point alone, so claim() computes it once with the same sqr() and the ~128 additions
+  // read it back.  It takes the LDS room the scalar used to have; of the scalar only the 32-bit word that holds the
+  // current bit stays in LDS (lds_kw), refetched from the caller's array once per 32 steps.  (Round 2 parked z2z2 in
+  // the element's output slot instead: 23 GB of L2-side traffic and no in-place calls -- removed; this form has neither.)
+  __shared__ u32 lds_zq[(FIXED ? 0 : 8 * QS) + 8];
+  __shared__ u32 lds_kw[2 * QS];                // the aligned 64-bit half-limb of slot e's scalar that holds its current bit
   __shared__ u32 lds_gid[QS];                   // element of slot e, relative to the workgroup's range
   __shared__ unsigned short lds_step[QS];
   __shared__ unsigned short lds_q[2][QRING];
   __shared__ __attribute__((aligned(16))) int lds_ctl[P_WORDS];
-  __shared__ __attribute__((aligned(16))) u32 lds_zz[8];   // FIXED && HOIST: base.z * base.z
+  __shared__ __attribute__((aligned(16))) u32 lds_zz[8];   // FIXED && HOIST: base.z * base.z (one for the workgroup)
   const size_t lo = (size_t)blockIdx.x * per_wg;
   const int range = (n - lo) < (size_t)per_wg ? (int)(n - lo) : (int)per_wg;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -201,9 +249,14 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   }
   __syncthreads();
 
-  // Claims the next element of the range for slot `e`: scalar into LDS, state = identity, step = 0.  multiply's
-  // early-outs (2121-2124: identity point or zero scalar) are answered at once.  Returns 0 (the first doubling
-  // is pending) or 2 when the range is used up (the slot dies).
+  // Claims the next element of the range for slot `e`.  multiply's early-outs (2121-2124: identity point or zero
+  // scalar) are answered at once.  The ladder's prefix is answered at once as well: until the scalar's top set bit
+  // (position t) every doubling is double(identity) = identity (1870) and the first addition is identity + point =
+  // point (Add's first early-out returns rhs as it is), so the slot starts with result = point at step 256 - t --
+  // exactly the state the reference is in after that addition.  (Besides the skipped operations this keeps identity
+  // results out of the queues: with them, 39 % of all batches held at least one lane on an early-out and ran Add's /
+  // double's rare leg for the whole wavefront.)  Returns 0 (a doubling is pending) or 2 when the range is used up
+  // (the slot dies).
   auto claim = [&](int e) -> int {
     for (;;) {
       const int rel = atomicAdd(&lds_ctl[P_NEXT], 1);
@@ -225,12 +278,39 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
         FEC_UNROLL for (int w = 0; w < 6; ++w) o[w] = make_uint4(w == 2 ? 1u : 0u, 0, 0, 0);  // identity (0, 1, 0)
         continue;
       }
-      lds_k[0 * QS + e] = k0.x; lds_k[1 * QS + e] = k0.y; lds_k[2 * QS + e] = k0.z; lds_k[3 * QS + e] = k0.w;
-      lds_k[4 * QS + e] = k1.x; lds_k[5 * QS + e] = k1.y; lds_k[6 * QS + e] = k1.z; lds_k[7 * QS + e] = k1.w;
-      FEC_UNROLL for (int w = 0; w < 24; ++w) lds_st[w * QS + e] = (w == 8) ? 1u : 0u;
+      const u32 kw[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+      int t = 0;  // top set bit of the scalar
+      FEC_UNROLL for (int w = 0; w < 8; ++w) t = kw[w] ? 32 * w + 31 - __builtin_clz(kw[w]) : t;
+      const p256::pt base = ld_base(points, FIXED ? 0 : g);
+      if (t == 0) {  // scalar == 1: 255 doublings of the identity, then identity + point
+        st_out(out + g * 24, base);
+        continue;
+      }
+      st_pt(lds_st + e, QS, base);
+      if (!FIXED) {
+        const fe zz = p256::sqr(base.z);
+        FEC_UNROLL for (int w = 0; w < 8; ++w) lds_zq[w * QS + e] = zz.w[w];
+      }
+      u32 c0 = 0, c1 = 0;  // the 64 bits that hold bit t - 1, the next one the ladder looks at
+      FEC_UNROLL for (int w = 0; w < 4; ++w) {
+        c0 = ((t - 1) >> 6) == w ? kw[2 * w] : c0;
+        c1 = ((t - 1) >> 6) == w ? kw[2 * w + 1] : c1;
+      }
+      lds_kw[e] = c0;
+      lds_kw[QS + e] = c1;
       lds_gid[e] = (u32)rel;
-      lds_step[e] = 0;
+      lds_step[e] = (unsigned short)(256 - t);
       return 0;
+    }
+  };
+  // step -> step + 1: when the new step's bit opens a new 64-bit limb of the scalar, that limb is fetched from the
+  // caller's array (three times per element)
+  auto advance = [&](int e, u32 gid, int step_new) {
+    const int b = 255 - step_new;
+    if (step_new < 256 && (b & 63) == 63) {
+      const v2u_t kk = __builtin_nontemporal_load(reinterpret_cast<const v2u_t*>(scalars + (lo + gid) * 8 + 2 * (b >> 6)));
+      lds_kw[e] = kk.x;
+      lds_kw[QS + e] = kk.y;
     }
   };
 
@@ -238,6 +318,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   int e = tid;
   int nxt = 3;
   unsigned spins = 0;
+  FEC_STAT_DECL;
   int fill = 0;  // initial fill passes done: slots [fill * QT, (fill + 1) * QT) are claimed on pass `fill`
   nxt = tid < range ? claim(e) : 3;
   for (;;) {
@@ -254,6 +335,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       th0 = th0 < 1 ? 1 : (th0 > 64 ? 64 : th0);
       const bool go = q_d >= th0 || q_a >= th0 || (fl == 0 && (q_d | q_a) != 0) || (rem == 0 && fl == 0) || ctl[C_ERR] != 0;
       if (!go) {
+        FEC_STAT(6, 1);
         __builtin_amdgcn_s_sleep(64);
         if (++spins > (1u << 22)) {
           if (lane == 0) ctl[C_ERR] = (int)FEC_DEVERR_SCHED_WATCHDOG;
@@ -262,9 +344,13 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
         continue;
       }
     }
+    FEC_STAT(4, 1);   // critical sections entered
     if (lane == 0) {
       const int my = atomicAdd(&lds_ctl[C_TICKET], 1);
-      while (ctl[C_SERVING] != my) __builtin_amdgcn_s_sleep(1);
+      while (ctl[C_SERVING] != my) {
+        FEC_STAT(5, 1);  // waits for the ticket
+        __builtin_amdgcn_s_sleep(1);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const CtlWords cw = ctl_read(ctl_addr);
@@ -325,16 +411,21 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     const bool live = active && !oob;
     bool fin = false;
     p256::pt res = p256::identity();
+    FEC_STAT(kind == 0 ? 0 : 2, 1);
+    FEC_STAT(kind == 0 ? 1 : 3, count);
     if (kind == 0) {
+      FEC_MARK("task_double_begin");
       res = pdouble_in_place(lds_st + e, QS);
+      FEC_MARK("task_double_end");
       if (live) {
         const int b = 255 - step;
-        const u32 bit = (lds_k[(b >> 5) * QS + e] >> (b & 31)) & 1u;
+        const u32 bit = (lds_kw[((b >> 5) & 1) * QS + e] >> (b & 31)) & 1u;
         if (bit) {
           nxt = 1;
         } else {
           ++step;
           lds_step[e] = (unsigned short)step;
+          advance(e, gid, step);
           nxt = 0;
           fin = step == 256;
         }
@@ -343,29 +434,28 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     } else {
       // inactive lanes add slot 0 and element 0 of the range: harmless, never stored
       const size_t g_el = lo + gid;
+      FEC_MARK("task_add_begin");
       res = padd_in_place(lds_st + e, QS, FIXED ? points : points + g_el * 24,
-                          (FIXED && HOIST) ? lds_zz : nullptr);
+                          FIXED ? (HOIST ? lds_zz : nullptr) : lds_zq + e, FIXED ? 1 : QS);
+      FEC_MARK("task_add_end");
       if (live) {
         ++step;
         lds_step[e] = (unsigned short)step;
+        advance(e, gid, step);
         nxt = 0;
         fin = step == 256;
         if (!fin) st_pt(lds_st + e, QS, res);
       }
     }
     if (fin) {  // the element is done: its result goes out (16-byte stores), the slot takes the next element
-      uint4* o = reinterpret_cast<uint4*>(out + (lo + gid) * 24);
-      FEC_UNROLL for (int w = 0; w < 2; ++w) {
-        o[w] = make_uint4(res.x.w[4 * w], res.x.w[4 * w + 1], res.x.w[4 * w + 2], res.x.w[4 * w + 3]);
-        o[2 + w] = make_uint4(res.y.w[4 * w], res.y.w[4 * w + 1], res.y.w[4 * w + 2], res.y.w[4 * w + 3]);
-        o[4 + w] = make_uint4(res.z.w[4 * w], res.z.w[4 * w + 1], res.z.w[4 * w + 2], res.z.w[4 * w + 3]);
-      }
+      st_out(out + (lo + gid) * 24, res);
       nxt = claim(e);
     }
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(oob) != 0, 0)) {
       if (oob) ctl[C_ERR] = (int)FEC_DEVERR_SCHED_INDEX;
     }
   }
+  FEC_STAT_FLUSH;
   __syncthreads();
   if (const int ec = lds_ctl[C_ERR]) {
     // Scheduler fault (watchdog, index guard, or the debug hook): zero-fill the workgroup's results AND set the ctx's

@@ -48,6 +48,15 @@ struct fe {
 };
 
 #define FEC_UNROLL _Pragma("unroll")
+// Region markers for tools/isa_mix.py --region: comment-only asm statements, compiled in ONLY for the analysis build
+// (-DFEC_ISA_MARKERS); the shipped library does not contain them.
+#ifdef FEC_ISA_MARKERS
+#define FEC_MARK(name) asm volatile("; FEC_MARK " name)
+#else
+#define FEC_MARK(name) \
+  do {                 \
+  } while (0)
+#endif
 
 #ifdef FEC_HOST_EMUL
 FEC_DEV lmask lanes_where(bool c) { return c ? ~0ull : 0ull; }

@@ -95,6 +95,64 @@ def lib():
     return _lib
 
 
+def cpu_model():
+    """Model string of the host CPU (bench.py prints it beside the CPU baseline)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+_native = None
+
+
+def native_lib():
+    """The SAME source built for the machine this runs on (gcc -O3 -march=native), for bench.py's cpu_baseline leg:
+    the shipped libforge_ec_oracle.so is built with -march=x86-64-v2 (no mulx / adx) so that it runs on any box the
+    snapshot travels to, which handicaps the CPU number printed beside the GPU one.  Built into oracle/_native/
+    (git- and gpurun-ignored; the file name carries a hash of this CPU's flags, so a build never runs on another
+    machine).  Returns (library, description); falls back to (lib(), "shipped ...") when gcc is missing or fails."""
+    global _native
+    if _native is not None:
+        return _native
+    import hashlib
+    import shutil
+    shipped = (lib(), "shipped build, gcc -O3 -march=x86-64-v2 (no gcc on this box, or the native build failed)")
+    try:
+        flags = ""
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = line
+                break
+        tag = hashlib.sha256((cpu_model() + flags).encode()).hexdigest()[:12]
+        out_dir = os.path.join(_HERE, "_native")
+        so = os.path.join(out_dir, "libforge_ec_oracle_%s.so" % tag)
+        src = os.path.join(_HERE, "forge_ec_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            gcc = shutil.which("gcc")
+            if not gcc:
+                _native = shipped
+                return _native
+            os.makedirs(out_dir, exist_ok=True)
+            subprocess.check_call([gcc, "-O3", "-march=native", "-fPIC", "-std=c11", "-shared", "-o", so, src, "-lpthread"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = ctypes.CDLL(so)
+        p = ctypes.c_void_p
+        L.fo_batch_mul.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_mul.restype = None
+        L.fo_batch_mul_fixed.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_mul_fixed.restype = None
+        L.fo_batch_double_mul.argtypes = [ctypes.c_int, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_double_mul.restype = None
+        _native = (L, "built on this box: gcc -O3 -march=native")
+    except Exception:
+        _native = shipped
+    return _native
+
+
 def _u64(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
 
@@ -172,27 +230,27 @@ def multiply(curve, point, scalar):
     return r
 
 
-def batch_mul(curve, scalars, points, nthreads=1):
+def batch_mul(curve, scalars, points, nthreads=1, L=None):
     scalars, points = _u64(scalars), _u64(points)
     n = scalars.size // 4
     out = np.zeros((n, POINT_LIMBS[curve]), dtype=np.uint64)
-    lib().fo_batch_mul(curve, _ptr(scalars), _ptr(points), _ptr(out), n, nthreads)
+    (L or lib()).fo_batch_mul(curve, _ptr(scalars), _ptr(points), _ptr(out), n, nthreads)
     return out
 
 
-def batch_mul_fixed(curve, scalars, base, nthreads=1):
+def batch_mul_fixed(curve, scalars, base, nthreads=1, L=None):
     scalars, base = _u64(scalars), _u64(base)
     n = scalars.size // 4
     out = np.zeros((n, POINT_LIMBS[curve]), dtype=np.uint64)
-    lib().fo_batch_mul_fixed(curve, _ptr(scalars), _ptr(base), _ptr(out), n, nthreads)
+    (L or lib()).fo_batch_mul_fixed(curve, _ptr(scalars), _ptr(base), _ptr(out), n, nthreads)
     return out
 
 
-def batch_double_mul(curve, u1, u2, q, nthreads=1):
+def batch_double_mul(curve, u1, u2, q, nthreads=1, L=None):
     u1, u2, q = _u64(u1), _u64(u2), _u64(q)
     n = u1.size // 4
     out = np.zeros((n, POINT_LIMBS[curve]), dtype=np.uint64)
-    lib().fo_batch_double_mul(curve, _ptr(u1), _ptr(u2), _ptr(q), _ptr(out), n, nthreads)
+    (L or lib()).fo_batch_double_mul(curve, _ptr(u1), _ptr(u2), _ptr(q), _ptr(out), n, nthreads)
     return out
 
 

@@ -60,6 +60,23 @@ def test_multi_ctx_other_elementwise_calls(oracle):
         r = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 59), V.field_elements(n, 2, 60)], axis=1))
         inf = (rng.integers(0, 8, size=n) == 0).astype(np.uint8)
         assert np.array_equal(ctx.eddsa_verify_ed25519(r, None, pk, inf, s, k), one.eddsa_verify_ed25519(r, None, pk, inf, s, k))
+        # ECDH, validate_point and the three codecs shard as well (fecgpu.h lists every sharded entry point)
+        for curve in (0, 1):
+            sk = V.scalars(n, curve, 71 + curve)
+            pkc = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 73), V.field_elements(n, curve, 74)], axis=1))
+            sec, st = ctx.batch_ecdh(curve, sk, pkc, inf)
+            sec1, st1 = one.batch_ecdh(curve, sk, pkc, inf)
+            assert np.array_equal(sec, sec1) and np.array_equal(st, st1)
+        for curve in (0, 1, 2):
+            xyc = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 75), V.field_elements(n, curve, 76)], axis=1))
+            assert np.array_equal(ctx.batch_validate_point(curve, xyc, inf), one.batch_validate_point(curve, xyc, inf))
+            comp = one.batch_compress(curve, xyc, inf)
+            for a_, b_ in zip(ctx.batch_decompress(curve, comp), one.batch_decompress(curve, comp)):
+                assert np.array_equal(a_, b_)
+            unc = one.batch_encode_uncompressed(curve, xyc, inf)
+            assert np.array_equal(ctx.batch_encode_uncompressed(curve, xyc, inf), unc)
+            for a_, b_ in zip(ctx.batch_decode_uncompressed(curve, unc), one.batch_decode_uncompressed(curve, unc)):
+                assert np.array_equal(a_, b_)
         # not element-wise: runs on devices[0]
         a = V.scalars(64, 1, 61)
         assert ctx.ecdsa_batch_verify(1, dg[:64], V.scalars(64, 1, 62), V.scalars(64, 1, 63), pk[:64], None, a)[0] == \

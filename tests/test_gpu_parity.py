@@ -167,6 +167,31 @@ def test_batch_mul_matches_oracle(gpu_ctx, oracle, curve):
     _assert_same(got, want, "%s batch_mul" % NAMES[curve])
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_single_bit_and_word_boundary_scalars(gpu_ctx, oracle, curve):
+    """Every top-bit position and every scalar-word boundary: the P-256 scheduler answers the ladder's prefix when it
+    claims an element (result = point at step 256 - t, t = the scalar's top set bit) and refetches the scalar word
+    that holds the current bit once per 32 steps; 2^t, 2^t + 1, 2^t - 1 and runs of ones across the word boundaries,
+    on a random point, on G (Z = 1: the doubling's z.is_one() leg right after the copy) and mixed into random
+    lanes so that wavefronts hold elements at very different steps."""
+    vals = []
+    for t in range(256):
+        vals += [1 << t, (1 << t) | 1, (1 << t) - 1 if t else 1]
+    for w in range(1, 8):
+        vals += [0xFFFFFFFF << (32 * w - 16) & ((1 << 256) - 1), (1 << (32 * w)) | (1 << (32 * w - 1)), 3 << (32 * w - 1)]
+    ek = np.array([V.limbs_of(v) for v in vals], dtype=np.uint64)
+    m = len(ek)
+    g = oracle.generator(curve)
+    rp = V.points(m, curve, 377)
+    k = np.concatenate([ek, ek, V.scalars(m, curve, 378)])
+    p = np.concatenate([rp, np.tile(g, (m, 1)), V.points(m, curve, 379)])
+    perm = np.random.default_rng(9).permutation(len(k))
+    k, p = np.ascontiguousarray(k[perm]), np.ascontiguousarray(p[perm])
+    _assert_same(gpu_ctx.batch_mul(curve, k, p), oracle.batch_mul(curve, k, p, nthreads=8), "%s single-bit scalars" % NAMES[curve])
+    _assert_same(gpu_ctx.batch_mul_fixed(curve, ek, g), oracle.batch_mul_fixed(curve, ek, g, nthreads=8),
+                 "%s single-bit scalars, fixed base" % NAMES[curve])
+
+
 def test_p256_ladder_takes_the_equal_points_branch(gpu_ctx, oracle):
     """P = (0, 2^63, z) satisfies double(P) ~ P under the reference's P-256 arithmetic (its Sub wraps
     mod 2^256: Y3 = 0 - 8*y^4 = 2^256 - 2^255), so `result + *point` finds projectively equal

@@ -33,7 +33,7 @@ def main():
     s = torch.cuda.Stream()
     torch.cuda.set_stream(s)
     for c in (0, 1, 2):
-        for logn in (10, 12, 14, 16):
+        for logn in [int(v) for v in os.environ.get("FEC_DM_LOG2", "10,12,14,16").split(",")]:
             n = 1 << logn
             u1, u2, q = dev(synth.scalars(n, c, 11)), dev(synth.scalars(n, c, 12)), dev(synth.points(n, c, 13))
             out = torch.empty_like(q)
@@ -45,7 +45,7 @@ def main():
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
             print(json.dumps({"row": "double_mul", "curve": NAMES[c], "n": n, "ms": round(best * 1e3, 3),
-                              "lib": os.path.relpath(_lib.SO_PATH, ROOT), "checksum": int(out.sum().item()) & 0xFFFFFFFF}), flush=True)
+                              "lib": os.path.relpath(_lib.SO_PATH, ROOT), "side_stream_max": os.environ.get("FEC_SIDE_STREAM_MAX", "default (98304)"), "checksum": int(out.sum().item()) & 0xFFFFFFFF}), flush=True)
 
 
 main()

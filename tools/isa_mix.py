@@ -3,6 +3,13 @@
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S forge_ec_amd/csrc/fecgpu.hip -o /tmp/fecgpu.s
     python tools/isa_mix.py /tmp/fecgpu.s <mangled-kernel-substring> [--loop outer|all] [--md]
+    python tools/isa_mix.py /tmp/kernels_p256.s <mangled-kernel-substring> --region task_add [--md]
+
+--region NAME (the scheduler kernels, whose loop body is "pop a batch, run ONE task"): the hot path between the
+comment markers `; FEC_MARK NAME_begin` and `; FEC_MARK NAME_end`, which the sources emit when compiled with
+-DFEC_ISA_MARKERS (limbs.hpp: FEC_MARK; the shipped library is built without them).  Also splits the region at
+every `;;#ASMSTART` block of field_asm.inc, so the table shows what sits INSIDE the generated field products and
+what the compiler put between them.
 
 The hot loop is the largest natural loop of the kernel (the 256-step ladder): the span from the
 target label of a backward branch to that branch.  Blocks the compiler placed outside that span
@@ -39,6 +46,39 @@ def classify(m):
     return "other"
 
 
+def region_mix(insts, asm_flags, label_at, marks, region, kernel, md):
+    """Hot path (rare lane masks = 0, like the ladder walk) from marker <region>_begin to <region>_end."""
+    b, e = marks.get(region + "_begin"), marks.get(region + "_end")
+    if b is None or e is None:
+        raise SystemExit("markers %s_begin / %s_end not found (compile with -DFEC_ISA_MARKERS)" % (region, region))
+    path, pc, scc, steps = [], b, None, 0
+    while pc != e and steps < 200000:
+        m, ops = insts[pc]
+        path.append((m, asm_flags[pc]))
+        steps += 1
+        if m in ("s_cmp_eq_u64", "s_cmp_lg_u64") and ops.replace(" ", "").endswith(",0"):
+            scc = 1 if m == "s_cmp_eq_u64" else 0
+        elif m.startswith(("s_cmp", "s_add", "s_sub", "s_and", "s_or", "s_xor", "s_lshl", "s_lshr", "s_bitcmp", "s_andn2", "s_orn2", "s_not")):
+            scc = None
+        taken = m == "s_branch" or (m == "s_cbranch_scc0" and scc == 0) or (m == "s_cbranch_scc1" and scc == 1) or \
+            m in ("s_cbranch_vccz", "s_cbranch_execnz")
+        pc = label_at[ops.split()[0].rstrip(",")] if taken else pc + 1
+    if pc != e:
+        raise SystemExit("the walk from %s_begin did not reach %s_end" % (region, region))
+    print("kernel: %s" % kernel)
+    for title, sel in (("whole region", lambda a: True), ("inside the field_asm.inc statements", lambda a: a),
+                       ("compiler-scheduled code between them", lambda a: not a)):
+        c = collections.Counter(classify(m) for m, a in path if sel(a))
+        valu = sum(v for k, v in c.items() if k.startswith("v_"))
+        print("region %s, %s: %d instructions, %d VALU" % (region, title, sum(c.values()), valu))
+        if md:
+            print("| class | count |\n|---|---|")
+        for name, _ in CLASSES + [("other", None)]:
+            if c.get(name, 0):
+                print(("| %s | %d |" if md else "%-36s %8d") % (name, c[name]))
+    print("top mnemonics: " + ", ".join("%s %d" % t for t in collections.Counter(m for m, _ in path).most_common(25)))
+
+
 def main():
     path, needle = sys.argv[1], sys.argv[2]
     md = "--md" in sys.argv
@@ -53,8 +93,18 @@ def main():
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[start:end]
     label_at, insts, headers = {}, [], []  # instruction index of each label; (mnemonic, operands)
+    marks, in_asm, asm_flags = {}, False, []   # FEC_MARK name -> instruction index; per instruction: inside an asm statement?
     for l in body:
         s = l.strip()
+        if "FEC_MARK" in s:
+            marks.setdefault(s.split("FEC_MARK", 1)[1].split()[0], len(insts))
+            continue
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
         mm = re.match(r"^(\.LBB\d+_\d+):", s)
         if mm:
             label_at[mm.group(1)] = len(insts)
@@ -66,6 +116,10 @@ def main():
             continue
         parts = s.split(None, 1)
         insts.append((parts[0], parts[1] if len(parts) > 1 else ""))
+        asm_flags.append(in_asm)
+    region = sys.argv[sys.argv.index("--region") + 1] if "--region" in sys.argv else None
+    if region:
+        return region_mix(insts, asm_flags, label_at, marks, region, body[0].rstrip(":"), md)
     loops = []
     for idx, (m, ops) in enumerate(insts):
         if m.startswith(("s_cbranch", "s_branch")):

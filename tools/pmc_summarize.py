@@ -13,8 +13,36 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
+import subprocess
 import sys
+
+
+def static_resources(tu, needle):
+    """VGPRs / AGPRs / scratch / occupancy / LDS of the kernel from the compiler's own remarks on the translation unit
+    (hipcc -Rpass-analysis=kernel-resource-usage): the `VGPR_Count` rocprofv3 records per dispatch is in allocation
+    units on gfx950 (84 for a kernel that allocates 168 registers), which misled a reader of the round-2 summaries."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "forge_ec_amd", "csrc", tu)
+    try:
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o",
+                              "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900).stderr
+    except Exception as e:  # no hipcc here: say so instead of guessing
+        return {"error": "hipcc remarks unavailable: %s" % e}
+    blocks = re.split(r"remark: [^\n]*Function Name: ", out)[1:]
+    res = []
+    for b in blocks:
+        name = b.split()[0]
+        if needle not in name:
+            continue
+        def field(label):
+            m = re.search(re.escape(label) + r": (\d+)", b)
+            return int(m.group(1)) if m else None
+        res.append({"mangled": name, "vgprs": field("VGPRs"), "agprs": field("AGPRs"), "sgprs": field("SGPRs"),
+                    "scratch_bytes_per_lane": field("ScratchSize [bytes/lane]"), "occupancy_waves_per_simd": field("Occupancy [waves/SIMD]"),
+                    "lds_bytes_per_block": field("LDS Size [bytes/block]")})
+    return res
 
 
 def main():
@@ -32,7 +60,8 @@ def main():
             per_dispatch[key] = per_dispatch.get(key, 0.0) + float(row["Counter_Value"])
             meta = {"kernel": row["Kernel_Name"][:120], "grid": int(row["Grid_Size"]),
                     "workgroup": int(row["Workgroup_Size"]), "lds_bytes": int(row["LDS_Block_Size"]),
-                    "scratch_bytes_per_lane": int(row["Scratch_Size"]), "vgpr": int(row["VGPR_Count"]),
+                    "scratch_bytes_per_lane": int(row["Scratch_Size"]),
+                    "vgpr_count_field_of_rocprofv3": int(row["VGPR_Count"]),   # allocation units, NOT registers: see code_object_static
                     "agpr": int(row["Accum_VGPR_Count"]), "sgpr": int(row["SGPR_Count"])}
             durs.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
         by_name = {}
@@ -54,7 +83,9 @@ def main():
     # the library sources must be the ones that were profiled: run this right after the passes
     out = {"workload": workload, "units_per_launch": units, "source_hash": fbuild.source_hash(),
            "kernel_tu": fbuild.WORKLOAD_TU.get(workload), "kernel_source_hash": fbuild.tu_closure_hash(fbuild.WORKLOAD_TU[workload], kernel_code_only=True) if workload in fbuild.WORKLOAD_TU else None,
-           "source_dir": src, "code_object": meta, "counters": counters, "kernel_stats": stats,
+           "source_dir": src, "code_object": meta,
+           "code_object_static": static_resources(fbuild.WORKLOAD_TU[workload], needle) if workload in fbuild.WORKLOAD_TU else None,
+           "counters": counters, "kernel_stats": stats,
            "duration_under_pmc_ms": (sum(durs) / len(durs)) if durs else None}
     c = {k: v["per_launch"] for k, v in counters.items()}
     derived = {}
@@ -68,6 +99,12 @@ def main():
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
             if k in c:
                 derived[k + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
+    if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_INSTS_VALU over the 1024 SIMDs (256 CUs x 4): cycles one SIMD spends
+        # per VALU wave-instruction.  This is the "VALU-issue bound" statement; VALUBusy (a derived counter that reads
+        # 102-104 % on these kernels) is kept in `counters` but is not a utilisation.
+        derived["valu_issue_cycles_per_inst_per_simd"] = (c["GRBM_GUI_ACTIVE"] / 8.0) / (c["SQ_INSTS_VALU"] / 1024.0)
+        derived["valu_insts_per_64_units"] = c["SQ_INSTS_VALU"] / (units / 64.0)
     if "SQ_INSTS_VALU" in c and meta:
         waves = meta["grid"] / 64.0
         derived["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / waves
