@@ -196,6 +196,9 @@ def valu_issue_cycles(pmc_json):
 def main():
     args = parse()
     import torch
+    if os.environ.get("FEC_AB_LIB"):  # same-box A/B of another build of the library (tools/pmc_quick.sh, tools/quick_perf.py)
+        from forge_ec_amd import _lib
+        _lib.SO_PATH = os.path.abspath(os.environ["FEC_AB_LIB"])
     import forge_ec_amd as F
     from forge_ec_amd import synth
     from forge_ec_amd.dist import shard_range

@@ -491,7 +491,10 @@ FEC_DEV ed::pt pdbl_mem(const u32* la, int stride) {
 // ---------------------------------------------------------------------------------------------------
 namespace {
 constexpr int PT = 768;     // threads per workgroup: 12 wavefronts, three per SIMD
-constexpr int PS = 1024;    // element slots per workgroup (12 x 64 in flight + 256 queued); swept: 896 -> 18.6 ms, 960 -> 19.1, 1024 -> 17.6, 1088 -> 17.8, 1152 -> 18.0 (same box)
+#ifndef FEC_ED_PS
+#define FEC_ED_PS 832
+#endif
+constexpr int PS = FEC_ED_PS;  // element slots per workgroup (12 x 64 in flight + 256 queued); swept: 896 -> 18.6 ms, 960 -> 19.1, 1024 -> 17.6, 1088 -> 17.8, 1152 -> 18.0 (same box)
 constexpr int PRING = 2048;  // ring capacity (power of two >= PS)
 enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace

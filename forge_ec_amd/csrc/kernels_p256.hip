@@ -206,7 +206,10 @@ FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u
 // ---------------------------------------------------------------------------------------------------
 namespace {
 constexpr int QT = 768;      // threads per workgroup: 12 wavefronts, three per SIMD
-constexpr int QS = 1024;     // element slots per workgroup (8 x 64 in flight + 512 queued)
+#ifndef FEC_P256_QS
+#define FEC_P256_QS 1024
+#endif
+constexpr int QS = FEC_P256_QS;  // element slots per workgroup (8 x 64 in flight + 512 queued)
 constexpr int QRING = 2048;  // ring capacity (power of two >= QS)
 enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace
@@ -415,7 +418,11 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     FEC_STAT(kind == 0 ? 1 : 3, count);
     if (kind == 0) {
       FEC_MARK("task_double_begin");
+#ifdef FEC_SCHED_STUB   // tools/microbench/sched_stats.hip: the scheduler alone (the task is a copy of the slot)
+      res = ld_pt(lds_st + e, QS);
+#else
       res = pdouble_in_place(lds_st + e, QS);
+#endif
       FEC_MARK("task_double_end");
       if (live) {
         const int b = 255 - step;
@@ -435,8 +442,13 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       // inactive lanes add slot 0 and element 0 of the range: harmless, never stored
       const size_t g_el = lo + gid;
       FEC_MARK("task_add_begin");
+#ifdef FEC_SCHED_STUB
+      res = ld_pt(lds_st + e, QS);
+      (void)g_el;
+#else
       res = padd_in_place(lds_st + e, QS, FIXED ? points : points + g_el * 24,
                           FIXED ? (HOIST ? lds_zz : nullptr) : lds_zq + e, FIXED ? 1 : QS);
+#endif
       FEC_MARK("task_add_end");
       if (live) {
         ++step;
