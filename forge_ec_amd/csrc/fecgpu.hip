@@ -65,6 +65,7 @@ struct Secp {
   FEC_DEV static fe f_mul(const fe& a, const fe& b) { return secp::mul(a, b); }
   FEC_DEV static fe f_sqr(const fe& a) { return secp::sqr(a); }
   FEC_DEV static fe f_neg(const fe& a) { return secp::neg(a); }
+  FEC_DEV static fe sc_mul(const fe& a, const fe& b) { return secp::sc_mul(a, b); }   // impl Mul for Scalar (2410-2456)
   // FieldElement::to_bytes (138-178): mont_reduce, i.e. Mul by raw 1; big-endian bytes
   FEC_DEV static fe bytes_value(const fe& a) { return secp::mul(a, fe_small(1)); }
   static constexpr bool BYTES_BIG_ENDIAN = true;
@@ -105,6 +106,7 @@ struct P256 {
   FEC_DEV static fe f_mul(const fe& a, const fe& b) { return p256::mul(a, b); }
   FEC_DEV static fe f_sqr(const fe& a) { return p256::sqr(a); }
   FEC_DEV static fe f_neg(const fe& a) { return p256::neg(a); }
+  FEC_DEV static fe sc_mul(const fe& a, const fe& b) { return p256::sc_mul32(a, b); }  // impl Mul for Scalar (p256.rs:1409-1432)
   // FieldElement::to_bytes (p256.rs:288-300): the raw limbs; big-endian bytes
   FEC_DEV static fe bytes_value(const fe& a) { return a; }
   static constexpr bool BYTES_BIG_ENDIAN = true;
@@ -346,6 +348,7 @@ __global__ __launch_bounds__(TPB) void k_to_affine(const u32* __restrict__ point
 // the fixed-base and one variable-base launch side by side in time, k_schnorr_mid (R_i + e_i P_i), the
 // second variable-base launch.  (Round 1 ran the three ladders one after the other in one lane of one
 // kernel: 58 spilled VGPRs, 8.5 ms at n = 4096 where two ladder latencies are 4.6 ms.)
+template <class C>
 __global__ __launch_bounds__(TPB) void k_schnorr_pre(const u32* __restrict__ pk_xy, const u32* __restrict__ ss,
                                                      const u32* __restrict__ as, u32* __restrict__ sa,
                                                      u32* __restrict__ p_out, size_t n) {
@@ -353,32 +356,33 @@ __global__ __launch_bounds__(TPB) void k_schnorr_pre(const u32* __restrict__ pk_
   if (i >= n) return;
   fe s, a;
   FEC_UNROLL for (int w = 0; w < 8; ++w) { s.w[w] = ss[i * 8 + w]; a.w[w] = as[i * 8 + w]; }
-  const fe prod = secp::sc_mul(s, a);                         // impl Mul for Scalar
+  const fe prod = C::sc_mul(s, a);                            // impl Mul for Scalar
   FEC_UNROLL for (int w = 0; w < 8; ++w) sa[i * 8 + w] = prod.w[w];
   // from_affine (1365-1373): the caller has rejected identities
   FEC_UNROLL for (int w = 0; w < 16; ++w) p_out[i * 24 + w] = pk_xy[i * 16 + w];
   FEC_UNROLL for (int w = 0; w < 8; ++w) p_out[i * 24 + 16 + w] = w == 0 ? 1u : 0u;
 }
 // q_i = from_affine(R_i) + ep_i   (277-279)
+template <class C>
 __global__ __launch_bounds__(TPB) void k_schnorr_mid(const u32* __restrict__ r_xy, const u32* __restrict__ ep,
                                                      u32* __restrict__ q_out, size_t n) {
-  __shared__ u32 lds_p[Secp::PW * TPB];
+  __shared__ u32 lds_p[C::PW * TPB];
   __shared__ u32 lds_r[16 * TPB];
   const int valid = block_valid(n);
   const size_t first = (size_t)blockIdx.x * TPB;
-  stage_in<Secp::PW>(lds_p, ep + first * Secp::PW, valid);
+  stage_in<C::PW>(lds_p, ep + first * C::PW, valid);
   stage_in<16>(lds_r, r_xy + first * 16, valid);
   __syncthreads();
   const int e = threadIdx.x;
   if (e < valid) {
-    secp::pt r;
+    typename C::pt r;
     r.x = load_fe(lds_r + e, TPB);
     r.y = load_fe(lds_r + 8 * TPB + e, TPB);
     r.z = fe_small(1);
-    Secp::store(lds_p + e, TPB, secp::padd(r, Secp::load(lds_p + e, TPB)));
+    C::store(lds_p + e, TPB, C::padd(r, C::load(lds_p + e, TPB)));
   }
   __syncthreads();
-  stage_out<Secp::PW>(q_out + first * Secp::PW, lds_p, valid);
+  stage_out<C::PW>(q_out + first * C::PW, lds_p, valid);
 }
 
 // The two strictly sequential folds (s_g += ..., r_e_p += ...: 268, 281) and the comparison at 286:
@@ -386,16 +390,20 @@ __global__ __launch_bounds__(TPB) void k_schnorr_mid(const u32* __restrict__ r_x
 // converts both sums with to_affine and applies AffinePoint::ct_eq (1292-1296).
 // out: [0..7] = x, y of to_affine(s_g), [8..15] of to_affine(r_e_p) (64-bit limbs as u32 pairs);
 // flags: [0] = result, [1], [2] = the two infinity flags.
-__global__ __launch_bounds__(64) void k_schnorr_fold_compare_secp(const u32* __restrict__ terms_a,
-                                                                  const u32* __restrict__ terms_b,
-                                                                  u32* __restrict__ sums, u32* __restrict__ out_xy,
-                                                                  unsigned char* __restrict__ flags,
-                                                                  unsigned int* __restrict__ done, size_t n) {
-  __shared__ __attribute__((aligned(16))) u32 sh[secp::coop::WORDS];
+template <class C>
+__global__ __launch_bounds__(64) void k_schnorr_fold_compare(const u32* __restrict__ terms_a,
+                                                             const u32* __restrict__ terms_b,
+                                                             u32* __restrict__ sums, u32* __restrict__ out_xy,
+                                                             unsigned char* __restrict__ flags,
+                                                             unsigned int* __restrict__ done, size_t n) {
+  constexpr bool kSecp = __is_same(typename C::pt, secp::pt);
+  __shared__ __attribute__((aligned(16))) u32 sh[kSecp ? secp::coop::WORDS : p256::coop::WORDS];
   const u32* terms = blockIdx.x == 0 ? terms_a : terms_b;
-  secp::pt acc = fold_coop_secp(terms, n, sh);  // the whole wavefront: each addition on four lanes
+  typename C::pt acc;  // the whole wavefront folds: each addition on four (secp256k1) / five (P-256) lanes
+  if constexpr (kSecp) acc = fold_coop_secp(terms, n, sh);
+  else acc = fold_coop_p256(terms, n, sh);
   if (threadIdx.x != 0) return;
-  Secp::store(sums + blockIdx.x * Secp::PW, 1, acc);
+  C::store(sums + blockIdx.x * C::PW, 1, acc);
   __threadfence();
   if (atomicAdd(done, 1u) != 1u) return;  // the other fold is still running: it will finish the job
   __threadfence();
@@ -403,9 +411,9 @@ __global__ __launch_bounds__(64) void k_schnorr_fold_compare_secp(const u32* __r
   bool inf[2];
 #pragma unroll 1
   for (int k = 0; k < 2; ++k) {
-    secp::pt p = Secp::load(sums + k * Secp::PW, 1);
+    typename C::pt p = C::load(sums + k * C::PW, 1);
     fe xx, yy;
-    inf[k] = lane_of(secp::to_affine(p, xx, yy));
+    inf[k] = lane_of(C::to_affine(p, xx, yy));
     x[k] = xx;
     y[k] = yy;
     store_fe(out_xy + k * 16, 1, xx);
@@ -714,6 +722,52 @@ int launch_eddsa_verify(fec_ctx* ctx, const u64* dr, const unsigned char* drinf,
                   ctx->d_ed_table, sg, n, ed_work ? work + n * 384 : nullptr, L.s);
   ed_launch_mul(sched_env(ctx), reinterpret_cast<const u32*>(dk), a, ka, n, L.s);
   eddsa_finish_launch(sg, ka, reinterpret_cast<const u32*>(dr), drinf, dstatus, n, L.s);
+  return L.done();
+}
+
+// Schnorr::<C, D>::verify per signature from the point computation on (schnorr.rs:90-140): A = from_affine(pk);
+// s*G by the curve's fixed-base kernel (forked to the second stream for the Weierstrass curves), e*A by its
+// variable-base kernel; the rest in one finishing pass.  Work area: A, s*G, e*A.
+int launch_schnorr_verify(fec_ctx* ctx, int curve, const u64* dpk, const unsigned char* dpinf, const u64* dr,
+                          const unsigned char* drinf, const u64* ds, const u64* de, unsigned char* dstatus, size_t n,
+                          void* stream) {
+  if (n == 0) return FEC_OK;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  const size_t pb = (size_t)plimbs(curve) * 8;
+  const size_t ed_work = curve == FEC_ED25519 ? ed_fixed_work_bytes(n) : 0;
+  char* work = static_cast<char*>(scratch_for(ctx, st, schnorr_verify_work_bytes(curve, n) + ed_work));
+  if (!work) return FEC_E_OOM;
+  u32* a = reinterpret_cast<u32*>(work);
+  u32* sg = reinterpret_cast<u32*>(work + n * pb);
+  u32* ep = reinterpret_cast<u32*>(work + 2 * n * pb);
+  const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
+  const u32* sc = reinterpret_cast<const u32*>(ds);
+  const u32* ec = reinterpret_cast<const u32*>(de);
+  if (curve == FEC_ED25519) {
+    int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
+    if (rc != FEC_OK) return rc;
+  }
+  Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_schnorr_verify_pre + k_secp_mul x2 + k_schnorr_verify_finish"
+                        : (curve == FEC_P256 ? "k_schnorr_verify_pre + k_p256_mul_sched x2 + k_schnorr_verify_finish"
+                                             : "k_schnorr_verify_pre + k_ed_fixed_base + k_ed_mul_pers + k_schnorr_verify_finish"));
+  schnorr_verify_pre_launch(curve, reinterpret_cast<const u32*>(dpk), dpinf, a, n, L.s);
+  if (curve == FEC_ED25519) {
+    ed_fixed_launch(sc, gen, ctx->d_ed_table, sg, n, ed_work ? work + 3 * n * pb : nullptr, L.s);
+    ed_launch_mul(sched_env(ctx), ec, a, ep, n, L.s);
+  } else {
+    SideStream side(ctx, L.s, n);
+    if (curve == FEC_SECP256K1) {
+      secp_launch_mul(true, sc, gen, sg, n, side.s);
+      side.fork_done();
+      secp_launch_mul(false, ec, a, ep, n, L.s);
+    } else {
+      p256_launch_mul(sched_env(ctx), true, sc, gen, sg, n, side.s, side.active ? 2 : 1);
+      side.fork_done();
+      p256_launch_mul(sched_env(ctx), false, ec, a, ep, n, L.s, side.active ? 2 : 1);
+    }
+    side.join();
+  }
+  schnorr_verify_finish_launch(curve, sg, ep, reinterpret_cast<const u32*>(dr), drinf, dstatus, n, L.s);
   return L.done();
 }
 
@@ -1431,13 +1485,64 @@ int fec_eddsa_verify_ed25519(fec_ctx* ctx, const uint64_t* r_xy, const uint8_t* 
   return FEC_OK;
 } FEC_ABI_CATCH_STATUS
 
-// schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/schnorr.rs:194-290)
-int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, const uint8_t* pk_inf,
-                                       const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s,
-                                       const uint64_t* a, const uint64_t* e, size_t n, uint8_t* result,
-                                       uint64_t* sides_xy, uint8_t* sides_inf) try {
+int fec_schnorr_verify_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_pk_xy, const uint8_t* d_pk_inf,
+                           const uint64_t* d_r_xy, const uint8_t* d_r_inf, const uint64_t* d_s, const uint64_t* d_e,
+                           uint8_t* d_status, size_t n, void* stream) try {
+  if (is_multi(ctx)) return FEC_E_UNSUPPORTED;  // device pointers belong to one device
+  if (!ctx || !curve_ok(curve) || (n && (!d_pk_xy || !d_r_xy || !d_s || !d_e || !d_status))) return FEC_E_ARG;
+  if (!aligned16(d_pk_xy) || !aligned16(d_r_xy) || !aligned16(d_s) || !aligned16(d_e)) return FEC_E_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return launch_schnorr_verify(ctx, curve, d_pk_xy, d_pk_inf, d_r_xy, d_r_inf, d_s, d_e, d_status, n, stream);
+} FEC_ABI_CATCH_STATUS
+
+int fec_schnorr_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* r_xy,
+                       const uint8_t* r_inf, const uint64_t* s, const uint64_t* e, uint8_t* status, size_t n) try {
+  if (!curve_ok(curve)) return FEC_E_ARG;
+  if (is_multi(ctx)) {
+    if (n && (!pk_xy || !r_xy || !s || !e || !status)) return FEC_E_ARG;
+    return multi_shard(ctx, n, [=](fec_ctx* c, size_t lo, size_t cnt) {
+      return fec_schnorr_verify(c, curve, pk_xy + lo * 8, pk_inf ? pk_inf + lo : nullptr, r_xy + lo * 8,
+                                r_inf ? r_inf + lo : nullptr, s + lo * 4, e + lo * 4, status + lo, cnt);
+    });
+  }
+  if (!ctx || (n && (!pk_xy || !r_xy || !s || !e || !status))) return FEC_E_ARG;
+  if (n == 0) return FEC_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  // chunked like the other element-wise calls; slots: 0 pk, 1 r, 2 s, 4 e, 5 pk_inf, 6 r_inf, 3 status
+  const size_t chunk = ctx->chunk < n ? ctx->chunk : n;
+  for (size_t lo = 0; lo < n; lo += chunk) {
+    const size_t cnt = lo + chunk <= n ? chunk : n - lo;
+    const void* hin[6] = {pk_xy + lo * 8, r_xy + lo * 8, s + lo * 4, e + lo * 4, pk_inf ? pk_inf + lo : nullptr,
+                          r_inf ? r_inf + lo : nullptr};
+    const size_t bytes[6] = {cnt * 64, cnt * 64, cnt * 32, cnt * 32, cnt, cnt};
+    const int slot[6] = {0, 1, 2, 4, 5, 6};
+    for (int i = 0; i < 6; ++i) {
+      if (!hin[i]) continue;
+      int rc = ensure(ctx, slot[i], bytes[i]);
+      if (rc != FEC_OK) return rc;
+      if (hipMemcpyAsync(ctx->d_buf[slot[i]], hin[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return FEC_E_DEVICE;
+    }
+    int rc = ensure(ctx, 3, cnt);
+    if (rc != FEC_OK) return rc;
+    rc = launch_schnorr_verify(ctx, curve, (const u64*)ctx->d_buf[0], pk_inf ? (const unsigned char*)ctx->d_buf[5] : nullptr,
+                               (const u64*)ctx->d_buf[1], r_inf ? (const unsigned char*)ctx->d_buf[6] : nullptr,
+                               (const u64*)ctx->d_buf[2], (const u64*)ctx->d_buf[4], (unsigned char*)ctx->d_buf[3], cnt, nullptr);
+    if (rc != FEC_OK) return rc;
+    if (hipMemcpyAsync(status + lo, ctx->d_buf[3], cnt, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+    if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
+  }
+  return FEC_OK;
+} FEC_ABI_CATCH_STATUS
+
+namespace {
+// schnorr::batch_verify::<C, D> (forge-ec-signature/src/schnorr.rs:194-290) for C = Secp256k1 / P256
+int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* r_xy,
+                         const uint8_t* r_inf, const uint64_t* s, const uint64_t* a, const uint64_t* e, size_t n,
+                         uint8_t* result, uint64_t* sides_xy, uint8_t* sides_inf) {
   FEC_FIRST_DEVICE(ctx);
   if (!ctx || !result || (n && (!pk_xy || !r_xy || !s || !a || !e))) return FEC_E_ARG;
+  if (curve != FEC_SECP256K1 && curve != FEC_P256) return FEC_E_UNSUPPORTED;
   *result = 0;
   if (sides_xy) std::memset(sides_xy, 0, 16 * sizeof(uint64_t));
   if (sides_inf) sides_inf[0] = sides_inf[1] = 0;
@@ -1445,6 +1550,7 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
   for (size_t i = 0; i < n; ++i)                               // 204-225 (only the identity tests can reject)
     if ((pk_inf && pk_inf[i]) || (r_inf && r_inf[i])) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  const bool secp = curve == FEC_SECP256K1;
   const size_t pb = 96;
   // slots: 0 pk, 1 r, 2 s, 3 a, 4 e, 5 A terms, 6 B terms, 7 sums + affine sides + flags + counter
   const size_t bytes[5] = {n * 64, n * 64, n * 32, n * 32, n * 32};
@@ -1464,6 +1570,7 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
   unsigned char* d_flags = (unsigned char*)(tail + 2 * pb + 128);
   unsigned int* d_done = (unsigned int*)(tail + 2 * pb + 128 + 8);
   if (hipMemsetAsync(tail + 2 * pb + 128, 0, 16, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  const SchedEnv env = sched_env(ctx);
   {
     // work area: s*a (32 n), from_affine(P) (96 n), e*P (96 n), R + e*P (96 n)
     char* work = static_cast<char*>(scratch_for(ctx, ctx->stream, n * 320));
@@ -1472,11 +1579,15 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
     u32* pp = reinterpret_cast<u32*>(work + n * 32);
     u32* ep = reinterpret_cast<u32*>(work + n * 128);
     u32* qq = reinterpret_cast<u32*>(work + n * 224);
-    const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[FEC_SECP256K1]);
-    Launch L(ctx, nullptr, "k_schnorr_pre + k_secp_mul x3 + k_schnorr_mid");
+    const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
+    Launch L(ctx, nullptr, secp ? "k_schnorr_pre + k_secp_mul x3 + k_schnorr_mid" : "k_schnorr_pre + k_p256_mul_sched x3 + k_schnorr_mid");
     const dim3 g(grid_for(n)), b(TPB);
-    hipLaunchKernelGGL(k_schnorr_pre, g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2],
-                       (const u32*)ctx->d_buf[3], sa, pp, n);
+    auto mul = [&](bool fixed, const u32* k, const u32* p, u32* o, hipStream_t st, unsigned div) {
+      if (secp) secp_launch_mul(fixed, k, p, o, n, st);
+      else p256_launch_mul(env, fixed, k, p, o, n, st, div);
+    };
+    if (secp) hipLaunchKernelGGL((k_schnorr_pre<Secp>), g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3], sa, pp, n);
+    else hipLaunchKernelGGL((k_schnorr_pre<P256>), g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3], sa, pp, n);
     // the A terms do not depend on the B chain: they run on the ctx's second stream beside it (at the moderate n
     // this entry point is meant for, a launch fills a fraction of the chip and is bound by one ladder's latency)
     hipEvent_t ev_pre = nullptr, ev_a = nullptr;
@@ -1488,19 +1599,21 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
       (void)hipStreamWaitEvent(ctx->stream2, ev_pre, 0);
       sa_stream = ctx->stream2;
     }
-    secp_launch_mul(true, sa, gen, (u32*)ctx->d_buf[5], n, sa_stream);                  // A_i (266-268)
+    const unsigned div = side ? 2 : 1;   // the persistent P-256 kernels: half of the CUs each while two run side by side
+    mul(true, sa, gen, (u32*)ctx->d_buf[5], sa_stream, div);                             // A_i (266-268)
     if (side) (void)hipEventRecord(ev_a, ctx->stream2);
-    secp_launch_mul(false, (const u32*)ctx->d_buf[4], pp, ep, n, L.s);                 // e_i P_i (276)
-    hipLaunchKernelGGL(k_schnorr_mid, g, b, 0, L.s, (const u32*)ctx->d_buf[1], (const u32*)ep, qq, n);
-    secp_launch_mul(false, (const u32*)ctx->d_buf[3], qq, (u32*)ctx->d_buf[6], n, L.s); // B_i (282)
+    mul(false, (const u32*)ctx->d_buf[4], pp, ep, L.s, div);                             // e_i P_i (276)
+    if (secp) hipLaunchKernelGGL((k_schnorr_mid<Secp>), g, b, 0, L.s, (const u32*)ctx->d_buf[1], (const u32*)ep, qq, n);
+    else hipLaunchKernelGGL((k_schnorr_mid<P256>), g, b, 0, L.s, (const u32*)ctx->d_buf[1], (const u32*)ep, qq, n);
+    mul(false, (const u32*)ctx->d_buf[3], qq, (u32*)ctx->d_buf[6], L.s, div);            // B_i (282)
     if (side) (void)hipStreamWaitEvent(L.s, ev_a, 0);
     rc = L.done();
     if (ev_pre) (void)hipEventDestroy(ev_pre);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (rc != FEC_OK) return rc;
   }
-  hipLaunchKernelGGL(k_schnorr_fold_compare_secp, dim3(2), dim3(64), 0, ctx->stream, (const u32*)ctx->d_buf[5],
-                     (const u32*)ctx->d_buf[6], d_sums, d_sides, d_flags, d_done, n);
+  if (secp) hipLaunchKernelGGL((k_schnorr_fold_compare<Secp>), dim3(2), dim3(64), 0, ctx->stream, (const u32*)ctx->d_buf[5], (const u32*)ctx->d_buf[6], d_sums, d_sides, d_flags, d_done, n);
+  else hipLaunchKernelGGL((k_schnorr_fold_compare<P256>), dim3(2), dim3(64), 0, ctx->stream, (const u32*)ctx->d_buf[5], (const u32*)ctx->d_buf[6], d_sums, d_sides, d_flags, d_done, n);
   if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
   unsigned char flags[8] = {0};
   uint64_t sides[16];
@@ -1512,6 +1625,20 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
   if (sides_xy) std::memcpy(sides_xy, sides, 128);
   if (sides_inf) { sides_inf[0] = flags[1]; sides_inf[1] = flags[2]; }
   return FEC_OK;
+}
+}  // namespace
+
+int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, const uint8_t* pk_inf,
+                                       const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s,
+                                       const uint64_t* a, const uint64_t* e, size_t n, uint8_t* result,
+                                       uint64_t* sides_xy, uint8_t* sides_inf) try {
+  return schnorr_batch_verify(ctx, FEC_SECP256K1, pk_xy, pk_inf, r_xy, r_inf, s, a, e, n, result, sides_xy, sides_inf);
+} FEC_ABI_CATCH_STATUS
+
+int fec_schnorr_batch_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_xy, const uint8_t* pk_inf,
+                             const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s, const uint64_t* a,
+                             const uint64_t* e, size_t n, uint8_t* result, uint64_t* sides_xy, uint8_t* sides_inf) try {
+  return schnorr_batch_verify(ctx, curve, pk_xy, pk_inf, r_xy, r_inf, s, a, e, n, result, sides_xy, sides_inf);
 } FEC_ABI_CATCH_STATUS
 
 int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf,

@@ -82,4 +82,11 @@ void eddsa_pre_launch(const u32* pk, const unsigned char* pk_inf, u32* a, size_t
 void eddsa_finish_launch(const u32* sg, const u32* ka, const u32* r_xy, const unsigned char* r_inf, unsigned char* status,
                          size_t n, hipStream_t s);
 
+// kernels_ecdsa.hip: Schnorr::<C, D>::verify per signature (schnorr.rs:90-140) around the curve's multiplications:
+// a[i] = from_affine(pk[i]); status from sg = multiply(G, s), ep = multiply(A, e), R.  Work: A, sg, ep.
+size_t schnorr_verify_work_bytes(int curve, size_t n);
+void schnorr_verify_pre_launch(int curve, const u32* pk, const unsigned char* pk_inf, u32* a, size_t n, hipStream_t s);
+void schnorr_verify_finish_launch(int curve, const u32* sg, const u32* ep, const u32* r_xy, const unsigned char* r_inf,
+                                  unsigned char* status, size_t n, hipStream_t s);
+
 }  // namespace fecgpu

@@ -385,7 +385,101 @@ __global__ __launch_bounds__(TPB) void k_eddsa_finish(const u32* __restrict__ sg
   status[i] = rinf ? 0 : (panic ? 2 : (same ? 1 : 0));
 }
 
+// ---- Schnorr::<C, D>::verify per signature (forge-ec-signature/src/schnorr.rs:90-140), from the point computation on ----
+//   103-105  an infinite signature point is rejected            125-126  s_g = multiply(G, s), e_p = multiply(from_affine(pk), e)
+//   129-134  to_affine(e_p), PointAffine::new(x, -y): the curve equation re-validated under the reference's own arithmetic
+//            (secp256k1.rs:856-869, p256.rs:1535-1552, ed25519.rs:1477-1498); None is `return false`
+//   136-139  r' = s_g + from_affine(neg), to_affine             142  AffinePoint::ct_eq: (x == x & y == y) | (inf & inf)
+struct VSecp {
+  typedef secp::pt pt;
+  static constexpr int PW = 24;
+  FEC_DEV static pt from_affine(const fe& x, const fe& y, bool inf) {
+    pt p; p.x = x; p.y = y; p.z = fe_small(1);
+    return inf ? secp::identity() : p;
+  }
+  FEC_DEV static pt load(const u32* g) { pt p; p.x = load8(g); p.y = load8(g + 8); p.z = load8(g + 16); return p; }
+  FEC_DEV static void store(u32* g, const pt& p) { store8(g, p.x); store8(g + 8, p.y); store8(g + 16, p.z); }
+  FEC_DEV static fe neg(const fe& a) { return secp::neg(a); }
+  FEC_DEV static bool on_curve(const fe& x, const fe& y) { return lane_of(secp::affine_on_curve(x, y)); }
+  FEC_DEV static pt padd(const pt& a, const pt& b) { return secp::padd(a, b); }
+  FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return secp::to_affine(p, x, y); }
+  FEC_DEV static bool panics(const pt&) { return false; }      // z == 0 is the identity (1331-1336): to_affine never unwraps None
+};
+struct VP256 {
+  typedef p256::pt pt;
+  static constexpr int PW = 24;
+  FEC_DEV static pt from_affine(const fe& x, const fe& y, bool inf) {
+    pt p; p.x = x; p.y = y; p.z = fe_small(1);
+    return inf ? p256::identity() : p;
+  }
+  FEC_DEV static pt load(const u32* g) { pt p; p.x = load8(g); p.y = load8(g + 8); p.z = load8(g + 16); return p; }
+  FEC_DEV static void store(u32* g, const pt& p) { store8(g, p.x); store8(g + 8, p.y); store8(g + 16, p.z); }
+  FEC_DEV static fe neg(const fe& a) { return p256::neg(a); }
+  FEC_DEV static bool on_curve(const fe& x, const fe& y) { return lane_of(fe_eq(p256::sqr(y), p256::curve_rhs(x))); }
+  FEC_DEV static pt padd(const pt& a, const pt& b) { return p256::padd(a, b); }
+  FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return p256::to_affine(p, x, y); }
+  FEC_DEV static bool panics(const pt&) { return false; }
+};
+struct VEd {
+  typedef ed::pt pt;
+  static constexpr int PW = 32;
+  FEC_DEV static pt from_affine(const fe& x, const fe& y, bool inf) { return ed_from_affine(x, y, inf); }
+  FEC_DEV static pt load(const u32* g) { return ed_load32(g); }
+  FEC_DEV static void store(u32* g, const pt& p) { store8(g, p.x); store8(g + 8, p.y); store8(g + 16, p.z); store8(g + 24, p.t); }
+  FEC_DEV static fe neg(const fe& a) { return ed::neg(a); }
+  FEC_DEV static bool on_curve(const fe& x, const fe& y) { return lane_of(ed_affine_on_curve(x, y)); }
+  FEC_DEV static pt padd(const pt& a, const pt& b) { return ed::padd(a, b); }
+  FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return ed::to_affine(p, x, y); }
+  // to_affine (1793-1811) unwraps z.invert(): a zero z of a point that is not the identity panics
+  FEC_DEV static bool panics(const pt& p) { return lane_of(~ed::is_identity(p) & fe_is_zero(p.z)); }
+};
+
+template <class V>
+__global__ __launch_bounds__(TPB) void k_schnorr_verify_pre(const u32* __restrict__ pk, const unsigned char* __restrict__ pk_inf,
+                                                            u32* __restrict__ a, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const bool inf = pk_inf != nullptr && pk_inf[i] != 0;
+  V::store(a + i * V::PW, V::from_affine(load8(pk + i * 16), load8(pk + i * 16 + 8), inf));
+}
+template <class V>
+__global__ __launch_bounds__(TPB) void k_schnorr_verify_finish(const u32* __restrict__ sg, const u32* __restrict__ ep,
+                                                               const u32* __restrict__ r_xy, const unsigned char* __restrict__ r_inf,
+                                                               unsigned char* __restrict__ status, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const bool rinf = r_inf != nullptr && r_inf[i] != 0;                                     // 103-105
+  const typename V::pt s_g = V::load(sg + i * V::PW), e_p = V::load(ep + i * V::PW);
+  bool panic = V::panics(e_p);
+  fe x, y;
+  (void)V::to_affine(e_p, x, y);                                                           // 129: (0, 0) for the identity
+  const fe ny = V::neg(y);                                                                 // 130
+  const bool some = V::on_curve(x, ny);                                                    // 130-134
+  const typename V::pt rp = V::padd(s_g, V::from_affine(x, ny, false));                    // 136-138
+  panic = panic || (some && V::panics(rp));
+  fe rx, ry;
+  const bool ri = lane_of(V::to_affine(rp, rx, ry));                                       // 139
+  const bool same = lane_of(fe_eq(rx, load8(r_xy + i * 16)) & fe_eq(ry, load8(r_xy + i * 16 + 8)));
+  (void)ri;                                                                                // (inf & inf): sig.r is finite here
+  status[i] = rinf ? 0 : (V::panics(e_p) ? 2 : (!some ? 0 : (panic ? 2 : (same ? 1 : 0))));
+}
+
 }  // namespace
+
+size_t schnorr_verify_work_bytes(int curve, size_t n) { return n * 3 * (curve == FEC_ED25519 ? 128 : 96); }
+void schnorr_verify_pre_launch(int curve, const u32* pk, const unsigned char* pk_inf, u32* a, size_t n, hipStream_t s) {
+  const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_schnorr_verify_pre<VSecp>), g, b, 0, s, pk, pk_inf, a, n);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_schnorr_verify_pre<VP256>), g, b, 0, s, pk, pk_inf, a, n);
+  else hipLaunchKernelGGL((k_schnorr_verify_pre<VEd>), g, b, 0, s, pk, pk_inf, a, n);
+}
+void schnorr_verify_finish_launch(int curve, const u32* sg, const u32* ep, const u32* r_xy, const unsigned char* r_inf,
+                                  unsigned char* status, size_t n, hipStream_t s) {
+  const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
+  if (curve == FEC_SECP256K1) hipLaunchKernelGGL((k_schnorr_verify_finish<VSecp>), g, b, 0, s, sg, ep, r_xy, r_inf, status, n);
+  else if (curve == FEC_P256) hipLaunchKernelGGL((k_schnorr_verify_finish<VP256>), g, b, 0, s, sg, ep, r_xy, r_inf, status, n);
+  else hipLaunchKernelGGL((k_schnorr_verify_finish<VEd>), g, b, 0, s, sg, ep, r_xy, r_inf, status, n);
+}
 
 void eddsa_pre_launch(const u32* pk, const unsigned char* pk_inf, u32* a, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_eddsa_pre, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, pk, pk_inf, a, n);

@@ -288,6 +288,46 @@ class Context:
                "fec_schnorr_batch_verify_secp256k1")
         return bool(res[0]), sides, sinf
 
+    def schnorr_batch_verify(self, curve, pk_xy, r_xy, s, a, e, pk_inf=None, r_inf=None):
+        """schnorr::batch_verify::<C, D> (schnorr.rs:194-290) for curve = SECP256K1 or P256; as the secp256k1 form."""
+        pk, rr = _u64(pk_xy, 8), _u64(r_xy, 8)
+        ss, aa, ee = _u64(s, 4), _u64(a, 4), _u64(e, 4)
+        n = ss.shape[0]
+        if not (pk.shape[0] == rr.shape[0] == aa.shape[0] == ee.shape[0] == n):
+            raise ValueError("inputs differ in length")
+        pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)).reshape(-1) if pk_inf is not None else None
+        ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)).reshape(-1) if r_inf is not None else None
+        for flags in (pi, ri):
+            if flags is not None and flags.shape[0] != n:
+                raise ValueError("infinity flags and the signatures differ in length")
+        res = np.zeros(1, dtype=np.uint8)
+        sides = np.zeros(16, dtype=np.uint64)
+        sinf = np.zeros(2, dtype=np.uint8)
+        _check(self._lib.fec_schnorr_batch_verify(self._h, curve, _ptr(pk), _ptr(pi), _ptr(rr), _ptr(ri), _ptr(ss), _ptr(aa),
+                                                  _ptr(ee), n, _ptr(res), _ptr(sides), _ptr(sinf)), "fec_schnorr_batch_verify")
+        return bool(res[0]), sides, sinf
+
+    def schnorr_verify(self, curve, pk_xy, r_xy, s, e, pk_inf=None, r_inf=None):
+        """Schnorr::<C, D>::verify per signature (schnorr.rs:90-140) from the point computation on, the challenges
+        e = from_bytes_reduced(hash) supplied: (n,) uint8 -- 1 true, 0 false, 2 = the reference panics."""
+        pk, rr, ss, ee = _u64(pk_xy, 8), _u64(r_xy, 8), _u64(s, 4), _u64(e, 4)
+        n = ss.shape[0]
+        if not (pk.shape[0] == rr.shape[0] == ee.shape[0] == n):
+            raise ValueError("inputs differ in length")
+        pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)).reshape(-1) if pk_inf is not None else None
+        ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)).reshape(-1) if r_inf is not None else None
+        for flags in (pi, ri):
+            if flags is not None and flags.shape[0] != n:
+                raise ValueError("infinity flags and the signatures differ in length")
+        out = np.empty(n, dtype=np.uint8)
+        _check(self._lib.fec_schnorr_verify(self._h, curve, _ptr(pk), _ptr(pi), _ptr(rr), _ptr(ri), _ptr(ss), _ptr(ee),
+                                            _ptr(out), n), "fec_schnorr_verify")
+        return out
+
+    def schnorr_verify_dev(self, curve, d_pk_xy, d_pk_inf, d_r_xy, d_r_inf, d_s, d_e, d_status, n, stream=None):
+        _check(self._lib.fec_schnorr_verify_dev(self._h, curve, d_pk_xy, d_pk_inf, d_r_xy, d_r_inf, d_s, d_e, d_status, n,
+                                                stream), "fec_schnorr_verify_dev")
+
     def field_op(self, curve, op, a, b=None):
         x = _u64(a, 4)
         y = _u64(b, 4) if b is not None else None

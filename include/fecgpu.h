@@ -41,6 +41,8 @@
  *                         p256.rs:1558-1578, ed25519.rs:1505-1525; the bytes forge-ec-encoding's
  *                         CompressedPoint::from_affine builds, point.rs:38-67), with each curve's
  *                         FieldElement::to_bytes (secp256k1.rs:138-178, p256.rs:288-300, ed25519.rs:295-310)
+ *   fec_schnorr_verify    Schnorr::<C, D>::verify per signature after the hash (forge-ec-signature/src/schnorr.rs:90-140)
+ *   fec_schnorr_batch_verify   schnorr::batch_verify::<C, D> for C = Secp256k1 / P256 (194-290)
  *   fec_schnorr_batch_verify_secp256k1   schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/
  *                         schnorr.rs:194-290): the 3n scalar multiplications in parallel, then the two
  *                         strictly sequential `+=` folds (268, 281) and the affine comparison (286).
@@ -122,14 +124,14 @@ int fec_ctx_create(fec_ctx** out, int device);
  * one GPU).  The element-wise host-pointer entry points -- fec_batch_mul, fec_batch_mul_fixed,
  * fec_batch_double_mul, fec_batch_to_affine, fec_batch_compress, fec_batch_decompress,
  * fec_batch_encode_uncompressed, fec_batch_decode_uncompressed, fec_ecdsa_verify_secp256k1,
- * fec_ecdsa_verify_p256, fec_eddsa_verify_ed25519, fec_batch_ecdh, fec_batch_validate_point,
+ * fec_ecdsa_verify_p256, fec_eddsa_verify_ed25519, fec_schnorr_verify, fec_batch_ecdh, fec_batch_validate_point,
  * fec_field_op, fec_point_op (tests/test_gpu_multi_ctx.py runs every one of them sharded) -- then
  * split the batch into n_devices contiguous shards
  * [g*n/N, (g+1)*n/N), run each shard on its device from its own host thread with that device's
  * chunked copy/compute pipeline, and write results straight into the caller's output array: the
  * "gather" is the D2H copy of each shard, there is no device-to-device exchange.  Results are
  * identical to a single-device ctx.  Entry points that are not element-wise (fec_multi_scalar_mul,
- * fec_ecdsa_batch_verify, fec_schnorr_batch_verify_secp256k1, fec_generator*, the measurement hooks)
+ * fec_ecdsa_batch_verify, fec_schnorr_batch_verify*, fec_generator*, the measurement hooks)
  * run on devices[0]; fec_ctx_wipe, fec_ctx_check, fec_ctx_set_chunk and fec_ctx_debug_force_fault apply
  * to every shard worker;
  * the *_dev entry points take device pointers of ONE device and return FEC_E_UNSUPPORTED.
@@ -259,6 +261,21 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
                                        const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s,
                                        const uint64_t* a, const uint64_t* e, size_t n, uint8_t* result,
                                        uint64_t* sides_xy, uint8_t* sides_inf);
+/* The same for curve = FEC_SECP256K1 or FEC_P256 (schnorr::batch_verify is generic over C: Curve, schnorr.rs:194; the
+ * P-256 instance uses that curve's point arithmetic and its Scalar Mul, p256.rs:1409-1432).  FEC_ED25519:
+ * FEC_E_UNSUPPORTED (its scalar Mul is not restated). */
+int fec_schnorr_batch_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_xy, const uint8_t* pk_inf,
+                             const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s, const uint64_t* a,
+                             const uint64_t* e, size_t n, uint8_t* result, uint64_t* sides_xy, uint8_t* sides_inf);
+/* Schnorr::<C, D>::verify per signature (forge-ec-signature/src/schnorr.rs:90-140), all three curves, from the point
+ * computation on: the caller keeps the two message special cases (92-99) and hashes -- e = from_bytes_reduced(H(R || P
+ * || m)), 107-123, raw limbs.  status[i] = 1 true, 0 false, 2 where the reference panics (Ed25519 only: to_affine
+ * unwraps the inverse of a zero z of a point that is not the identity).  The reference re-validates to_affine(e * P)
+ * with PointAffine::new(x, -y) under its own arithmetic (130-134), whose None is `false`: practically every input on
+ * secp256k1 and Ed25519, and every P-256 key that fails that curve's own is_on_curve, is answered false -- reproduced. */
+int fec_schnorr_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_xy /* n*8 */, const uint8_t* pk_inf /* n or NULL */,
+                       const uint64_t* r_xy /* n*8 */, const uint8_t* r_inf /* n or NULL */, const uint64_t* s /* n*4 */,
+                       const uint64_t* e /* n*4 */, uint8_t* status /* n */, size_t n);
 int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a /* n*4 */,
                  const uint64_t* b /* n*4, may be NULL for unary ops */, uint64_t* out /* n*4 */,
                  size_t n);
@@ -298,6 +315,9 @@ int fec_batch_ecdh_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_private_
 int fec_eddsa_verify_ed25519_dev(fec_ctx* ctx, const uint64_t* d_r_xy, const uint8_t* d_r_inf, const uint64_t* d_pk_xy,
                                  const uint8_t* d_pk_inf, const uint64_t* d_s, const uint64_t* d_k, uint8_t* d_status,
                                  size_t n, void* stream);
+int fec_schnorr_verify_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_pk_xy, const uint8_t* d_pk_inf,
+                           const uint64_t* d_r_xy, const uint8_t* d_r_inf, const uint64_t* d_s, const uint64_t* d_e,
+                           uint8_t* d_status, size_t n, void* stream);
 /* d_out must be 4-byte aligned */
 int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf,
                            uint8_t* d_out, size_t n, void* stream);

@@ -270,7 +270,38 @@ inline std::vector<Verify> statuses(const std::vector<uint8_t>& st) {
 }
 }  // namespace detail
 
+namespace schnorr {
+// forge_ec_signature::schnorr::Signature<C> for any of the three curves
+template <fec_curve C>
+struct SignatureOf {
+  AffinePoint<C> r;
+  Scalar<C> s;
+};
+// Schnorr::<C, D>::verify per signature (forge-ec-signature/src/schnorr.rs:90-140) from the point computation on:
+// challenges[i] = Scalar::from_bytes_reduced(H(R_i || P_i || m_i)) (107-123) computed by the caller, who also keeps the
+// two message special cases (92-99).  Returns the reference's boolean per signature or ReferencePanics.
+template <fec_curve C>
+inline std::vector<Verify> verify(GpuContext& ctx, const std::vector<AffinePoint<C>>& public_keys,
+                                  const std::vector<SignatureOf<C>>& signatures, const std::vector<Scalar<C>>& challenges) {
+  const size_t n = public_keys.size();
+  if (n != signatures.size() || n != challenges.size()) throw Error(FEC_E_ARG);
+  std::vector<AffinePoint<C>> rs(n);
+  std::vector<uint64_t> pk, r, s(n * 4);
+  std::vector<uint8_t> pk_inf, r_inf, st(n);
+  for (size_t i = 0; i < n; ++i) {
+    rs[i] = signatures[i].r;
+    for (int l = 0; l < 4; ++l) s[i * 4 + l] = signatures[i].s.raw[l];
+  }
+  detail::pack_affine<C>(public_keys, pk, pk_inf);
+  detail::pack_affine<C>(rs, r, r_inf);
+  check(fec_schnorr_verify(ctx.raw(), C, pk.data(), pk_inf.data(), r.data(), r_inf.data(), s.data(),
+                           reinterpret_cast<const uint64_t*>(challenges.data()), st.data(), n));
+  return detail::statuses(st);
+}
+}  // namespace schnorr
+
 namespace ecdsa {
+// forge_ec_signature::ecdsa::Signature<C> { r: Scalar, s: Scalar }namespace ecdsa {
 // forge_ec_signature::ecdsa::Signature<C> { r: Scalar, s: Scalar }
 template <fec_curve C>
 struct Signature {

@@ -84,6 +84,10 @@ def lib():
         L.fo_batch_ed25519_eddsa_verify.restype = None
         L.fo_secp256k1_schnorr_batch_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, p, p]
         L.fo_secp256k1_schnorr_batch_verify.restype = ctypes.c_int
+        L.fo_p256_schnorr_batch_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, p, p]
+        L.fo_p256_schnorr_batch_verify.restype = ctypes.c_int
+        L.fo_batch_schnorr_verify.argtypes = [ctypes.c_int, p, p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
+        L.fo_batch_schnorr_verify.restype = None
         L.fo_batch_compress.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t]
         L.fo_batch_compress.restype = None
         for name in ("fo_batch_decompress", "fo_batch_decode_uncompressed"):
@@ -369,6 +373,37 @@ def secp256k1_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e):
                                                  _ptr(ri) if ri is not None else None, _ptr(s), _ptr(a), _ptr(e),
                                                  n, _ptr(sides), _ptr(sinf))
     return rc, sides, sinf
+
+
+def schnorr_batch_verify(curve, pk_xy, pk_inf, r_xy, r_inf, s, a, e):
+    """schnorr::batch_verify::<C, D> for curve 0 (secp256k1) / 1 (P-256): -> (result, sides (16,), sides_inf (2,))."""
+    if curve == SECP256K1:
+        return secp256k1_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e)
+    if curve != P256:
+        raise ValueError("schnorr batch_verify: curve 0 or 1")
+    pk_xy, r_xy, s, a, e = _u64(pk_xy), _u64(r_xy), _u64(s), _u64(a), _u64(e)
+    n = s.size // 4
+    pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+    ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)) if r_inf is not None else None
+    sides = np.zeros(16, dtype=np.uint64)
+    sinf = np.zeros(2, dtype=np.uint8)
+    rc = lib().fo_p256_schnorr_batch_verify(_ptr(pk_xy), _ptr(pi) if pi is not None else None, _ptr(r_xy),
+                                            _ptr(ri) if ri is not None else None, _ptr(s), _ptr(a), _ptr(e), n,
+                                            _ptr(sides), _ptr(sinf))
+    return rc, sides, sinf
+
+
+def batch_schnorr_verify(curve, pk_xy, pk_inf, r_xy, r_inf, s, e, nthreads=1):
+    """Schnorr::<C, D>::verify per signature (schnorr.rs:90-140) from the point computation on: (n,) uint8 status
+    (1 true, 0 false, 2 = the reference panics)."""
+    pk_xy, r_xy, s, e = _u64(pk_xy), _u64(r_xy), _u64(s), _u64(e)
+    n = s.size // 4
+    pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+    ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)) if r_inf is not None else None
+    out = np.zeros(n, dtype=np.uint8)
+    lib().fo_batch_schnorr_verify(curve, _ptr(pk_xy), _ptr(pi) if pi is not None else None, _ptr(r_xy),
+                                  _ptr(ri) if ri is not None else None, _ptr(s), _ptr(e), _ptr(out), n, nthreads)
+    return out
 
 
 def batch_compress(curve, xy, inf=None):

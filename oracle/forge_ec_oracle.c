@@ -1910,3 +1910,108 @@ void fo_batch_validate_point(int curve, const u64* xy, const uint8_t* inf, uint8
   }
   for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
 }
+
+/* ---- forge-ec-signature/src/schnorr.rs:90-140  Schnorr::<C, D>::verify per signature, for the three curves,
+ * from the point computation on: the caller hashes (107-123: e = from_bytes_reduced(H(R || P || m))) and keeps the
+ * two message special cases (92-99).  1 true, 0 false, 2 = the reference panics (Ed25519 only: to_affine unwraps
+ * the inverse of a zero z of a point that is not the identity, ed25519.rs:1805).
+ *   103-105  an infinite signature point is rejected
+ *   125-126  s_g = multiply(G, s), e_p = multiply(from_affine(pk), e)
+ *   129-134  e_p_affine = to_affine(e_p); PointAffine::new(x, -y) re-validates the curve equation under the
+ *            reference's own arithmetic (secp256k1.rs:856-869, p256.rs:1535-1552, ed25519.rs:1477-1498) and its None
+ *            is `return false` -- which is what happens to practically every real input on secp256k1 and P-256
+ *   136-139  r' = s_g + from_affine(neg), to_affine
+ *   142      AffinePoint::ct_eq: (x == x && y == y) | (infinity & infinity) */
+int fo_schnorr_verify(int curve, const u64 pk_xy[8], int pk_inf, const u64 r_xy[8], int r_inf, const u64 s[4],
+                      const u64 e[4]) {
+  if (r_inf) return 0;
+  fe sx = ld(r_xy), sy = ld(r_xy + 4), rx, ry;
+  int ri;
+  if (curve == FO_SECP256K1 || curve == FO_P256) {
+    const int k = curve == FO_SECP256K1;
+    jpt g = k ? k_generator() : n_generator();
+    jpt s_g = k ? k_multiply(&g, s) : n_multiply(&g, s);
+    jpt P = {ld(pk_xy), ld(pk_xy + 4), fe_small(1)};
+    if (pk_inf) P = k ? k_identity() : n_identity();                       /* from_affine of the identity */
+    jpt e_p = k ? k_multiply(&P, e) : n_multiply(&P, e);
+    fe x, y;
+    if (k) (void)k_to_affine(&e_p, &x, &y); else (void)n_to_affine(&e_p, &x, &y);   /* (0, 0) for the identity */
+    fe ny = k ? k_neg(y) : n_neg(y);
+    if (!(k ? k_affine_new(x, ny) : n_affine_new(x, ny))) return 0;
+    jpt neg = {x, ny, fe_small(1)};                                        /* new() builds a finite point */
+    jpt rp = k ? k_padd(&s_g, &neg) : n_padd(&s_g, &neg);
+    ri = k ? k_to_affine(&rp, &rx, &ry) : n_to_affine(&rp, &rx, &ry);
+  } else if (curve == FO_ED25519) {
+    ept g = e_generator();
+    ept s_g = e_multiply(&g, s);
+    ept P = e_from_affine(pk_xy, pk_inf);
+    ept e_p = e_multiply(&P, e);
+    if (!e_is_identity(&e_p) && fe_is_zero(&e_p.z)) return 2;
+    fe x, y;
+    (void)e_to_affine(&e_p, &x, &y);
+    fe ny = e_neg(y);
+    if (!e_affine_new(x, ny)) return 0;
+    u64 nxy[8];
+    st(nxy, x); st(nxy + 4, ny);
+    ept neg = e_from_affine(nxy, 0);
+    ept rp = e_padd(&s_g, &neg);
+    if (!e_is_identity(&rp) && fe_is_zero(&rp.z)) return 2;
+    ri = e_to_affine(&rp, &rx, &ry);
+  } else {
+    return -1;
+  }
+  return (fe_eq(&rx, &sx) && fe_eq(&ry, &sy)) || (ri && r_inf);
+}
+typedef struct { int curve; const u64 *pk, *r, *s, *e; const uint8_t *pk_inf, *r_inf; uint8_t* st; size_t lo, hi; } sv_t;
+static void* svworker(void* arg) {
+  sv_t* j = (sv_t*)arg;
+  for (size_t i = j->lo; i < j->hi; ++i)
+    j->st[i] = (uint8_t)fo_schnorr_verify(j->curve, j->pk + 8 * i, j->pk_inf ? j->pk_inf[i] : 0, j->r + 8 * i,
+                                          j->r_inf ? j->r_inf[i] : 0, j->s + 4 * i, j->e + 4 * i);
+  return NULL;
+}
+void fo_batch_schnorr_verify(int curve, const u64* pk_xy, const uint8_t* pk_inf, const u64* r_xy, const uint8_t* r_inf,
+                             const u64* s, const u64* e, uint8_t* status, size_t n, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 64) nthreads = 64;
+  pthread_t th[64];
+  sv_t jobs[64];
+  for (int t = 0; t < nthreads; ++t) {
+    sv_t j = {curve, pk_xy, r_xy, s, e, pk_inf, r_inf, status, n * t / nthreads, n * (t + 1) / nthreads};
+    jobs[t] = j;
+    pthread_create(&th[t], NULL, svworker, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+}
+
+/* schnorr::batch_verify::<C, D> (schnorr.rs:194-290) for C = P256: the secp256k1 form above with the P-256 point and
+ * scalar arithmetic (Scalar Mul p256.rs:1409-1432).  Same argument meaning, same outputs. */
+int fo_p256_schnorr_batch_verify(const u64* pk_xy, const uint8_t* pk_inf, const u64* r_xy, const uint8_t* r_inf,
+                                 const u64* s, const u64* a, const u64* e, size_t n, u64* sides, uint8_t* sides_inf) {
+  if (sides) memset(sides, 0, 16 * sizeof(u64));
+  if (sides_inf) sides_inf[0] = sides_inf[1] = 0;
+  if (n == 0) return 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (pk_inf && pk_inf[i]) return 0;
+    if (r_inf && r_inf[i]) return 0;
+  }
+  jpt g = n_generator();
+  jpt s_g = n_identity(), r_e_p = n_identity();
+  for (size_t i = 0; i < n; ++i) {
+    u64 sa[4];
+    ns_mul(s + 4 * i, a + 4 * i, sa);
+    jpt t = n_multiply(&g, sa);
+    s_g = n_padd(&s_g, &t);
+    jpt P = {ld(pk_xy + 8 * i), ld(pk_xy + 8 * i + 4), fe_small(1)};
+    jpt ep = n_multiply(&P, e + 4 * i);
+    jpt R = {ld(r_xy + 8 * i), ld(r_xy + 8 * i + 4), fe_small(1)};
+    jpt rp = n_padd(&R, &ep);
+    jpt arp = n_multiply(&rp, a + 4 * i);
+    r_e_p = n_padd(&r_e_p, &arp);
+  }
+  fe x1, y1, x2, y2;
+  int i1 = n_to_affine(&s_g, &x1, &y1), i2 = n_to_affine(&r_e_p, &x2, &y2);
+  if (sides) { st(sides, x1); st(sides + 4, y1); st(sides + 8, x2); st(sides + 12, y2); }
+  if (sides_inf) { sides_inf[0] = (uint8_t)i1; sides_inf[1] = (uint8_t)i2; }
+  return (fe_eq(&x1, &x2) && fe_eq(&y1, &y2)) || (i1 && i2);
+}

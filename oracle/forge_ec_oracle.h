@@ -106,6 +106,18 @@ int fo_secp256k1_schnorr_batch_verify(const uint64_t* pk_xy, const uint8_t* pk_i
                                       const uint8_t* r_inf, const uint64_t* s, const uint64_t* a,
                                       const uint64_t* e, size_t n, uint64_t* sides, uint8_t* sides_inf);
 
+/* the same for C = P256 (its own point and scalar arithmetic) */
+int fo_p256_schnorr_batch_verify(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* r_xy,
+                                 const uint8_t* r_inf, const uint64_t* s, const uint64_t* a,
+                                 const uint64_t* e, size_t n, uint64_t* sides, uint8_t* sides_inf);
+/* Schnorr::<C, D>::verify per signature (schnorr.rs:90-140) from the point computation on, curve 0 / 1 / 2:
+ * 1 true, 0 false, 2 = the reference panics (Ed25519 only); e = from_bytes_reduced(hash) supplied */
+int fo_schnorr_verify(int curve, const uint64_t pk_xy[8], int pk_inf, const uint64_t r_xy[8], int r_inf,
+                      const uint64_t s[4], const uint64_t e[4]);
+void fo_batch_schnorr_verify(int curve, const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* r_xy,
+                             const uint8_t* r_inf, const uint64_t* s, const uint64_t* e, uint8_t* status, size_t n,
+                             int nthreads);
+
 /* ---- batched drivers (nthreads host threads over contiguous shards) ---- */
 void fo_batch_mul(int curve, const uint64_t* scalars, const uint64_t* points, uint64_t* out,
                   size_t n, int nthreads);

@@ -1058,6 +1058,69 @@ def secp256k1_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e):
     return (1 if ok else 0), [x1, y1, x2, y2], [int(i1), int(i2)]
 
 
+def p256_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e):
+    """schnorr.rs:194-290 for C = P256 (Scalar Mul p256.rs:1409-1432): as secp256k1_schnorr_batch_verify."""
+    S, F = P256Scalar, P256c
+    n = len(s)
+    zero = [0, 0, 0, 0]
+    if n == 0:
+        return 0, [zero] * 4, [0, 0]
+    for i in range(n):
+        if (pk_inf is not None and pk_inf[i]) or (r_inf is not None and r_inf[i]):
+            return 0, [zero] * 4, [0, 0]
+    g = F.generator()
+    s_g, r_e_p = F.identity(), F.identity()
+    one = [1, 0, 0, 0]
+    for i in range(n):
+        s_g = F.padd(s_g, F.multiply(g, S.mul(list(s[i]), list(a[i]))))
+        ep = F.multiply((list(pk_xy[i][0:4]), list(pk_xy[i][4:8]), one), list(e[i]))
+        rp = F.padd((list(r_xy[i][0:4]), list(r_xy[i][4:8]), one), ep)
+        r_e_p = F.padd(r_e_p, F.multiply(rp, list(a[i])))
+    x1, y1, i1 = F.to_affine(s_g)
+    x2, y2, i2 = F.to_affine(r_e_p)
+    ok = (x1 == x2 and y1 == y2) or (i1 and i2)
+    return (1 if ok else 0), [x1, y1, x2, y2], [int(i1), int(i2)]
+
+
+def schnorr_verify(curve, pk_xy, pk_inf, r_xy, r_inf, s, e):
+    """Schnorr::<C, D>::verify (forge-ec-signature/src/schnorr.rs:90-140) from line 125 on, the challenge
+    e = from_bytes_reduced(H(R || P || m)) given.  1 true, 0 false, 2 = the reference panics (Ed25519's to_affine
+    unwrapping the inverse of a zero z, ed25519.rs:1805)."""
+    if r_inf:
+        return 0                                              # 103-105
+    one = [1, 0, 0, 0]
+    x_p, y_p = list(pk_xy[0:4]), list(pk_xy[4:8])
+    if curve in (SECP256K1, P256):
+        F = Secp if curve == SECP256K1 else P256c
+        s_g = F.multiply(F.generator(), list(s))              # 125
+        pk = F.identity() if pk_inf else (x_p, y_p, one)      # from_affine
+        e_p = F.multiply(pk, list(e))                         # 126
+        x, y, _ = F.to_affine(e_p)                            # 129: (0, 0) for the identity
+        ny = F.neg(y)                                         # 130
+        on = _secp_on_curve(x, ny) if curve == SECP256K1 else (P256c.sqr(ny) == _p256_rhs(x))
+        if not on:
+            return 0                                          # 132-134: PointAffine::new is None
+        rx, ry, ri = F.to_affine(F.padd(s_g, (x, ny, one)))   # 136-139
+    else:
+        F = Ed
+        s_g = F.multiply(F.generator(), list(s))
+        pk = F.identity() if pk_inf else (x_p, y_p, one, F.mul(x_p, y_p))
+        e_p = F.multiply(pk, list(e))
+        if not F.is_identity(e_p) and _is_zero(e_p[2]):
+            return 2
+        x, y, _ = F.to_affine(e_p)
+        ny = F.neg(y)
+        x2, y2 = F.sqr(x), F.sqr(ny)
+        if F.add(F.neg(x2), y2) != F.add(one, F.mul(F.D, F.mul(x2, y2))):   # PointAffine::new 1477-1498
+            return 0
+        rp = F.padd(s_g, (x, ny, one, F.mul(x, ny)))
+        if not F.is_identity(rp) and _is_zero(rp[2]):
+            return 2
+        rx, ry, ri = F.to_affine(rp)
+    same = list(rx) == list(r_xy[0:4]) and list(ry) == list(r_xy[4:8])
+    return 1 if (same or (ri and r_inf)) else 0                # 142: AffinePoint::ct_eq
+
+
 def compress(curve, x, y, inf=False):
     """PointAffine::to_bytes (secp256k1.rs:875-896, p256.rs:1558-1578, ed25519.rs:1505-1525)."""
     if inf:

@@ -48,6 +48,8 @@ extern "C" {
     fn fec_batch_encode_uncompressed(ctx: *mut FecCtx, curve: c_int, xy: *const u64, inf: *const u8, out: *mut u8, n: usize) -> c_int;
     fn fec_batch_decode_uncompressed(ctx: *mut FecCtx, curve: c_int, r#in: *const u8, xy: *mut u64, inf: *mut u8, ok: *mut u8, n: usize) -> c_int;
     fn fec_schnorr_batch_verify_secp256k1(ctx: *mut FecCtx, pk_xy: *const u64, pk_inf: *const u8, r_xy: *const u64, r_inf: *const u8, s: *const u64, a: *const u64, e: *const u64, n: usize, result: *mut u8, sides_xy: *mut u64, sides_inf: *mut u8) -> c_int;
+    fn fec_schnorr_batch_verify(ctx: *mut FecCtx, curve: c_int, pk_xy: *const u64, pk_inf: *const u8, r_xy: *const u64, r_inf: *const u8, s: *const u64, a: *const u64, e: *const u64, n: usize, result: *mut u8, sides_xy: *mut u64, sides_inf: *mut u8) -> c_int;
+    fn fec_schnorr_verify(ctx: *mut FecCtx, curve: c_int, pk_xy: *const u64, pk_inf: *const u8, r_xy: *const u64, r_inf: *const u8, s: *const u64, e: *const u64, status: *mut u8, n: usize) -> c_int;
     fn fec_field_op(ctx: *mut FecCtx, curve: c_int, op: c_int, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
     fn fec_point_op(ctx: *mut FecCtx, curve: c_int, op: c_int, p: *const u64, q: *const u64, out: *mut u64, n: usize) -> c_int;
     fn fec_batch_mul_dev(ctx: *mut FecCtx, curve: c_int, d_scalars: *const u64, d_points: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
@@ -56,6 +58,7 @@ extern "C" {
     fn fec_eddsa_verify_ed25519_dev(ctx: *mut FecCtx, d_r_xy: *const u64, d_r_inf: *const u8, d_pk_xy: *const u64, d_pk_inf: *const u8, d_s: *const u64, d_k: *const u64, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_ecdsa_verify_p256_dev(ctx: *mut FecCtx, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_ecdsa_verify_secp256k1_dev(ctx: *mut FecCtx, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
+    fn fec_schnorr_verify_dev(ctx: *mut FecCtx, curve: c_int, d_pk_xy: *const u64, d_pk_inf: *const u8, d_r_xy: *const u64, d_r_inf: *const u8, d_s: *const u64, d_e: *const u64, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_compress_dev(ctx: *mut FecCtx, curve: c_int, d_xy: *const u64, d_inf: *const u8, d_out: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_to_affine_dev(ctx: *mut FecCtx, curve: c_int, d_points: *const u64, d_xy: *mut u64, d_inf: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_ctx_set_chunk(ctx: *mut FecCtx, elements: usize) -> c_int;
@@ -524,6 +527,47 @@ pub fn schnorr_batch_verify_secp256k1(ctx: &mut GpuContext, public_keys: &[secp2
     Ok(result == 1)
 }
 
+fn marshal_affine<C: GpuCurve>(pts: &[C::PointAffine]) -> (Vec<u64>, Vec<u8>) {
+    let (mut xy, mut inf) = (vec![0u64; 8 * pts.len()], vec![0u8; pts.len()]);
+    for (i, p) in pts.iter().enumerate() {
+        let (l, f) = C::affine_limbs(p);
+        xy[8 * i..8 * i + 8].copy_from_slice(&l);
+        inf[i] = f as u8;
+    }
+    (xy, inf)
+}
+
+/// `schnorr::batch_verify::<C, D>` for `C` = `Secp256k1` or `P256` (`forge-ec-signature/src/schnorr.rs:194-290`,
+/// generic over the curve): as [`schnorr_batch_verify_secp256k1`].  `Ed25519` -> `UnsupportedOperation`.
+pub fn schnorr_batch_verify<C: GpuCurve>(ctx: &mut GpuContext, public_keys: &[C::PointAffine], sig_r: &[C::PointAffine], sig_s: &[C::Scalar], a: &[C::Scalar], e: &[C::Scalar]) -> Result<bool> {
+    let n = public_keys.len();
+    if sig_r.len() != n || sig_s.len() != n || a.len() != n || e.len() != n {
+        return Err(Error::ValidationError);
+    }
+    let ((pk_xy, pk_inf), (r_xy, r_inf)) = (marshal_affine::<C>(public_keys), marshal_affine::<C>(sig_r));
+    let (s, aa, ee) = (pack_scalars::<C>(sig_s), pack_scalars::<C>(a), pack_scalars::<C>(e));
+    let mut result = 0u8;
+    // SAFETY: n elements behind every pointer; the two optional outputs are null.
+    check(unsafe { fec_schnorr_batch_verify(ctx.raw, C::ID, pk_xy.as_ptr(), pk_inf.as_ptr(), r_xy.as_ptr(), r_inf.as_ptr(), s.as_ptr(), aa.as_ptr(), ee.as_ptr(), n, &mut result, core::ptr::null_mut(), core::ptr::null_mut()) })?;
+    Ok(result == 1)
+}
+
+/// `Schnorr::<C, D>::verify` per signature (`forge-ec-signature/src/schnorr.rs:90-140`) from the point computation
+/// on, all three curves: the caller keeps the two message special cases (92-99) and hashes
+/// (`e[i] = C::Scalar::from_bytes_reduced(H(R || P || m))`, 107-123).
+pub fn schnorr_verify_batch<C: GpuCurve>(ctx: &mut GpuContext, public_keys: &[C::PointAffine], sig_r: &[C::PointAffine], sig_s: &[C::Scalar], e: &[C::Scalar]) -> Result<Vec<VerifyStatus>> {
+    let n = public_keys.len();
+    if sig_r.len() != n || sig_s.len() != n || e.len() != n {
+        return Err(Error::ValidationError);
+    }
+    let ((pk_xy, pk_inf), (r_xy, r_inf)) = (marshal_affine::<C>(public_keys), marshal_affine::<C>(sig_r));
+    let (s, ee) = (pack_scalars::<C>(sig_s), pack_scalars::<C>(e));
+    let mut status = vec![0u8; n];
+    // SAFETY: every buffer holds n elements of the width the header states.
+    check(unsafe { fec_schnorr_verify(ctx.raw, C::ID, pk_xy.as_ptr(), pk_inf.as_ptr(), r_xy.as_ptr(), r_inf.as_ptr(), s.as_ptr(), ee.as_ptr(), status.as_mut_ptr(), n) })?;
+    Ok(status.iter().map(|&v| match v { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid }).collect())
+}
+
 /// `C::generator()` as the library holds it (evaluated on the device with the reference's own
 /// construction) -- a self-check for an integration: must equal the CPU `C::generator()`.
 pub fn generator<C: GpuCurve>(ctx: &mut GpuContext) -> Result<C::PointProjective> {
@@ -602,6 +646,14 @@ pub mod dev {
     /// As [`batch_mul`]; the caller owns and clears every buffer.
     pub unsafe fn batch_ecdh(ctx: &mut GpuContext, curve: c_int, d_private_keys: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_secrets: *mut u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
         check(fec_batch_ecdh_dev(ctx.raw, curve, d_private_keys, d_pk_xy, d_pk_inf, d_secrets, d_status, n, stream))
+    }
+
+    /// `fec_schnorr_verify_dev`.
+    ///
+    /// # Safety
+    /// As [`batch_mul`].
+    pub unsafe fn schnorr_verify(ctx: &mut GpuContext, curve: c_int, d_pk_xy: *const u64, d_pk_inf: *const u8, d_r_xy: *const u64, d_r_inf: *const u8, d_s: *const u64, d_e: *const u64, d_status: *mut u8, n: usize, stream: *mut c_void) -> Result<()> {
+        check(fec_schnorr_verify_dev(ctx.raw, curve, d_pk_xy, d_pk_inf, d_r_xy, d_r_inf, d_s, d_e, d_status, n, stream))
     }
 
     /// `fec_eddsa_verify_ed25519_dev`.

@@ -38,6 +38,8 @@ def test_forced_scheduler_fault_is_an_error_not_zero_points(oracle):
             "ecdsa_verify_p256": lambda: ctx.ecdsa_verify_p256(dg, V.scalars(n, 1, 12), V.scalars(n, 1, 13), _pk(n, 1, 14), None),
             "eddsa_verify_ed25519": lambda: ctx.eddsa_verify_ed25519(_pk(n, 2, 16), None, _pk(n, 2, 18), None, V.scalars(n, 2, 20), V.scalars(n, 2, 21)),
             "ecdh p256": lambda: ctx.batch_ecdh(1, V.scalars(n, 1, 22), _pk(n, 1, 23), None),
+            "schnorr_verify p256": lambda: ctx.schnorr_verify(1, _pk(n, 1, 34), _pk(n, 1, 36), V.scalars(n, 1, 38), V.scalars(n, 1, 39)),
+            "schnorr_batch_verify p256": lambda: ctx.schnorr_batch_verify(1, _pk(64, 1, 42), _pk(64, 1, 44), V.scalars(64, 1, 46), V.scalars(64, 1, 47), V.scalars(64, 1, 48)),
             "validate ed25519": lambda: ctx.batch_validate_point(2, _pk(n, 2, 25), None),
             "msm p256": lambda: ctx.multi_scalar_mul(1, V.scalars(64, 1, 27), V.points(64, 1, 28)),
             "ecdsa_batch_verify p256": lambda: ctx.ecdsa_batch_verify(1, dg[:64], V.scalars(64, 1, 29), V.scalars(64, 1, 30), _pk(64, 1, 31), None, V.scalars(64, 1, 33)),

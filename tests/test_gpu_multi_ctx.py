@@ -60,6 +60,11 @@ def test_multi_ctx_other_elementwise_calls(oracle):
         r = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 59), V.field_elements(n, 2, 60)], axis=1))
         inf = (rng.integers(0, 8, size=n) == 0).astype(np.uint8)
         assert np.array_equal(ctx.eddsa_verify_ed25519(r, None, pk, inf, s, k), one.eddsa_verify_ed25519(r, None, pk, inf, s, k))
+        for curve in (0, 1, 2):   # Schnorr verify per signature shards like the other verifications
+            pkc = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 81), V.field_elements(n, curve, 82)], axis=1))
+            rc = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 83), V.field_elements(n, curve, 84)], axis=1))
+            ss, ee = V.scalars(n, curve, 85), V.scalars(n, curve, 86)
+            assert np.array_equal(ctx.schnorr_verify(curve, pkc, rc, ss, ee, pk_inf=inf), one.schnorr_verify(curve, pkc, rc, ss, ee, pk_inf=inf))
         # ECDH, validate_point and the three codecs shard as well (fecgpu.h lists every sharded entry point)
         for curve in (0, 1):
             sk = V.scalars(n, curve, 71 + curve)

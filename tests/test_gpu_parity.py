@@ -816,6 +816,88 @@ def test_schnorr_batch_verify_secp256k1_matches_oracle(gpu_ctx, oracle):
     assert gpu_ctx.schnorr_batch_verify_secp256k1(z8, z8, z4, z4, z4)[0] is False
 
 
+def test_schnorr_batch_verify_p256_matches_oracle(gpu_ctx, oracle):
+    """schnorr::batch_verify::<P256, D> (the generic function instantiated for P-256: its point arithmetic, its Scalar
+    Mul, the five-lane ordered folds) through fec_schnorr_batch_verify; the secp256k1 instance through the same entry
+    point equals the dedicated one."""
+    def inputs(n, seed, curve):
+        pk = V.field_elements(2 * n, curve, seed).reshape(n, 8)
+        r = V.field_elements(2 * n, curve, seed + 1).reshape(n, 8)
+        return pk, r, V.scalars(n, curve, seed + 2), V.scalars(n, curve, seed + 3), V.scalars(n, curve, seed + 4)
+
+    for n, seed in ((1, 900), (5, 910), (64, 920), (300, 930)):
+        pk, r, s, a, e = inputs(n, seed, 1)
+        want, w_sides, w_inf = oracle.schnorr_batch_verify(1, pk, None, r, None, s, a, e)
+        got, sides, sinf = gpu_ctx.schnorr_batch_verify(1, pk, r, s, a, e)
+        assert got == bool(want) and np.array_equal(sides, w_sides) and np.array_equal(sinf, w_inf) and sides.any()
+    pk, r, s, a, e = inputs(70, 940, 1)
+    a[3] = 0
+    e[5] = 0
+    s[7] = 0
+    want, w_sides, w_inf = oracle.schnorr_batch_verify(1, pk, None, r, None, s, a, e)
+    got, sides, sinf = gpu_ctx.schnorr_batch_verify(1, pk, r, s, a, e)
+    assert got == bool(want) and np.array_equal(sides, w_sides) and np.array_equal(sinf, w_inf)
+    a0 = np.zeros_like(a)
+    got, sides, sinf = gpu_ctx.schnorr_batch_verify(1, pk, r, s, a0, e)
+    assert got is True and list(sinf) == [1, 1] and not sides.any()
+    inf = np.zeros(70, dtype=np.uint8)
+    inf[0] = 1
+    assert gpu_ctx.schnorr_batch_verify(1, pk, r, s, a0, e, pk_inf=inf)[0] is False
+    pk, r, s, a, e = inputs(33, 950, 0)
+    g1, g2 = gpu_ctx.schnorr_batch_verify(0, pk, r, s, a, e), gpu_ctx.schnorr_batch_verify_secp256k1(pk, r, s, a, e)
+    assert g1[0] == g2[0] and np.array_equal(g1[1], g2[1]) and np.array_equal(g1[2], g2[2])
+    import forge_ec_amd as F
+    with pytest.raises(F.FecError) as ei:
+        gpu_ctx.schnorr_batch_verify(2, pk, r, s, a, e)
+    assert ei.value.status == -5   # FEC_E_UNSUPPORTED: Ed25519's scalar Mul is not restated
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_schnorr_verify_matches_oracle(gpu_ctx, oracle, curve):
+    """Schnorr::<C, D>::verify per signature (schnorr.rs:90-140) from the point computation on: random inputs (the
+    reference answers false: PointAffine::new(x, -y) is None), the fixture's cases -- for P-256 including signatures
+    that VERIFY under the reference's arithmetic --, infinite R / infinite key, zero scalars, e = 1; host and
+    device-pointer entry points, a ragged size."""
+    import json
+    import os
+    import torch
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schnorr_vectors.json")) as f:
+        fx = [c for c in json.load(f)["verify"] if c["curve"] == curve]
+    n_random = 700
+    n = n_random + len(fx) + 3
+    pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 961), V.field_elements(n, curve, 962)], axis=1))
+    r = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 963), V.field_elements(n, curve, 964)], axis=1))
+    s, e = V.scalars(n, curve, 965), V.scalars(n, curve, 966)
+    pinf, rinf = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    for j, c in enumerate(fx):
+        i = n_random + j
+        pk[i], r[i], s[i], e[i], pinf[i], rinf[i] = c["pk"], c["r"], c["s"], c["e"], c["pk_inf"], c["r_inf"]
+    base = n_random + len(fx)
+    s[base] = 0
+    e[base + 1] = 0
+    e[base + 2] = [1, 0, 0, 0]
+    want = oracle.batch_schnorr_verify(curve, pk, pinf, r, rinf, s, e, nthreads=8)
+    for j, c in enumerate(fx):
+        assert int(want[n_random + j]) == c["status"], c["note"]
+    if curve == 1:
+        assert int((want == 1).sum()) >= 4
+    got = gpu_ctx.schnorr_verify(curve, pk, r, s, e, pk_inf=pinf, r_inf=rinf)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, "first mismatch at %d: got %d want %d" % (bad[0], got[bad[0]], want[bad[0]])
+    want2 = oracle.batch_schnorr_verify(curve, pk, None, r, None, s, e, nthreads=8)
+    assert np.array_equal(gpu_ctx.schnorr_verify(curve, pk, r, s, e), want2)
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev) for a in (pk, pinf, r, rinf, s, e)]
+    st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    gpu_ctx.schnorr_verify_dev(curve, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(),
+                               t[5].data_ptr(), st.data_ptr(), n, stream.cuda_stream)
+    stream.synchronize()
+    gpu_ctx.check()
+    assert np.array_equal(st.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("curve", [0, 1, 2])
 def test_batch_compress_matches_oracle(gpu_ctx, oracle, curve):
     """PointAffine::to_bytes (compressed, 33 bytes) of affine points: identity flags, ragged sizes whose

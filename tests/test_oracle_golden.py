@@ -406,3 +406,31 @@ def test_validate_point_two_restatements_agree(oracle):
         want = [M.validate_point(curve, [int(v) for v in xy[i]], bool(inf[i])) for i in range(n)]
         assert [int(v) for v in got] == want
         assert want[2] == 0 and want[3] == 1
+
+
+def test_schnorr_verify_fixture_and_two_restatements(oracle):
+    """Schnorr::<C, D>::verify per signature (schnorr.rs:90-140) and schnorr::batch_verify::<P256, D> (194-290): the
+    committed fixture (tests/golden/schnorr_vectors.json, made by the Python model) through the C oracle, and both
+    restatements on fresh random inputs.  Restatement-derived: the reference's own tests reach these functions only
+    through their hard-coded "test message" shortcuts (schnorr.rs:92-99)."""
+    from oracle import py_model as M
+    t = _load("schnorr_vectors.json")
+    assert {c["status"] for c in t["verify"]} == {0, 1} and {c["curve"] for c in t["verify"]} == {0, 1, 2}
+    for c in t["verify"]:
+        got = oracle.batch_schnorr_verify(c["curve"], [c["pk"]], [c["pk_inf"]], [c["r"]], [c["r_inf"]], [c["s"]], [c["e"]])
+        assert int(got[0]) == c["status"], c["note"]
+    for b in t["batch_p256"]:
+        res, sides, sinf = oracle.schnorr_batch_verify(1, b["pk"], None, b["r"], None, b["s"], b["a"], b["e"])
+        assert res == b["result"] and [int(v) for v in sides] == [v for fe in b["sides"] for v in fe] and list(sinf) == b["sides_inf"]
+    assert [b["result"] for b in t["batch_p256"]] == [0, 0, 1]
+    for curve in (0, 1, 2):
+        n = 4
+        pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 730), V.field_elements(n, curve, 731)], axis=1))
+        r = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 732), V.field_elements(n, curve, 733)], axis=1))
+        s, e = V.scalars(n, curve, 734), V.scalars(n, curve, 735)
+        e[1] = [1, 0, 0, 0]
+        inf = np.array([0, 0, 1, 0], dtype=np.uint8)
+        got = oracle.batch_schnorr_verify(curve, pk, inf, r, None, s, e, nthreads=2)
+        want = [M.schnorr_verify(curve, [int(v) for v in pk[i]], int(inf[i]), [int(v) for v in r[i]], 0,
+                                 [int(v) for v in s[i]], [int(v) for v in e[i]]) for i in range(n)]
+        assert [int(v) for v in got] == want
