@@ -60,6 +60,20 @@ def main():
     t0 = time.perf_counter(); got = ctx.eddsa_verify_ed25519(rr, rinf, pk, pinf, s, k); t1 = time.perf_counter()
     want = O.batch_ed25519_eddsa_verify(rr, rinf, pk, pinf, s, k, nthreads=16); t2 = time.perf_counter()
     total += report("eddsa_verify ed25519", got, want, t1 - t0, t2 - t1)
+    for curve in (0, 1, 2):   # Schnorr verify per signature (P-256: a quarter of the keys true curve points, e = 1 for some)
+        m4 = n >> 2
+        pk = np.ascontiguousarray(np.concatenate([V.field_elements(m4, curve, 9041), V.field_elements(m4, curve, 9042)], axis=1))
+        rr = np.ascontiguousarray(np.concatenate([V.field_elements(m4, curve, 9043), V.field_elements(m4, curve, 9044)], axis=1))
+        ss, ee = V.scalars(m4, curve, 9045), V.scalars(m4, curve, 9046)
+        ee[::5] = [1, 0, 0, 0]
+        pinf = (rng.integers(0, 16, size=m4) == 0).astype(np.uint8)
+        rinf = (rng.integers(0, 64, size=m4) == 0).astype(np.uint8)
+        t0 = time.perf_counter(); got = ctx.schnorr_verify(curve, pk, rr, ss, ee, pk_inf=pinf, r_inf=rinf); t1 = time.perf_counter()
+        want = O.batch_schnorr_verify(curve, pk, pinf, rr, rinf, ss, ee, nthreads=16); t2 = time.perf_counter()
+        bad = int(np.count_nonzero(got != want))
+        print(json.dumps({"pipeline": "schnorr_verify curve %d" % curve, "n": m4, "mismatches": bad, "gpu_s": round(t1 - t0, 3),
+                          "oracle_s": round(t2 - t1, 1)}), flush=True)
+        total += bad
     for curve in (0, 1):
         sk = V.scalars(n, curve, 9021)
         pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 9022), V.field_elements(n, curve, 9023)], axis=1))
