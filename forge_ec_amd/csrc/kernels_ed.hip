@@ -550,7 +550,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
 
   int kind = -1, count = 0;
   int e = tid;
-  int nxt = 3;  // 0 D-ready, 1 A-ready, 2 slot died, 3 none
+  int nxt = 3;  // the element's next step: 0 doubling only (bit clear), 1 addition then doubling (bit set); 2 slot died, 3 none
   unsigned spins = 0;
   bool first_fill = true;
   // initial fill: slots 0..511 now, slots 512..PS-1 on the second pass; both enter the queues through the
@@ -642,28 +642,34 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
     gid = oob ? 0u : gid;
     const bool live = active && !oob;
     bool fin = false;
-    if (kind == 1) {  // A_i: result = result + addend  (2083-2086, bit i set); the result stays in its output slot
+    // ONE task = one step i of the reference's loop (2075-2091) for 64 elements that agree on scalar bit i:
+    //   queue 1 (bit set):   A_i: result = result + addend (2083-2086), then D_i
+    //   queue 0 (bit clear): D_i: addend = addend.double() (2089)
+    // The doubling of step 255 is never used and never done.  (Round 2 queued A_i and D_i separately: 383 visits of
+    // the scheduler per element instead of 255 for the same arithmetic.)
+    if (kind == 1) {  // the result stays in its output slot
       // inactive lanes read element 0 of the range (always present) and slot 0: computed, never stored
       u32* slot = out + (lo + gid) * 32;
       FEC_MARK("task_add_begin");
       const ed::pt res = padd_mem(slot, lds_ad + e, PS);
       FEC_MARK("task_add_end");
-      if (live) {
-        st_glb(slot, res);
-        fin = step == 255;  // the last doubling is never used
-        nxt = 0;            // then D_i
-      }
-    } else {  // D_i: addend = addend.double()  (2089), then step i + 1
+      if (live) st_glb(slot, res);
+    }
+    {
       FEC_MARK("task_double_begin");
       const ed::pt d = pdbl_mem(lds_ad + e, PS);
       FEC_MARK("task_double_end");
       if (live) {
-        st_lds(lds_ad + e, PS, d);
-        ++step;
-        const u32 bit = scalar_bit(scalars, lo + gid, step);
-        lds_step[e] = (unsigned short)step;
-        fin = !bit && step == 255;
-        nxt = bit ? 1 : 0;
+        if (step == 255) {  // (only reached through queue 1: A_255 was the element's last operation)
+          fin = true;
+        } else {
+          st_lds(lds_ad + e, PS, d);
+          ++step;
+          const u32 bit = scalar_bit(scalars, lo + gid, step);
+          lds_step[e] = (unsigned short)step;
+          fin = !bit && step == 255;
+          nxt = bit ? 1 : 0;
+        }
       }
     }
     if (fin) nxt = claim(e);  // the element is done (its result is in place): the slot takes the next element

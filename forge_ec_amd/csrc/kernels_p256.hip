@@ -6,8 +6,8 @@
 // Executing the addition for whole wavefronts under a mask wastes half of it; a step-synchronous
 // compaction (round 1) packs it but leaves SIMDs idle at three barriers per step (PMC: 40 % of wave
 // cycles parked, VALUBusy 82 %, profiles/pmc_r02_base_p256).  Here a workgroup keeps 1024 elements'
-// state (X, Y, Z, scalar, step) in LDS slots, and its eight wavefronts pull BATCHES from two ready queues:
-// 64 elements that all need a doubling, or 64 elements that all need an addition.  Elements therefore
+// state in LDS slots, and its wavefronts pull BATCHES from two ready queues: 64 elements whose next step has a
+// clear scalar bit (a doubling), or 64 elements whose next step has a set bit (a doubling and then the addition).  Elements therefore
 // advance at their own pace (each one still sees exactly the reference's operation sequence, so
 // results are bit-identical), every batch is full until the workgroup's whole range is done, there is no
 // workgroup barrier inside the ladder, and a wavefront holds no point state between batches.
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   // point (Add's first early-out returns rhs as it is), so the slot starts with result = point at step 256 - t --
   // exactly the state the reference is in after that addition.  (Besides the skipped operations this keeps identity
   // results out of the queues: with them, 39 % of all batches held at least one lane on an early-out and ran Add's /
-  // double's rare leg for the whole wavefront.)  Returns 0 (a doubling is pending) or 2 when the range is used up
-  // (the slot dies).
+  // double's rare leg for the whole wavefront.)  Returns the scalar bit of the element's next step (= the queue it
+  // goes to) or 2 when the range is used up (the slot dies).
   auto claim = [&](int e) -> int {
     for (;;) {
       const int rel = atomicAdd(&lds_ctl[P_NEXT], 1);
@@ -303,18 +303,23 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       lds_kw[QS + e] = c1;
       lds_gid[e] = (u32)rel;
       lds_step[e] = (unsigned short)(256 - t);
-      return 0;
+      return (int)((((t - 1) & 32) ? c1 : c0) >> ((t - 1) & 31)) & 1;   // the bit of step 256 - t
     }
   };
-  // step -> step + 1: when the new step's bit opens a new 64-bit limb of the scalar, that limb is fetched from the
-  // caller's array (three times per element)
-  auto advance = [&](int e, u32 gid, int step_new) {
+  // The scalar bit of step `step_new` (< 256).  When that step opens a new 64-bit limb of the scalar the limb is
+  // fetched from the caller's array (three times per element) and cached in the slot.
+  auto step_bit = [&](int e, u32 gid, int step_new) -> u32 {
     const int b = 255 - step_new;
-    if (step_new < 256 && (b & 63) == 63) {
+    u32 w;
+    if ((b & 63) == 63) {
       const v2u_t kk = __builtin_nontemporal_load(reinterpret_cast<const v2u_t*>(scalars + (lo + gid) * 8 + 2 * (b >> 6)));
       lds_kw[e] = kk.x;
       lds_kw[QS + e] = kk.y;
+      w = kk.y;
+    } else {
+      w = lds_kw[((b >> 5) & 1) * QS + e];
     }
+    return (w >> (b & 31)) & 1u;
   };
 
   int kind = -1, count = 0;
@@ -416,30 +421,22 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     p256::pt res = p256::identity();
     FEC_STAT(kind == 0 ? 0 : 2, 1);
     FEC_STAT(kind == 0 ? 1 : 3, count);
-    if (kind == 0) {
-      FEC_MARK("task_double_begin");
+    // ONE task = one step of the reference's loop (2126-2134) for 64 elements that agree on the step's scalar bit:
+    //   queue 0 (bit clear): result = result.double()
+    //   queue 1 (bit set):   result = result.double(); result = result + point
+    // (Round 2 queued the doubling and the addition separately: 381 visits of the scheduler per element instead of 254,
+    // i.e. a third more of its 200-250 instructions and of its lock traffic for the same arithmetic.)
+    FEC_MARK("task_double_begin");
 #ifdef FEC_SCHED_STUB   // tools/microbench/sched_stats.hip: the scheduler alone (the task is a copy of the slot)
-      res = ld_pt(lds_st + e, QS);
+    res = ld_pt(lds_st + e, QS);
 #else
-      res = pdouble_in_place(lds_st + e, QS);
+    res = pdouble_in_place(lds_st + e, QS);
 #endif
-      FEC_MARK("task_double_end");
-      if (live) {
-        const int b = 255 - step;
-        const u32 bit = (lds_kw[((b >> 5) & 1) * QS + e] >> (b & 31)) & 1u;
-        if (bit) {
-          nxt = 1;
-        } else {
-          ++step;
-          lds_step[e] = (unsigned short)step;
-          advance(e, gid, step);
-          nxt = 0;
-          fin = step == 256;
-        }
-        if (!fin) st_pt(lds_st + e, QS, res);
-      }
-    } else {
-      // inactive lanes add slot 0 and element 0 of the range: harmless, never stored
+    FEC_MARK("task_double_end");
+    if (kind == 1) {
+      // the addition reads its first operand from the slot (a lane's LDS accesses stay in order); inactive lanes add
+      // slot 0 and element 0 of the range: harmless, never stored
+      if (live) st_pt(lds_st + e, QS, res);
       const size_t g_el = lo + gid;
       FEC_MARK("task_add_begin");
 #ifdef FEC_SCHED_STUB
@@ -450,13 +447,14 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
                           FIXED ? (HOIST ? lds_zz : nullptr) : lds_zq + e, FIXED ? 1 : QS);
 #endif
       FEC_MARK("task_add_end");
-      if (live) {
-        ++step;
-        lds_step[e] = (unsigned short)step;
-        advance(e, gid, step);
-        nxt = 0;
-        fin = step == 256;
-        if (!fin) st_pt(lds_st + e, QS, res);
+    }
+    if (live) {
+      ++step;
+      lds_step[e] = (unsigned short)step;
+      fin = step == 256;
+      if (!fin) {
+        st_pt(lds_st + e, QS, res);
+        nxt = (int)step_bit(e, gid, step);
       }
     }
     if (fin) {  // the element is done: its result goes out (16-byte stores), the slot takes the next element
