@@ -207,9 +207,13 @@ FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u
 namespace {
 constexpr int QT = 768;      // threads per workgroup: 12 wavefronts, three per SIMD
 #ifndef FEC_P256_QS
-#define FEC_P256_QS 1024
+#define FEC_P256_QS 832
 #endif
-constexpr int QS = FEC_P256_QS;  // element slots per workgroup (8 x 64 in flight + 512 queued)
+#ifndef FEC_TICKET_SLEEP
+#define FEC_TICKET_SLEEP 1
+#endif
+constexpr int QS = FEC_P256_QS;  // element slots per workgroup (12 x 64 in flight + 64 queued).  Same-box sweeps (profiles/slot_sweep_r03.txt):
+                                 // 1024 -> 23.79 ms / 527 MB of L2-side traffic, 960 -> 24.79, 896 -> 24.21, 832 -> 23.91 ms / 378 MB
 constexpr int QRING = 2048;  // ring capacity (power of two >= QS)
 enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace
@@ -222,11 +226,11 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   __shared__ u32 lds_st[24 * QS];               // X, Y, Z of slot e: word w at lds_st[w * QS + e]
   // z2z2 = base.z * base.z of slot e's element (variable base): one of the sixteen products of EVERY addition of an
   // element depends on its base point alone, so claim() computes it once with the same sqr() and the ~128 additions
-  // read it back.  It takes the LDS room the scalar used to have; of the scalar only the 32-bit word that holds the
-  // current bit stays in LDS (lds_kw), refetched from the caller's array once per 32 steps.  (Round 2 parked z2z2 in
-  // the element's output slot instead: 23 GB of L2-side traffic and no in-place calls -- removed; this form has neither.)
+  // read it back.  With 832 slots it fits beside the whole scalar (160 B per slot, 146 KiB in all).  (Round 2 parked
+  // z2z2 in the element's output slot instead: 23 GB of L2-side traffic and no in-place calls -- removed; this form has
+  // neither.)
   __shared__ u32 lds_zq[(FIXED ? 0 : 8 * QS) + 8];
-  __shared__ u32 lds_kw[2 * QS];                // the aligned 64-bit half-limb of slot e's scalar that holds its current bit
+  __shared__ u32 lds_k[8 * QS];                 // scalar of slot e: word w at lds_k[w * QS + e]
   __shared__ u32 lds_gid[QS];                   // element of slot e, relative to the workgroup's range
   __shared__ unsigned short lds_step[QS];
   __shared__ unsigned short lds_q[2][QRING];
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   // goes to) or 2 when the range is used up (the slot dies).
   auto claim = [&](int e) -> int {
     for (;;) {
-      const int rel = atomicAdd(&lds_ctl[P_NEXT], 1);
+      const int rel = lds_fetch_add(ctl, P_NEXT, 1);
       if (rel >= range) return 2;
       const size_t g = lo + rel;
       const uint4* ks = reinterpret_cast<const uint4*>(scalars + g * 8);
@@ -294,32 +298,20 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
         const fe zz = p256::sqr(base.z);
         FEC_UNROLL for (int w = 0; w < 8; ++w) lds_zq[w * QS + e] = zz.w[w];
       }
-      u32 c0 = 0, c1 = 0;  // the 64 bits that hold bit t - 1, the next one the ladder looks at
-      FEC_UNROLL for (int w = 0; w < 4; ++w) {
-        c0 = ((t - 1) >> 6) == w ? kw[2 * w] : c0;
-        c1 = ((t - 1) >> 6) == w ? kw[2 * w + 1] : c1;
+      u32 cur = 0;  // the word that holds bit t - 1, the next one the ladder looks at
+      FEC_UNROLL for (int w = 0; w < 8; ++w) {
+        lds_k[w * QS + e] = kw[w];
+        cur = ((t - 1) >> 5) == w ? kw[w] : cur;
       }
-      lds_kw[e] = c0;
-      lds_kw[QS + e] = c1;
       lds_gid[e] = (u32)rel;
       lds_step[e] = (unsigned short)(256 - t);
-      return (int)((((t - 1) & 32) ? c1 : c0) >> ((t - 1) & 31)) & 1;   // the bit of step 256 - t
+      return (int)(cur >> ((t - 1) & 31)) & 1;   // the bit of step 256 - t
     }
   };
-  // The scalar bit of step `step_new` (< 256).  When that step opens a new 64-bit limb of the scalar the limb is
-  // fetched from the caller's array (three times per element) and cached in the slot.
-  auto step_bit = [&](int e, u32 gid, int step_new) -> u32 {
+  // the scalar bit of step `step_new` (< 256): bit 255 - step_new (2127-2129)
+  auto step_bit = [&](int e, int step_new) -> u32 {
     const int b = 255 - step_new;
-    u32 w;
-    if ((b & 63) == 63) {
-      const v2u_t kk = __builtin_nontemporal_load(reinterpret_cast<const v2u_t*>(scalars + (lo + gid) * 8 + 2 * (b >> 6)));
-      lds_kw[e] = kk.x;
-      lds_kw[QS + e] = kk.y;
-      w = kk.y;
-    } else {
-      w = lds_kw[((b >> 5) & 1) * QS + e];
-    }
-    return (w >> (b & 31)) & 1u;
+    return (lds_k[(b >> 5) * QS + e] >> (b & 31)) & 1u;
   };
 
   int kind = -1, count = 0;
@@ -354,10 +346,10 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     }
     FEC_STAT(4, 1);   // critical sections entered
     if (lane == 0) {
-      const int my = atomicAdd(&lds_ctl[C_TICKET], 1);
+      const int my = lds_fetch_add(ctl, C_TICKET, 1);   // (lane 0 only: a plain ds_add_rtn, not the atomic optimiser's mbcnt sequence)
       while (ctl[C_SERVING] != my) {
         FEC_STAT(5, 1);  // waits for the ticket
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(FEC_TICKET_SLEEP);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -454,7 +446,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       fin = step == 256;
       if (!fin) {
         st_pt(lds_st + e, QS, res);
-        nxt = (int)step_bit(e, gid, step);
+        nxt = (int)step_bit(e, step);
       }
     }
     if (fin) {  // the element is done: its result goes out (16-byte stores), the slot takes the next element
