@@ -66,10 +66,13 @@ def _worker(rank, world, port, n, curve, q, dst="all"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,dst", [(10, "all"), (11, "all"), (10, 0), (11, 0), (11, 1)])
+@pytest.mark.parametrize("n,dst", [(10, "all"), (11, "all"), (10, 0), (11, 0), (11, 1), (16, 0)])
 def test_two_rank_gloo_gather_reassembles_the_batch(oracle, n, dst):
     """world_size 2 over gloo: the shard + gather path of bench.py, in both forms -- gather to the
-    consumer rank (the default: only rank `dst` receives the batch) and all-gather."""
+    consumer rank (the default: only rank `dst` receives the batch) and all-gather.  This IS the strong-scaling
+    split of `bench.py --scaling strong`: ONE global batch of n elements (the same data whatever the world size),
+    every rank keeps its contiguous dist.shard_range and the gathered batch must equal the unsharded result --
+    ragged (n = 11) and even (n = 16 = 2^4, the shape of the two 8-GPU BASELINE configurations)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
