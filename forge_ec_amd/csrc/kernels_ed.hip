@@ -480,7 +480,7 @@ FEC_DEV ed::pt pdbl_mem(const u32* la, int stride) {
 
 // ---------------------------------------------------------------------------------------------------
 // One workgroup of TWELVE wavefronts per CU (three per SIMD, 168 VGPRs) owns a contiguous RANGE of elements and
-// keeps PS = 1024 of them in slots -- the addend in LDS (128 B per slot, 128 KiB), the running result in the
+// keeps PS = 832 of them in slots -- the addend in LDS (128 B per slot, 104 KiB), the running result in the
 // element's slot of the OUTPUT array (read and rewritten by ~128 additions per element; L2 / Infinity Cache
 // traffic) -- refilling a slot from the range the moment its element finishes: no
 // workgroup tail until the whole range is done.  Add and double read their operands from memory where they are
@@ -494,7 +494,8 @@ constexpr int PT = 768;     // threads per workgroup: 12 wavefronts, three per S
 #ifndef FEC_ED_PS
 #define FEC_ED_PS 832
 #endif
-constexpr int PS = FEC_ED_PS;  // element slots per workgroup (12 x 64 in flight + 256 queued); swept: 896 -> 18.6 ms, 960 -> 19.1, 1024 -> 17.6, 1088 -> 17.8, 1152 -> 18.0 (same box)
+constexpr int PS = FEC_ED_PS;  // element slots per workgroup (12 x 64 in flight + 64 queued).  Same-box sweeps (profiles/slot_sweep_r03.txt), ms and
+                               // L2-side traffic per 2^20: 1024 -> 17.87 / 27.0 GB, 960 -> 19.05, 896 -> 18.43, 864 -> 18.10, 832 -> 17.75 / 18.4 GB, 800 -> 19.95, 768 -> 19.02
 constexpr int PRING = 2048;  // ring capacity (power of two >= PS)
 enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace

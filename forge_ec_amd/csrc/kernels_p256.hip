@@ -5,7 +5,7 @@
 // Every step doubles, but only the lanes whose bit is set need the (twice as expensive) addition.
 // Executing the addition for whole wavefronts under a mask wastes half of it; a step-synchronous
 // compaction (round 1) packs it but leaves SIMDs idle at three barriers per step (PMC: 40 % of wave
-// cycles parked, VALUBusy 82 %, profiles/pmc_r02_base_p256).  Here a workgroup keeps 1024 elements'
+// cycles parked, VALUBusy 82 %, profiles/pmc_r02_base_p256).  Here a workgroup keeps 832 elements'
 // state in LDS slots, and its wavefronts pull BATCHES from two ready queues: 64 elements whose next step has a
 // clear scalar bit (a doubling), or 64 elements whose next step has a set bit (a doubling and then the addition).  Elements therefore
 // advance at their own pace (each one still sees exactly the reference's operation sequence, so
@@ -86,10 +86,9 @@ FEC_DEV p256::pt ld_base(const u32* points, size_t g) {
   return p;
 }
 
-// Streaming accesses (a result is written once, a scalar is read eight words in 256 steps) carry the non-temporal
-// hint so that they do not push the base points -- re-read by every addition -- out of the XCD's L2.
+// Streaming accesses (a result is written once) carry the non-temporal hint so that they do not push the base points
+// -- re-read by every addition -- out of the XCD's L2.
 typedef u32 v4u_t __attribute__((ext_vector_type(4)));
-typedef u32 v2u_t __attribute__((ext_vector_type(2)));
 FEC_DEV void st_stream(u32* g, u32 a, u32 b, u32 c, u32 d) {
   v4u_t v = {a, b, c, d};
   __builtin_nontemporal_store(v, reinterpret_cast<v4u_t*>(g));
@@ -198,11 +197,14 @@ FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u
 
 // ---------------------------------------------------------------------------------------------------
 // Persistent workgroups (the shape of k_ed_mul_pers): one workgroup of TWELVE wavefronts per CU -- three per SIMD,
-// 168 VGPRs, the asm field blocks at v[122:167] -- owns a contiguous RANGE of elements and keeps QS = 1024 of them
-// in LDS slots (point 96 B + scalar 32 B), refilling a slot from the range the moment its element finishes: no
-// workgroup tail until the whole range is done.  History of this round per 2^20 batch: 512 elements per workgroup,
-// two workgroups of four wavefronts per CU 28.55 ms; persistent, eight wavefronts 28.2-28.4 ms; twelve wavefronts
-// with the operands of Add / double left in memory (padd_in_place, pdouble_in_place: no spills) 26.3 ms.
+// 168 VGPRs, the asm field blocks at v[122:167] -- owns a contiguous RANGE of elements and keeps QS = 832 of them
+// in LDS slots (point 96 B + scalar 32 B + z2z2 of the base point 32 B), refilling a slot from the range the moment its
+// element finishes: no workgroup tail until the whole range is done.  History per 2^20 batch -- round 2: 512 elements
+// per workgroup, two workgroups of four wavefronts per CU 28.55 ms; persistent, eight wavefronts 28.2-28.4 ms; twelve
+// wavefronts with the operands of Add / double left in memory (padd_in_place, pdouble_in_place: no spills) 26.3 ms;
+// rare legs in place, control words in LDS address space 24.9 ms -- round 3: the ladder's prefix answered by claim(),
+// z2z2 once per element 24.3 ms; one task per ladder step 23.8 ms; 832 slots with the whole scalar in LDS: the same
+// time at 1.05x the algorithmic bytes instead of 2.2x.
 // ---------------------------------------------------------------------------------------------------
 namespace {
 constexpr int QT = 768;      // threads per workgroup: 12 wavefronts, three per SIMD
