@@ -151,16 +151,22 @@ FEC_DEV p256::pt pdouble_in_place(const u32* lp, int stride) {
 // `lzz` (when not null): z2z2 = q.z * q.z of this addend in LDS (word w at lzz[w * zstride]), computed once per element
 // (or per launch for a fixed base) by the same sqr() -- the addend of an element never changes, and its square is one of
 // the sixteen products of every addition.
-FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u32* lzz, int zstride) {
+//
+// AFFINE (every lane's addend has z == 1 -- the generator, or a key that came through from_affine -- and every lane's
+// x1, y1 are below p, which the caller has tested): z2z2 = 1 * 1 is 1, and u1 = x1 * 1, s1 = y1 * 1 * 1 are x1 and y1
+// themselves, because Mul by the canonical 1 is reduce_wide of the operand followed by reduce() (544-704, 88-99), i.e.
+// the operand's canonical form.  Four of the sixteen products are gone, nothing else changes.
+template <bool AFFINE>
+FEC_DEV p256::pt padd_body(const u32* lp, int stride, const u32* gq, const u32* lzz, int zstride) {
   using namespace p256;
-  const fe z1 = ld_coord(lp, stride, 2), z2 = ld_base_coord(gq, 2);
-  const lmask idp = fe_is_zero(z1), idq = fe_is_zero(z2);
-  const fe z1z1 = sqr(z1), z2z2 = lzz ? ld_coord(lzz, zstride, 0) : sqr(z2);
+  const fe z1 = ld_coord(lp, stride, 2), z2 = AFFINE ? fe_small(1) : ld_base_coord(gq, 2);
+  const lmask idp = fe_is_zero(z1), idq = AFFINE ? (lmask)0 : fe_is_zero(z2);
+  const fe z1z1 = sqr(z1), z2z2 = AFFINE ? fe_small(1) : (lzz ? ld_coord(lzz, zstride, 0) : sqr(z2));
   const fe zs = sub(sub(sqr(add(z1, z2)), z1z1), z2z2);
-  const fe s1 = mul(mul(ld_coord(lp, stride, 1), z2), z2z2);
+  const fe s1 = AFFINE ? ld_coord(lp, stride, 1) : mul(mul(ld_coord(lp, stride, 1), z2), z2z2);
   __builtin_amdgcn_sched_barrier(0);  // keep the loads of q's coordinates where they are used (register budget)
   const fe s2 = mul(mul(ld_base_coord(gq, 1), z1), z1z1);
-  const fe u1 = mul(ld_coord(lp, stride, 0), z2z2);
+  const fe u1 = AFFINE ? ld_coord(lp, stride, 0) : mul(ld_coord(lp, stride, 0), z2z2);
   __builtin_amdgcn_sched_barrier(0);
   const fe u2 = mul(ld_base_coord(gq, 0), z1z1);
   const lmask ueq = fe_eq(u1, u2);
@@ -191,6 +197,17 @@ FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u
     if (nd != 0) o = pt_select(o, pdouble(p), nd);
   }
   return o;
+}
+// `q_affine` is wave-uniform: the caller knows that the addend of every lane that counts has z == 1
+FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u32* lzz, int zstride, bool q_affine) {
+  if (q_affine) {
+    // x1, y1 < p?  A value >= p has an all-ones top word (the reference's own Sub emits such values about once per
+    // 2^20 scalar-muls): the wavefront then takes the general form, whose products canonicalise them
+    const u32 x7 = lp[7 * stride], y7 = lp[15 * stride];
+    if (__builtin_expect(lanes_where(x7 == 0xFFFFFFFFu || y7 == 0xFFFFFFFFu) == 0, 1))
+      return padd_body<true>(lp, stride, gq, lzz, zstride);
+  }
+  return padd_body<false>(lp, stride, gq, lzz, zstride);
 }
 
 }  // namespace
@@ -306,7 +323,9 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
         cur = ((t - 1) >> 5) == w ? kw[w] : cur;
       }
       lds_gid[e] = (u32)rel;
-      lds_step[e] = (unsigned short)(256 - t);
+      // bit 15 of the step word: this element's base point has z == 1 (Add then needs four products fewer)
+      const bool z_one = lane_of(fe_eq(base.z, fe_small(1)));
+      lds_step[e] = (unsigned short)((256 - t) | (z_one ? 0x8000 : 0));
       return (int)(cur >> ((t - 1) & 31)) & 1;   // the bit of step 256 - t
     }
   };
@@ -404,7 +423,8 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     spins = 0;
     const bool active = lane < count;
     e = active ? lds_q[kind][(start + lane) & (QRING - 1)] : 0;
-    int step = active ? lds_step[e] : 0;
+    const int step_word = active ? lds_step[e] : 0x8000;   // (a lane without an element does not veto the z == 1 form)
+    int step = step_word & 0x7FFF;
     // Every global address below is formed from this index (written by claim(), always < range): a broken queue must
     // never address memory outside the workgroup's own range -- such a lane works on element 0, stores nothing, raises C_ERR.
     u32 gid = active ? lds_gid[e] : 0u;
@@ -437,14 +457,15 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       res = ld_pt(lds_st + e, QS);
       (void)g_el;
 #else
+      const bool all_affine = __builtin_amdgcn_ballot_w64(live && !(step_word & 0x8000)) == 0;
       res = padd_in_place(lds_st + e, QS, FIXED ? points : points + g_el * 24,
-                          FIXED ? (HOIST ? lds_zz : nullptr) : lds_zq + e, FIXED ? 1 : QS);
+                          FIXED ? (HOIST ? lds_zz : nullptr) : lds_zq + e, FIXED ? 1 : QS, all_affine);
 #endif
       FEC_MARK("task_add_end");
     }
     if (live) {
       ++step;
-      lds_step[e] = (unsigned short)step;
+      lds_step[e] = (unsigned short)(step | (step_word & 0x8000));
       fin = step == 256;
       if (!fin) {
         st_pt(lds_st + e, QS, res);

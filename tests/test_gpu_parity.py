@@ -192,6 +192,39 @@ def test_single_bit_and_word_boundary_scalars(gpu_ctx, oracle, curve):
                  "%s single-bit scalars, fixed base" % NAMES[curve])
 
 
+def test_p256_affine_addend_premise_and_kernel(gpu_ctx, oracle):
+    """The P-256 scheduler drops four of Add's sixteen products when the addend has z == 1 and x1, y1 are below p
+    (kernels_p256.hip: padd_body<true>).  The premise -- the reference's Mul by the canonical 1 returns the canonical
+    form of its operand, and 1 * 1 is 1 -- is checked on the oracle and on the GPU field kernels over random, edge
+    and non-canonical operands; then the kernel itself: bases with z == 1 (affine keys, the generator, arbitrary and
+    NON-canonical x, y), mixed with projective bases so that wavefronts hold both kinds, fixed and variable base."""
+    one = np.array([V.limbs_of(1)], dtype=np.uint64)
+    vals = [V.limbs_of(v) for v in V.edge_field_values(1)]
+    a = np.ascontiguousarray(np.concatenate([np.array(vals, dtype=np.uint64), V.field_elements(3000, 1, 471),
+                                             V.splitmix64(4 * 500, V.SEED, 472).reshape(-1, 4)]))
+    b = np.ascontiguousarray(np.tile(one, (a.shape[0], 1)))
+    got = gpu_ctx.field_op(1, F_MUL, a, b)
+    p = V.PRIME[1]
+    for i in range(a.shape[0]):
+        v = V.int_of(a[i])
+        assert V.int_of(got[i]) == (v if v < p else v - p), hex(v)
+        if i < 200:
+            assert [int(x) for x in oracle.field_op(1, "mul", a[i], one[0])] == [int(x) for x in got[i]]
+    assert [int(x) for x in gpu_ctx.field_op(1, F_SQR, one)[0]] == [1, 0, 0, 0]
+    n = 3000
+    k = V.scalars(n, 1, 473)
+    pts = V.points(n, 1, 474)
+    pts[::2, 8:12] = [1, 0, 0, 0]                              # every other base affine: mixed wavefronts
+    raw = V.splitmix64(8 * n, V.SEED, 475).reshape(n, 8)
+    pts[::6, 0:8] = raw[::6]                                   # some affine bases with arbitrary 256-bit (possibly >= p) x, y
+    _assert_same(gpu_ctx.batch_mul(1, k, pts), oracle.batch_mul(1, k, pts, nthreads=8), "p256 mixed affine / projective bases")
+    aff = pts.copy()
+    aff[:, 8:12] = [1, 0, 0, 0]                                # all affine: every addition batch takes the short form
+    _assert_same(gpu_ctx.batch_mul(1, k, aff), oracle.batch_mul(1, k, aff, nthreads=8), "p256 affine bases")
+    for base in (oracle.generator(1), np.ascontiguousarray(aff[6])):
+        _assert_same(gpu_ctx.batch_mul_fixed(1, k, base), oracle.batch_mul_fixed(1, k, base, nthreads=8), "p256 fixed affine base")
+
+
 def test_p256_ladder_takes_the_equal_points_branch(gpu_ctx, oracle):
     """P = (0, 2^63, z) satisfies double(P) ~ P under the reference's P-256 arithmetic (its Sub wraps
     mod 2^256: Y3 = 0 - 8*y^4 = 2^256 - 2^255), so `result + *point` finds projectively equal
