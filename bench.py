@@ -381,7 +381,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl,
                        "curve": curve, "kind": kind, "batch_per_gpu": n, "global_batch": n_global,
-                       "result_gather": (modes[0] if dist is not None else "n/a"),
+                       "result_gather": ("n/a" if dist is None else modes[0] + (
+                           " (this backend has no gather: all-gather used)" if modes[0] == "rank0" and gather0 is not None and gather0[0].dst is None else "")),
                        "device": info["name"], "compute_units": info["compute_units"]},
             "roofline": {
                 "bound": "int-valu", "achieved": achieved / 1e12, "peak": PEAK_MAD32_FORMULA / 1e12,

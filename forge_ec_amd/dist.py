@@ -25,6 +25,26 @@ def shard_sizes(n, world):
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
+_GATHER_OK = {}
+
+
+def _gather_supported(device, group, dst):
+    """One tiny dist.gather at construction time (a collective: every rank of the group runs it): does this backend
+    implement gather to one rank?  All ranks see the same answer, so they all pick the same collective afterwards."""
+    key = (dist.get_backend(group), str(device).split(":")[0])
+    if key not in _GATHER_OK:
+        try:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            probe = torch.zeros(1, dtype=torch.int64, device=device)
+            blocks = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)] if rank == dst else None
+            dst_global = dst if group is None else dist.get_global_rank(group, dst)
+            dist.gather(probe, gather_list=blocks, dst=dst_global, group=group)
+            _GATHER_OK[key] = True
+        except (RuntimeError, NotImplementedError):
+            _GATHER_OK[key] = False
+    return _GATHER_OK[key]
+
+
 class ResultGather:
     """Gather of the per-rank result shards into the full (n, limbs) result on rank `dst`
     (default 0), or on every rank when dst is None.
@@ -45,6 +65,9 @@ class ResultGather:
         self.limbs = limbs
         self.sizes = shard_sizes(n_total, self.world)
         self.pad = max(self.sizes)
+        if dst is not None and not _gather_supported(device, group, dst):
+            # (a backend build without gather: every rank then receives the batch -- more traffic, same result on rank dst)
+            self.dst = dst = None
         self.consumer = dst is None or dst == self.rank
         # only a consumer holds the assembled batch; the other ranks own one send block
         self.buf = torch.empty((self.world * self.pad, limbs), dtype=dtype, device=device) if self.consumer else None
