@@ -859,6 +859,7 @@ int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, siz
       return FEC_E_DEVICE;
     return FEC_OK;
   };
+  return drained(ctx, [&]() -> int {  // (a failure half-way leaves nothing queued on the caller's arrays)
   for (size_t c = 0; c < nchunks; ++c) {
     const int lane = (int)(c & 1);
     const size_t lo = c * chunk, cnt = (lo + chunk <= n ? chunk : n - lo);
@@ -886,6 +887,7 @@ int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, siz
   int rc = copy_back(nchunks - 1);
   if (rc != FEC_OK) return rc;
   return sync_and_check(ctx, ctx->stream, ctx->stream2);
+  }());
 }
 
 // Multi-device ctx: contiguous shards [g*n/N, (g+1)*n/N), one host thread per shard worker, each
@@ -1153,12 +1155,15 @@ int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, 
   if (curve == FEC_ED25519) {
     // the addend table is built once, on the ctx's first stream, before the pipeline starts
     if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-    int rc = ensure(ctx, 1, pb);
+    int rc = drained(ctx, [&]() -> int {
+      int r = ensure(ctx, 1, pb);
+      if (r != FEC_OK) return r;
+      if (hipMemcpyAsync(ctx->d_buf[1], base, pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+      r = ensure_ed_table(ctx, (const u64*)ctx->d_buf[1], base, ctx->stream);
+      if (r != FEC_OK) return r;
+      return hipStreamSynchronize(ctx->stream) == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
+    }());
     if (rc != FEC_OK) return rc;
-    if (hipMemcpyAsync(ctx->d_buf[1], base, pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-    rc = ensure_ed_table(ctx, (const u64*)ctx->d_buf[1], base, ctx->stream);
-    if (rc != FEC_OK) return rc;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return FEC_E_LAUNCH;
   }
   const HostIn in[3] = {{scalars, 32, 0}, {base, 0, pb}, {nullptr, 0, 0}};
   return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void*, void* o, size_t cnt, void* s) {
@@ -1191,6 +1196,7 @@ int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars,
   if (!ctx || !curve_ok(curve) || !out || (n && (!scalars || !points))) return FEC_E_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   const size_t pb = (size_t)plimbs(curve) * 8;
+  return drained(ctx, [&]() -> int {
   int rc = ensure(ctx, 6, (n ? n : 1) * pb);   // products stay on the device
   if (rc == FEC_OK) rc = ensure(ctx, 7, pb);
   if (rc != FEC_OK) return rc;
@@ -1219,8 +1225,8 @@ int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars,
     if (rc != FEC_OK) return rc;
   }
   if (hipMemcpyAsync(out, ctx->d_buf[7], pb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
-  return FEC_OK;
+  return sync_and_check(ctx, ctx->stream);
+  }());
 } FEC_ABI_CATCH_STATUS
 
 namespace {
@@ -1245,6 +1251,7 @@ int ecdsa_verify_host(fec_ctx* ctx, int curve, const uint8_t* digests, const uin
   if (!ctx || (n && (!digests || !r || !s || !pk_xy || !status))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return drained(ctx, [&]() -> int {
   const void* hin[5] = {digests, r, s, pk_xy, pk_inf};
   const size_t bytes[5] = {n * 32, n * 32, n * 32, n * 64, n};
   const int slot[5] = {0, 1, 2, 4, 5};
@@ -1262,8 +1269,8 @@ int ecdsa_verify_host(fec_ctx* ctx, int curve, const uint8_t* digests, const uin
                            pk_inf ? (const unsigned char*)ctx->d_buf[5] : nullptr, (unsigned char*)ctx->d_buf[3], n, nullptr);
   if (rc != FEC_OK) return rc;
   if (hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
-  return FEC_OK;
+  return sync_and_check(ctx, ctx->stream);
+  }());
 }
 }  // namespace
 
@@ -1300,6 +1307,13 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
   if (detail) std::memset(detail, 0, 16 * sizeof(uint64_t));
   if (n == 0) return FEC_OK;                                   // 289-291: false
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  // (the host targets of the device-to-host copies live outside the drained scope: a copy queued before a failure is
+  // waited for while they still exist)
+  std::unique_ptr<unsigned char[]> flags(new (std::nothrow) unsigned char[n]);  // no exception may cross the C ABI
+  if (!flags) return FEC_E_OOM;
+  unsigned char res = 0;
+  uint64_t det[16];
+  return drained(ctx, [&]() -> int {
   // slots: 0 digests, 1 r, 2 s, 3 pk, 4 a, 5 pk_inf, 6 work area, 7 r_sum + detail + result
   const void* hin[6] = {digests, r, s, pk_xy, a, pk_inf};
   const size_t bytes[6] = {n * 32, n * 32, n * 32, n * 64, n * 32, n};
@@ -1323,8 +1337,6 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
     if (rc != FEC_OK) return rc;
   }
   // the loop returns at the first signature that fails a check (317-342): nothing after it is computed
-  std::unique_ptr<unsigned char[]> flags(new (std::nothrow) unsigned char[n]);  // no exception may cross the C ABI
-  if (!flags) return FEC_E_OOM;
   if (hipMemcpyAsync(flags.get(), work + n * 352, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
   if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   for (size_t i = 0; i < n; ++i)
@@ -1350,8 +1362,6 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
     rc = L.done();
     if (rc != FEC_OK) return rc;
   }
-  unsigned char res = 0;
-  uint64_t det[16];
   if (hipMemcpyAsync(&res, tail + 96 + 128, 1, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipMemcpyAsync(det, tail + 96, 128, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
     return FEC_E_DEVICE;
@@ -1359,6 +1369,7 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
   *result = res;
   if (detail) std::memcpy(detail, det, 128);
   return FEC_OK;
+  }());
 } FEC_ABI_CATCH_STATUS
 
 int fec_batch_validate_point_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf, uint8_t* d_ok,
@@ -1381,6 +1392,7 @@ int fec_batch_validate_point(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, 
   if (!ctx || (n && (!xy || !ok))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return drained(ctx, [&]() -> int {
   int rc = ensure(ctx, 0, n * 64);
   if (rc == FEC_OK && inf) rc = ensure(ctx, 1, n);
   if (rc == FEC_OK) rc = ensure(ctx, 2, n);
@@ -1391,8 +1403,8 @@ int fec_batch_validate_point(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, 
                        (unsigned char*)ctx->d_buf[2], n, nullptr);
   if (rc != FEC_OK) return rc;
   if (hipMemcpyAsync(ok, ctx->d_buf[2], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
-  return FEC_OK;
+  return sync_and_check(ctx, ctx->stream);
+  }());
 } FEC_ABI_CATCH_STATUS
 
 int fec_batch_ecdh_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_private_keys, const uint64_t* d_pk_xy,
@@ -1464,6 +1476,7 @@ int fec_eddsa_verify_ed25519(fec_ctx* ctx, const uint64_t* r_xy, const uint8_t* 
   if (!ctx || (n && (!r_xy || !pk_xy || !s || !k || !status))) return FEC_E_ARG;
   if (n == 0) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  return drained(ctx, [&]() -> int {
   const void* hin[6] = {r_xy, pk_xy, s, k, r_inf, pk_inf};
   const size_t bytes[6] = {n * 64, n * 64, n * 32, n * 32, n, n};
   const int slot[6] = {0, 1, 2, 4, 5, 6};
@@ -1481,8 +1494,8 @@ int fec_eddsa_verify_ed25519(fec_ctx* ctx, const uint64_t* r_xy, const uint8_t* 
                            (const u64*)ctx->d_buf[2], (const u64*)ctx->d_buf[4], (unsigned char*)ctx->d_buf[3], n, nullptr);
   if (rc != FEC_OK) return rc;
   if (hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
-  return FEC_OK;
+  return sync_and_check(ctx, ctx->stream);
+  }());
 } FEC_ABI_CATCH_STATUS
 
 int fec_schnorr_verify_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_pk_xy, const uint8_t* d_pk_inf,
@@ -1510,6 +1523,7 @@ int fec_schnorr_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_xy, con
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   // chunked like the other element-wise calls; slots: 0 pk, 1 r, 2 s, 4 e, 5 pk_inf, 6 r_inf, 3 status
   const size_t chunk = ctx->chunk < n ? ctx->chunk : n;
+  return drained(ctx, [&]() -> int {
   for (size_t lo = 0; lo < n; lo += chunk) {
     const size_t cnt = lo + chunk <= n ? chunk : n - lo;
     const void* hin[6] = {pk_xy + lo * 8, r_xy + lo * 8, s + lo * 4, e + lo * 4, pk_inf ? pk_inf + lo : nullptr,
@@ -1533,6 +1547,7 @@ int fec_schnorr_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_xy, con
     if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   }
   return FEC_OK;
+  }());
 } FEC_ABI_CATCH_STATUS
 
 namespace {
@@ -1552,6 +1567,9 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   const bool secp = curve == FEC_SECP256K1;
   const size_t pb = 96;
+  unsigned char flags[8] = {0};  // (host targets of the last copies: outside the drained scope, see fec_ecdsa_batch_verify)
+  uint64_t sides[16];
+  return drained(ctx, [&]() -> int {
   // slots: 0 pk, 1 r, 2 s, 3 a, 4 e, 5 A terms, 6 B terms, 7 sums + affine sides + flags + counter
   const size_t bytes[5] = {n * 64, n * 64, n * 32, n * 32, n * 32};
   const void* src[5] = {pk_xy, r_xy, s, a, e};
@@ -1615,8 +1633,6 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
   if (secp) hipLaunchKernelGGL((k_schnorr_fold_compare<Secp>), dim3(2), dim3(64), 0, ctx->stream, (const u32*)ctx->d_buf[5], (const u32*)ctx->d_buf[6], d_sums, d_sides, d_flags, d_done, n);
   else hipLaunchKernelGGL((k_schnorr_fold_compare<P256>), dim3(2), dim3(64), 0, ctx->stream, (const u32*)ctx->d_buf[5], (const u32*)ctx->d_buf[6], d_sums, d_sides, d_flags, d_done, n);
   if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
-  unsigned char flags[8] = {0};
-  uint64_t sides[16];
   if (hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipMemcpyAsync(sides, d_sides, 128, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
     return FEC_E_DEVICE;
@@ -1625,6 +1641,7 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
   if (sides_xy) std::memcpy(sides_xy, sides, 128);
   if (sides_inf) { sides_inf[0] = flags[1]; sides_inf[1] = flags[2]; }
   return FEC_OK;
+  }());
 }
 }  // namespace
 
@@ -1675,6 +1692,7 @@ static int decode_host(fec_ctx* ctx, int op, fec_curve curve, const uint8_t* in,
                        uint8_t* inf, uint8_t* ok, size_t n) {
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   const size_t chunk = ctx->chunk < n ? ctx->chunk : n;
+  return drained(ctx, [&]() -> int {
   for (size_t lo = 0; lo < n; lo += chunk) {
     const size_t cnt = lo + chunk <= n ? chunk : n - lo;
     int rc = ensure(ctx, 0, chunk * in_stride);
@@ -1698,6 +1716,7 @@ static int decode_host(fec_ctx* ctx, int op, fec_curve curve, const uint8_t* in,
     if (rc != FEC_OK) return rc;
   }
   return FEC_OK;
+  }());
 }
 
 int fec_batch_decompress(fec_ctx* ctx, fec_curve curve, const uint8_t* in, uint64_t* xy, uint8_t* inf, uint8_t* ok,
@@ -1769,6 +1788,7 @@ int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points, u
   if (n == 0) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   size_t pb = (size_t)plimbs(curve) * 8;
+  return drained(ctx, [&]() -> int {
   int rc = ensure(ctx, 0, n * pb);
   if (rc == FEC_OK) rc = ensure(ctx, 3, n * 64);
   if (rc == FEC_OK) rc = ensure(ctx, 1, n);
@@ -1781,8 +1801,8 @@ int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points, u
   if (hipMemcpyAsync(xy, ctx->d_buf[3], n * 64, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipMemcpyAsync(inf, ctx->d_buf[1], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
     return FEC_E_DEVICE;
-  if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
-  return FEC_OK;
+  return sync_and_check(ctx, ctx->stream);
+  }());
 } FEC_ABI_CATCH_STATUS
 
 int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a, const uint64_t* b,

@@ -214,6 +214,19 @@ inline int sync_and_check(fec_ctx* ctx, hipStream_t a, hipStream_t b = nullptr) 
   return take_device_error(ctx);
 }
 
+// The way out of a host-pointer entry point whose work was queued on the ctx's own streams.  A call that fails half-way
+// (an allocation, a refused copy, a launch error) may still have copies from or into the caller's arrays queued, and the
+// caller is free to release those arrays as soon as the call is back: the streams are drained first, and a device error
+// word raised by the abandoned launches is dropped with them instead of being reported by the next, unrelated call.
+inline int drained(fec_ctx* ctx, int rc) {
+  if (rc == FEC_OK) return rc;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+  (void)hipGetLastError();
+  (void)take_device_error(ctx);
+  return rc;
+}
+
 // Host-pointer call over chunks of ctx->chunk elements with up to four per-element inputs (slots 0-3)
 // and two per-element outputs (slots 4-5): H2D, body(d_in[4], d_out[2], count), D2H per chunk on the
 // ctx stream.  Device staging and any per-element scratch the body allocates stay bounded by one
@@ -223,6 +236,7 @@ inline int host_chunked(fec_ctx* ctx, size_t n, const void* const in[4], const s
                         const size_t out_stride[2], F body) {
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   const size_t chunk = ctx->chunk < n ? ctx->chunk : n;
+  return drained(ctx, [&]() -> int {
   for (size_t lo = 0; lo < n; lo += chunk) {
     const size_t cnt = lo + chunk <= n ? chunk : n - lo;
     void* d_in[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -254,6 +268,7 @@ inline int host_chunked(fec_ctx* ctx, size_t n, const void* const in[4], const s
     if (rc != FEC_OK) return rc;
   }
   return FEC_OK;
+  }());
 }
 
 }  // namespace host

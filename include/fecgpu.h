@@ -66,7 +66,9 @@
  * Multi-GPU comes in two forms: fec_ctx_create_multi -- ONE ctx whose
  * element-wise host-pointer calls are sharded over several devices inside the library (what a Rust
  * caller binds) -- or one process per GPU, each with its own single-device ctx and the *_dev entry
- * points (what bench.py does under torch.distributed).
+ * points (what bench.py does under torch.distributed).  Every call makes its ctx's device the calling
+ * thread's current HIP device (hipSetDevice) and leaves it so.  When a host-pointer call returns -- with
+ * any status -- nothing it queued is still reading or writing the caller's arrays.
  *
  * Errors: 0 on success, negative fec_status otherwise.  The library itself never calls abort() and no
  * C++ exception leaves it (every entry point is a function-try-block).  A fault that a KERNEL reports
