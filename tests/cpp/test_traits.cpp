@@ -186,6 +186,38 @@ static void signature_layer_and_codecs() {
     CHECK(st[1] == Verify::False, "EdDSA verify: another R does not");
     CHECK(st[2] == Verify::False, "EdDSA verify: an infinite R is false (174-177)");
   }
+  // Schnorr::verify (schnorr.rs:90-140) on P-256 with the challenge e = 1: e*P is P itself (multiply by 1 returns the
+  // point as it is), so R = to_affine(s*G + (x, -y, 1)) verifies (136-142) -- for a public key whose negation passes
+  // the reference's PointAffine::new (132-134).  G itself does not (x^3 < 3x takes Sub's wrapping branch, p256.rs:470-496);
+  // the true 3*G (canonical-math mode) does.  Another R does not verify; an infinite R is false (103-105)
+  {
+    auto g = P256::generator();
+    auto g3 = canon::mul_base<FEC_P256>(ctx, {Limbs{3, 0, 0, 0}});
+    CHECK(g3.status[0] == 0, "canonical 3*G is finite");
+    P256::PointAffine pa;
+    pa.x_ = P256::Field::from_raw(g3.points[0].x);
+    pa.y_ = P256::Field::from_raw(g3.points[0].y);
+    std::vector<P256::PointAffine> pks(3, pa);
+    std::vector<schnorr::SignatureOf<FEC_P256>> sigs(3);
+    std::vector<P256::ScalarT> e(3, P256::ScalarT::from(1));
+    P256::PointProjective neg_p;
+    const auto ny = -pa.y_;
+    for (int l = 0; l < 4; ++l) {
+      neg_p.c[l] = pa.x_.raw[l];
+      neg_p.c[4 + l] = ny.raw[l];
+    }
+    neg_p.c[8] = 1;
+    for (uint64_t i = 0; i < 3; ++i) {
+      sigs[i].s = P256::ScalarT::from(4242 + i);
+      sigs[i].r = P256::to_affine(P256::multiply(g, sigs[i].s) + neg_p);
+    }
+    sigs[1].r = P256::to_affine(P256::multiply(g, P256::ScalarT::from(5)));
+    sigs[2].r.infinity = true;
+    auto st = schnorr::verify<FEC_P256>(ctx, pks, sigs, e);
+    CHECK(st[0] == Verify::True, "Schnorr verify: R = s*G - e*P verifies (P-256, e = 1)");
+    CHECK(st[1] == Verify::False, "Schnorr verify: another R does not");
+    CHECK(st[2] == Verify::False, "Schnorr verify: an infinite R is false (103-105)");
+  }
   // KeyExchange::derive_shared_secret (secp256k1.rs:1884-1904): the secret is x.to_bytes() of multiply(pk, sk) --
   // the same bytes PointAffine::to_bytes carries after its tag; a zero private key gives the identity -> Err
   {

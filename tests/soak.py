@@ -1,7 +1,7 @@
 """Whole-batch differential soak on the GPU box: every element of large random batches of the verification /
 key-exchange / validation pipelines against the C oracle (16 host threads).  Prints one JSON line per pipeline.
 
-  python tests/soak.py [log2-batch, default 19]
+  python tests/soak.py [log2-batch, default 19] [seed offset, default 0: another offset is another set of batches]
 """
 import json
 import os
@@ -20,41 +20,50 @@ from oracle import c_oracle as O  # noqa: E402
 
 def main():
     n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 19)
+    so = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     ctx = F.Context(0)
-    rng = np.random.default_rng(20261004)
+    rng = np.random.default_rng(20261004 + so)
 
     def report(name, got, want, t_gpu, t_cpu):
         bad = int(np.count_nonzero(np.any(np.asarray(got).reshape(n, -1) != np.asarray(want).reshape(n, -1), axis=1)))
         hist = {int(k): int(v) for k, v in zip(*np.unique(np.asarray(want).reshape(n, -1)[:, -1] if np.asarray(want).ndim > 1 else want, return_counts=True))} if np.asarray(want).ndim == 1 else None
-        print(json.dumps({"pipeline": name, "n": n, "mismatches": bad, "status_histogram": hist,
+        print(json.dumps({"pipeline": name, "n": n, "seed_offset": so, "mismatches": bad, "status_histogram": hist,
                           "gpu_s": round(t_gpu, 3), "oracle_s": round(t_cpu, 1)}), flush=True)
         return bad
 
     total = 0
     for curve in (0, 1, 2):   # whole-batch fixed-base and variable-base multiplications
         g = O.generator(curve)
-        k = V.scalars(n, curve, 8001 + curve)
+        k = V.scalars(n, curve, 8001 + curve + so)
         k[::1001] = 0
         t0 = time.perf_counter(); got = ctx.batch_mul_fixed(curve, k, g); t1 = time.perf_counter()
         want = O.batch_mul_fixed(curve, k, g, nthreads=16); t2 = time.perf_counter()
         total += report("multiply fixed-base curve %d" % curve, got, want, t1 - t0, t2 - t1)
-        p = V.points(n, curve, 8011 + curve)
+        p = V.points(n, curve, 8011 + curve + so)
         p[7::997] = O.identity(curve)
         t0 = time.perf_counter(); got = ctx.batch_mul(curve, k, p); t1 = time.perf_counter()
         want = O.batch_mul(curve, k, p, nthreads=16); t2 = time.perf_counter()
         total += report("multiply variable-base curve %d" % curve, got, want, t1 - t0, t2 - t1)
+    for curve in (0, 1, 2):   # multiply(G, u1) + multiply(Q, u2) (BASELINE configs[4] is the secp256k1 one)
+        u1, u2 = V.scalars(n, curve, 8021 + curve + so), V.scalars(n, curve, 8031 + curve + so)
+        u1[::1003] = 0
+        q = V.points(n, curve, 8041 + curve + so)
+        q[5::991] = O.identity(curve)
+        t0 = time.perf_counter(); got = ctx.batch_double_mul(curve, u1, u2, q); t1 = time.perf_counter()
+        want = O.batch_double_mul(curve, u1, u2, q, nthreads=16); t2 = time.perf_counter()
+        total += report("double multiplication curve %d" % curve, got, want, t1 - t0, t2 - t1)
     for curve, fn, ofn in ((0, ctx.ecdsa_verify_secp256k1, O.batch_secp256k1_ecdsa_verify), (1, ctx.ecdsa_verify_p256, O.batch_p256_ecdsa_verify)):
         dg = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
         dg[::3, 0] &= 0x7F
-        r, s = V.scalars(n, curve, 9001), V.scalars(n, curve, 9002)
-        pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 9003), V.field_elements(n, curve, 9004)], axis=1))
+        r, s = V.scalars(n, curve, 9001 + so), V.scalars(n, curve, 9002 + so)
+        pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 9003 + so), V.field_elements(n, curve, 9004 + so)], axis=1))
         inf = (rng.integers(0, 64, size=n) == 0).astype(np.uint8)
         t0 = time.perf_counter(); got = fn(dg, r, s, pk, inf); t1 = time.perf_counter()
         want = ofn(dg, r, s, pk, inf, nthreads=16); t2 = time.perf_counter()
         total += report("ecdsa_verify " + ("secp256k1" if curve == 0 else "p256"), got, want, t1 - t0, t2 - t1)
-    s, k = V.scalars(n, 2, 9011), V.scalars(n, 2, 9012)
-    pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 9013), V.field_elements(n, 2, 9014)], axis=1))
-    rr = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 9015), V.field_elements(n, 2, 9016)], axis=1))
+    s, k = V.scalars(n, 2, 9011 + so), V.scalars(n, 2, 9012 + so)
+    pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 9013 + so), V.field_elements(n, 2, 9014 + so)], axis=1))
+    rr = np.ascontiguousarray(np.concatenate([V.field_elements(n, 2, 9015 + so), V.field_elements(n, 2, 9016 + so)], axis=1))
     pinf = (rng.integers(0, 16, size=n) == 0).astype(np.uint8)
     rinf = (rng.integers(0, 64, size=n) == 0).astype(np.uint8)
     t0 = time.perf_counter(); got = ctx.eddsa_verify_ed25519(rr, rinf, pk, pinf, s, k); t1 = time.perf_counter()
@@ -62,9 +71,9 @@ def main():
     total += report("eddsa_verify ed25519", got, want, t1 - t0, t2 - t1)
     for curve in (0, 1, 2):   # Schnorr verify per signature (P-256: a quarter of the keys true curve points, e = 1 for some)
         m4 = n >> 2
-        pk = np.ascontiguousarray(np.concatenate([V.field_elements(m4, curve, 9041), V.field_elements(m4, curve, 9042)], axis=1))
-        rr = np.ascontiguousarray(np.concatenate([V.field_elements(m4, curve, 9043), V.field_elements(m4, curve, 9044)], axis=1))
-        ss, ee = V.scalars(m4, curve, 9045), V.scalars(m4, curve, 9046)
+        pk = np.ascontiguousarray(np.concatenate([V.field_elements(m4, curve, 9041 + so), V.field_elements(m4, curve, 9042 + so)], axis=1))
+        rr = np.ascontiguousarray(np.concatenate([V.field_elements(m4, curve, 9043 + so), V.field_elements(m4, curve, 9044 + so)], axis=1))
+        ss, ee = V.scalars(m4, curve, 9045 + so), V.scalars(m4, curve, 9046 + so)
         ee[::5] = [1, 0, 0, 0]
         pinf = (rng.integers(0, 16, size=m4) == 0).astype(np.uint8)
         rinf = (rng.integers(0, 64, size=m4) == 0).astype(np.uint8)
@@ -75,8 +84,8 @@ def main():
                           "oracle_s": round(t2 - t1, 1)}), flush=True)
         total += bad
     for curve in (0, 1):
-        sk = V.scalars(n, curve, 9021)
-        pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 9022), V.field_elements(n, curve, 9023)], axis=1))
+        sk = V.scalars(n, curve, 9021 + so)
+        pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 9022 + so), V.field_elements(n, curve, 9023 + so)], axis=1))
         if curve == 1:  # true curve points for a quarter of the batch: the reference accepts about half of them
             import random
             pr, pb = V.PRIME[1], 0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B
@@ -94,7 +103,7 @@ def main():
         total += report("ecdh " + ("secp256k1" if curve == 0 else "p256") + " (Ok: %d)" % int((wst == 0).sum()),
                         np.concatenate([sec, st[:, None]], axis=1), np.concatenate([wsec, wst[:, None]], axis=1), t1 - t0, t2 - t1)
     m = n >> 2
-    xy = np.ascontiguousarray(np.concatenate([V.field_elements(m, 2, 9031), V.field_elements(m, 2, 9032)], axis=1))
+    xy = np.ascontiguousarray(np.concatenate([V.field_elements(m, 2, 9031 + so), V.field_elements(m, 2, 9032 + so)], axis=1))
     xy[::7, :4] = 0
     inf = (rng.integers(0, 16, size=m) == 0).astype(np.uint8)
     t0 = time.perf_counter(); got = ctx.batch_validate_point(2, xy, inf); t1 = time.perf_counter()
