@@ -515,7 +515,60 @@ const u64 GEN_ED[16] = {0x1A1462FAFB9683F2ULL, 0xD2E8A68B8B30C404ULL, 0xA0C0F3A1
                         0xA6FB8EEBCEAA2C8DULL, 0x5FD9C9E6CC3CCCCCULL, 1, 0, 0, 0,
                         0, 0, 0, 0};  // T is filled in on the device
 const u64 FE_ONE[4] = {1, 0, 0, 0};
+// Fixed-base prefix tables: 2^24 entries by default (secp256k1 3.0 GiB, built in ~45 ms on the first fixed-base launch;
+// 24 of the 256 ladder steps are then a table fetch); at most 2^28 (48 GiB for secp256k1: sized for 288 GB of HBM).
+constexpr unsigned kDefaultPrefixBits = 24, kMaxPrefixBits = 28;
 
+
+// The fixed-base prefix table of `curve`'s generator() (kernels_secp.hip: k_secp_mul MODE 2 / 3), built on the first
+// fixed-base launch that can use it, on that launch's stream.  Refused memory is not an error: the launches then run the
+// whole ladder (SchedEnv carries a null table).
+void ensure_gen_prefix(fec_ctx* ctx, int curve, hipStream_t s) {
+  if (ctx->prefix_bits == 0 || ctx->gen_prefix_tried[curve]) return;
+  ctx->gen_prefix_tried[curve] = true;
+  const unsigned w = ctx->prefix_bits;
+  const size_t entries = (size_t)1 << w;
+  // secp256k1: the ladder's pair (r0, r1); P-256: the running result; Ed25519: the running result (X, Y, Z, T)
+  const size_t entry_words = curve == FEC_SECP256K1 ? 48 : (curve == FEC_P256 ? 24 : 32);
+  void* t = nullptr;
+  void* idx = nullptr;
+  auto give_up = [&] {
+    (void)hipGetLastError();
+    if (t) (void)hipFree(t);
+    if (idx) (void)hipFree(idx);
+  };
+  if (hipMalloc(&t, entries * entry_words * sizeof(u32)) != hipSuccess) return give_up();
+  const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
+  order_after_previous(ctx, s);
+  if (curve == FEC_SECP256K1) {
+    secp_prefix_build_launch(gen, static_cast<u32*>(t), (int)w, s);
+  } else {
+    // P-256 / Ed25519: entry i is multiply(G, i) itself -- the leading steps of a small scalar leave the running result
+    // at the identity (P-256: doublings of the identity, p256.rs:1870; Ed25519: no addition below the first set bit), so
+    // the multiplication kernels produce the table from the scalars 0 .. 2^w - 1 (no table of their own yet: SchedEnv
+    // still carries a null one for this curve).
+    if (hipMalloc(&idx, entries * 32) != hipSuccess) return give_up();
+    index_scalars_launch(static_cast<u32*>(idx), entries, s);
+    if (curve == FEC_P256) p256_launch_mul(sched_env(ctx), true, static_cast<const u32*>(idx), gen, static_cast<u32*>(t), entries, s);
+    else ed_fixed_launch(sched_env(ctx), static_cast<const u32*>(idx), gen, ctx->d_ed_table, static_cast<u32*>(t), entries, nullptr, s);
+  }
+  // once per ctx and curve: wait here, so that a failed build (a launch error, a scheduler fault -- its error word stays
+  // set for the caller's own check) never becomes a table
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+      (ctx->h_err && *reinterpret_cast<volatile unsigned*>(ctx->h_err) != 0))
+    return give_up();
+  if (idx) (void)hipFree(idx);
+  ctx->d_gen_prefix[curve] = static_cast<u32*>(t);
+  ctx->gen_prefix_bits[curve] = w;
+}
+void drop_gen_prefix(fec_ctx* ctx) {  // (hipFree waits for the device: no launch is still reading a table)
+  for (int c = 0; c < 3; ++c) {
+    if (ctx->d_gen_prefix[c]) (void)hipFree(ctx->d_gen_prefix[c]);
+    ctx->d_gen_prefix[c] = nullptr;
+    ctx->gen_prefix_bits[c] = 0;
+    ctx->gen_prefix_tried[c] = false;
+  }
+}
 
 // Build (or reuse) the Ed25519 addend table for the base at device address d_base.  `host_base`
 // (may be null) is the same point on the host and lets repeated calls with one base skip the build.
@@ -539,10 +592,11 @@ int launch_ed_fixed(fec_ctx* ctx, const u64* ds, const u64* dbase, const u64* ho
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int rc = ensure_ed_table(ctx, dbase, host_base, s);
   if (rc != FEC_OK) return rc;
+  if (dbase == ctx->d_gen[FEC_ED25519]) ensure_gen_prefix(ctx, FEC_ED25519, s);
   void* work = nullptr;  // the batch-wide popcount sort of large batches: per-stream scratch
   if (ed_fixed_work_bytes(n) != 0 && !(work = scratch_for(ctx, s, ed_fixed_work_bytes(n)))) return FEC_E_OOM;
   Launch L(ctx, stream, work ? "k_ed_fixed_sorted (+ k_ed_pc_hist, k_ed_pc_scan, k_ed_pc_scatter)" : "k_ed_fixed_base");
-  ed_fixed_launch(reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(dbase), ctx->d_ed_table,
+  ed_fixed_launch(sched_env(ctx), reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(dbase), ctx->d_ed_table,
                   reinterpret_cast<u32*>(dout), n, work, L.s);
   return L.done();
 }
@@ -557,9 +611,10 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
   const char* name = curve == FEC_SECP256K1 ? (fixed ? "k_secp_mul<fixed>" : "k_secp_mul<var>")
                      : curve == FEC_P256    ? (fixed ? "k_p256_mul_sched<fixed>" : "k_p256_mul_sched<var>")
                                             : "k_ed_mul_pers";
+  if (fixed && dp == ctx->d_gen[curve]) ensure_gen_prefix(ctx, curve, stream ? (hipStream_t)stream : ctx->stream);
   Launch L(ctx, stream, name);
   switch (curve) {
-    case FEC_SECP256K1: secp_launch_mul(fixed, s, p, o, n, L.s); break;
+    case FEC_SECP256K1: secp_launch_mul(sched_env(ctx), fixed, s, p, o, n, L.s); break;
     case FEC_P256: p256_launch_mul(sched_env(ctx), fixed, s, p, o, n, L.s); break;
     default: ed_launch_mul(sched_env(ctx), s, p, o, n, L.s); break;
   }
@@ -624,6 +679,7 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
     int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
     if (rc != FEC_OK) return rc;
   }
+  ensure_gen_prefix(ctx, curve, st);
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op"
                         : (curve == FEC_P256 ? "k_p256_mul_sched x2 + k_point_op" : "k_ed_fixed_base + k_ed_mul_pers + k_point_op"));
   // The fixed-base product runs on the ctx's second stream beside the variable-base one (the persistent kernels, one
@@ -636,9 +692,9 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
   }();
   SideStream side(ctx, L.s, n, curve == FEC_ED25519 ? (size_t)1 << 15 : side_max);
   if (curve == FEC_SECP256K1) {  // the 3-waves-per-SIMD ladder twice (fixed G, then Q) beats the fused 2-wave kernel
-    secp_launch_mul(true, a, gen, ta, n, side.s);
+    secp_launch_mul(sched_env(ctx), true, a, gen, ta, n, side.s);
     side.fork_done();
-    secp_launch_mul(false, b2, q, tb, n, L.s);
+    secp_launch_mul(sched_env(ctx), false, b2, q, tb, n, L.s);
     side.join();
     hipLaunchKernelGGL((k_point_op<Secp>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   } else if (curve == FEC_P256) {
@@ -648,7 +704,7 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
     side.join();
     hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   } else {
-    ed_fixed_launch(a, gen, ctx->d_ed_table, ta, n, ed_work ? scratch + 2 * n * pb : nullptr, side.s);  // (ed_work != 0 only where the side stream is off)
+    ed_fixed_launch(sched_env(ctx), a, gen, ctx->d_ed_table, ta, n, ed_work ? scratch + 2 * n * pb : nullptr, side.s);  // (ed_work != 0 only where the side stream is off)
     side.fork_done();
     ed_launch_mul(sched_env(ctx), b2, q, tb, n, L.s, side.active ? 2 : 1);
     side.join();
@@ -693,6 +749,7 @@ int launch_ecdsa_verify(fec_ctx* ctx, int curve, const unsigned char* dd, const 
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   void* work = scratch_for(ctx, st, ecdsa_work_bytes(n));
   if (!work) return FEC_E_OOM;
+  ensure_gen_prefix(ctx, curve, st);
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_ecdsa_pre + k_secp_mul x2 + k_ecdsa_finish"
                                                : "k_ecdsa_pre + k_p256_mul_sched x2 + k_ecdsa_finish");
   ecdsa_launch(sched_env(ctx), curve, dd, reinterpret_cast<const u32*>(dr), reinterpret_cast<const u32*>(ds),
@@ -716,9 +773,10 @@ int launch_eddsa_verify(fec_ctx* ctx, const u64* dr, const unsigned char* drinf,
   u32* ka = reinterpret_cast<u32*>(work + n * 256);
   int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
   if (rc != FEC_OK) return rc;
+  ensure_gen_prefix(ctx, FEC_ED25519, st);
   Launch L(ctx, stream, "k_eddsa_pre + k_ed_fixed_base + k_ed_mul_pers + k_eddsa_finish");
   eddsa_pre_launch(reinterpret_cast<const u32*>(dpk), dpinf, a, n, L.s);
-  ed_fixed_launch(reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(ctx->d_gen[FEC_ED25519]),
+  ed_fixed_launch(sched_env(ctx), reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(ctx->d_gen[FEC_ED25519]),
                   ctx->d_ed_table, sg, n, ed_work ? work + n * 384 : nullptr, L.s);
   ed_launch_mul(sched_env(ctx), reinterpret_cast<const u32*>(dk), a, ka, n, L.s);
   eddsa_finish_launch(sg, ka, reinterpret_cast<const u32*>(dr), drinf, dstatus, n, L.s);
@@ -747,19 +805,20 @@ int launch_schnorr_verify(fec_ctx* ctx, int curve, const u64* dpk, const unsigne
     int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
     if (rc != FEC_OK) return rc;
   }
+  ensure_gen_prefix(ctx, curve, st);
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_schnorr_verify_pre + k_secp_mul x2 + k_schnorr_verify_finish"
                         : (curve == FEC_P256 ? "k_schnorr_verify_pre + k_p256_mul_sched x2 + k_schnorr_verify_finish"
                                              : "k_schnorr_verify_pre + k_ed_fixed_base + k_ed_mul_pers + k_schnorr_verify_finish"));
   schnorr_verify_pre_launch(curve, reinterpret_cast<const u32*>(dpk), dpinf, a, n, L.s);
   if (curve == FEC_ED25519) {
-    ed_fixed_launch(sc, gen, ctx->d_ed_table, sg, n, ed_work ? work + 3 * n * pb : nullptr, L.s);
+    ed_fixed_launch(sched_env(ctx), sc, gen, ctx->d_ed_table, sg, n, ed_work ? work + 3 * n * pb : nullptr, L.s);
     ed_launch_mul(sched_env(ctx), ec, a, ep, n, L.s);
   } else {
     SideStream side(ctx, L.s, n);
     if (curve == FEC_SECP256K1) {
-      secp_launch_mul(true, sc, gen, sg, n, side.s);
+      secp_launch_mul(sched_env(ctx), true, sc, gen, sg, n, side.s);
       side.fork_done();
-      secp_launch_mul(false, ec, a, ep, n, L.s);
+      secp_launch_mul(sched_env(ctx), false, ec, a, ep, n, L.s);
     } else {
       p256_launch_mul(sched_env(ctx), true, sc, gen, sg, n, side.s, side.active ? 2 : 1);
       side.fork_done();
@@ -963,6 +1022,12 @@ int fec_ctx_create(fec_ctx** out, int device) try {
   {
     const char* e = std::getenv("FEC_CANON_COMB4");
     ctx->canon_use_comb8 = !(e && e[0] == '1');
+    const char* w = std::getenv("FEC_FIXED_PREFIX_BITS");   // fixed-base prefix tables (ensure_gen_prefix): 0 = off
+    ctx->prefix_bits = kDefaultPrefixBits;
+    if (w && *w) {
+      const unsigned long v = std::strtoul(w, nullptr, 10);
+      ctx->prefix_bits = v > kMaxPrefixBits ? kMaxPrefixBits : (unsigned)v;
+    }
   }
   if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
       std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0 ||
@@ -1008,6 +1073,8 @@ int fec_ctx_create(fec_ctx** out, int device) try {
                             ctx->d_gen[2] + 12, 1) == FEC_OK;
     ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
     ok = ok && hipMemcpy(ctx->h_gen_ed, ctx->d_gen[2], 128, hipMemcpyDeviceToHost) == hipSuccess;
+    for (int c = 0; c < 3 && ok; ++c)
+      ok = hipMemcpy(ctx->h_gen[c], ctx->d_gen[c], (size_t)plimbs(c) * 8, hipMemcpyDeviceToHost) == hipSuccess;
     if (!ok) {
       (void)hipGetLastError();
       fec_ctx_destroy(ctx);
@@ -1073,6 +1140,7 @@ void fec_ctx_destroy(fec_ctx* ctx) try {
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   ctx->h_err = ctx->d_err = nullptr;
   if (ctx->d_ed_table) (void)hipFree(ctx->d_ed_table);
+  drop_gen_prefix(ctx);
   for (auto& e : ctx->stream_scratch)
     if (e.buf) (void)hipFree(e.buf);
   if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
@@ -1165,10 +1233,14 @@ int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, 
     }());
     if (rc != FEC_OK) return rc;
   }
+  // the reference's generator() is recognised by value: the launches then name the ctx's own device copy, whose
+  // prefix table (ensure_gen_prefix) they can start from
+  const bool is_gen = std::memcmp(base, ctx->h_gen[curve], pb) == 0;
   const HostIn in[3] = {{scalars, 32, 0}, {base, 0, pb}, {nullptr, 0, 0}};
   return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void*, void* o, size_t cnt, void* s) {
-    if (curve == FEC_ED25519) return launch_ed_fixed(ctx, (const u64*)a, (const u64*)b, base, (u64*)o, cnt, s);
-    return launch_mul(ctx, curve, true, (const u64*)a, (const u64*)b, (u64*)o, cnt, s);
+    const u64* db = is_gen ? ctx->d_gen[curve] : (const u64*)b;
+    if (curve == FEC_ED25519) return launch_ed_fixed(ctx, (const u64*)a, db, base, (u64*)o, cnt, s);
+    return launch_mul(ctx, curve, true, (const u64*)a, db, (u64*)o, cnt, s);
   });
 } FEC_ABI_CATCH_STATUS
 
@@ -1346,6 +1418,7 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
     }
   u32* ta = reinterpret_cast<u32*>(work + n * 160);
   u32* tb = reinterpret_cast<u32*>(work + n * 256);
+  ensure_gen_prefix(ctx, curve, ctx->stream);
   {
     Launch L(ctx, nullptr, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op + k_fold_sum + k_ecdsa_batch_finish"
                                                   : "k_p256_mul_sched x2 + k_point_op + k_fold_sum + k_ecdsa_batch_finish");
@@ -1588,7 +1661,6 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
   unsigned char* d_flags = (unsigned char*)(tail + 2 * pb + 128);
   unsigned int* d_done = (unsigned int*)(tail + 2 * pb + 128 + 8);
   if (hipMemsetAsync(tail + 2 * pb + 128, 0, 16, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  const SchedEnv env = sched_env(ctx);
   {
     // work area: s*a (32 n), from_affine(P) (96 n), e*P (96 n), R + e*P (96 n)
     char* work = static_cast<char*>(scratch_for(ctx, ctx->stream, n * 320));
@@ -1598,10 +1670,12 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
     u32* ep = reinterpret_cast<u32*>(work + n * 128);
     u32* qq = reinterpret_cast<u32*>(work + n * 224);
     const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
+    ensure_gen_prefix(ctx, curve, ctx->stream);
+    const SchedEnv env = sched_env(ctx);
     Launch L(ctx, nullptr, secp ? "k_schnorr_pre + k_secp_mul x3 + k_schnorr_mid" : "k_schnorr_pre + k_p256_mul_sched x3 + k_schnorr_mid");
     const dim3 g(grid_for(n)), b(TPB);
     auto mul = [&](bool fixed, const u32* k, const u32* p, u32* o, hipStream_t st, unsigned div) {
-      if (secp) secp_launch_mul(fixed, k, p, o, n, st);
+      if (secp) secp_launch_mul(env, fixed, k, p, o, n, st);
       else p256_launch_mul(env, fixed, k, p, o, n, st, div);
     };
     if (secp) hipLaunchKernelGGL((k_schnorr_pre<Secp>), g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3], sa, pp, n);
@@ -1934,6 +2008,22 @@ int fec_ctx_debug_force_fault(fec_ctx* ctx, int enabled) try {
     return FEC_OK;
   }
   ctx->debug_force_fault = enabled ? 1u : 0u;
+  return FEC_OK;
+} FEC_ABI_CATCH_STATUS
+
+int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits) try {
+  if (!ctx || bits > kMaxPrefixBits) return FEC_E_ARG;
+  if (is_multi(ctx)) {
+    int rc = FEC_OK;
+    for (fec_ctx* c : ctx->children) {
+      const int r = fec_ctx_set_fixed_prefix_bits(c, bits);
+      if (rc == FEC_OK) rc = r;
+    }
+    return rc;
+  }
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  drop_gen_prefix(ctx);   // the tables are rebuilt at the new size by the next fixed-base launches
+  ctx->prefix_bits = bits;
   return FEC_OK;
 } FEC_ABI_CATCH_STATUS
 

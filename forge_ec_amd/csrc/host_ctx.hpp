@@ -31,6 +31,7 @@ struct fec_ctx {
   u64 ed_table_base[16] = {0};                  // the base point the table was built for
   bool ed_table_valid = false;
   u64 h_gen_ed[16] = {0};                       // host copy of the Ed25519 generator (table cache key)
+  u64 h_gen[3][16] = {{0}, {0}, {0}};           // host copies of the three generators (fec_batch_mul_fixed recognises them by value)
   // canonical-math mode: comb table of affine multiples of G, per-element window-table scratch
   u32* d_canon_comb[3] = {nullptr, nullptr, nullptr};   // per curve
   bool canon_comb_ready[3] = {false, false, false};
@@ -66,6 +67,12 @@ struct fec_ctx {
   unsigned* h_err = nullptr;       // host view
   unsigned* d_err = nullptr;       // device view of the same word
   unsigned debug_force_fault = 0;  // fec_ctx_debug_force_fault
+  // Fixed-base prefix tables of the reference's generator() (kernels.hpp: SchedEnv; fecgpu.hip: ensure_gen_prefix):
+  // built on the first fixed-base launch of a curve, 2^prefix_bits entries; prefix_bits 0 = off.
+  u32* d_gen_prefix[3] = {nullptr, nullptr, nullptr};
+  unsigned gen_prefix_bits[3] = {0, 0, 0};   // bits of the table that exists (0 = none yet / allocation refused)
+  bool gen_prefix_tried[3] = {false, false, false};
+  unsigned prefix_bits = 0;                  // wanted (FEC_FIXED_PREFIX_BITS at ctx creation, fec_ctx_set_fixed_prefix_bits)
   bool in_multi_chunk_pipeline = false;  // set by host_pipeline while it runs more than one chunk (fecgpu.hip: SideStream)
 };
 
@@ -188,6 +195,11 @@ inline SchedEnv sched_env(const fec_ctx* ctx) {
   e.err = ctx->d_err;
   e.cus = ctx->prop.multiProcessorCount > 0 ? (unsigned)ctx->prop.multiProcessorCount : 256u;
   e.force_fault = ctx->debug_force_fault;
+  for (int c = 0; c < 3; ++c) {
+    e.gen[c] = reinterpret_cast<const u32*>(ctx->d_gen[c]);
+    e.gen_prefix[c] = ctx->d_gen_prefix[c];
+    e.gen_prefix_bits[c] = ctx->d_gen_prefix[c] ? ctx->gen_prefix_bits[c] : 0;
+  }
   return e;
 }
 

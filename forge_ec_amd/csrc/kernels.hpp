@@ -14,10 +14,16 @@ namespace fecgpu {
 //   cus         CU count of the ctx's OWN device (one persistent workgroup per CU)
 //   force_fault debug hook (fec_ctx_debug_force_fault): the kernels raise their C_ERR word at once, so that the
 //               whole error path can be exercised by a test
+//   gen, gen_prefix, gen_prefix_bits   per curve: the device address of the reference's generator() and its fixed-base
+//               prefix table (the state of multiply(G, k) after the first gen_prefix_bits steps, for every pattern of
+//               those bits; null / 0 = none).  A fixed-base launch whose base IS that address starts from the table.
 struct SchedEnv {
   unsigned* err = nullptr;
   unsigned cus = 256;
   unsigned force_fault = 0;
+  const u32* gen[3] = {nullptr, nullptr, nullptr};
+  const u32* gen_prefix[3] = {nullptr, nullptr, nullptr};
+  unsigned gen_prefix_bits[3] = {0, 0, 0};
 };
 enum : unsigned { FEC_DEVERR_SCHED_WATCHDOG = 1u, FEC_DEVERR_SCHED_INDEX = 2u, FEC_DEVERR_FORCED = 4u };
 
@@ -36,10 +42,15 @@ void ed_build_table_launch(const u32* base, u32* table, hipStream_t s);
 // `work`: ed_fixed_work_bytes(n) bytes of device scratch owned by the launch's stream (0 bytes / null for small
 // batches: the batch-wide popcount sort pays from 2^16 elements on).
 size_t ed_fixed_work_bytes(size_t n);
-void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, void* work, hipStream_t s);
+void ed_fixed_launch(const SchedEnv& env, const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, void* work,
+                     hipStream_t s);
+// scalars[i] = i for i < n (8 words each): the inputs from which a fixed-base prefix table is computed
+void index_scalars_launch(u32* scalars, size_t n, hipStream_t s);
 
 // kernels_secp.hip: secp256k1 Curve::multiply, lane-per-element ladder at three wavefronts per SIMD.
-void secp_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
+void secp_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
+// table[g] (48 words: r0, r1) = the ladder's state for base `base` after wbits steps whose bits are g, msb first
+void secp_prefix_build_launch(const u32* base, u32* table, int wbits, hipStream_t s);
 
 // kernels_codec.hip: op 0 = PointAffine::from_bytes (in: n*33 bytes -> out xy, out2 inf, out3 ok),
 // op 1 = UncompressedPoint::to_affine (in: n*65 bytes -> xy, inf, ok), op 2 = UncompressedPoint::from_affine

@@ -66,8 +66,8 @@ struct ESecp {
   FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return secp::to_affine(p, x, y); }
   FEC_DEV static fe wmul(const fe& a, const fe& b) { return secp::sc_mul(a, b); }   // impl Mul for Scalar
   FEC_DEV static fe wadd(const fe& a, const fe& b) { return secp::sc_add(a, b); }   // impl Add for Scalar
-  static void launch_mul(const SchedEnv&, bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s, unsigned = 1) {
-    secp_launch_mul(fixed, k, p, o, n, s);
+  static void launch_mul(const SchedEnv& env, bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s, unsigned = 1) {
+    secp_launch_mul(env, fixed, k, p, o, n, s);
   }
 };
 

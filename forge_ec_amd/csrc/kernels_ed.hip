@@ -134,8 +134,13 @@ FEC_DEV ed::pt padd_table(const ed::pt& p, const u32* e, const u32* g) {
   return o;
 }
 
-// ed::multiply_fixed with the addend read in place (see padd_table)
-FEC_DEV ed::pt multiply_fixed_in_place(const ed::pt& base, const u32* tab, const u32* gtab, const u32* kw) {
+// ed::multiply_fixed with the addend read in place (see padd_table).
+// `prefix` / `wbits` (fecgpu.hip: ensure_gen_prefix; null / 0 = none): the result after the scalar's first wbits bits --
+// bits 0 .. wbits - 1, the ones multiply consumes first (2073-2094) -- depends on those bits alone; entry `low` of the
+// prefix table is that result (32 words), computed once per ctx by this very kernel as multiply(base, low).  A lane
+// whose low bits are not all zero starts from its entry and goes on with bit wbits.
+FEC_DEV ed::pt multiply_fixed_in_place(const ed::pt& base, const u32* tab, const u32* gtab, const u32* kw, const u32* prefix,
+                                       int wbits) {
   using namespace ed;
   u32 any = 0;
   FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kw[i * KSTRIDE];
@@ -143,6 +148,8 @@ FEC_DEV ed::pt multiply_fixed_in_place(const ed::pt& base, const u32* tab, const
   pt result = identity();
   int wi = 0;
   u32 cur = kw[0];
+  const u32 low = wbits > 0 ? cur & ((1u << wbits) - 1u) : 0u;
+  cur ^= low;
   {
     // The lane's FIRST addition is identity() + addend, which Add answers with the addend through its first
     // early-out (1869-1871): a copy of the table entry instead of nine products.
@@ -150,10 +157,11 @@ FEC_DEV ed::pt multiply_fixed_in_place(const ed::pt& base, const u32* tab, const
       ++wi;
       cur = kw[wi * KSTRIDE];
     }
-    const bool have = cur != 0;
-    const pt q = ld_words(gtab + (have ? (u32)wi * 32u + (u32)__builtin_ctz(cur) : 0u) * 32u);
-    cur &= cur - 1;  // (0 stays 0)
-    result = pt_select(result, q, lanes_where(have));
+    const bool have = cur != 0, pre = low != 0;
+    const u32* src = pre ? prefix + (size_t)low * 32u : gtab + (have ? (u32)wi * 32u + (u32)__builtin_ctz(cur) : 0u) * 32u;
+    const pt q = ld_words(src);
+    if (!pre) cur &= cur - 1;  // (0 stays 0)
+    result = pt_select(result, q, lanes_where(have || pre));
   }
 #pragma unroll 1
   for (;;) {
@@ -185,7 +193,8 @@ FEC_DEV ed::pt multiply_fixed_in_place(const ed::pt& base, const u32* tab, const
 __global__ __launch_bounds__(TPB, 3) void k_ed_fixed_base(const u32* __restrict__ scalars,
                                                        const u32* __restrict__ base,
                                                        const u32* __restrict__ table,
-                                                       u32* __restrict__ out, size_t n) {
+                                                       u32* __restrict__ out, size_t n,
+                                                       const u32* __restrict__ prefix, int wbits) {
   __shared__ u32 lds_k[8 * TPB];
   __shared__ u32 lds_t[256 * FT_STRIDE];   // the addend table (see padd_table); reused to stage the results out once every lane is done
   __shared__ int lds_bin[260];
@@ -211,9 +220,11 @@ __global__ __launch_bounds__(TPB, 3) void k_ed_fixed_base(const u32* __restrict_
   for (int v = e; v < 260; v += TPB) lds_bin[v] = 0;
   __syncthreads();
   // ---- counting sort of the workgroup's elements by popcount ----
-  int pc = 0;
+  int pc = 0;   // additions of the element + 1 (the first one is a copy, or the prefix-table entry)
   if (e < valid) {
-    FEC_UNROLL for (int w = 0; w < 8; ++w) pc += __builtin_popcount(lds_k[w * TPB + e]);
+    const u32 k0 = lds_k[e], low = wbits > 0 ? k0 & ((1u << wbits) - 1u) : 0u;
+    pc = __builtin_popcount(k0 ^ low) + (low != 0 ? 1 : 0);
+    FEC_UNROLL for (int w = 1; w < 8; ++w) pc += __builtin_popcount(lds_k[w * TPB + e]);
   }
   atomicAdd(&lds_bin[pc + 1], 1);  // padding lanes count as popcount 0 and sort to the front
   __syncthreads();
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(TPB, 3) void k_ed_fixed_base(const u32* __restrict_
   ed::pt r = ed::identity();
   if (src < valid) {
     ed::pt b = ld_words(base);
-    r = multiply_fixed_in_place(b, lds_t, table, lds_k + src);
+    r = multiply_fixed_in_place(b, lds_t, table, lds_k + src, prefix, wbits);
   }
   __syncthreads();                      // every lane has read its last table entry
   static_assert(256 * FT_STRIDE >= 32 * TPB, "the table region holds the staged results");
@@ -275,23 +286,27 @@ constexpr size_t ED_PERM_OFFSET = 4096;    // bytes
 static_assert(ED_CURSOR_AT >= ED_BINS && (size_t)(ED_CURSOR_AT + ED_BINS) * sizeof(int) <= ED_PERM_OFFSET,
               "hist, cursor and the permutation must not overlap");
 
-FEC_DEV int scalar_popcount(const u32* scalars, size_t g) {
+// additions of element g + 1: its set bits, the low wbits bits counting as one when a prefix table answers them
+FEC_DEV int scalar_popcount(const u32* scalars, size_t g, int wbits) {
   const uint4* k = reinterpret_cast<const uint4*>(scalars + g * 8);
-  const uint4 a = k[0], b = k[1];
-  return __builtin_popcount(a.x) + __builtin_popcount(a.y) + __builtin_popcount(a.z) + __builtin_popcount(a.w) +
+  uint4 a = k[0];
+  const uint4 b = k[1];
+  const u32 low = wbits > 0 ? a.x & ((1u << wbits) - 1u) : 0u;
+  a.x ^= low;
+  return (low != 0 ? 1 : 0) + __builtin_popcount(a.x) + __builtin_popcount(a.y) + __builtin_popcount(a.z) + __builtin_popcount(a.w) +
          __builtin_popcount(b.x) + __builtin_popcount(b.y) + __builtin_popcount(b.z) + __builtin_popcount(b.w);
 }
 }  // namespace
 
 // hist[b] += number of elements with popcount b (hist zeroed by the launcher)
-__global__ __launch_bounds__(SORT_T) void k_ed_pc_hist(const u32* __restrict__ scalars, size_t n, int* __restrict__ hist) {
+__global__ __launch_bounds__(SORT_T) void k_ed_pc_hist(const u32* __restrict__ scalars, size_t n, int* __restrict__ hist, int wbits) {
   __shared__ int lh[ED_BINS];
   for (int v = threadIdx.x; v < ED_BINS; v += SORT_T) lh[v] = 0;
   __syncthreads();
   const size_t first = (size_t)blockIdx.x * SORT_T * SORT_E;
   FEC_UNROLL for (int k = 0; k < SORT_E; ++k) {
     const size_t g = first + (size_t)k * SORT_T + threadIdx.x;
-    if (g < n) atomicAdd(&lh[scalar_popcount(scalars, g)], 1);
+    if (g < n) atomicAdd(&lh[scalar_popcount(scalars, g, wbits)], 1);
   }
   __syncthreads();
   for (int v = threadIdx.x; v < ED_BINS; v += SORT_T)
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(64) void k_ed_pc_scan(const int* __restrict__ hist,
 }
 // perm[position] = element index, positions handed out bin by bin (order inside a bin is immaterial)
 __global__ __launch_bounds__(SORT_T) void k_ed_pc_scatter(const u32* __restrict__ scalars, size_t n, int* __restrict__ cursor,
-                                                        u32* __restrict__ perm) {
+                                                        u32* __restrict__ perm, int wbits) {
   __shared__ int lh[ED_BINS];
   __shared__ int lbase[ED_BINS];
   for (int v = threadIdx.x; v < ED_BINS; v += SORT_T) lh[v] = 0;
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(SORT_T) void k_ed_pc_scatter(const u32* __restrict_
     pc[k] = -1;
     rank[k] = 0;
     if (g < n) {
-      pc[k] = scalar_popcount(scalars, g);
+      pc[k] = scalar_popcount(scalars, g, wbits);
       rank[k] = atomicAdd(&lh[pc[k]], 1);
     }
   }
@@ -341,7 +356,8 @@ __global__ __launch_bounds__(TPB, 3) void k_ed_fixed_sorted(const u32* __restric
                                                          const u32* __restrict__ base,
                                                          const u32* __restrict__ table,
                                                          const u32* __restrict__ perm,
-                                                         u32* __restrict__ out, size_t n) {
+                                                         u32* __restrict__ out, size_t n,
+                                                         const u32* __restrict__ prefix, int wbits) {
   __shared__ u32 lds_k[8 * TPB];
   __shared__ u32 lds_t[256 * FT_STRIDE];
   const int valid = block_valid(n);
@@ -370,7 +386,7 @@ __global__ __launch_bounds__(TPB, 3) void k_ed_fixed_sorted(const u32* __restric
   __syncthreads();
   if (e < valid) {
     const ed::pt b = ld_words(base);
-    st_glb(out + g * 32, multiply_fixed_in_place(b, lds_t, table, lds_k + e));
+    st_glb(out + g * 32, multiply_fixed_in_place(b, lds_t, table, lds_k + e, prefix, wbits));
   }
 }
 
@@ -701,10 +717,15 @@ void ed_build_table_launch(const u32* base, u32* table, hipStream_t s) {
   hipLaunchKernelGGL(k_ed_build_table, dim3(1), dim3(64), 0, s, base, table);
 }
 size_t ed_fixed_work_bytes(size_t n) { return n >= ED_SORT_MIN ? ED_PERM_OFFSET + n * sizeof(u32) : 0; }
-void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, void* work, hipStream_t s) {
+void ed_fixed_launch(const SchedEnv& env, const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, void* work,
+                     hipStream_t s) {
   const unsigned grid = (unsigned)((n + TPB - 1) / TPB);
+  // the generator's prefix table (multiply_fixed_in_place), when the ctx has one and `base` is the generator
+  const bool tab = base == env.gen[FEC_ED25519] && env.gen_prefix[FEC_ED25519] != nullptr && env.gen_prefix_bits[FEC_ED25519] > 0;
+  const u32* prefix = tab ? env.gen_prefix[FEC_ED25519] : nullptr;
+  const int wbits = tab ? (int)env.gen_prefix_bits[FEC_ED25519] : 0;
   if (n < ED_SORT_MIN || work == nullptr) {  // small batch (or no work area): quartiles of each workgroup's own 256 elements
-    hipLaunchKernelGGL(k_ed_fixed_base, dim3(grid), dim3(TPB), 0, s, scalars, base, table, out, n);
+    hipLaunchKernelGGL(k_ed_fixed_base, dim3(grid), dim3(TPB), 0, s, scalars, base, table, out, n, prefix, wbits);
     return;
   }
   int* hist = static_cast<int*>(work);
@@ -712,10 +733,22 @@ void ed_fixed_launch(const u32* scalars, const u32* base, const u32* table, u32*
   u32* perm = reinterpret_cast<u32*>(static_cast<char*>(work) + ED_PERM_OFFSET);
   const unsigned sgrid = (unsigned)((n + (size_t)SORT_T * SORT_E - 1) / ((size_t)SORT_T * SORT_E));
   (void)hipMemsetAsync(hist, 0, ED_PERM_OFFSET, s);
-  hipLaunchKernelGGL(k_ed_pc_hist, dim3(sgrid), dim3(SORT_T), 0, s, scalars, n, hist);
+  hipLaunchKernelGGL(k_ed_pc_hist, dim3(sgrid), dim3(SORT_T), 0, s, scalars, n, hist, wbits);
   hipLaunchKernelGGL(k_ed_pc_scan, dim3(1), dim3(64), 0, s, (const int*)hist, cursor);
-  hipLaunchKernelGGL(k_ed_pc_scatter, dim3(sgrid), dim3(SORT_T), 0, s, scalars, n, cursor, perm);
-  hipLaunchKernelGGL(k_ed_fixed_sorted, dim3(grid), dim3(TPB), 0, s, scalars, base, table, (const u32*)perm, out, n);
+  hipLaunchKernelGGL(k_ed_pc_scatter, dim3(sgrid), dim3(SORT_T), 0, s, scalars, n, cursor, perm, wbits);
+  hipLaunchKernelGGL(k_ed_fixed_sorted, dim3(grid), dim3(TPB), 0, s, scalars, base, table, (const u32*)perm, out, n, prefix, wbits);
+}
+
+// scalars[i] = i (one 32-bit word, the rest zero): the inputs of a prefix-table build (fecgpu.hip: ensure_gen_prefix)
+__global__ __launch_bounds__(TPB) void k_index_scalars(u32* __restrict__ scalars, size_t n) {
+  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  uint4* o = reinterpret_cast<uint4*>(scalars + i * 8);
+  o[0] = make_uint4((u32)i, 0, 0, 0);
+  o[1] = make_uint4(0, 0, 0, 0);
+}
+void index_scalars_launch(u32* scalars, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_index_scalars, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, scalars, n);
 }
 
 void ed_launch_mul(const SchedEnv& env, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,

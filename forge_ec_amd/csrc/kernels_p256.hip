@@ -241,7 +241,8 @@ enum { P_NEXT = C_WORDS, P_WORDS };
 template <bool FIXED, bool HOIST>
 __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict__ scalars, const u32* __restrict__ points,
                                                       u32* __restrict__ out, size_t n, unsigned per_wg,
-                                                      unsigned* __restrict__ err, unsigned force_fault) {
+                                                      unsigned* __restrict__ err, unsigned force_fault,
+                                                      const u32* __restrict__ prefix, int wbits) {
   __shared__ u32 lds_st[24 * QS];               // X, Y, Z of slot e: word w at lds_st[w * QS + e]
   // z2z2 = base.z * base.z of slot e's element (variable base): one of the sixteen products of EVERY addition of an
   // element depends on its base point alone, so claim() computes it once with the same sqr() and the ~128 additions
@@ -312,7 +313,17 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
         st_out(out + g * 24, base);
         continue;
       }
-      st_pt(lds_st + e, QS, base);
+      // Fixed base with a prefix table (fecgpu.hip: ensure_gen_prefix): the result after the first wbits steps --
+      // bits 255 .. 256 - wbits -- depends on those bits alone; entry `idx` of the table is that result (24 words),
+      // computed once per ctx by this very kernel (multiply(base, idx) performs the same doublings and additions after
+      // its leading doublings of the identity).  Pattern 0 is the identity: the top-bit shortcut below covers it.
+      const u32 idx = FIXED && wbits > 0 ? kw[7] >> (32 - wbits) : 0u;
+      p256::pt start = base;
+      if (idx != 0) {
+        t = 256 - wbits;   // the slot starts at step wbits
+        start = ld_base(prefix, idx);
+      }
+      st_pt(lds_st + e, QS, start);
       if (!FIXED) {
         const fe zz = p256::sqr(base.z);
         FEC_UNROLL for (int w = 0; w < 8; ++w) lds_zq[w * QS + e] = zz.w[w];
@@ -507,15 +518,17 @@ void p256_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const 
   const unsigned per_wg = (unsigned)((n + grid - 1) / grid);
   grid = (n + per_wg - 1) / per_wg;
   if (fixed) {
+    const bool tab = points == env.gen[FEC_P256] && env.gen_prefix[FEC_P256] != nullptr && env.gen_prefix_bits[FEC_P256] > 0;
     hipLaunchKernelGGL((k_p256_mul_sched<true, true>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg,
-                       env.err, env.force_fault);
+                       env.err, env.force_fault, tab ? env.gen_prefix[FEC_P256] : (const u32*)nullptr,
+                       tab ? (int)env.gen_prefix_bits[FEC_P256] : 0);
     return;
   }
   // Variable base: z2z2 is recomputed by every addition.  Parking it in the element's (still unused) output slot was
   // 2.6 % faster (25.0 -> 24.4 ms) but pushed a workgroup's working set out of its XCD's L2 -- 23 GB of L2-side
   // fetches per launch instead of 0.44 (profiles/pmc_r02br_p256_hoist.json) -- and broke in-place calls; not kept.
   hipLaunchKernelGGL((k_p256_mul_sched<false, false>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg,
-                     env.err, env.force_fault);
+                     env.err, env.force_fault, (const u32*)nullptr, 0);
 }
 
 }  // namespace fecgpu

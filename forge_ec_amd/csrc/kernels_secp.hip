@@ -103,35 +103,71 @@ FEC_DEV secp::pt padd_slots(const u32* lp, const u32* lq, lmask& need_double) {
 
 }  // namespace
 
-template <bool FIXED>
+// MODE 0: variable base (points[i]); 1: one base (points[0]); 2: one base whose ladder starts from the PREFIX TABLE;
+// 3: builds that table.
+//
+// The prefix table of a fixed base (fecgpu.hip: ensure_gen_prefix).  The ladder's state after its first w steps --
+// the pair (r0, r1) -- depends on the base and on the first w scalar bits alone, so for the reference's generator() it
+// is computed once per ctx for all 2^w bit patterns (by this very loop, MODE 3: the same additions and doublings on the
+// same operands as a full multiplication would run) and kept in HBM: 2^w entries of 48 words, r0 then r1.  A
+// multiplication by the generator (MODE 2) fetches its entry and runs the remaining 256 - w steps: w / 256 of the work
+// is not redone for every element.  (The table is indexed by the bits in ladder order: step i reads bit 7 - i % 8 of
+// byte i / 8 of the scalar's little-endian bytes, 2655-2659, so the first 32 steps are bswap32 of word 0, msb first.)
+template <int MODE>
 __global__ __launch_bounds__(TPB, 3) void k_secp_mul(const u32* __restrict__ scalars,
                                                   const u32* __restrict__ points,
-                                                  u32* __restrict__ out, size_t n) {
+                                                  u32* __restrict__ out, size_t n,
+                                                  const u32* __restrict__ prefix, int wbits) {
   __shared__ u32 lds[48 * TPB];  // word w of lane e: r0 at lds[w * TPB + e], r1 at lds[(24 + w) * TPB + e]
   const int valid = block_valid(n);
   const size_t first = (size_t)blockIdx.x * TPB;
   const int e = threadIdx.x;
-  if (!FIXED) stage_in<24>(lds, points + first * 24, valid);
+  if (MODE == 0) stage_in<24>(lds, points + first * 24, valid);
   __syncthreads();
   if (e < valid) {
-    const u32* kg = scalars + (first + e) * 8;
-    secp::pt r1 = FIXED ? ld3(points, 1) : ld3(lds + e, TPB);
-    u32 any = 0;
-    FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kg[i];
-    const lmask early = secp::is_identity(r1) | lanes_where(any == 0);
+    const size_t g = first + e;
+    const u32* kg = scalars + g * 8;
+    lmask early = 0;
     // The two ladder points LIVE in LDS: slot 0 (words 0..23) holds r0, slot 1 (words 24..47) r1.  A step reads both,
     // adds them, re-reads the one the reference's kept doubling takes, and writes the sum and the doubling back to
     // the slots the bit selects -- one address select per access instead of a register select per word.
     u32* const slot0 = lds + e;
-    st3(slot0, TPB, secp::identity());
-    st3(slot0 + 24 * TPB, TPB, r1);
-    u32 kword = 0;
+    int i0 = 0, i1 = 256;
+    if (MODE != 3) {
+      u32 any = 0;
+      FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kg[i];
+      early = lanes_where(any == 0);
+    }
+    if (MODE == 2) {  // (the generator is not the identity: only the zero scalar leaves early, 2636-2639)
+      const u32 idx = __builtin_bswap32(kg[0]) >> (32 - wbits);
+      const uint4* row = reinterpret_cast<const uint4*>(prefix + (size_t)idx * 48);
+      FEC_UNROLL for (int q = 0; q < 12; ++q) {
+        const uint4 x = row[q];
+        slot0[(4 * q + 0) * TPB] = x.x;
+        slot0[(4 * q + 1) * TPB] = x.y;
+        slot0[(4 * q + 2) * TPB] = x.z;
+        slot0[(4 * q + 3) * TPB] = x.w;
+      }
+      i0 = wbits;
+    } else {
+      const secp::pt r1 = MODE != 0 ? ld3(points, 1) : ld3(lds + e, TPB);
+      if (MODE != 3) early |= secp::is_identity(r1);
+      st3(slot0, TPB, secp::identity());
+      st3(slot0 + 24 * TPB, TPB, r1);
+      if (MODE == 3) i1 = wbits;
+    }
+    u32 kword = MODE == 3 ? 0u : kg[i0 >> 5];
 #pragma unroll 1
-    for (int i = 0; i < 256; ++i) {
-      if ((i & 31) == 0) kword = kg[i >> 5];
-      // bit i of the ladder (2655-2659): byte i/8 of the little-endian bytes, MSB first in the byte
-      const int sh = (((i >> 3) & 3) << 3) + 7 - (i & 7);
-      const u32 b = (kword >> sh) & 1u;
+    for (int i = i0; i < i1; ++i) {
+      u32 b;
+      if (MODE == 3) {
+        b = (u32)(g >> (wbits - 1 - i)) & 1u;   // entry g: its bits are the ladder's first wbits bits, msb first
+      } else {
+        if ((i & 31) == 0) kword = kg[i >> 5];
+        // bit i of the ladder (2655-2659): byte i/8 of the little-endian bytes, MSB first in the byte
+        const int sh = (((i >> 3) & 3) << 3) + 7 - (i & 7);
+        b = (kword >> sh) & 1u;
+      }
       lmask nd;
       secp::pt s = padd_slots(slot0, slot0 + 24 * TPB, nd);
       if (__builtin_expect(nd != 0, 0)) {  // Add (1469-1473) returns self.double(): never on random inputs
@@ -147,17 +183,29 @@ __global__ __launch_bounds__(TPB, 3) void k_secp_mul(const u32* __restrict__ sca
       st3(slot_s, TPB, s);
       st3(slot_d, TPB, secp::pdouble(din));
     }
-    const secp::pt r0 = secp::pt_select(ld3(slot0, TPB), secp::identity(), early);
-    st3(slot0, TPB, r0);
+    if (MODE != 3) {
+      const secp::pt r0 = secp::pt_select(ld3(slot0, TPB), secp::identity(), early);
+      st3(slot0, TPB, r0);
+    }
   }
   __syncthreads();
-  stage_out<24>(out + first * 24, lds, valid);
+  if (MODE == 3) stage_out<48>(out + first * 48, lds, valid);
+  else stage_out<24>(out + first * 24, lds, valid);
 }
 
-void secp_launch_mul(bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s) {
+void secp_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s) {
   const unsigned grid = (unsigned)((n + TPB - 1) / TPB);
-  if (fixed) hipLaunchKernelGGL((k_secp_mul<true>), dim3(grid), dim3(TPB), 0, s, scalars, points, out, n);
-  else hipLaunchKernelGGL((k_secp_mul<false>), dim3(grid), dim3(TPB), 0, s, scalars, points, out, n);
+  const int w = (int)env.gen_prefix_bits[FEC_SECP256K1];
+  if (fixed && w > 0 && points == env.gen[FEC_SECP256K1] && env.gen_prefix[FEC_SECP256K1] != nullptr)
+    hipLaunchKernelGGL((k_secp_mul<2>), dim3(grid), dim3(TPB), 0, s, scalars, points, out, n, env.gen_prefix[FEC_SECP256K1], w);
+  else if (fixed) hipLaunchKernelGGL((k_secp_mul<1>), dim3(grid), dim3(TPB), 0, s, scalars, points, out, n, (const u32*)nullptr, 0);
+  else hipLaunchKernelGGL((k_secp_mul<0>), dim3(grid), dim3(TPB), 0, s, scalars, points, out, n, (const u32*)nullptr, 0);
+}
+
+void secp_prefix_build_launch(const u32* base, u32* table, int wbits, hipStream_t s) {
+  const size_t entries = (size_t)1 << wbits;
+  hipLaunchKernelGGL((k_secp_mul<3>), dim3((unsigned)((entries + TPB - 1) / TPB)), dim3(TPB), 0, s, (const u32*)nullptr, base, table,
+                     entries, (const u32*)nullptr, wbits);
 }
 
 }  // namespace fecgpu

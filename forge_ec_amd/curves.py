@@ -68,6 +68,10 @@ class Context:
         """fec_ctx_debug_force_fault: test hook -- scheduler kernels raise their fault word at once."""
         _check(self._lib.fec_ctx_debug_force_fault(self._h, 1 if enabled else 0), "fec_ctx_debug_force_fault")
 
+    def set_fixed_prefix_bits(self, bits):
+        """fec_ctx_set_fixed_prefix_bits: size of the generator's fixed-base prefix tables (0 = off, default 24)."""
+        _check(self._lib.fec_ctx_set_fixed_prefix_bits(self._h, int(bits)), "fec_ctx_set_fixed_prefix_bits")
+
     def device_count(self):
         return int(self._lib.fec_ctx_device_count(self._h))
 

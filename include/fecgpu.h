@@ -134,7 +134,7 @@ int fec_ctx_create(fec_ctx** out, int device);
  * "gather" is the D2H copy of each shard, there is no device-to-device exchange.  Results are
  * identical to a single-device ctx.  Entry points that are not element-wise (fec_multi_scalar_mul,
  * fec_ecdsa_batch_verify, fec_schnorr_batch_verify*, fec_generator*, the measurement hooks)
- * run on devices[0]; fec_ctx_wipe, fec_ctx_check, fec_ctx_set_chunk and fec_ctx_debug_force_fault apply
+ * run on devices[0]; fec_ctx_wipe, fec_ctx_check, fec_ctx_set_chunk, fec_ctx_set_fixed_prefix_bits and fec_ctx_debug_force_fault apply
  * to every shard worker;
  * the *_dev entry points take device pointers of ONE device and return FEC_E_UNSUPPORTED.
  * devices == NULL means ordinals 0..n_devices-1. */
@@ -341,6 +341,15 @@ int fec_ctx_check(fec_ctx* ctx);
  * multiplication, also inside the composed entry points) raises its fault word at once, exactly as its watchdog
  * would: outputs are zero-filled and the call (or fec_ctx_check) returns FEC_E_LAUNCH. */
 int fec_ctx_debug_force_fault(fec_ctx* ctx, int enabled);
+
+/* Fixed-base prefix tables.  The state of Curve::multiply(generator(), k) after its first `bits` steps depends on the
+ * first `bits` scalar bits alone, so a ctx computes it once -- with the same kernels, on the first fixed-base launch of
+ * a curve -- for all 2^bits patterns and keeps the table in HBM; every multiplication by the generator (fec_batch_mul_fixed
+ * with fec_generator's point, the u1*G of the ECDSA / Schnorr entry points, fec_batch_double_mul) then fetches its entry
+ * and runs the remaining steps.  Results are bit-identical with or without the table.  Default 24 bits (secp256k1:
+ * 3.0 GiB of device memory per ctx; env FEC_FIXED_PREFIX_BITS at ctx creation), at most 28, 0 = off.  Changing the
+ * size drops the existing tables.  If the memory is refused the launches run the whole ladder. */
+int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits);
 
 /* Host-pointer batches are processed as a two-lane pipeline of `elements`-sized chunks (default
  * 2^18): copies of one chunk overlap the kernel of the other, and device staging memory is bounded

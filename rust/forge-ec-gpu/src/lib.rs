@@ -6,7 +6,7 @@
 //! below is diffed against include/fecgpu.h by tests/test_rust_shim_signatures.py.
 #![deny(missing_docs)]
 
-use core::ffi::{c_char, c_double, c_float, c_int, c_void};
+use core::ffi::{c_char, c_double, c_float, c_int, c_uint, c_void};
 
 use forge_ec_core::{Curve, Error, Result};
 use forge_ec_curves::{ed25519, p256, secp256k1};
@@ -28,6 +28,7 @@ extern "C" {
     fn fec_ctx_wipe(ctx: *mut FecCtx) -> c_int;
     fn fec_ctx_check(ctx: *mut FecCtx) -> c_int;
     fn fec_ctx_debug_force_fault(ctx: *mut FecCtx, enabled: c_int) -> c_int;
+    fn fec_ctx_set_fixed_prefix_bits(ctx: *mut FecCtx, bits: c_uint) -> c_int;
     fn fec_generator(ctx: *mut FecCtx, curve: c_int, out: *mut u64) -> c_int;
     fn fec_generator_dev(ctx: *mut FecCtx, curve: c_int) -> *const u64;
     fn fec_batch_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
@@ -135,6 +136,13 @@ impl GpuContext {
     pub fn debug_force_fault(&mut self, enabled: bool) -> Result<()> {
         // SAFETY: self.raw is a live ctx.
         check(unsafe { fec_ctx_debug_force_fault(self.raw, enabled as c_int) })
+    }
+
+    /// Size of the generator's fixed-base prefix tables (`fec_ctx_set_fixed_prefix_bits`): 2^bits entries per curve,
+    /// 0 = off, default 24.  Results do not depend on it.
+    pub fn set_fixed_prefix_bits(&mut self, bits: u32) -> Result<()> {
+        // SAFETY: self.raw is a live ctx.
+        check(unsafe { fec_ctx_set_fixed_prefix_bits(self.raw, bits as c_uint) })
     }
 
     /// Elements per pipeline chunk of the host-pointer calls (tuning knob; results do not depend on it).

@@ -294,6 +294,49 @@ def test_batch_mul_fixed_matches_oracle(gpu_ctx, oracle, curve):
     _assert_same(got, want, "%s batch_mul_fixed(random base)" % NAMES[curve])
 
 
+def _prefix_scalars(curve, bits, seed):
+    """Scalars around the fixed-base prefix table's index: the table is indexed by the first `bits` bits the ladder
+    consumes -- secp256k1: byte 0 msb first, then byte 1 ... (2655-2659); P-256: from bit 255 down (2126-2134);
+    Ed25519: from bit 0 up (2073-2094) -- so both ends of the scalar get all-zero, all-one and one-bit patterns."""
+    rows = [[0, 0, 0, 0], [1, 0, 0, 0], [2, 0, 0, 0], [0x80, 0, 0, 0], [0xFF, 0, 0, 0], [0, 0, 0, 1 << 63], [0, 0, 0, 1]]
+    full = (1 << 64) - 1
+    for b in sorted({1, bits - 1, bits, bits + 1, 31, 32, 33}):
+        if not 0 < b < 64:
+            continue
+        low, high = (1 << b) - 1, full ^ ((1 << (64 - b)) - 1)
+        rows += [[low, 0, 0, 0], [full ^ low, full, full, full >> 4], [1 << b, 0, 0, 0],         # low end
+                 [0, 0, 0, high >> 4], [full, full, full, (full ^ high) >> 4], [5, 0, 0, 1 << (63 - b)]]   # high end
+    rnd = V.scalars(700, curve, seed)
+    zlow = rnd[:100].copy(); zlow[:, 0] &= ~np.uint64((1 << min(bits, 63)) - 1)     # index 0 at the low end
+    zhigh = rnd[100:200].copy(); zhigh[:, 3] &= np.uint64((1 << (64 - min(bits, 63))) - 1)   # index 0 at the high end
+    return np.ascontiguousarray(np.concatenate([np.array(rows, dtype=np.uint64), zlow, zhigh, rnd]))
+
+
+@pytest.mark.parametrize("bits", [0, 1, 7, 13, 24])
+@pytest.mark.parametrize("curve", CURVES)
+def test_fixed_base_prefix_table_is_invisible(oracle, curve, bits):
+    """fec_ctx_set_fixed_prefix_bits: multiply(G, k) starts from the table entry of k's first `bits` ladder bits; the
+    results -- fixed-base call, double multiplication, a second call that reuses the table -- are the oracle's for every
+    table size, a base that is not the generator takes the plain kernels."""
+    import forge_ec_amd as F
+    ctx = F.Context(0)
+    try:
+        ctx.set_fixed_prefix_bits(bits)
+        k = _prefix_scalars(curve, max(bits, 1), 3311 + bits)
+        g = oracle.generator(curve)
+        want = oracle.batch_mul_fixed(curve, k, g, nthreads=8)
+        _assert_same(ctx.batch_mul_fixed(curve, k, g), want, "%s batch_mul_fixed(G), %d-bit prefix table" % (NAMES[curve], bits))
+        _assert_same(ctx.batch_mul_fixed(curve, k[::-1].copy(), g), want[::-1], "%s second call on the table" % NAMES[curve])
+        base = V.points(1, curve, 3312)[0]
+        _assert_same(ctx.batch_mul_fixed(curve, k[:200], base), oracle.batch_mul_fixed(curve, k[:200], base, nthreads=8),
+                     "%s batch_mul_fixed(another base) beside the table" % NAMES[curve])
+        u2, q = V.scalars(len(k), curve, 3313), V.points(len(k), curve, 3314)
+        _assert_same(ctx.batch_double_mul(curve, k, u2, q), oracle.batch_double_mul(curve, k, u2, q, nthreads=8),
+                     "%s batch_double_mul, %d-bit prefix table" % (NAMES[curve], bits))
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_batch_double_mul_matches_oracle(gpu_ctx, oracle, curve):
     n = 600

@@ -21,7 +21,7 @@ def c_to_rust(t):
     const = "const " in t or t.startswith("const")
     stars = t.count("*")
     base = t.replace("const", "").replace("*", "").strip()
-    prim = {"int": "c_int", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "void": "c_void", "char": "c_char",
+    prim = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "void": "c_void", "char": "c_char",
             "float": "c_float", "double": "c_double", "fec_ctx": "FecCtx"}
     if base in ENUMS:
         base = "int"
