@@ -80,6 +80,9 @@ def parse():
                     help="N>1: `both` (default) = time the K steps with the gather of the result shards to rank 0 over RCCL "
                          "(overlapped with the next step; this is `value`) and again without it (`gather.none`); or one of "
                          "rank0 / all (all-gather to every rank) / none only")
+    ap.add_argument("--fixed-prefix-bits", type=int, default=None,
+                    help="fixed-base workloads: size of the generator's prefix table (fec_ctx_set_fixed_prefix_bits; "
+                         "0 = off; default: the library's, 24)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (all legs together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -174,9 +177,13 @@ def committed_pmc(workload, n):
 # MAD32 of the reference's op sequence that `roofline.achieved` is priced with: the kernels need fewer multiplies than the
 # reference performs (closed-form Montgomery recurrence, exact squarings, z2z2 computed once per element), so `frac` is
 # NOT the share of issue slots spent multiplying -- carries outnumber multiplies in every one of them.
+# Fixed-base workloads: `b` = bits of the generator's prefix table (fecgpu.h: fec_ctx_set_fixed_prefix_bits) -- the first
+# b ladder steps (Ed25519: the additions of the b low bits, b / 2 on average) are a table fetch, not executed.
 EXECUTED_MULS = {
-    "secp256k1-var": 256 * 1600, "secp256k1-fixed": 256 * 1600, "secp256k1-double": 2 * 256 * 1600 + 1600,
-    "p256-var": 256 * 324 + 128 * 848, "ed25519-var": 255 * 536 + 128 * 648, "ed25519-fixed": 128 * 648,
+    "secp256k1-var": lambda b: 256 * 1600, "secp256k1-fixed": lambda b: (256 - b) * 1600,
+    "secp256k1-double": lambda b: (512 - b) * 1600 + 1600,
+    "p256-var": lambda b: 256 * 324 + 128 * 848, "ed25519-var": lambda b: 255 * 536 + 128 * 648,
+    "ed25519-fixed": lambda b: (128 - b // 2) * 648,
 }
 # the size BASELINE.json quotes for a workload's configuration (strong scaling default)
 BASELINE_LOG2_GLOBAL = {"p256-var": 22, "secp256k1-double": 20}
@@ -275,6 +282,31 @@ def main():
                                            dst=0 if m == "rank0" else None) for _ in range(2)]
 
     launched = {"name": None}  # the kernel(s) the library reports for the timed launch
+
+    # Fixed-base prefix table of the generator (fixed and double workloads): built by the first launch that can use it.
+    # Timed here, outside every timed region: one 256-element call that builds it, one that finds it.
+    prefix = None
+    if kind in ("fixed", "double"):
+        if args.fixed_prefix_bits is not None:
+            ctx.set_fixed_prefix_bits(args.fixed_prefix_bits)
+
+        def small_call():
+            t0 = time.perf_counter()
+            if kind == "fixed":
+                ctx.batch_mul_fixed_dev(cid, d_in[0].data_ptr(), ctx.generator_dev(cid), d_out[0].data_ptr(), min(n, 256), stream)
+            else:
+                ctx.batch_double_mul_dev(cid, d_in[0].data_ptr(), d_in[1].data_ptr(), d_in[2].data_ptr(), d_out[0].data_ptr(),
+                                         min(n, 256), stream)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3
+        first_ms, second_ms = small_call(), small_call()
+        bits = ctx.fixed_prefix_bits(cid)
+        entry_bytes = {0: 192, 1: 96, 2: 128}[cid]
+        prefix = {"bits": bits, "table_bytes": (entry_bytes << bits) if bits else 0,
+                  "build_ms_once_per_ctx": round(max(first_ms - second_ms, 0.0), 3),
+                  "note": "state of multiply(G, k) after its first `bits` steps for every pattern of those bits, computed by the "
+                          "same kernels on the first fixed-base launch and kept in HBM; results are identical without it "
+                          "(--fixed-prefix-bits 0)"}
 
     def step(i, timed, gather):
         buf = i & 1
@@ -390,7 +422,8 @@ def main():
                 "traffic_source": pmc["source"],
                 "traffic_note": TRAFFIC_NOTES.get(workload),
                 "kernel": kname, "kernel_ms": kernel_ms,
-                "algorithmic_mad32_per_unit": alg, "executed_mul_insts_per_unit": EXECUTED_MULS.get(workload),
+                "algorithmic_mad32_per_unit": alg, "executed_mul_insts_per_unit": EXECUTED_MULS[workload](prefix["bits"] if prefix else 0),
+                "fixed_base_prefix_table": prefix,
                 "units_per_launch": n,
                 "peak_measured": peak_measured / 1e12, "frac_of_measured_peak": achieved / peak_measured,
                 "valu_issue_cycles_per_inst_per_simd": pmc["valu_issue_cycles"],

@@ -2011,6 +2011,12 @@ int fec_ctx_debug_force_fault(fec_ctx* ctx, int enabled) try {
   return FEC_OK;
 } FEC_ABI_CATCH_STATUS
 
+int fec_ctx_fixed_prefix_bits(fec_ctx* ctx, fec_curve curve) try {
+  FEC_FIRST_DEVICE(ctx);
+  if (!ctx || !curve_ok(curve)) return FEC_E_ARG;
+  return ctx->d_gen_prefix[curve] ? (int)ctx->gen_prefix_bits[curve] : 0;
+} FEC_ABI_CATCH_STATUS
+
 int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits) try {
   if (!ctx || bits > kMaxPrefixBits) return FEC_E_ARG;
   if (is_multi(ctx)) {

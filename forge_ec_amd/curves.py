@@ -72,6 +72,12 @@ class Context:
         """fec_ctx_set_fixed_prefix_bits: size of the generator's fixed-base prefix tables (0 = off, default 24)."""
         _check(self._lib.fec_ctx_set_fixed_prefix_bits(self._h, int(bits)), "fec_ctx_set_fixed_prefix_bits")
 
+    def fixed_prefix_bits(self, curve):
+        """fec_ctx_fixed_prefix_bits: bits of the prefix table `curve` has now (0 = none)."""
+        r = self._lib.fec_ctx_fixed_prefix_bits(self._h, int(curve))
+        _check(min(r, 0), "fec_ctx_fixed_prefix_bits")
+        return r
+
     def device_count(self):
         return int(self._lib.fec_ctx_device_count(self._h))
 

@@ -350,6 +350,9 @@ int fec_ctx_debug_force_fault(fec_ctx* ctx, int enabled);
  * 3.0 GiB of device memory per ctx; env FEC_FIXED_PREFIX_BITS at ctx creation), at most 28, 0 = off.  Changing the
  * size drops the existing tables.  If the memory is refused the launches run the whole ladder. */
 int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits);
+/* bits of the prefix table `curve` has at this moment (0 = none: not built yet, switched off, or memory refused);
+ * negative fec_status on a bad argument.  Multi-device ctx: the first shard worker's. */
+int fec_ctx_fixed_prefix_bits(fec_ctx* ctx, fec_curve curve);
 
 /* Host-pointer batches are processed as a two-lane pipeline of `elements`-sized chunks (default
  * 2^18): copies of one chunk overlap the kernel of the other, and device staging memory is bounded

@@ -29,6 +29,7 @@ extern "C" {
     fn fec_ctx_check(ctx: *mut FecCtx) -> c_int;
     fn fec_ctx_debug_force_fault(ctx: *mut FecCtx, enabled: c_int) -> c_int;
     fn fec_ctx_set_fixed_prefix_bits(ctx: *mut FecCtx, bits: c_uint) -> c_int;
+    fn fec_ctx_fixed_prefix_bits(ctx: *mut FecCtx, curve: c_int) -> c_int;
     fn fec_generator(ctx: *mut FecCtx, curve: c_int, out: *mut u64) -> c_int;
     fn fec_generator_dev(ctx: *mut FecCtx, curve: c_int) -> *const u64;
     fn fec_batch_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
@@ -143,6 +144,14 @@ impl GpuContext {
     pub fn set_fixed_prefix_bits(&mut self, bits: u32) -> Result<()> {
         // SAFETY: self.raw is a live ctx.
         check(unsafe { fec_ctx_set_fixed_prefix_bits(self.raw, bits as c_uint) })
+    }
+
+    /// Bits of the prefix table curve `C` has at this moment (0 = none).
+    pub fn fixed_prefix_bits<C: GpuCurve>(&mut self) -> Result<u32> {
+        // SAFETY: self.raw is a live ctx.
+        let r = unsafe { fec_ctx_fixed_prefix_bits(self.raw, C::ID) };
+        if r < 0 { check(r)?; }
+        Ok(r as u32)
     }
 
     /// Elements per pipeline chunk of the host-pointer calls (tuning knob; results do not depend on it).

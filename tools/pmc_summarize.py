@@ -34,7 +34,7 @@ def static_resources(tu, needle):
     res = []
     for b in blocks:
         name = b.split()[0]
-        if needle not in name:
+        if needle.split("<")[0] not in name:   # (mangled names: the template arguments of the needle are not comparable)
             continue
         def field(label):
             m = re.search(re.escape(label) + r": (\d+)", b)
