@@ -284,7 +284,8 @@ def main():
     launched = {"name": None}  # the kernel(s) the library reports for the timed launch
 
     # Fixed-base prefix table of the generator (fixed and double workloads): built by the first launch that can use it.
-    # Timed here, outside every timed region: one 256-element call that builds it, one that finds it.
+    # Timed here, outside every timed region: one call that builds it, one that finds it (both over the whole batch, so
+    # that every launch of the workload's kernel in a profile of this command is a full-size one).
     prefix = None
     if kind in ("fixed", "double"):
         if args.fixed_prefix_bits is not None:
@@ -293,10 +294,10 @@ def main():
         def small_call():
             t0 = time.perf_counter()
             if kind == "fixed":
-                ctx.batch_mul_fixed_dev(cid, d_in[0].data_ptr(), ctx.generator_dev(cid), d_out[0].data_ptr(), min(n, 256), stream)
+                ctx.batch_mul_fixed_dev(cid, d_in[0].data_ptr(), ctx.generator_dev(cid), d_out[0].data_ptr(), n, stream)
             else:
                 ctx.batch_double_mul_dev(cid, d_in[0].data_ptr(), d_in[1].data_ptr(), d_in[2].data_ptr(), d_out[0].data_ptr(),
-                                         min(n, 256), stream)
+                                         n, stream)
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) * 1e3
         first_ms, second_ms = small_call(), small_call()
