@@ -23,6 +23,7 @@
 #include "secp256k1.hpp"
 #include "host_ctx.hpp"
 #include "kernels.hpp"
+#include "cu_split.hpp"
 
 namespace fecgpu {
 
@@ -698,9 +699,11 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
     side.join();
     hipLaunchKernelGGL((k_point_op<Secp>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   } else if (curve == FEC_P256) {
-    p256_launch_mul(sched_env(ctx), true, a, gen, ta, n, side.s, side.active ? 2 : 1);
+    SchedEnv ef = sched_env(ctx), ev = ef;
+    if (side.active) p256_cu_split(sched_env(ctx), n, kP256VarMs, ef, ev);   // the CUs in proportion to the two launches' work
+    p256_launch_mul(ef, true, a, gen, ta, n, side.s);
     side.fork_done();
-    p256_launch_mul(sched_env(ctx), false, b2, q, tb, n, L.s, side.active ? 2 : 1);
+    p256_launch_mul(ev, false, b2, q, tb, n, L.s);
     side.join();
     hipLaunchKernelGGL((k_point_op<P256>), g, b, 0, L.s, (int)FEC_P_ADD, (const u32*)ta, (const u32*)tb, o, n);
   } else {
@@ -820,9 +823,11 @@ int launch_schnorr_verify(fec_ctx* ctx, int curve, const u64* dpk, const unsigne
       side.fork_done();
       secp_launch_mul(sched_env(ctx), false, ec, a, ep, n, L.s);
     } else {
-      p256_launch_mul(sched_env(ctx), true, sc, gen, sg, n, side.s, side.active ? 2 : 1);
+      SchedEnv ef = sched_env(ctx), ev = ef;
+      if (side.active) p256_cu_split(sched_env(ctx), n, kP256VarAffineMs, ef, ev);   // (e * from_affine(P): affine addend)
+      p256_launch_mul(ef, true, sc, gen, sg, n, side.s);
       side.fork_done();
-      p256_launch_mul(sched_env(ctx), false, ec, a, ep, n, L.s, side.active ? 2 : 1);
+      p256_launch_mul(ev, false, ec, a, ep, n, L.s);
     }
     side.join();
   }
@@ -1674,9 +1679,9 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
     const SchedEnv env = sched_env(ctx);
     Launch L(ctx, nullptr, secp ? "k_schnorr_pre + k_secp_mul x3 + k_schnorr_mid" : "k_schnorr_pre + k_p256_mul_sched x3 + k_schnorr_mid");
     const dim3 g(grid_for(n)), b(TPB);
-    auto mul = [&](bool fixed, const u32* k, const u32* p, u32* o, hipStream_t st, unsigned div) {
-      if (secp) secp_launch_mul(env, fixed, k, p, o, n, st);
-      else p256_launch_mul(env, fixed, k, p, o, n, st, div);
+    auto mul = [&](bool fixed, const u32* k, const u32* p, u32* o, hipStream_t st, const SchedEnv& e) {
+      if (secp) secp_launch_mul(e, fixed, k, p, o, n, st);
+      else p256_launch_mul(e, fixed, k, p, o, n, st);
     };
     if (secp) hipLaunchKernelGGL((k_schnorr_pre<Secp>), g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3], sa, pp, n);
     else hipLaunchKernelGGL((k_schnorr_pre<P256>), g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3], sa, pp, n);
@@ -1691,13 +1696,16 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
       (void)hipStreamWaitEvent(ctx->stream2, ev_pre, 0);
       sa_stream = ctx->stream2;
     }
-    const unsigned div = side ? 2 : 1;   // the persistent P-256 kernels: half of the CUs each while two run side by side
-    mul(true, sa, gen, (u32*)ctx->d_buf[5], sa_stream, div);                             // A_i (266-268)
+    // the persistent P-256 kernels: the CUs in proportion to the work on either stream (one fixed-base launch beside
+    // two variable-base ones) while they run side by side
+    SchedEnv ef = env, ev = env;
+    if (side && !secp) p256_cu_split(env, n, kP256VarAffineMs + kP256VarMs, ef, ev);
+    mul(true, sa, gen, (u32*)ctx->d_buf[5], sa_stream, ef);                              // A_i (266-268)
     if (side) (void)hipEventRecord(ev_a, ctx->stream2);
-    mul(false, (const u32*)ctx->d_buf[4], pp, ep, L.s, div);                             // e_i P_i (276)
+    mul(false, (const u32*)ctx->d_buf[4], pp, ep, L.s, ev);                              // e_i P_i (276)
     if (secp) hipLaunchKernelGGL((k_schnorr_mid<Secp>), g, b, 0, L.s, (const u32*)ctx->d_buf[1], (const u32*)ep, qq, n);
     else hipLaunchKernelGGL((k_schnorr_mid<P256>), g, b, 0, L.s, (const u32*)ctx->d_buf[1], (const u32*)ep, qq, n);
-    mul(false, (const u32*)ctx->d_buf[3], qq, (u32*)ctx->d_buf[6], L.s, div);            // B_i (282)
+    mul(false, (const u32*)ctx->d_buf[3], qq, (u32*)ctx->d_buf[6], L.s, ev);             // B_i (282)
     if (side) (void)hipStreamWaitEvent(L.s, ev_a, 0);
     rc = L.done();
     if (ev_pre) (void)hipEventDestroy(ev_pre);

@@ -13,6 +13,7 @@
 #include "../../include/fecgpu.h"
 #include "ed25519.hpp"
 #include "kernels.hpp"
+#include "cu_split.hpp"
 #include "p256.hpp"
 #include "secp256k1.hpp"
 #include "staging.hpp"
@@ -105,9 +106,12 @@ struct EP256 {
   FEC_DEV static lmask to_affine(const pt& p, fe& x, fe& y) { return p256::to_affine(p, x, y); }
   FEC_DEV static fe wmul(const fe& a, const fe& b) { return p256::sc_mul32(a, b); }
   FEC_DEV static fe wadd(const fe& a, const fe& b) { return p256::sc_fe(p256::sc_add(p256::sc_of(a), p256::sc_of(b))); }
+  // cu_divisor == 2: this launch runs beside its fixed- / variable-base twin on another stream (cu_split.hpp)
   static void launch_mul(const SchedEnv& env, bool fixed, const u32* k, const u32* p, u32* o, size_t n, hipStream_t s,
                          unsigned cu_divisor = 1) {
-    p256_launch_mul(env, fixed, k, p, o, n, s, cu_divisor);
+    SchedEnv ef = env, ev = env;
+    if (cu_divisor == 2) p256_cu_split(env, n, kP256VarAffineMs, ef, ev);   // (u2 * from_affine(public key): affine addend)
+    p256_launch_mul(fixed ? ef : ev, fixed, k, p, o, n, s);
   }
 };
 
