@@ -556,8 +556,10 @@ void ensure_gen_prefix(fec_ctx* ctx, int curve, hipStream_t s) {
   // once per ctx and curve: wait here, so that a failed build (a launch error, a scheduler fault -- its error word stays
   // set for the caller's own check) never becomes a table
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
-      (ctx->h_err && *reinterpret_cast<volatile unsigned*>(ctx->h_err) != 0))
+      (ctx->h_err && *reinterpret_cast<volatile unsigned*>(ctx->h_err) != 0)) {
+    ctx->gen_prefix_tried[curve] = false;   // (not a question of memory: the next fixed-base launch tries again)
     return give_up();
+  }
   if (idx) (void)hipFree(idx);
   ctx->d_gen_prefix[curve] = static_cast<u32*>(t);
   ctx->gen_prefix_bits[curve] = w;

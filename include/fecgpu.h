@@ -348,7 +348,8 @@ int fec_ctx_debug_force_fault(fec_ctx* ctx, int enabled);
  * with fec_generator's point, the u1*G of the ECDSA / Schnorr entry points, fec_batch_double_mul) then fetches its entry
  * and runs the remaining steps.  Results are bit-identical with or without the table.  Default 24 bits (secp256k1:
  * 3.0 GiB of device memory per ctx; env FEC_FIXED_PREFIX_BITS at ctx creation), at most 28, 0 = off.  Changing the
- * size drops the existing tables.  If the memory is refused the launches run the whole ladder. */
+ * size drops the existing tables.  If the memory is refused the launches run the whole ladder.  The launch that builds a
+ * table waits for the build (14-45 ms, once per ctx and curve) before it returns, *_dev entry points included. */
 int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits);
 /* bits of the prefix table `curve` has at this moment (0 = none: not built yet, switched off, or memory refused);
  * negative fec_status on a bad argument.  Multi-device ctx: the first shard worker's. */
