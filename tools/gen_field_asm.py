@@ -52,6 +52,15 @@ def vp(n):
     return "v[%d:%d]" % (n, n + 1)
 
 
+# The capture of a v_mad_u64_u32's carry, directly behind it: VOP2 (implicit vcc).  In isolation the VOP3 encoding is
+# the cheaper one behind a mad (mad + addc_e32 9.6 cycles per pair per SIMD at three wavefronts, mad + addc_e64 8.7:
+# tools/microbench/valu_occ.hip); in the kernels it is the slower one (secp256k1 28.72 -> 29.20 ms, P-256 23.79 -> 24.10,
+# Ed25519 table kernel 5.03 -> 5.19, same box, round 3) -- eight bytes to fetch instead of four, 1 100 times per ladder step.
+# Likewise the column's closing v_mov moved between the last mad and its capture (free in isolation: mad, mov, addc 9.5
+# cycles against 9.6 for mad, addc): 28.84 -> 28.97 ms, nothing for the other kernels.
+CAPTURE = "v_addc_co_u32_e32 %s, vcc, 0, %s, vcc"
+
+
 def interleave(main, side):
     """Spread the instructions of `side` through `main`: one after every main instruction that is
     not a v_mad (so a mad and the v_addc that consumes its carry stay adjacent)."""
@@ -86,7 +95,7 @@ def mul_wide_columns(A, B, VB, side_for_column=None, first_col_src=None):
                     main.append("v_addc_co_u32_e64 %s, vcc, 0, 0, vcc" % v(C + 1))
             else:
                 main.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (vp(q), A[i], B[j], vp(q)))
-                main.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (v(C + 1), v(C + 1)))
+                main.append(CAPTURE % (v(C + 1), v(C + 1)))
         if k != 14:
             main.append("v_mov_b32_e32 %s, %s" % (v(C), v(q + 1)))
         side = side_for_column(k) if side_for_column else []
@@ -281,7 +290,7 @@ def sqr_wide_columns(A, VB, sink):
                     ins.append("v_addc_co_u32_e64 %s, vcc, 0, 0, vcc" % v(C + 1))
             else:
                 ins.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (vp(q), A[i], A[j], vp(q)))
-                ins.append("v_addc_co_u32_e32 %s, vcc, 0, %s, vcc" % (v(C + 1), v(C + 1)))
+                ins.append(CAPTURE % (v(C + 1), v(C + 1)))
         if k != 13:
             ins.append("v_mov_b32_e32 %s, %s" % (v(C), v(q + 1)))
         if k % 2 == 1:  # spread the independent squares through the columns
