@@ -416,6 +416,10 @@ def test_abi_argument_errors(gpu_ctx):
     assert L.fec_field_op(h, 0, 9, buf, buf, buf, 1) == -1        # unknown op
     assert L.fec_batch_mul(h, 0, None, None, None, 0) == 0        # empty batch is fine
     assert L.fec_batch_mul_dev(h, 0, ctypes.c_void_p(8), ctypes.c_void_p(16), ctypes.c_void_p(16), 1, None) == -1
+    assert L.fec_ctx_set_fixed_prefix_bits(h, 29) == -1           # at most 28 bits
+    assert L.fec_ctx_set_fixed_prefix_bits(None, 8) == -1
+    assert L.fec_ctx_fixed_prefix_bits(h, 5) == -1                # unknown curve
+    assert L.fec_ctx_fixed_prefix_bits(None, 0) == -1
 
 
 def test_ed25519_fixed_base_device_path_reuses_table(gpu_ctx, oracle):
