@@ -46,6 +46,13 @@ WORKLOADS = {
     "ed25519-var": ("ed25519", "var", 248832, 288, "-"),
     "secp256k1-fixed": ("secp256k1", "fixed", 693248, 128, "north_star fixed-base target"),
 }
+# for the workloads whose work depends on the scalars' set bits the per-run figure is computed from
+# the actual batch (mean popcount pc of this rank's scalars), not from the popcount-128 average of the table above
+ALG_FROM_POPCOUNT = {
+    "p256-var": lambda pc: 256 * 576 + pc * 1024,        # 256 doublings (9 Mul) + one addition (16 Mul) per set bit
+    "ed25519-fixed": lambda pc: pc * 648,                # one addition (9 Mul of 72 MAD32) per set bit
+    "ed25519-var": lambda pc: (256 + pc) * 648,          # 256 doublings of the addend + one addition per set bit
+}
 CURVE_ID = {"secp256k1": 0, "p256": 1, "ed25519": 2}
 # where the PMC traffic is far above the algorithmic bytes ON PURPOSE
 TRAFFIC_NOTES = {
@@ -80,6 +87,9 @@ def parse():
                     help="N>1: `both` (default) = time the K steps with the gather of the result shards to rank 0 over RCCL "
                          "(overlapped with the next step; this is `value`) and again without it (`gather.none`); or one of "
                          "rank0 / all (all-gather to every rank) / none only")
+    ap.add_argument("--scalars-below-l", action="store_true",
+                    help="Ed25519 workloads: scalars below 2^252 < l (the reference's Scalar::random leaves them below "
+                         "2^255 - 19, the default here; SURVEY.md section 8d asks for this run as well)")
     ap.add_argument("--fixed-prefix-bits", type=int, default=None,
                     help="fixed-base workloads: size of the generator's prefix table (fec_ctx_set_fixed_prefix_bits; "
                          "0 = off; default: the library's, 24)")
@@ -247,6 +257,8 @@ def main():
     # ONE global batch (the same data whatever N is), every rank generates it and keeps its contiguous shard.
     def gen(count, seed_off):
         k = synth.scalars(count, cid, 1000 + seed_off)
+        if args.scalars_below_l and curve == "ed25519":
+            k[:, 3] &= np.uint64((1 << 60) - 1)   # < 2^252 < l; a scalar that became zero is as rare as 2^-252
         arrs = [k]
         if kind in ("var", "double"):
             arrs.append(synth.points(count, cid, 1001 + seed_off) if kind == "var" else synth.scalars(count, cid, 1001 + seed_off))
@@ -257,6 +269,9 @@ def main():
         inputs = [np.ascontiguousarray(a[lo:lo + n]) for a in gen(n_global, 0)]
     else:
         inputs = gen(n, 3 * rank)
+    mean_popcount = float(np.unpackbits(np.ascontiguousarray(inputs[0]).view(np.uint8)).sum()) / n
+    if workload in ALG_FROM_POPCOUNT:
+        alg = ALG_FROM_POPCOUNT[workload](mean_popcount)
     d_in = [torch.from_numpy(a.view(np.int64)).cuda() for a in inputs]
     d_out = [torch.empty((n, limbs), dtype=torch.int64, device="cuda") for _ in range(2)]
     # All launches and collectives are ordered on ONE explicit (non-default) torch stream: the library
@@ -405,6 +420,8 @@ def main():
                      "2^%d %s scalar-muls (global)" % (n_global.bit_length() - 1, workload), n_global.bit_length() - 1, world, n))
         else:
             wl = "2^%d %s scalar-muls per GPU per step (BASELINE.json %s)" % (args.log2_batch, workload, cfg)
+        if args.scalars_below_l and curve == "ed25519":
+            wl += "; scalars below 2^252 < l"
         out = {
             "metric": "%s scalar-muls/sec (batched, %s)" % (
                 workload, "bit-exact vs CPU oracle on the parity sample" if cpu else "parity check not run in this invocation"),
@@ -423,7 +440,7 @@ def main():
                 "traffic_source": pmc["source"],
                 "traffic_note": TRAFFIC_NOTES.get(workload),
                 "kernel": kname, "kernel_ms": kernel_ms,
-                "algorithmic_mad32_per_unit": alg, "executed_mul_insts_per_unit": EXECUTED_MULS[workload](prefix["bits"] if prefix else 0),
+                "algorithmic_mad32_per_unit": alg, "mean_scalar_popcount": mean_popcount, "executed_mul_insts_per_unit": EXECUTED_MULS[workload](prefix["bits"] if prefix else 0),
                 "fixed_base_prefix_table": prefix,
                 "units_per_launch": n,
                 "peak_measured": peak_measured / 1e12, "frac_of_measured_peak": achieved / peak_measured,
