@@ -486,6 +486,25 @@ __global__ __launch_bounds__(TPB) void k_peak_mad32(u32* out, u32 seed) {
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = (u32)cs ^ (u32)(cs >> 32);
 }
 
+// ---- fixed-base prefix tables, one level per launch (ensure_gen_prefix) -------------------------------------------
+// P-256 (p256.rs:2126-2134, one step of the loop): child[g] = double(parent[g >> 1]), + base if g & 1
+__global__ __launch_bounds__(TPB) void k_p256_prefix_level(const u32* __restrict__ parent, u32* __restrict__ child,
+                                                           const u32* __restrict__ base, size_t n) {
+  const size_t g = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= n) return;
+  p256::pt r = p256::pdouble(P256::load(parent + (g >> 1) * 24, 1));
+  if (g & 1) r = p256::padd(r, P256::load(base, 1));
+  P256::store(child + g * 24, 1, r);
+}
+// Ed25519 (ed25519.rs:2073-2094): the result after the low j + 1 bits whose bit j is set = the result after the low j
+// bits + addend_j (`addend` = entry j of the doubling-chain table): upper[g] = lower[g] + addend, in place
+__global__ __launch_bounds__(TPB) void k_ed_prefix_level(const u32* __restrict__ lower, u32* __restrict__ upper,
+                                                         const u32* __restrict__ addend, size_t n) {
+  const size_t g = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= n) return;
+  Ed::store(upper + g * 32, 1, ed::padd(Ed::load(lower + g * 32, 1), Ed::load(addend, 1)));
+}
+
 }  // namespace fecgpu
 
 
@@ -519,49 +538,80 @@ const u64 FE_ONE[4] = {1, 0, 0, 0};
 // Fixed-base prefix tables: 2^24 entries by default (secp256k1 3.0 GiB, built in ~45 ms on the first fixed-base launch;
 // 24 of the 256 ladder steps are then a table fetch); at most 2^28 (48 GiB for secp256k1: sized for 288 GB of HBM).
 constexpr unsigned kDefaultPrefixBits = 24, kMaxPrefixBits = 28;
+// ... and only for a ctx that multiplies by the generator in earnest: the table of a curve is built by the launch that
+// takes the ctx past this many such multiplications (FEC_FIXED_PREFIX_AFTER; 0 after an explicit
+// fec_ctx_set_fixed_prefix_bits).  2^21: the allocation and the build (tens of ms) are then below two batches' saving.
+constexpr size_t kPrefixAfter = (size_t)1 << 21;
 
 
-// The fixed-base prefix table of `curve`'s generator() (kernels_secp.hip: k_secp_mul MODE 2 / 3), built on the first
-// fixed-base launch that can use it, on that launch's stream.  Refused memory is not an error: the launches then run the
-// whole ladder (SchedEnv carries a null table).
-void ensure_gen_prefix(fec_ctx* ctx, int curve, hipStream_t s) {
+// The fixed-base prefix table of `curve`'s generator() (kernels_secp.hip: k_secp_mul MODE 2 / 3; kernels_p256.hip: claim();
+// kernels_ed.hip: multiply_fixed_in_place), built on the stream of the fixed-base launch that takes the ctx past
+// `prefix_after` multiplications by the generator (a table costs GiBs of device memory and milliseconds: a ctx that
+// multiplies a few thousand scalars never pays for one; an explicit fec_ctx_set_fixed_prefix_bits builds at the next
+// launch).  `n`: the elements of this launch.  Refused memory is not an error: the launches then run the whole ladder
+// (SchedEnv carries a null table).
+//
+// The table grows level by level, every level one launch that performs ONE step of the reference's loop per entry:
+//   secp256k1  level j entry g = one ladder step from level j-1 entry g >> 1 with the bit g & 1 (k_secp_mul<3>);
+//              level 0 = (identity, G); levels alternate between the table and a scratch of half its size
+//   P-256      level j entry g = double(level j-1 entry g >> 1), + G if g & 1; level 0 = identity; same two buffers
+//   Ed25519    entries [2^j, 2^(j+1)) = entries [0, 2^j) + addend_j, in place; entry 0 = identity
+// 2^(w+1) steps in all -- 2 to 4 ms at w = 24 -- instead of w steps per entry.
+void ensure_gen_prefix(fec_ctx* ctx, int curve, hipStream_t s, size_t n) {
   if (ctx->prefix_bits == 0 || ctx->gen_prefix_tried[curve]) return;
+  ctx->fixed_elems[curve] += n;
+  if (ctx->fixed_elems[curve] < ctx->prefix_after) return;
   ctx->gen_prefix_tried[curve] = true;
   const unsigned w = ctx->prefix_bits;
   const size_t entries = (size_t)1 << w;
   // secp256k1: the ladder's pair (r0, r1); P-256: the running result; Ed25519: the running result (X, Y, Z, T)
   const size_t entry_words = curve == FEC_SECP256K1 ? 48 : (curve == FEC_P256 ? 24 : 32);
   void* t = nullptr;
-  void* idx = nullptr;
+  void* half = nullptr;
   auto give_up = [&] {
     (void)hipGetLastError();
     if (t) (void)hipFree(t);
-    if (idx) (void)hipFree(idx);
+    if (half) (void)hipFree(half);
   };
   if (hipMalloc(&t, entries * entry_words * sizeof(u32)) != hipSuccess) return give_up();
-  const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
+  if (curve != FEC_ED25519 && hipMalloc(&half, (entries / 2 ? entries / 2 : 1) * entry_words * sizeof(u32)) != hipSuccess) return give_up();
   order_after_previous(ctx, s);
-  if (curve == FEC_SECP256K1) {
-    secp_prefix_build_launch(gen, static_cast<u32*>(t), (int)w, s);
-  } else {
-    // P-256 / Ed25519: entry i is multiply(G, i) itself -- the leading steps of a small scalar leave the running result
-    // at the identity (P-256: doublings of the identity, p256.rs:1870; Ed25519: no addition below the first set bit), so
-    // the multiplication kernels produce the table from the scalars 0 .. 2^w - 1 (no table of their own yet: SchedEnv
-    // still carries a null one for this curve).
-    if (hipMalloc(&idx, entries * 32) != hipSuccess) return give_up();
-    index_scalars_launch(static_cast<u32*>(idx), entries, s);
-    if (curve == FEC_P256) p256_launch_mul(sched_env(ctx), true, static_cast<const u32*>(idx), gen, static_cast<u32*>(t), entries, s);
-    else ed_fixed_launch(sched_env(ctx), static_cast<const u32*>(idx), gen, ctx->d_ed_table, static_cast<u32*>(t), entries, nullptr, s);
+  u32 first[48] = {0};   // level 0 / entry 0
+  if (curve == FEC_SECP256K1) {        // (identity, G): identity = (0, one(), 0) with one() = raw 1 (secp256k1.rs:1322, 585)
+    first[8] = 1;
+    std::memcpy(first + 24, ctx->h_gen[curve], 96);
+  } else if (curve == FEC_P256) {      // identity = (0, 1, 0) (p256.rs:1827)
+    first[8] = 1;
+  } else {                             // identity = (0, 1, 1, 0) (ed25519.rs:1776)
+    first[8] = 1;
+    first[16] = 1;
   }
-  // once per ctx and curve: wait here, so that a failed build (a launch error, a scheduler fault -- its error word stays
-  // set for the caller's own check) never becomes a table
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
-      (ctx->h_err && *reinterpret_cast<volatile unsigned*>(ctx->h_err) != 0)) {
+  u32* tab = static_cast<u32*>(t);
+  u32* buf[2] = {tab, static_cast<u32*>(half)};                    // level j lives in buf[(w - j) & 1]
+  u32* level0 = curve == FEC_ED25519 ? tab : buf[w & 1];
+  if (hipMemcpyAsync(level0, first, entry_words * sizeof(u32), hipMemcpyHostToDevice, s) != hipSuccess) return give_up();
+  const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
+  for (unsigned j = 1; j <= w; ++j) {
+    const size_t cnt = (size_t)1 << j;                             // entries of level j
+    if (curve == FEC_SECP256K1) {
+      secp_prefix_level_launch(buf[(w - j + 1) & 1], buf[(w - j) & 1], cnt, s);
+    } else if (curve == FEC_P256) {
+      hipLaunchKernelGGL(k_p256_prefix_level, dim3(grid_for(cnt)), dim3(TPB), 0, s, (const u32*)buf[(w - j + 1) & 1],
+                         buf[(w - j) & 1], gen, cnt);
+    } else {                                                       // addend_(j-1) = entry j - 1 of the doubling-chain table
+      hipLaunchKernelGGL(k_ed_prefix_level, dim3(grid_for(cnt / 2)), dim3(TPB), 0, s, (const u32*)tab, tab + (cnt / 2) * 32,
+                         (const u32*)(ctx->d_ed_table + (size_t)(j - 1) * 32), cnt / 2);
+    }
+  }
+  // once per ctx and curve: wait here (`first` is on this stack), so that a failed build never becomes a table
+  const bool launch_failed = hipGetLastError() != hipSuccess;
+  const bool sync_failed = hipStreamSynchronize(s) != hipSuccess;
+  if (launch_failed || sync_failed) {
     ctx->gen_prefix_tried[curve] = false;   // (not a question of memory: the next fixed-base launch tries again)
     return give_up();
   }
-  if (idx) (void)hipFree(idx);
-  ctx->d_gen_prefix[curve] = static_cast<u32*>(t);
+  if (half) (void)hipFree(half);
+  ctx->d_gen_prefix[curve] = tab;
   ctx->gen_prefix_bits[curve] = w;
 }
 void drop_gen_prefix(fec_ctx* ctx) {  // (hipFree waits for the device: no launch is still reading a table)
@@ -595,7 +645,7 @@ int launch_ed_fixed(fec_ctx* ctx, const u64* ds, const u64* dbase, const u64* ho
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int rc = ensure_ed_table(ctx, dbase, host_base, s);
   if (rc != FEC_OK) return rc;
-  if (dbase == ctx->d_gen[FEC_ED25519]) ensure_gen_prefix(ctx, FEC_ED25519, s);
+  if (dbase == ctx->d_gen[FEC_ED25519]) ensure_gen_prefix(ctx, FEC_ED25519, s, n);
   void* work = nullptr;  // the batch-wide popcount sort of large batches: per-stream scratch
   if (ed_fixed_work_bytes(n) != 0 && !(work = scratch_for(ctx, s, ed_fixed_work_bytes(n)))) return FEC_E_OOM;
   Launch L(ctx, stream, work ? "k_ed_fixed_sorted (+ k_ed_pc_hist, k_ed_pc_scan, k_ed_pc_scatter)" : "k_ed_fixed_base");
@@ -614,7 +664,7 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
   const char* name = curve == FEC_SECP256K1 ? (fixed ? "k_secp_mul<fixed>" : "k_secp_mul<var>")
                      : curve == FEC_P256    ? (fixed ? "k_p256_mul_sched<fixed>" : "k_p256_mul_sched<var>")
                                             : "k_ed_mul_pers";
-  if (fixed && dp == ctx->d_gen[curve]) ensure_gen_prefix(ctx, curve, stream ? (hipStream_t)stream : ctx->stream);
+  if (fixed && dp == ctx->d_gen[curve]) ensure_gen_prefix(ctx, curve, stream ? (hipStream_t)stream : ctx->stream, n);
   Launch L(ctx, stream, name);
   switch (curve) {
     case FEC_SECP256K1: secp_launch_mul(sched_env(ctx), fixed, s, p, o, n, L.s); break;
@@ -682,7 +732,7 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
     int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
     if (rc != FEC_OK) return rc;
   }
-  ensure_gen_prefix(ctx, curve, st);
+  ensure_gen_prefix(ctx, curve, st, n);
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op"
                         : (curve == FEC_P256 ? "k_p256_mul_sched x2 + k_point_op" : "k_ed_fixed_base + k_ed_mul_pers + k_point_op"));
   // The fixed-base product runs on the ctx's second stream beside the variable-base one (the persistent kernels, one
@@ -754,7 +804,7 @@ int launch_ecdsa_verify(fec_ctx* ctx, int curve, const unsigned char* dd, const 
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   void* work = scratch_for(ctx, st, ecdsa_work_bytes(n));
   if (!work) return FEC_E_OOM;
-  ensure_gen_prefix(ctx, curve, st);
+  ensure_gen_prefix(ctx, curve, st, n);
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_ecdsa_pre + k_secp_mul x2 + k_ecdsa_finish"
                                                : "k_ecdsa_pre + k_p256_mul_sched x2 + k_ecdsa_finish");
   ecdsa_launch(sched_env(ctx), curve, dd, reinterpret_cast<const u32*>(dr), reinterpret_cast<const u32*>(ds),
@@ -778,7 +828,7 @@ int launch_eddsa_verify(fec_ctx* ctx, const u64* dr, const unsigned char* drinf,
   u32* ka = reinterpret_cast<u32*>(work + n * 256);
   int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
   if (rc != FEC_OK) return rc;
-  ensure_gen_prefix(ctx, FEC_ED25519, st);
+  ensure_gen_prefix(ctx, FEC_ED25519, st, n);
   Launch L(ctx, stream, "k_eddsa_pre + k_ed_fixed_base + k_ed_mul_pers + k_eddsa_finish");
   eddsa_pre_launch(reinterpret_cast<const u32*>(dpk), dpinf, a, n, L.s);
   ed_fixed_launch(sched_env(ctx), reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(ctx->d_gen[FEC_ED25519]),
@@ -810,7 +860,7 @@ int launch_schnorr_verify(fec_ctx* ctx, int curve, const u64* dpk, const unsigne
     int rc = ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, st);
     if (rc != FEC_OK) return rc;
   }
-  ensure_gen_prefix(ctx, curve, st);
+  ensure_gen_prefix(ctx, curve, st, n);
   Launch L(ctx, stream, curve == FEC_SECP256K1 ? "k_schnorr_verify_pre + k_secp_mul x2 + k_schnorr_verify_finish"
                         : (curve == FEC_P256 ? "k_schnorr_verify_pre + k_p256_mul_sched x2 + k_schnorr_verify_finish"
                                              : "k_schnorr_verify_pre + k_ed_fixed_base + k_ed_mul_pers + k_schnorr_verify_finish"));
@@ -1035,6 +1085,8 @@ int fec_ctx_create(fec_ctx** out, int device) try {
       const unsigned long v = std::strtoul(w, nullptr, 10);
       ctx->prefix_bits = v > kMaxPrefixBits ? kMaxPrefixBits : (unsigned)v;
     }
+    const char* after = std::getenv("FEC_FIXED_PREFIX_AFTER");
+    ctx->prefix_after = after && *after ? (size_t)std::strtoull(after, nullptr, 10) : kPrefixAfter;
   }
   if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
       std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0 ||
@@ -1425,7 +1477,7 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
     }
   u32* ta = reinterpret_cast<u32*>(work + n * 160);
   u32* tb = reinterpret_cast<u32*>(work + n * 256);
-  ensure_gen_prefix(ctx, curve, ctx->stream);
+  ensure_gen_prefix(ctx, curve, ctx->stream, n);
   {
     Launch L(ctx, nullptr, curve == FEC_SECP256K1 ? "k_secp_mul x2 + k_point_op + k_fold_sum + k_ecdsa_batch_finish"
                                                   : "k_p256_mul_sched x2 + k_point_op + k_fold_sum + k_ecdsa_batch_finish");
@@ -1677,7 +1729,7 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
     u32* ep = reinterpret_cast<u32*>(work + n * 128);
     u32* qq = reinterpret_cast<u32*>(work + n * 224);
     const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
-    ensure_gen_prefix(ctx, curve, ctx->stream);
+    ensure_gen_prefix(ctx, curve, ctx->stream, n);
     const SchedEnv env = sched_env(ctx);
     Launch L(ctx, nullptr, secp ? "k_schnorr_pre + k_secp_mul x3 + k_schnorr_mid" : "k_schnorr_pre + k_p256_mul_sched x3 + k_schnorr_mid");
     const dim3 g(grid_for(n)), b(TPB);
@@ -2040,6 +2092,7 @@ int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits) try {
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   drop_gen_prefix(ctx);   // the tables are rebuilt at the new size by the next fixed-base launches
   ctx->prefix_bits = bits;
+  ctx->prefix_after = 0;  // asked for explicitly: no waiting for the ctx to have multiplied enough
   return FEC_OK;
 } FEC_ABI_CATCH_STATUS
 

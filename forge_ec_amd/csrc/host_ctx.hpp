@@ -73,6 +73,8 @@ struct fec_ctx {
   unsigned gen_prefix_bits[3] = {0, 0, 0};   // bits of the table that exists (0 = none yet / allocation refused)
   bool gen_prefix_tried[3] = {false, false, false};
   unsigned prefix_bits = 0;                  // wanted (FEC_FIXED_PREFIX_BITS at ctx creation, fec_ctx_set_fixed_prefix_bits)
+  size_t fixed_elems[3] = {0, 0, 0};         // multiplications by the generator this ctx has been asked for, per curve
+  size_t prefix_after = 0;                   // a table is built once fixed_elems reaches this (see fecgpu.hip: kPrefixAfter)
   bool in_multi_chunk_pipeline = false;  // set by host_pipeline while it runs more than one chunk (fecgpu.hip: SideStream)
 };
 

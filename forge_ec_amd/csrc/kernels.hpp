@@ -49,8 +49,9 @@ void index_scalars_launch(u32* scalars, size_t n, hipStream_t s);
 
 // kernels_secp.hip: secp256k1 Curve::multiply, lane-per-element ladder at three wavefronts per SIMD.
 void secp_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
-// table[g] (48 words: r0, r1) = the ladder's state for base `base` after wbits steps whose bits are g, msb first
-void secp_prefix_build_launch(const u32* base, u32* table, int wbits, hipStream_t s);
+// One level of the fixed-base prefix table: child[g] (48 words: r0, r1) = one ladder step from parent[g >> 1] with the
+// bit g & 1; level 0 is the single entry (identity, base)
+void secp_prefix_level_launch(const u32* parent, u32* child, size_t child_entries, hipStream_t s);
 
 // kernels_codec.hip: op 0 = PointAffine::from_bytes (in: n*33 bytes -> out xy, out2 inf, out3 ok),
 // op 1 = UncompressedPoint::to_affine (in: n*65 bytes -> xy, inf, ok), op 2 = UncompressedPoint::from_affine

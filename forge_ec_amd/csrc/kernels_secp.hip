@@ -104,15 +104,17 @@ FEC_DEV secp::pt padd_slots(const u32* lp, const u32* lq, lmask& need_double) {
 }  // namespace
 
 // MODE 0: variable base (points[i]); 1: one base (points[0]); 2: one base whose ladder starts from the PREFIX TABLE;
-// 3: builds that table.
+// 3: builds one level of that table from the level below.
 //
 // The prefix table of a fixed base (fecgpu.hip: ensure_gen_prefix).  The ladder's state after its first w steps --
 // the pair (r0, r1) -- depends on the base and on the first w scalar bits alone, so for the reference's generator() it
-// is computed once per ctx for all 2^w bit patterns (by this very loop, MODE 3: the same additions and doublings on the
-// same operands as a full multiplication would run) and kept in HBM: 2^w entries of 48 words, r0 then r1.  A
-// multiplication by the generator (MODE 2) fetches its entry and runs the remaining 256 - w steps: w / 256 of the work
-// is not redone for every element.  (The table is indexed by the bits in ladder order: step i reads bit 7 - i % 8 of
-// byte i / 8 of the scalar's little-endian bytes, 2655-2659, so the first 32 steps are bswap32 of word 0, msb first.)
+// is computed once per ctx for all 2^w bit patterns and kept in HBM: 2^w entries of 48 words, r0 then r1.  It grows
+// level by level (MODE 3): entry g of level j is ONE ladder step -- this very loop body, the same addition and
+// doubling on the same operands as a full multiplication runs -- from entry g >> 1 of level j - 1 with the bit g & 1;
+// level 0 is the ladder's initial state (identity, base).  2^(w+1) steps in all, 3.6 ms for w = 24.  A multiplication
+// by the generator (MODE 2) fetches its entry and runs the remaining 256 - w steps: w / 256 of the work is not redone
+// for every element.  (The table is indexed by the bits in ladder order: step i reads bit 7 - i % 8 of byte i / 8 of
+// the scalar's little-endian bytes, 2655-2659, so the first 32 steps are bswap32 of word 0, msb first.)
 template <int MODE>
 __global__ __launch_bounds__(TPB, 3) void k_secp_mul(const u32* __restrict__ scalars,
                                                   const u32* __restrict__ points,
@@ -138,8 +140,9 @@ __global__ __launch_bounds__(TPB, 3) void k_secp_mul(const u32* __restrict__ sca
       FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kg[i];
       early = lanes_where(any == 0);
     }
-    if (MODE == 2) {  // (the generator is not the identity: only the zero scalar leaves early, 2636-2639)
-      const u32 idx = __builtin_bswap32(kg[0]) >> (32 - wbits);
+    if (MODE == 2 || MODE == 3) {  // (the generator is not the identity: only the zero scalar leaves early, 2636-2639)
+      // MODE 3: `prefix` is the level below, this element's parent entry is g >> 1
+      const u32 idx = MODE == 3 ? (u32)(g >> 1) : __builtin_bswap32(kg[0]) >> (32 - wbits);
       const uint4* row = reinterpret_cast<const uint4*>(prefix + (size_t)idx * 48);
       FEC_UNROLL for (int q = 0; q < 12; ++q) {
         const uint4 x = row[q];
@@ -148,20 +151,20 @@ __global__ __launch_bounds__(TPB, 3) void k_secp_mul(const u32* __restrict__ sca
         slot0[(4 * q + 2) * TPB] = x.z;
         slot0[(4 * q + 3) * TPB] = x.w;
       }
-      i0 = wbits;
+      i0 = MODE == 3 ? 0 : wbits;
+      if (MODE == 3) i1 = 1;
     } else {
       const secp::pt r1 = MODE != 0 ? ld3(points, 1) : ld3(lds + e, TPB);
-      if (MODE != 3) early |= secp::is_identity(r1);
+      early |= secp::is_identity(r1);
       st3(slot0, TPB, secp::identity());
       st3(slot0 + 24 * TPB, TPB, r1);
-      if (MODE == 3) i1 = wbits;
     }
     u32 kword = MODE == 3 ? 0u : kg[i0 >> 5];
 #pragma unroll 1
     for (int i = i0; i < i1; ++i) {
       u32 b;
       if (MODE == 3) {
-        b = (u32)(g >> (wbits - 1 - i)) & 1u;   // entry g: its bits are the ladder's first wbits bits, msb first
+        b = (u32)g & 1u;   // entry g of this level: the parent's bits, then this one
       } else {
         if ((i & 31) == 0) kword = kg[i >> 5];
         // bit i of the ladder (2655-2659): byte i/8 of the little-endian bytes, MSB first in the byte
@@ -202,10 +205,9 @@ void secp_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const 
   else hipLaunchKernelGGL((k_secp_mul<0>), dim3(grid), dim3(TPB), 0, s, scalars, points, out, n, (const u32*)nullptr, 0);
 }
 
-void secp_prefix_build_launch(const u32* base, u32* table, int wbits, hipStream_t s) {
-  const size_t entries = (size_t)1 << wbits;
-  hipLaunchKernelGGL((k_secp_mul<3>), dim3((unsigned)((entries + TPB - 1) / TPB)), dim3(TPB), 0, s, (const u32*)nullptr, base, table,
-                     entries, (const u32*)nullptr, wbits);
+void secp_prefix_level_launch(const u32* parent, u32* child, size_t child_entries, hipStream_t s) {
+  hipLaunchKernelGGL((k_secp_mul<3>), dim3((unsigned)((child_entries + TPB - 1) / TPB)), dim3(TPB), 0, s, (const u32*)nullptr,
+                     (const u32*)nullptr, child, child_entries, parent, 0);
 }
 
 }  // namespace fecgpu

@@ -343,13 +343,17 @@ int fec_ctx_check(fec_ctx* ctx);
 int fec_ctx_debug_force_fault(fec_ctx* ctx, int enabled);
 
 /* Fixed-base prefix tables.  The state of Curve::multiply(generator(), k) after its first `bits` steps depends on the
- * first `bits` scalar bits alone, so a ctx computes it once -- with the same kernels, on the first fixed-base launch of
- * a curve -- for all 2^bits patterns and keeps the table in HBM; every multiplication by the generator (fec_batch_mul_fixed
- * with fec_generator's point, the u1*G of the ECDSA / Schnorr entry points, fec_batch_double_mul) then fetches its entry
- * and runs the remaining steps.  Results are bit-identical with or without the table.  Default 24 bits (secp256k1:
- * 3.0 GiB of device memory per ctx; env FEC_FIXED_PREFIX_BITS at ctx creation), at most 28, 0 = off.  Changing the
- * size drops the existing tables.  If the memory is refused the launches run the whole ladder.  The launch that builds a
- * table waits for the build (14-45 ms, once per ctx and curve) before it returns, *_dev entry points included. */
+ * first `bits` scalar bits alone, so a ctx computes it once -- one step of the reference's loop per entry and level, with
+ * the same arithmetic -- for all 2^bits patterns and keeps the table in HBM; every multiplication by the generator
+ * (fec_batch_mul_fixed with fec_generator's point, the u1*G of the ECDSA / Schnorr entry points, fec_batch_double_mul)
+ * then fetches its entry and runs the remaining steps.  Results are bit-identical with or without the table.
+ * Default: 24 bits (secp256k1 3.0 GiB, P-256 1.5 GiB, Ed25519 2.0 GiB of device memory per ctx), built by the launch
+ * that takes the ctx past 2^21 multiplications by that curve's generator (env FEC_FIXED_PREFIX_BITS /
+ * FEC_FIXED_PREFIX_AFTER at ctx creation) -- a ctx that multiplies a few thousand scalars never allocates one.  This
+ * call sets the size (at most 28 bits, 0 = off), drops the existing tables and makes the next fixed-base launch of a
+ * curve build its table at once.  If the memory is refused the launches run the whole ladder.  The launch that builds
+ * a table waits for the build (2-4 ms of kernels at 24 bits, plus the allocation) before it returns, *_dev entry points
+ * included. */
 int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits);
 /* bits of the prefix table `curve` has at this moment (0 = none: not built yet, switched off, or memory refused);
  * negative fec_status on a bad argument.  Multi-device ctx: the first shard worker's. */

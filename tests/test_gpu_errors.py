@@ -153,21 +153,23 @@ def test_destroy_and_wipe_report_success():
     other.close()
 
 
-def test_fault_during_a_prefix_table_build_leaves_no_table(oracle):
-    """The P-256 prefix table is produced by the scheduler kernel itself: a fault while it is built (the debug hook)
-    is reported by the call that triggered the build, no table is kept, and the next fixed-base call builds it."""
+def test_prefix_table_policy_and_faults(oracle):
+    """A ctx left to its defaults builds a prefix table only once it has multiplied 2^21 scalars by the generator; after
+    fec_ctx_set_fixed_prefix_bits the next fixed-base launch builds it.  The build does not run a scheduler kernel, so
+    the forced fault hits the multiplication that follows it: the call fails, the table stays, the next call is right."""
     import forge_ec_amd as F
     n = 500
     k = V.scalars(n, 1, 71)
     with F.Context(0) as ctx:
-        ctx.set_fixed_prefix_bits(9)
         g = ctx.generator(1)
+        want = oracle.batch_mul_fixed(1, k, oracle.generator(1), nthreads=8)
+        assert np.array_equal(ctx.batch_mul_fixed(1, k, g), want)
+        assert ctx.fixed_prefix_bits(1) == 0          # 500 multiplications: no table
+        ctx.set_fixed_prefix_bits(9)
         ctx.debug_force_fault(True)
         with pytest.raises(F.FecError) as ei:
             ctx.batch_mul_fixed(1, k, g)
         assert ei.value.status == FEC_E_LAUNCH
-        assert ctx.fixed_prefix_bits(1) == 0
         ctx.debug_force_fault(False)
-        got = ctx.batch_mul_fixed(1, k, g)
+        assert np.array_equal(ctx.batch_mul_fixed(1, k, g), want)
         assert ctx.fixed_prefix_bits(1) == 9
-        assert np.array_equal(got, oracle.batch_mul_fixed(1, k, oracle.generator(1), nthreads=8))
