@@ -535,7 +535,7 @@ const u64 GEN_ED[16] = {0x1A1462FAFB9683F2ULL, 0xD2E8A68B8B30C404ULL, 0xA0C0F3A1
                         0xA6FB8EEBCEAA2C8DULL, 0x5FD9C9E6CC3CCCCCULL, 1, 0, 0, 0,
                         0, 0, 0, 0};  // T is filled in on the device
 const u64 FE_ONE[4] = {1, 0, 0, 0};
-// Fixed-base prefix tables: 2^24 entries by default (secp256k1 3.0 GiB, built in ~45 ms on the first fixed-base launch;
+// Fixed-base prefix tables: 2^24 entries by default (secp256k1 3.0 GiB, built level by level in a few ms, see ensure_gen_prefix;
 // 24 of the 256 ladder steps are then a table fetch); at most 2^28 (48 GiB for secp256k1: sized for 288 GB of HBM).
 constexpr unsigned kDefaultPrefixBits = 24, kMaxPrefixBits = 28;
 // ... and only for a ctx that multiplies by the generator in earnest: the table of a curve is built by the launch that

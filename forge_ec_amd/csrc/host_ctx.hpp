@@ -68,7 +68,7 @@ struct fec_ctx {
   unsigned* d_err = nullptr;       // device view of the same word
   unsigned debug_force_fault = 0;  // fec_ctx_debug_force_fault
   // Fixed-base prefix tables of the reference's generator() (kernels.hpp: SchedEnv; fecgpu.hip: ensure_gen_prefix):
-  // built on the first fixed-base launch of a curve, 2^prefix_bits entries; prefix_bits 0 = off.
+  // built by the fixed-base launch that takes the ctx past prefix_after multiplications, 2^prefix_bits entries; 0 = off.
   u32* d_gen_prefix[3] = {nullptr, nullptr, nullptr};
   unsigned gen_prefix_bits[3] = {0, 0, 0};   // bits of the table that exists (0 = none yet / allocation refused)
   bool gen_prefix_tried[3] = {false, false, false};
