@@ -496,6 +496,19 @@ __global__ __launch_bounds__(TPB) void k_p256_prefix_level(const u32* __restrict
   if (g & 1) r = p256::padd(r, P256::load(base, 1));
   P256::store(child + g * 24, 1, r);
 }
+// level 0 / entry 0: the multiplication's initial state -- secp256k1 (identity, base) with identity = (0, one(), 0), one()
+// = raw 1 (secp256k1.rs:1322, 585); P-256 the identity (0, 1, 0) (p256.rs:1827); Ed25519 the identity (0, 1, 1, 0)
+// (ed25519.rs:1776)
+__global__ __launch_bounds__(64) void k_prefix_level0(int curve, const u32* __restrict__ base, u32* __restrict__ dst) {
+  const int t = threadIdx.x;
+  const int words = curve == FEC_SECP256K1 ? 48 : (curve == FEC_P256 ? 24 : 32);
+  if (t >= words) return;
+  u32 v = 0;
+  if (t == 8) v = 1u;
+  if (curve == FEC_ED25519 && t == 16) v = 1u;
+  if (curve == FEC_SECP256K1 && t >= 24) v = base[t - 24];
+  dst[t] = v;
+}
 // Ed25519 (ed25519.rs:2073-2094): the result after the low j + 1 bits whose bit j is set = the result after the low j
 // bits + addend_j (`addend` = entry j of the doubling-chain table): upper[g] = lower[g] + addend, in place
 __global__ __launch_bounds__(TPB) void k_ed_prefix_level(const u32* __restrict__ lower, u32* __restrict__ upper,
@@ -557,15 +570,36 @@ constexpr size_t kPrefixAfter = (size_t)1 << 21;
 //   P-256      level j entry g = double(level j-1 entry g >> 1), + G if g & 1; level 0 = identity; same two buffers
 //   Ed25519    entries [2^j, 2^(j+1)) = entries [0, 2^j) + addend_j, in place; entry 0 = identity
 // 2^(w+1) steps in all -- 2 to 4 ms at w = 24 -- instead of w steps per entry.
+constexpr size_t prefix_entry_words(int curve) { return curve == FEC_SECP256K1 ? 48 : (curve == FEC_P256 ? 24 : 32); }
+// bytes of the two buffers a w-bit table of `curve` is built in: the table, and (not Ed25519) the scratch of half its size
+inline size_t prefix_table_bytes(int curve, unsigned w) { return ((size_t)1 << w) * prefix_entry_words(curve) * sizeof(u32); }
+inline size_t prefix_half_bytes(int curve, unsigned w) { return curve == FEC_ED25519 ? 0 : (w ? prefix_table_bytes(curve, w - 1) : prefix_entry_words(curve) * sizeof(u32)); }
+
+// Queues the w level launches that fill `tab` (2^w entries) for the base at device address `base` on stream s.
+// `ed_addends`: the Ed25519 doubling-chain table of that base (ensure_ed_table).
+void queue_prefix_levels(int curve, const u32* base, const u32* ed_addends, unsigned w, u32* tab, u32* half, hipStream_t s) {
+  u32* buf[2] = {tab, half};                                       // level j lives in buf[(w - j) & 1]
+  hipLaunchKernelGGL(k_prefix_level0, dim3(1), dim3(64), 0, s, curve, base, curve == FEC_ED25519 ? tab : buf[w & 1]);
+  for (unsigned j = 1; j <= w; ++j) {
+    const size_t cnt = (size_t)1 << j;                             // entries of level j
+    if (curve == FEC_SECP256K1) {
+      secp_prefix_level_launch(buf[(w - j + 1) & 1], buf[(w - j) & 1], cnt, s);
+    } else if (curve == FEC_P256) {
+      hipLaunchKernelGGL(k_p256_prefix_level, dim3(grid_for(cnt)), dim3(TPB), 0, s, (const u32*)buf[(w - j + 1) & 1],
+                         buf[(w - j) & 1], base, cnt);
+    } else {                                                       // addend_(j-1) = entry j - 1 of the doubling-chain table
+      hipLaunchKernelGGL(k_ed_prefix_level, dim3(grid_for(cnt / 2)), dim3(TPB), 0, s, (const u32*)tab, tab + (cnt / 2) * 32,
+                         ed_addends + (size_t)(j - 1) * 32, cnt / 2);
+    }
+  }
+}
+
 void ensure_gen_prefix(fec_ctx* ctx, int curve, hipStream_t s, size_t n) {
   if (ctx->prefix_bits == 0 || ctx->gen_prefix_tried[curve]) return;
   ctx->fixed_elems[curve] += n;
   if (ctx->fixed_elems[curve] < ctx->prefix_after) return;
   ctx->gen_prefix_tried[curve] = true;
   const unsigned w = ctx->prefix_bits;
-  const size_t entries = (size_t)1 << w;
-  // secp256k1: the ladder's pair (r0, r1); P-256: the running result; Ed25519: the running result (X, Y, Z, T)
-  const size_t entry_words = curve == FEC_SECP256K1 ? 48 : (curve == FEC_P256 ? 24 : 32);
   void* t = nullptr;
   void* half = nullptr;
   auto give_up = [&] {
@@ -573,37 +607,12 @@ void ensure_gen_prefix(fec_ctx* ctx, int curve, hipStream_t s, size_t n) {
     if (t) (void)hipFree(t);
     if (half) (void)hipFree(half);
   };
-  if (hipMalloc(&t, entries * entry_words * sizeof(u32)) != hipSuccess) return give_up();
-  if (curve != FEC_ED25519 && hipMalloc(&half, (entries / 2 ? entries / 2 : 1) * entry_words * sizeof(u32)) != hipSuccess) return give_up();
+  if (hipMalloc(&t, prefix_table_bytes(curve, w)) != hipSuccess) return give_up();
+  if (prefix_half_bytes(curve, w) != 0 && hipMalloc(&half, prefix_half_bytes(curve, w)) != hipSuccess) return give_up();
   order_after_previous(ctx, s);
-  u32 first[48] = {0};   // level 0 / entry 0
-  if (curve == FEC_SECP256K1) {        // (identity, G): identity = (0, one(), 0) with one() = raw 1 (secp256k1.rs:1322, 585)
-    first[8] = 1;
-    std::memcpy(first + 24, ctx->h_gen[curve], 96);
-  } else if (curve == FEC_P256) {      // identity = (0, 1, 0) (p256.rs:1827)
-    first[8] = 1;
-  } else {                             // identity = (0, 1, 1, 0) (ed25519.rs:1776)
-    first[8] = 1;
-    first[16] = 1;
-  }
-  u32* tab = static_cast<u32*>(t);
-  u32* buf[2] = {tab, static_cast<u32*>(half)};                    // level j lives in buf[(w - j) & 1]
-  u32* level0 = curve == FEC_ED25519 ? tab : buf[w & 1];
-  if (hipMemcpyAsync(level0, first, entry_words * sizeof(u32), hipMemcpyHostToDevice, s) != hipSuccess) return give_up();
-  const u32* gen = reinterpret_cast<const u32*>(ctx->d_gen[curve]);
-  for (unsigned j = 1; j <= w; ++j) {
-    const size_t cnt = (size_t)1 << j;                             // entries of level j
-    if (curve == FEC_SECP256K1) {
-      secp_prefix_level_launch(buf[(w - j + 1) & 1], buf[(w - j) & 1], cnt, s);
-    } else if (curve == FEC_P256) {
-      hipLaunchKernelGGL(k_p256_prefix_level, dim3(grid_for(cnt)), dim3(TPB), 0, s, (const u32*)buf[(w - j + 1) & 1],
-                         buf[(w - j) & 1], gen, cnt);
-    } else {                                                       // addend_(j-1) = entry j - 1 of the doubling-chain table
-      hipLaunchKernelGGL(k_ed_prefix_level, dim3(grid_for(cnt / 2)), dim3(TPB), 0, s, (const u32*)tab, tab + (cnt / 2) * 32,
-                         (const u32*)(ctx->d_ed_table + (size_t)(j - 1) * 32), cnt / 2);
-    }
-  }
-  // once per ctx and curve: wait here (`first` is on this stack), so that a failed build never becomes a table
+  queue_prefix_levels(curve, reinterpret_cast<const u32*>(ctx->d_gen[curve]), ctx->d_ed_table, w, static_cast<u32*>(t),
+                      static_cast<u32*>(half), s);
+  // once per ctx and curve: wait here, so that a failed build never becomes a table
   const bool launch_failed = hipGetLastError() != hipSuccess;
   const bool sync_failed = hipStreamSynchronize(s) != hipSuccess;
   if (launch_failed || sync_failed) {
@@ -611,8 +620,41 @@ void ensure_gen_prefix(fec_ctx* ctx, int curve, hipStream_t s, size_t n) {
     return give_up();
   }
   if (half) (void)hipFree(half);
-  ctx->d_gen_prefix[curve] = tab;
+  ctx->d_gen_prefix[curve] = static_cast<u32*>(t);
   ctx->gen_prefix_bits[curve] = w;
+}
+
+// Any OTHER fixed base: a table for this one launch, in the launch stream's scratch, sized to the batch -- 2^w entries
+// with w = log2(n) - 2 cost n / 2 steps to build and save n * w: from 2^16 elements on.  `front`: bytes of the scratch
+// the caller needs for itself, in front of the table.  On success `env` names the table for `base`; the scratch pointer
+// is returned through `scratch` (null: no scratch could be had -- the caller's own `front` bytes included).
+void per_call_prefix(fec_ctx* ctx, int curve, const u32* base, size_t n, hipStream_t s, size_t front, SchedEnv& env,
+                     void** scratch) {
+  *scratch = nullptr;
+  unsigned w = 0;
+  if (ctx->prefix_bits != 0 && n >= ((size_t)1 << 16)) {
+    unsigned lg = 0;
+    while (((size_t)2 << lg) <= n) ++lg;                           // floor(log2(n))
+    w = lg - 2;
+    if (w > ctx->prefix_bits) w = ctx->prefix_bits;
+    if (w > 22) w = 22;
+  }
+  const size_t fr = (front + 255) & ~(size_t)255;
+  const size_t bytes = fr + (w ? prefix_table_bytes(curve, w) + prefix_half_bytes(curve, w) : 0);
+  if (bytes == 0) return;
+  char* p = static_cast<char*>(scratch_for(ctx, s, bytes));
+  if (!p && w) {                                                   // no room for a table: the caller's own bytes alone
+    w = 0;
+    p = front ? static_cast<char*>(scratch_for(ctx, s, fr)) : nullptr;
+  }
+  *scratch = p;
+  if (!p || w == 0) return;
+  u32* tab = reinterpret_cast<u32*>(p + fr);
+  u32* half = prefix_half_bytes(curve, w) ? reinterpret_cast<u32*>(p + fr + prefix_table_bytes(curve, w)) : nullptr;
+  queue_prefix_levels(curve, base, ctx->d_ed_table, w, tab, half, s);
+  env.gen[curve] = base;
+  env.gen_prefix[curve] = tab;
+  env.gen_prefix_bits[curve] = w;
 }
 void drop_gen_prefix(fec_ctx* ctx) {  // (hipFree waits for the device: no launch is still reading a table)
   for (int c = 0; c < 3; ++c) {
@@ -645,11 +687,22 @@ int launch_ed_fixed(fec_ctx* ctx, const u64* ds, const u64* dbase, const u64* ho
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int rc = ensure_ed_table(ctx, dbase, host_base, s);
   if (rc != FEC_OK) return rc;
-  if (dbase == ctx->d_gen[FEC_ED25519]) ensure_gen_prefix(ctx, FEC_ED25519, s, n);
-  void* work = nullptr;  // the batch-wide popcount sort of large batches: per-stream scratch
-  if (ed_fixed_work_bytes(n) != 0 && !(work = scratch_for(ctx, s, ed_fixed_work_bytes(n)))) return FEC_E_OOM;
-  Launch L(ctx, stream, work ? "k_ed_fixed_sorted (+ k_ed_pc_hist, k_ed_pc_scan, k_ed_pc_scatter)" : "k_ed_fixed_base");
-  ed_fixed_launch(sched_env(ctx), reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(dbase), ctx->d_ed_table,
+  const bool is_gen = dbase == ctx->d_gen[FEC_ED25519];
+  if (is_gen) ensure_gen_prefix(ctx, FEC_ED25519, s, n);
+  // per-stream scratch: the batch-wide popcount sort of large batches, and behind it the prefix table of a base that is
+  // not the generator (per_call_prefix)
+  void* work = nullptr;
+  const size_t work_bytes = ed_fixed_work_bytes(n);
+  Launch L(ctx, stream, work_bytes ? "k_ed_fixed_sorted (+ k_ed_pc_hist, k_ed_pc_scan, k_ed_pc_scatter)" : "k_ed_fixed_base");
+  SchedEnv env = sched_env(ctx);
+  if (is_gen) {
+    if (work_bytes != 0 && !(work = scratch_for(ctx, s, work_bytes))) return FEC_E_OOM;
+  } else {
+    per_call_prefix(ctx, FEC_ED25519, reinterpret_cast<const u32*>(dbase), n, L.s, work_bytes, env, &work);
+    if (work_bytes != 0 && !work) return FEC_E_OOM;
+    if (work_bytes == 0) work = nullptr;   // (the scratch then holds the table alone: no sort area)
+  }
+  ed_fixed_launch(env, reinterpret_cast<const u32*>(ds), reinterpret_cast<const u32*>(dbase), ctx->d_ed_table,
                   reinterpret_cast<u32*>(dout), n, work, L.s);
   return L.done();
 }
@@ -666,10 +719,15 @@ int launch_mul(fec_ctx* ctx, int curve, bool fixed, const u64* ds, const u64* dp
                                             : "k_ed_mul_pers";
   if (fixed && dp == ctx->d_gen[curve]) ensure_gen_prefix(ctx, curve, stream ? (hipStream_t)stream : ctx->stream, n);
   Launch L(ctx, stream, name);
+  SchedEnv env = sched_env(ctx);
+  if (fixed && dp != ctx->d_gen[curve]) {   // a base of the caller's own: a table for this launch (per_call_prefix)
+    void* unused = nullptr;
+    per_call_prefix(ctx, curve, p, n, L.s, 0, env, &unused);
+  }
   switch (curve) {
-    case FEC_SECP256K1: secp_launch_mul(sched_env(ctx), fixed, s, p, o, n, L.s); break;
-    case FEC_P256: p256_launch_mul(sched_env(ctx), fixed, s, p, o, n, L.s); break;
-    default: ed_launch_mul(sched_env(ctx), s, p, o, n, L.s); break;
+    case FEC_SECP256K1: secp_launch_mul(env, fixed, s, p, o, n, L.s); break;
+    case FEC_P256: p256_launch_mul(env, fixed, s, p, o, n, L.s); break;
+    default: ed_launch_mul(env, s, p, o, n, L.s); break;
   }
   return L.done();
 }

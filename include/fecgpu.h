@@ -353,7 +353,9 @@ int fec_ctx_debug_force_fault(fec_ctx* ctx, int enabled);
  * call sets the size (at most 28 bits, 0 = off), drops the existing tables and makes the next fixed-base launch of a
  * curve build its table at once.  If the memory is refused the launches run the whole ladder.  The launch that builds
  * a table waits for the build (2-4 ms of kernels at 24 bits, plus the allocation) before it returns, *_dev entry points
- * included. */
+ * included.  A fixed base that is NOT the generator (fec_batch_mul_fixed with a point of the caller's own) gets a table
+ * for the one launch, in the launch stream's scratch, sized to the batch (2^(log2(n) - 2) entries, from 2^16 elements
+ * on, never more than `bits`); 0 switches that off as well. */
 int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits);
 /* bits of the prefix table `curve` has at this moment (0 = none: not built yet, switched off, or memory refused);
  * negative fec_status on a bad argument.  Multi-device ctx: the first shard worker's. */

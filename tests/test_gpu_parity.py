@@ -338,6 +338,26 @@ def test_fixed_base_prefix_table_is_invisible(oracle, curve, bits):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_fixed_base_of_the_callers_own_gets_a_table_per_launch(gpu_ctx, oracle, curve):
+    """From 2^16 elements on a fixed base that is not the generator is multiplied from a prefix table built for that one
+    launch (fecgpu.hip: per_call_prefix; 2^14 entries here): projective base with z != 1, every element against the oracle,
+    and the same call again with the tables switched off."""
+    import forge_ec_amd as F
+    n = (1 << 16) + 37
+    k = V.scalars(n, curve, 3411)
+    k[:_prefix_scalars(curve, 14, 1).shape[0]] = _prefix_scalars(curve, 14, 3412)
+    base = V.points(1, curve, 3413)[0]
+    want = oracle.batch_mul_fixed(curve, k, base, nthreads=8)
+    _assert_same(gpu_ctx.batch_mul_fixed(curve, k, base), want, "%s batch_mul_fixed(own base), table per launch" % NAMES[curve])
+    ctx = F.Context(0)
+    try:
+        ctx.set_fixed_prefix_bits(0)
+        _assert_same(ctx.batch_mul_fixed(curve, k, base), want, "%s batch_mul_fixed(own base), tables off" % NAMES[curve])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_batch_double_mul_matches_oracle(gpu_ctx, oracle, curve):
     n = 600
     u1 = V.scalars(n, curve, 321)
