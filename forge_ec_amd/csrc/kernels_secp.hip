@@ -140,7 +140,8 @@ __global__ __launch_bounds__(TPB, 3) void k_secp_mul(const u32* __restrict__ sca
       FEC_UNROLL for (int i = 0; i < 8; ++i) any |= kg[i];
       early = lanes_where(any == 0);
     }
-    if (MODE == 2 || MODE == 3) {  // (the generator is not the identity: only the zero scalar leaves early, 2636-2639)
+    if (MODE == 2) early |= secp::is_identity(ld3(points, 1));   // (2636-2639: a caller's own base may be the identity)
+    if (MODE == 2 || MODE == 3) {
       // MODE 3: `prefix` is the level below, this element's parent entry is g >> 1
       const u32 idx = MODE == 3 ? (u32)(g >> 1) : __builtin_bswap32(kg[0]) >> (32 - wbits);
       const uint4* row = reinterpret_cast<const uint4*>(prefix + (size_t)idx * 48);

@@ -349,6 +349,9 @@ def test_fixed_base_of_the_callers_own_gets_a_table_per_launch(gpu_ctx, oracle, 
     base = V.points(1, curve, 3413)[0]
     want = oracle.batch_mul_fixed(curve, k, base, nthreads=8)
     _assert_same(gpu_ctx.batch_mul_fixed(curve, k, base), want, "%s batch_mul_fixed(own base), table per launch" % NAMES[curve])
+    ident = oracle.identity(curve)   # multiply's first early-out (identity point) must win over the table
+    _assert_same(gpu_ctx.batch_mul_fixed(curve, k, ident), oracle.batch_mul_fixed(curve, k, ident, nthreads=8),
+                 "%s batch_mul_fixed(identity), table per launch" % NAMES[curve])
     ctx = F.Context(0)
     try:
         ctx.set_fixed_prefix_bits(0)
