@@ -46,6 +46,17 @@ class GpuContext {
     int rc = fec_ctx_check(ctx_);
     if (rc != FEC_OK) throw Error(rc);
   }
+  // fec_ctx_set_fixed_prefix_bits / fec_ctx_fixed_prefix_bits: the fixed-base prefix tables (fecgpu.h); results never
+  // depend on them
+  void set_fixed_prefix_bits(unsigned bits) {
+    int rc = fec_ctx_set_fixed_prefix_bits(ctx_, bits);
+    if (rc != FEC_OK) throw Error(rc);
+  }
+  unsigned fixed_prefix_bits(fec_curve curve) {
+    int rc = fec_ctx_fixed_prefix_bits(ctx_, curve);
+    if (rc < 0) throw Error(rc);
+    return (unsigned)rc;
+  }
   static GpuContext& global() {  // process-wide default context on device 0
     static GpuContext g(0);
     return g;

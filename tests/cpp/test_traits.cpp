@@ -262,6 +262,26 @@ static void signature_layer_and_codecs() {
 }
 
 // canonical-math mode through the C++ mirror: published points and a round trip
+// the fixed-base prefix tables through the C++ mirror: same products with a 10-bit table, without one, and by default
+static void fixed_base_prefix_tables() {
+  GpuContext ctx(0);
+  auto g = P256::generator();
+  std::vector<P256::ScalarT> k;
+  for (uint64_t i = 0; i < 300; ++i) k.push_back(P256::ScalarT::from_raw(Limbs{i * 0x9E3779B97F4A7C15ULL + 1, i, ~i, (i * 77) << 40}));
+  auto plain = P256::batch_multiply_fixed(ctx, g, k);
+  ctx.set_fixed_prefix_bits(10);
+  auto tabled = P256::batch_multiply_fixed(ctx, g, k);
+  CHECK(ctx.fixed_prefix_bits(FEC_P256) == 10, "an explicit set_fixed_prefix_bits builds the table at the next fixed-base launch");
+  bool same = plain.size() == tabled.size();
+  for (size_t i = 0; same && i < plain.size(); ++i) same = plain[i].c == tabled[i].c;
+  CHECK(same, "batch_multiply_fixed(G): identical with and without the prefix table");
+  ctx.set_fixed_prefix_bits(0);
+  auto off = P256::batch_multiply_fixed(ctx, g, k);
+  same = off.size() == plain.size();
+  for (size_t i = 0; same && i < plain.size(); ++i) same = plain[i].c == off[i].c;
+  CHECK(same && ctx.fixed_prefix_bits(FEC_P256) == 0, "tables off: same products, no table");
+}
+
 static void canonical_mode() {
   GpuContext ctx(0);
   // secp256k1: 1*G, 2*G, 3*G (3*G.x is the BIP-340 vector-0 public key)
@@ -286,6 +306,7 @@ static void canonical_mode() {
 int main() {
   try {
     canonical_mode();
+    fixed_base_prefix_tables();
     secp256k1_field_arithmetic();
     secp256k1_point_arithmetic();
     secp256k1_scalar_multiplication();
