@@ -1015,9 +1015,10 @@ struct HostIn {
   size_t bytes;   // only for stride == 0
 };
 template <class F>
-int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, size_t out_stride, F body) {
+int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, size_t out_stride, F body,
+                  bool scheduler_kernel = false) {
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  const size_t chunk = ctx->chunk;
+  const size_t chunk = pipeline_chunk(ctx, scheduler_kernel);
   const size_t nchunks = (n + chunk - 1) / chunk;
   struct InPipeline {  // (SideStream: a multi-chunk pipeline keeps both streams busy by itself)
     fec_ctx* c;
@@ -1322,7 +1323,7 @@ int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const 
   const HostIn in[3] = {{scalars, 32, 0}, {points, pb, 0}, {nullptr, 0, 0}};
   return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void*, void* o, size_t cnt, void* s) {
     return launch_mul(ctx, curve, false, (const u64*)a, (const u64*)b, (u64*)o, cnt, s);
-  });
+  }, curve != FEC_SECP256K1);
 } FEC_ABI_CATCH_STATUS
 
 int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* base,
@@ -1358,7 +1359,7 @@ int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, 
     const u64* db = is_gen ? ctx->d_gen[curve] : (const u64*)b;
     if (curve == FEC_ED25519) return launch_ed_fixed(ctx, (const u64*)a, db, base, (u64*)o, cnt, s);
     return launch_mul(ctx, curve, true, (const u64*)a, db, (u64*)o, cnt, s);
-  });
+  }, curve == FEC_P256);
 } FEC_ABI_CATCH_STATUS
 
 int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, const uint64_t* u2,
@@ -1376,7 +1377,7 @@ int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
   const HostIn in[3] = {{u1, 32, 0}, {u2, 32, 0}, {q, pb, 0}};
   return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void* c, void* o, size_t cnt, void* s) {
     return launch_double_mul(ctx, curve, (const u64*)a, (const u64*)b, (const u64*)c, (u64*)o, cnt, s);
-  });
+  }, curve == FEC_ED25519);   // (P-256: its two launches divide the CUs, a chunk is several fills either way)
 } FEC_ABI_CATCH_STATUS
 
 int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points,
@@ -1389,8 +1390,9 @@ int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars,
   int rc = ensure(ctx, 6, (n ? n : 1) * pb);   // products stay on the device
   if (rc == FEC_OK) rc = ensure(ctx, 7, pb);
   if (rc != FEC_OK) return rc;
-  for (size_t lo = 0; lo < n; lo += ctx->chunk) {  // the independent products, chunked
-    const size_t cnt = lo + ctx->chunk <= n ? ctx->chunk : n - lo;
+  const size_t msm_chunk = pipeline_chunk(ctx, curve != FEC_SECP256K1);
+  for (size_t lo = 0; lo < n; lo += msm_chunk) {  // the independent products, chunked
+    const size_t cnt = lo + msm_chunk <= n ? msm_chunk : n - lo;
     rc = ensure(ctx, 0, cnt * 32);
     if (rc == FEC_OK) rc = ensure(ctx, 1, cnt * pb);
     if (rc != FEC_OK) return rc;
@@ -1641,7 +1643,7 @@ int fec_batch_ecdh(fec_ctx* ctx, fec_curve curve, const uint64_t* private_keys, 
   return host_chunked(ctx, n, in, in_stride, outs, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
     return launch_ecdh(ctx, curve, (const u64*)d[0], (const u64*)d[1], (const unsigned char*)d[2], (unsigned char*)o[0],
                        (unsigned char*)o[1], cnt, nullptr);
-  });
+  }, curve == FEC_P256);
 } FEC_ABI_CATCH_STATUS
 
 int fec_eddsa_verify_ed25519_dev(fec_ctx* ctx, const uint64_t* d_r_xy, const uint8_t* d_r_inf, const uint64_t* d_pk_xy,
@@ -1712,7 +1714,8 @@ int fec_schnorr_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_xy, con
   if (n == 0) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   // chunked like the other element-wise calls; slots: 0 pk, 1 r, 2 s, 4 e, 5 pk_inf, 6 r_inf, 3 status
-  const size_t chunk = ctx->chunk < n ? ctx->chunk : n;
+  const size_t pc = pipeline_chunk(ctx, curve == FEC_ED25519);
+  const size_t chunk = pc < n ? pc : n;
   return drained(ctx, [&]() -> int {
   for (size_t lo = 0; lo < n; lo += chunk) {
     const size_t cnt = lo + chunk <= n ? chunk : n - lo;
@@ -2156,11 +2159,16 @@ int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits) try {
 
 int fec_ctx_set_chunk(fec_ctx* ctx, size_t elements) try {
   if (is_multi(ctx)) {
-    for (fec_ctx* c : ctx->children) c->chunk = elements ? elements : c->chunk;
-    return elements ? FEC_OK : FEC_E_ARG;
+    if (elements == 0) return FEC_E_ARG;
+    for (fec_ctx* c : ctx->children) {
+      c->chunk = elements;
+      c->chunk_explicit = true;
+    }
+    return FEC_OK;
   }
   if (!ctx || elements == 0) return FEC_E_ARG;
   ctx->chunk = elements;
+  ctx->chunk_explicit = true;
   return FEC_OK;
 } FEC_ABI_CATCH_STATUS
 

@@ -25,7 +25,8 @@ struct fec_ctx {
   void* d_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t stream2 = nullptr;
-  size_t chunk = (size_t)1 << 18;  // elements per pipeline chunk
+  size_t chunk = (size_t)1 << 18;  // elements per pipeline chunk (see host::pipeline_chunk)
+  bool chunk_explicit = false;     // fec_ctx_set_chunk was called: its value is used as it is
   u64* d_gen[3] = {nullptr, nullptr, nullptr};  // reference generator() per curve, device copy
   u32* d_ed_table = nullptr;                    // Ed25519 fixed-base addend table (256 x 32 words)
   u64 ed_table_base[16] = {0};                  // the base point the table was built for
@@ -228,6 +229,19 @@ inline int sync_and_check(fec_ctx* ctx, hipStream_t a, hipStream_t b = nullptr) 
   return take_device_error(ctx);
 }
 
+// Elements per chunk of a host-pointer call.  The persistent scheduler kernels (P-256, Ed25519 variable base: one
+// workgroup per CU, 832 element slots each -- FEC_P256_QS / FEC_ED_PS) are at their best when a chunk fills every slot
+// exactly once: with 2^18 elements a workgroup gets 1 024, the last 192 start when the first 832 have finished and
+// run a whole ladder at a quarter of the occupancy -- 2^20 P-256 multiplications through the host-pointer entry point
+// 33.6 ms in chunks of 2^18, 28.0 ms in chunks of 212 992 = 256 x 832 (Ed25519 25.7 -> 20.6 ms;
+// tools/host_chunk_probe.py).  A value set with fec_ctx_set_chunk is used as it is.
+constexpr size_t kSchedSlotsPerCu = 832;
+inline size_t pipeline_chunk(const fec_ctx* ctx, bool scheduler_kernel) {
+  if (ctx->chunk_explicit || !scheduler_kernel) return ctx->chunk;
+  const size_t cus = ctx->prop.multiProcessorCount > 0 ? (size_t)ctx->prop.multiProcessorCount : 256;
+  return cus * kSchedSlotsPerCu;
+}
+
 // The way out of a host-pointer entry point whose work was queued on the ctx's own streams.  A call that fails half-way
 // (an allocation, a refused copy, a launch error) may still have copies from or into the caller's arrays queued, and the
 // caller is free to release those arrays as soon as the call is back: the streams are drained first, and a device error
@@ -247,9 +261,10 @@ inline int drained(fec_ctx* ctx, int rc) {
 // chunk however large n is.  A null input / output pointer is passed through as null.
 template <class F>
 inline int host_chunked(fec_ctx* ctx, size_t n, const void* const in[4], const size_t in_stride[4], void* const out[2],
-                        const size_t out_stride[2], F body) {
+                        const size_t out_stride[2], F body, bool scheduler_kernel = false) {
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  const size_t chunk = ctx->chunk < n ? ctx->chunk : n;
+  const size_t pc = pipeline_chunk(ctx, scheduler_kernel);
+  const size_t chunk = pc < n ? pc : n;
   return drained(ctx, [&]() -> int {
   for (size_t lo = 0; lo < n; lo += chunk) {
     const size_t cnt = lo + chunk <= n ? chunk : n - lo;
