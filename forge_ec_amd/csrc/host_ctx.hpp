@@ -26,7 +26,7 @@ struct fec_ctx {
   size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t stream2 = nullptr;
   size_t chunk = (size_t)1 << 18;  // elements per pipeline chunk (see host::pipeline_chunk)
-  bool chunk_explicit = false;     // fec_ctx_set_chunk was called: its value is used as it is
+  bool chunk_explicit = false;     // fec_ctx_set_chunk was called
   u64* d_gen[3] = {nullptr, nullptr, nullptr};  // reference generator() per curve, device copy
   u32* d_ed_table = nullptr;                    // Ed25519 fixed-base addend table (256 x 32 words)
   u64 ed_table_base[16] = {0};                  // the base point the table was built for
@@ -229,18 +229,11 @@ inline int sync_and_check(fec_ctx* ctx, hipStream_t a, hipStream_t b = nullptr) 
   return take_device_error(ctx);
 }
 
-// Elements per chunk of a host-pointer call.  The persistent scheduler kernels (P-256, Ed25519 variable base: one
-// workgroup per CU, 832 element slots each -- FEC_P256_QS / FEC_ED_PS) are at their best when a chunk fills every slot
-// exactly once: with 2^18 elements a workgroup gets 1 024, the last 192 start when the first 832 have finished and
-// run a whole ladder at a quarter of the occupancy -- 2^20 P-256 multiplications through the host-pointer entry point
-// 33.6 ms in chunks of 2^18, 28.0 ms in chunks of 212 992 = 256 x 832 (Ed25519 25.7 -> 20.6 ms;
-// tools/host_chunk_probe.py).  A value set with fec_ctx_set_chunk is used as it is.
-constexpr size_t kSchedSlotsPerCu = 832;
-inline size_t pipeline_chunk(const fec_ctx* ctx, bool scheduler_kernel) {
-  if (ctx->chunk_explicit || !scheduler_kernel) return ctx->chunk;
-  const size_t cus = ctx->prop.multiProcessorCount > 0 ? (size_t)ctx->prop.multiProcessorCount : 256;
-  return cus * kSchedSlotsPerCu;
-}
+// Elements per chunk of a host-pointer call: 2^18 unless fec_ctx_set_chunk says otherwise.  (A chunk gives a persistent
+// scheduler workgroup 1 024 elements: the launchers then take the 1 024-slot instantiation of the kernel, one fill --
+// kernels_p256.hip: wide_slots_pay.  With 832 slots only, such a chunk cost 2^20 P-256 multiplications through the
+// host-pointer entry point 34.2 ms instead of 26.0: tools/host_chunk_probe.py, profiles/host_chunk_r03.txt.)
+inline size_t pipeline_chunk(const fec_ctx* ctx, bool /*scheduler_kernel*/) { return ctx->chunk; }
 
 // The way out of a host-pointer entry point whose work was queued on the ctx's own streams.  A call that fails half-way
 // (an allocation, a refused copy, a launch error) may still have copies from or into the caller's arrays queued, and the

@@ -510,12 +510,16 @@ constexpr int PT = 768;     // threads per workgroup: 12 wavefronts, three per S
 #ifndef FEC_ED_PS
 #define FEC_ED_PS 832
 #endif
-constexpr int PS = FEC_ED_PS;  // element slots per workgroup (12 x 64 in flight + 64 queued).  Same-box sweeps (profiles/slot_sweep_r03.txt), ms and
-                               // L2-side traffic per 2^20: 1024 -> 17.87 / 27.0 GB, 960 -> 19.05, 896 -> 18.43, 864 -> 18.10, 832 -> 17.75 / 18.4 GB, 800 -> 19.95, 768 -> 19.02
+constexpr int PS_MAIN = FEC_ED_PS;  // element slots per workgroup (12 x 64 in flight + 64 queued).  Same-box sweeps (profiles/slot_sweep_r03.txt), ms and
+                                    // L2-side traffic per 2^20: 1024 -> 17.87 / 27.0 GB, 960 -> 19.05, 896 -> 18.43, 864 -> 18.10, 832 -> 17.75 / 18.4 GB, 800 -> 19.95, 768 -> 19.02
+// The second instantiation, 1 024 slots: for launches whose workgroups get a little more than a whole number of
+// 832-element fills (2^18 elements: 1 024 per workgroup, 6.6 ms against 5.0) -- see kernels_p256.hip: wide_slots_pay.
+constexpr int PS_WIDE = 1024;
 constexpr int PRING = 2048;  // ring capacity (power of two >= PS)
 enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace
 
+template <int PS>
 __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ scalars, const u32* __restrict__ points,
                                                     u32* __restrict__ out, size_t n, unsigned per_wg,
                                                     unsigned* __restrict__ err, unsigned force_fault) {
@@ -761,8 +765,19 @@ void ed_launch_mul(const SchedEnv& env, const u32* scalars, const u32* points, u
   if (grid > cap) grid = cap;
   const unsigned per_wg = (unsigned)((n + grid - 1) / grid);
   grid = (n + per_wg - 1) / per_wg;
-  hipLaunchKernelGGL(k_ed_mul_pers, dim3((unsigned)grid), dim3(PT), 0, s, scalars, points, out, n, per_wg, env.err,
-                     env.force_fault);
+  // PS_WIDE when the workgroups' elements are a little more than a whole number of PS_MAIN-element fills and a (near)
+  // whole number of PS_WIDE-element ones, up to three fills (the rule of kernels_p256.hip: wide_slots_pay)
+  bool wide = false;
+  if (per_wg > (unsigned)PS_MAIN && per_wg <= 3u * PS_WIDE) {
+    auto waste = [per_wg](unsigned q) { return (double)(((per_wg + q - 1) / q) * q) / (double)per_wg; };
+    wide = waste(PS_WIDE) + 0.04 < waste(PS_MAIN);
+  }
+  if (wide)
+    hipLaunchKernelGGL((k_ed_mul_pers<PS_WIDE>), dim3((unsigned)grid), dim3(PT), 0, s, scalars, points, out, n, per_wg, env.err,
+                       env.force_fault);
+  else
+    hipLaunchKernelGGL((k_ed_mul_pers<PS_MAIN>), dim3((unsigned)grid), dim3(PT), 0, s, scalars, points, out, n, per_wg, env.err,
+                       env.force_fault);
 }
 
 }  // namespace fecgpu

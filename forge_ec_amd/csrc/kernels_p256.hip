@@ -231,14 +231,19 @@ constexpr int QT = 768;      // threads per workgroup: 12 wavefronts, three per 
 #ifndef FEC_TICKET_SLEEP
 #define FEC_TICKET_SLEEP 1
 #endif
-constexpr int QS = FEC_P256_QS;  // element slots per workgroup (12 x 64 in flight + 64 queued).  Same-box sweeps (profiles/slot_sweep_r03.txt):
-                                 // 1024 -> 23.79 ms / 527 MB of L2-side traffic, 960 -> 24.79, 896 -> 24.21, 832 -> 23.91 ms / 378 MB
+constexpr int QS_MAIN = FEC_P256_QS;  // element slots per workgroup (12 x 64 in flight + 64 queued).  Same-box sweeps (profiles/slot_sweep_r03.txt):
+                                      // 1024 -> 23.79 ms / 527 MB of L2-side traffic, 960 -> 24.79, 896 -> 24.21, 832 -> 23.91 ms / 378 MB
+// The second instantiation: 1 024 slots, the scalar NOT in LDS (there is no room for it beside 1 024 points and z2z2:
+// a step's bit is read from the caller's array instead).  For launches whose workgroups get a little more than a
+// whole number of 832-element fills -- the late, thinly occupied last fill costs 5-22 % there (2^18 elements: 1 024 per
+// workgroup, 8.25 ms against 6.8; 2^19: 13.3 against 12.7) -- p256_launch_mul picks it by the per-workgroup count.
+constexpr int QS_WIDE = 1024;
 constexpr int QRING = 2048;  // ring capacity (power of two >= QS)
 enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace
 
 // HOIST (fixed base): z2z2 of the base point is computed once per workgroup into LDS instead of by every addition.
-template <bool FIXED, bool HOIST>
+template <bool FIXED, bool HOIST, int QS>
 __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict__ scalars, const u32* __restrict__ points,
                                                       u32* __restrict__ out, size_t n, unsigned per_wg,
                                                       unsigned* __restrict__ err, unsigned force_fault,
@@ -250,7 +255,8 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   // z2z2 in the element's output slot instead: 23 GB of L2-side traffic and no in-place calls -- removed; this form has
   // neither.)
   __shared__ u32 lds_zq[(FIXED ? 0 : 8 * QS) + 8];
-  __shared__ u32 lds_k[8 * QS];                 // scalar of slot e: word w at lds_k[w * QS + e]
+  constexpr bool KLDS = QS <= QS_MAIN;          // the whole scalar of every slot in LDS (not with QS_WIDE slots: no room)
+  __shared__ u32 lds_k[KLDS ? 8 * QS : 8];      // scalar of slot e: word w at lds_k[w * QS + e]
   __shared__ u32 lds_gid[QS];                   // element of slot e, relative to the workgroup's range
   __shared__ unsigned short lds_step[QS];
   __shared__ unsigned short lds_q[2][QRING];
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       }
       u32 cur = 0;  // the word that holds bit t - 1, the next one the ladder looks at
       FEC_UNROLL for (int w = 0; w < 8; ++w) {
-        lds_k[w * QS + e] = kw[w];
+        if (KLDS) lds_k[w * QS + e] = kw[w];
         cur = ((t - 1) >> 5) == w ? kw[w] : cur;
       }
       lds_gid[e] = (u32)rel;
@@ -343,7 +349,8 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   // the scalar bit of step `step_new` (< 256): bit 255 - step_new (2127-2129)
   auto step_bit = [&](int e, int step_new) -> u32 {
     const int b = 255 - step_new;
-    return (lds_k[(b >> 5) * QS + e] >> (b & 31)) & 1u;
+    if (KLDS) return (lds_k[(b >> 5) * QS + e] >> (b & 31)) & 1u;
+    return (scalars[(lo + lds_gid[e]) * 8 + (b >> 5)] >> (b & 31)) & 1u;   // (lds_gid[e] < range: written by claim())
   };
 
   int kind = -1, count = 0;
@@ -507,6 +514,18 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   }
 }
 
+namespace {
+// Which instantiation a launch whose workgroups own `per_wg` elements each takes: QS_WIDE when those elements are a
+// little more than a whole number of QS_MAIN-element fills and a (near) whole number of QS_WIDE-element ones -- a fill
+// of leftovers starts late and runs thinly occupied -- and only up to three fills (beyond that the refills overlap and
+// the leaner LDS image with the scalar in it wins: 23.9 against 24.3 ms at 2^20).
+inline bool wide_slots_pay(unsigned per_wg) {
+  if (per_wg <= (unsigned)QS_MAIN || per_wg > 3u * QS_WIDE) return false;
+  auto waste = [per_wg](unsigned q) { return (double)(((per_wg + q - 1) / q) * q) / (double)per_wg; };
+  return waste(QS_WIDE) + 0.04 < waste(QS_MAIN);
+}
+}  // namespace
+
 void p256_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,
                      unsigned cu_divisor) {
   // one workgroup per CU (or per cu_divisor-th CU) of the ctx's own device, each with a contiguous range of at least
@@ -517,18 +536,26 @@ void p256_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const 
   if (grid > cap) grid = cap;
   const unsigned per_wg = (unsigned)((n + grid - 1) / grid);
   grid = (n + per_wg - 1) / per_wg;
+  const bool wide = wide_slots_pay(per_wg);
+  const dim3 g((unsigned)grid), b(QT);
   if (fixed) {
     const bool tab = points == env.gen[FEC_P256] && env.gen_prefix[FEC_P256] != nullptr && env.gen_prefix_bits[FEC_P256] > 0;
-    hipLaunchKernelGGL((k_p256_mul_sched<true, true>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg,
-                       env.err, env.force_fault, tab ? env.gen_prefix[FEC_P256] : (const u32*)nullptr,
-                       tab ? (int)env.gen_prefix_bits[FEC_P256] : 0);
+    const u32* pre = tab ? env.gen_prefix[FEC_P256] : (const u32*)nullptr;
+    const int wbits = tab ? (int)env.gen_prefix_bits[FEC_P256] : 0;
+    // (no QS_WIDE instantiation for the fixed base: with the table pointers live as well it spills three registers)
+    hipLaunchKernelGGL((k_p256_mul_sched<true, true, QS_MAIN>), g, b, 0, s, scalars, points, out, n, per_wg, env.err,
+                       env.force_fault, pre, wbits);
     return;
   }
   // Variable base: z2z2 is recomputed by every addition.  Parking it in the element's (still unused) output slot was
   // 2.6 % faster (25.0 -> 24.4 ms) but pushed a workgroup's working set out of its XCD's L2 -- 23 GB of L2-side
   // fetches per launch instead of 0.44 (profiles/pmc_r02br_p256_hoist.json) -- and broke in-place calls; not kept.
-  hipLaunchKernelGGL((k_p256_mul_sched<false, false>), dim3((unsigned)grid), dim3(QT), 0, s, scalars, points, out, n, per_wg,
-                     env.err, env.force_fault, (const u32*)nullptr, 0);
+  if (wide)
+    hipLaunchKernelGGL((k_p256_mul_sched<false, false, QS_WIDE>), g, b, 0, s, scalars, points, out, n, per_wg, env.err,
+                       env.force_fault, (const u32*)nullptr, 0);
+  else
+    hipLaunchKernelGGL((k_p256_mul_sched<false, false, QS_MAIN>), g, b, 0, s, scalars, points, out, n, per_wg, env.err,
+                       env.force_fault, (const u32*)nullptr, 0);
 }
 
 }  // namespace fecgpu

@@ -361,11 +361,9 @@ int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits);
  * negative fec_status on a bad argument.  Multi-device ctx: the first shard worker's. */
 int fec_ctx_fixed_prefix_bits(fec_ctx* ctx, fec_curve curve);
 
-/* Host-pointer batches are processed as a two-lane pipeline of `elements`-sized chunks: copies of one
- * chunk overlap the kernel of the other, and device staging memory is bounded by two chunks for any n.
- * Default: 2^18 elements, and for the entry points that run a persistent scheduler kernel (P-256, Ed25519
- * variable base) the size that fills every element slot of the chip exactly once (CUs x 832 = 212 992).
- * A value set here is used as it is by every entry point.  Tuning/test knob; results do not depend on it. */
+/* Host-pointer batches are processed as a two-lane pipeline of `elements`-sized chunks (default
+ * 2^18): copies of one chunk overlap the kernel of the other, and device staging memory is bounded
+ * by two chunks for any n.  Tuning/test knob; results do not depend on it. */
 int fec_ctx_set_chunk(fec_ctx* ctx, size_t elements);
 
 /* ---- measurement hooks ---- */

@@ -404,6 +404,27 @@ def test_scheduler_kernels_at_slot_and_wavefront_boundaries(gpu_ctx, oracle, cur
         assert np.array_equal(gpu_ctx.batch_mul_fixed(curve, k, g), oracle.batch_mul_fixed(curve, k, g, nthreads=16)), (curve, n)
 
 
+@pytest.mark.parametrize("curve", [1, 2])
+def test_scheduler_kernels_wide_slot_instantiation(gpu_ctx, oracle, curve):
+    """A launch whose workgroups own between 832 and 1 024 elements each (here 256 000 elements on 256 CUs) takes the
+    1 024-slot instantiation of the scheduler kernel (P-256: the scalar's bits then come from the caller's array, not
+    from LDS); 2 000 per workgroup likewise.  Device-pointer call (one launch), every element against the oracle."""
+    import torch
+    for n in (256 * 1000, 256 * 2000 + 77):
+        k, p = V.scalars(n, curve, 3511), V.points(n, curve, 3512)
+        k[::997] = 0
+        p[3::1009] = oracle.identity(curve)
+        dk = torch.from_numpy(k.view(np.int64)).cuda()
+        dp = torch.from_numpy(p.view(np.int64)).cuda()
+        do = torch.empty_like(dp)
+        torch.cuda.synchronize()
+        gpu_ctx.batch_mul_dev(curve, dk.data_ptr(), dp.data_ptr(), do.data_ptr(), n)
+        gpu_ctx.check()
+        torch.cuda.synchronize()
+        got = do.cpu().numpy().view(np.uint64)
+        _assert_same(got, oracle.batch_mul(curve, k, p, nthreads=16), "%s batch_mul_dev, %d elements" % (NAMES[curve], n))
+
+
 def test_host_pipeline_chunking_is_invisible(gpu_ctx, oracle):
     """The host-pointer path pipelines chunks over two streams; results must not depend on the
     chunk size (1 chunk, many chunks, ragged last chunk, odd and even chunk counts)."""
