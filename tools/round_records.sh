@@ -16,4 +16,7 @@ print("%-18s %8.2f M/s  kernel %.2f ms  frac %.3f  cpu %d cores %.1f k/s (1 thre
     t["cpu_baseline"]["cores"], t["cpu_baseline"]["value"] / 1e3, t["cpu_baseline"]["single_thread"]["value"] / 1e3))
 PY
 done
+for WL in ed25519-fixed ed25519-var; do   # the Ed25519 workloads again with scalars below l
+  timeout -k 10 300 python bench.py --workload $WL --steps 10 --warmup 2 --scalars-below-l > gpurun_out/bench_${TAG}_${WL}_below_l.json 2> /dev/null || { echo "bench $WL --scalars-below-l failed"; exit 1; }
+done
 bash tools/pmc_refresh.sh $TAG
