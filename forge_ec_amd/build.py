@@ -18,7 +18,7 @@ OBJ_DIR = os.path.join(SRC_DIR, "_obj")
 SO = os.path.join(HERE, "libfecgpu.so")
 STAMP = SO + ".sha256"
 SOURCES = ["fecgpu.hip", "canon.hip", "kernels_p256.hip", "kernels_ed.hip", "kernels_secp.hip", "kernels_codec.hip", "kernels_ecdsa.hip"]
-HEADERS = ["coop.hpp", "sched_ctl.hpp", "limbs.hpp", "staging.hpp", "host_ctx.hpp", "secp256k1.hpp", "p256.hpp", "ed25519.hpp",
+HEADERS = ["coop.hpp", "sched_lf.hpp", "limbs.hpp", "staging.hpp", "host_ctx.hpp", "secp256k1.hpp", "p256.hpp", "ed25519.hpp",
            "canon_curves.hpp", "canon_kernels.hpp", "field_asm.inc", "kernels.hpp", "cu_split.hpp", os.path.join("..", "..", "include", "fecgpu.h"),
            os.path.join("..", "..", "include", "fecgpu_canon.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]

@@ -17,7 +17,7 @@
 #include "ed25519.hpp"
 #include "staging.hpp"
 #include "kernels.hpp"
-#include "sched_ctl.hpp"
+#include "sched_lf.hpp"
 
 namespace fecgpu {
 
@@ -508,51 +508,47 @@ FEC_DEV ed::pt pdbl_mem(const u32* la, int stride) {
 namespace {
 constexpr int PT = 768;     // threads per workgroup: 12 wavefronts, three per SIMD
 #ifndef FEC_ED_PS
-#define FEC_ED_PS 832
+#define FEC_ED_PS 864
 #endif
 constexpr int PS_MAIN = FEC_ED_PS;  // element slots per workgroup (12 x 64 in flight + 64 queued).  Same-box sweeps (profiles/slot_sweep_r03.txt), ms and
                                     // L2-side traffic per 2^20: 1024 -> 17.87 / 27.0 GB, 960 -> 19.05, 896 -> 18.43, 864 -> 18.10, 832 -> 17.75 / 18.4 GB, 800 -> 19.95, 768 -> 19.02
 // The second instantiation, 1 024 slots: for launches whose workgroups get a little more than a whole number of
 // 832-element fills (2^18 elements: 1 024 per workgroup, 6.6 ms against 5.0) -- see kernels_p256.hip: wide_slots_pay.
 constexpr int PS_WIDE = 1024;
-constexpr int PRING = 2048;  // ring capacity (power of two >= PS)
-enum { P_NEXT = C_WORDS, P_WORDS };
 }  // namespace
 
 template <int PS>
 __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ scalars, const u32* __restrict__ points,
                                                     u32* __restrict__ out, size_t n, unsigned per_wg,
                                                     unsigned* __restrict__ err, unsigned force_fault) {
+  constexpr int RING = PS < 1024 ? 1024 : 2048;   // ring positions: more than there are slots (sched_lf.hpp)
+  static_assert(PS <= 1024, "a ring entry holds a ten-bit slot number");
   __shared__ u32 lds_ad[32 * PS];              // addend of slot e: word w at lds_ad[w * PS + e]; the running result
                                                // lives in the element's slot of `out`
   __shared__ u32 lds_gid[PS];                  // element of slot e, relative to the workgroup's range
   __shared__ unsigned short lds_step[PS];      // current step i of slot e (A_i / D_i pending)
-  __shared__ unsigned short lds_q[2][PRING];   // ready rings: [0] needs the doubling D_i, [1] needs the addition A_i
-  __shared__ __attribute__((aligned(16))) int lds_ctl[P_WORDS];
+  __shared__ __attribute__((aligned(16))) int lds_lf[LF_INTS<RING>];   // control words + the rings D, A, F (sched_lf.hpp)
   const size_t lo = (size_t)blockIdx.x * per_wg;
   const int range = (n - lo) < (size_t)per_wg ? (int)(n - lo) : (int)per_wg;
   const int tid = threadIdx.x, lane = tid & 63;
-  // control words through an LDS-address-space pointer (sched_ctl.hpp) in ONE opaque base register: otherwise every
-  // word's (link-time constant, > 64 KiB) LDS address is hoisted into a VGPR of its own -- ten registers the
+  // control words through an LDS-address-space pointer in ONE opaque base register: otherwise every
+  // word's (link-time constant, > 64 KiB) LDS address is hoisted into a VGPR of its own -- registers the
   // three-wavefront budget does not have
-  lds_int_ptr ctl = (lds_int_ptr)lds_ctl;
+  lds_int_ptr ctl = (lds_int_ptr)lds_lf;
   asm volatile("" : "+v"(ctl));
   const unsigned ctl_addr = (unsigned)(size_t)ctl;
-  if (tid == 0) {
-    FEC_UNROLL for (int w = 0; w < P_WORDS; ++w) lds_ctl[w] = 0;
-    lds_ctl[C_REMAIN] = range < PS ? range : PS;   // live slots
-    if (force_fault) lds_ctl[C_ERR] = (int)FEC_DEVERR_FORCED;   // debug hook: every wavefront leaves at its first critical section
-  }
+  // every slot starts in the free ring: the wavefronts' first pops are claims of 64 elements each
+  lf_init<RING>(lds_lf, tid, PT, range < PS ? range : PS, force_fault ? (unsigned)FEC_DEVERR_FORCED : 0u);
   __syncthreads();
 
   // Claims the next element of the range for slot `e` (lane-private): loads its point as the addend, sets
   // result = identity, step = 0.  multiply's early-outs (2063-2066: identity point or zero scalar) are
   // answered at once and the slot takes the next element.  Returns the first pending operation
-  // (1 = A_0 if bit 0 is set, else 0 = D_0), or 2 when the range is used up (the slot dies).
+  // (LF_NXT_A = A_0 if bit 0 is set, else LF_NXT_D = D_0), or LF_NXT_DEAD when the range is used up (the slot dies).
   auto claim = [&](int e) -> int {
     for (;;) {
-      const int rel = lds_fetch_add(ctl, P_NEXT, 1);
-      if (rel >= range) return 2;
+      const int rel = lds_fetch_add(ctl, LF_NEXT, 1);
+      if (rel >= range) return LF_NXT_DEAD;
       const size_t g = lo + rel;
       const ed::pt base = ld_glb(points + g * 32);
       u32 any = 0;
@@ -565,110 +561,42 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
       lds_gid[e] = (u32)rel;
       st_glb(out + g * 32, ed::identity());
       lds_step[e] = 0;
-      return (scalars[g * 8] & 1u) ? 1 : 0;
+      return (scalars[g * 8] & 1u) ? LF_NXT_A : LF_NXT_D;
     }
   };
 
-  int kind = -1, count = 0;
-  int e = tid;
-  int nxt = 3;  // the element's next step: 0 doubling only (bit clear), 1 addition then doubling (bit set); 2 slot died, 3 none
-  unsigned spins = 0;
-  bool first_fill = true;
-  // initial fill: slots 0..511 now, slots 512..PS-1 on the second pass; both enter the queues through the
-  // ordinary push of the scheduler loop
-  nxt = tid < range ? claim(e) : 3;  // a counted slot that finds the range used up (early-outs took more) dies: 2
+  int e = 0;
+  int nxt = LF_NXT_NONE;  // the element's next step: ring D doubling only (bit clear), ring A addition then doubling (bit set)
+  unsigned watchdog = 0;
   for (;;) {
-    const lmask m_d = __builtin_amdgcn_ballot_w64(nxt == 0), m_a = __builtin_amdgcn_ballot_w64(nxt == 1);
-    const int n_d = __builtin_popcountll(m_d), n_a = __builtin_popcountll(m_a);
-    const int n_fin = __builtin_popcountll(__builtin_amdgcn_ballot_w64(nxt == 2));
-    const lmask below = (1ull << lane) - 1;
-    const int rank_d = __builtin_popcountll(m_d & below), rank_a = __builtin_popcountll(m_a & below);
-    if (n_d + n_a + n_fin == 0 && !first_fill) {  // nothing to push: wait OUTSIDE the lock on hints
-      const int q_d = ctl[C_TAIL_D] - ctl[C_HEAD_D], q_a = ctl[C_TAIL_A] - ctl[C_HEAD_A];
-      const int fl = ctl[C_INFLIGHT], rem = ctl[C_REMAIN];
-      int th0 = rem >> 3;
-      th0 = th0 < 1 ? 1 : (th0 > 64 ? 64 : th0);
-      const bool go = q_d >= th0 || q_a >= th0 || (fl == 0 && (q_d | q_a) != 0) || (rem == 0 && fl == 0) || ctl[C_ERR] != 0;
-      if (!go) {
-        __builtin_amdgcn_s_sleep(64);
-        if (++spins > (1u << 22)) {  // watchdog (~10 s): cannot happen unless the queue logic is broken
-          if (lane == 0) ctl[C_ERR] = (int)FEC_DEVERR_SCHED_WATCHDOG;
-          break;
-        }
-        continue;
-      }
-    }
-    // ---- critical section (FIFO ticket lock, lane 0) ----
-    if (lane == 0) {
-      const int my = lds_fetch_add(ctl, C_TICKET, 1);
-      while (ctl[C_SERVING] != my) __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const CtlWords cw = ctl_read(ctl_addr);
-    int t_d = cw.tail_d, t_a = cw.tail_a;
-    if (nxt == 0) lds_q[0][(t_d + rank_d) & (PRING - 1)] = (unsigned short)e;
-    if (nxt == 1) lds_q[1][(t_a + rank_a) & (PRING - 1)] = (unsigned short)e;
-    t_d += n_d;
-    t_a += n_a;
-    int inflight = cw.inflight - count;
-    const int remain = cw.remain - n_fin;
-    int h_d = cw.head_d, h_a = cw.head_a;
-    const int av_d = t_d - h_d, av_a = t_a - h_a;
-    const int err = cw.err;
-    int th = remain >> 3;
-    th = th < 1 ? 1 : (th > 64 ? 64 : th);
-    int pick = -1;
-    if (!first_fill) {  // the first pass only pushes (its second half of the initial fill is still to come)
-      if (av_a >= th && av_a >= av_d) pick = 1;
-      else if (av_d >= th) pick = 0;
-      else if (av_a >= th) pick = 1;
-      else if (inflight == 0 && (av_a | av_d) != 0) pick = av_a > av_d ? 1 : 0;
-    }
-    int start = 0;
-    count = 0;
-    if (pick == 0) {
-      count = av_d < 64 ? av_d : 64;
-      start = h_d;
-      h_d += count;
-    } else if (pick == 1) {
-      count = av_a < 64 ? av_a : 64;
-      start = h_a;
-      h_a += count;
-    }
-    inflight += count;
-    const bool finished = (!first_fill && remain == 0 && inflight == 0) || err != 0;
-    if (lane == 0) ctl_write(ctl_addr, h_d, t_d, h_a, t_a, inflight, remain);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) ctl[C_SERVING] = ctl[C_SERVING] + 1;
-    // ---- end of critical section ----
-    kind = pick;
-    nxt = 3;
-    if (finished) break;
-    if (first_fill) {  // second part of the initial fill: slots PT..PS-1
-      first_fill = false;
-      e = PT + tid;
-      if (e < PS && e < range) nxt = claim(e);
+    // hand on what the last batch left (sched_lf.hpp: no lock, no turn to wait for; the release fence in front of the
+    // publishing add orders this batch's result stores before the entries that hand the slots on), take the next one
+    lf_push<RING>(ctl_addr, lane, nxt, e);
+    nxt = LF_NXT_NONE;
+    const LfPop pop = lf_pop<RING>(ctl_addr, lane, watchdog, (u32)FEC_DEVERR_SCHED_WATCHDOG);
+    if (pop.kind < 0) break;
+    if (!lf_entry<RING>(ctl_addr, pop, lane, (u32)FEC_DEVERR_SCHED_WATCHDOG, e)) break;   // inactive lanes compute on slot 0: never stored
+    const bool active = lane < pop.count;
+    if (pop.kind == LF_Q_F) {   // free slots: each takes the next element of the range (64 claims at full width)
+      if (active) nxt = claim(e);
       continue;
     }
-    if (kind < 0) continue;
-    spins = 0;
-    const bool active = lane < count;
-    e = active ? lds_q[kind][(start + lane) & (PRING - 1)] : 0;   // inactive lanes compute on slot 0: never stored
+    const int kind = pop.kind;
     int step = active ? lds_step[e] : 0;
     // Every global address below is formed from this index.  It is written by claim() and always < range; the test
     // keeps a broken queue (which the design excludes and the watchdog would report) from ever addressing memory
-    // outside the workgroup's own range: such a lane works on element 0 of the range, stores nothing, and raises C_ERR.
+    // outside the workgroup's own range: such a lane works on element 0 of the range, stores nothing, and raises the error.
     u32 gid = active ? lds_gid[e] : 0u;
     const bool oob = gid >= (u32)range;
     gid = oob ? 0u : gid;
     const bool live = active && !oob;
     bool fin = false;
     // ONE task = one step i of the reference's loop (2075-2091) for 64 elements that agree on scalar bit i:
-    //   queue 1 (bit set):   A_i: result = result + addend (2083-2086), then D_i
-    //   queue 0 (bit clear): D_i: addend = addend.double() (2089)
+    //   ring A (bit set):   A_i: result = result + addend (2083-2086), then D_i
+    //   ring D (bit clear): D_i: addend = addend.double() (2089)
     // The doubling of step 255 is never used and never done.  (Round 2 queued A_i and D_i separately: 383 visits of
     // the scheduler per element instead of 255 for the same arithmetic.)
-    if (kind == 1) {  // the result stays in its output slot
+    if (kind == LF_Q_A) {  // the result stays in its output slot
       // inactive lanes read element 0 of the range (always present) and slot 0: computed, never stored
       u32* slot = out + (lo + gid) * 32;
       FEC_MARK("task_add_begin");
@@ -681,7 +609,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
       const ed::pt d = pdbl_mem(lds_ad + e, PS);
       FEC_MARK("task_double_end");
       if (live) {
-        if (step == 255) {  // (only reached through queue 1: A_255 was the element's last operation)
+        if (step == 255) {  // (only reached through ring A: A_255 was the element's last operation)
           fin = true;
         } else {
           st_lds(lds_ad + e, PS, d);
@@ -689,21 +617,20 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
           const u32 bit = scalar_bit(scalars, lo + gid, step);
           lds_step[e] = (unsigned short)step;
           fin = !bit && step == 255;
-          nxt = bit ? 1 : 0;
+          nxt = bit ? LF_NXT_A : LF_NXT_D;
         }
       }
     }
-    if (fin) nxt = claim(e);  // the element is done (its result is in place): the slot takes the next element
+    if (fin) nxt = LF_NXT_FREE;  // the element is done (its result is in place): the slot joins the free ring
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(oob) != 0, 0)) {
-      if (oob) ctl[C_ERR] = (int)FEC_DEVERR_SCHED_INDEX;
+      lf_raise(ctl_addr, lane, (u32)FEC_DEVERR_SCHED_INDEX);
+      nxt = LF_NXT_NONE;
     }
     // slots (LDS addend, output-array result) are lane-private between the pop and the push; every access to an
-    // element's output slot comes from THIS workgroup (one CU, one vector L1), and the workgroup-scope release
-    // fence inside the critical section (s_waitcnt vmcnt(0) lgkmcnt(0)) orders this batch's stores before the
-    // queue entries that hand the slots on
+    // element's output slot comes from THIS workgroup (one CU, one vector L1)
   }
   __syncthreads();
-  if (const int ec = lds_ctl[C_ERR]) {
+  if (const int ec = lds_lf[LF_ERR]) {
     // Scheduler fault (watchdog, index guard, or the debug hook): the workgroup's results are not trustworthy.  They are
     // zero-filled AND the ctx's error word is set, which the host reads after its synchronisation: the call returns
     // FEC_E_LAUNCH (fecgpu.hip: sync_and_check, fec_ctx_check) instead of FEC_OK with plausible-looking points.

@@ -23,13 +23,13 @@
 #include "p256.hpp"
 #include "staging.hpp"
 #include "kernels.hpp"
-#include "sched_ctl.hpp"
+#include "sched_lf.hpp"
 
 namespace fecgpu {
 
 // Scheduler statistics for tools/microbench/sched_stats.hip (compiled in only with -DFEC_SCHED_STATS; the shipped
 // library has none of it): [0] doubling batches, [1] lanes in them, [2] addition batches, [3] lanes in them,
-// [4] doubling batches that took the rare leg, [5] addition batches that took the rare leg, [6] polls of waiting wavefronts
+// [6] sleeps and lost races of waiting wavefronts, [7] claim tasks (batches of free slots taking their next elements)
 // (wave-local counters, flushed with one atomic per counter per wavefront when the kernel ends: counting with an atomic
 // per event slowed the kernel 2000-fold and measured the atomics)
 #ifdef FEC_SCHED_STATS
@@ -226,10 +226,7 @@ FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u
 namespace {
 constexpr int QT = 768;      // threads per workgroup: 12 wavefronts, three per SIMD
 #ifndef FEC_P256_QS
-#define FEC_P256_QS 832
-#endif
-#ifndef FEC_TICKET_SLEEP
-#define FEC_TICKET_SLEEP 1
+#define FEC_P256_QS 864
 #endif
 constexpr int QS_MAIN = FEC_P256_QS;  // element slots per workgroup (12 x 64 in flight + 64 queued).  Same-box sweeps (profiles/slot_sweep_r03.txt):
                                       // 1024 -> 23.79 ms / 527 MB of L2-side traffic, 960 -> 24.79, 896 -> 24.21, 832 -> 23.91 ms / 378 MB
@@ -238,8 +235,11 @@ constexpr int QS_MAIN = FEC_P256_QS;  // element slots per workgroup (12 x 64 in
 // whole number of 832-element fills -- the late, thinly occupied last fill costs 5-22 % there (2^18 elements: 1 024 per
 // workgroup, 8.25 ms against 6.8; 2^19: 13.3 against 12.7) -- p256_launch_mul picks it by the per-workgroup count.
 constexpr int QS_WIDE = 1024;
-constexpr int QRING = 2048;  // ring capacity (power of two >= QS)
-enum { P_NEXT = C_WORDS, P_WORDS };
+// Fixed base: no z2z2 per slot (one for the workgroup), so the scalar fits beside the point at any slot count
+#ifndef FEC_P256_QS_FIXED
+#define FEC_P256_QS_FIXED FEC_P256_QS
+#endif
+constexpr int QS_FIXED = FEC_P256_QS_FIXED;
 }  // namespace
 
 // HOIST (fixed base): z2z2 of the base point is computed once per workgroup into LDS instead of by every addition.
@@ -248,6 +248,8 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
                                                       u32* __restrict__ out, size_t n, unsigned per_wg,
                                                       unsigned* __restrict__ err, unsigned force_fault,
                                                       const u32* __restrict__ prefix, int wbits) {
+  constexpr int RING = QS < 1024 ? 1024 : 2048;   // ring positions: more than there are slots (sched_lf.hpp)
+  static_assert(QS <= 1024, "a ring entry holds a ten-bit slot number");
   __shared__ u32 lds_st[24 * QS];               // X, Y, Z of slot e: word w at lds_st[w * QS + e]
   // z2z2 = base.z * base.z of slot e's element (variable base): one of the sixteen products of EVERY addition of an
   // element depends on its base point alone, so claim() computes it once with the same sqr() and the ~128 additions
@@ -255,18 +257,17 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   // z2z2 in the element's output slot instead: 23 GB of L2-side traffic and no in-place calls -- removed; this form has
   // neither.)
   __shared__ u32 lds_zq[(FIXED ? 0 : 8 * QS) + 8];
-  constexpr bool KLDS = QS <= QS_MAIN;          // the whole scalar of every slot in LDS (not with QS_WIDE slots: no room)
+  constexpr bool KLDS = FIXED || QS <= QS_MAIN;          // the whole scalar of every slot in LDS (not with QS_WIDE slots: no room)
   __shared__ u32 lds_k[KLDS ? 8 * QS : 8];      // scalar of slot e: word w at lds_k[w * QS + e]
   __shared__ u32 lds_gid[QS];                   // element of slot e, relative to the workgroup's range
   __shared__ unsigned short lds_step[QS];
-  __shared__ unsigned short lds_q[2][QRING];
-  __shared__ __attribute__((aligned(16))) int lds_ctl[P_WORDS];
+  __shared__ __attribute__((aligned(16))) int lds_lf[LF_INTS<RING>];   // control words + the rings D, A, F (sched_lf.hpp)
   __shared__ __attribute__((aligned(16))) u32 lds_zz[8];   // FIXED && HOIST: base.z * base.z (one for the workgroup)
   const size_t lo = (size_t)blockIdx.x * per_wg;
   const int range = (n - lo) < (size_t)per_wg ? (int)(n - lo) : (int)per_wg;
   const int tid = threadIdx.x, lane = tid & 63;
-  // control words through an LDS-address-space pointer (sched_ctl.hpp): one opaque base register, immediate offsets
-  lds_int_ptr ctl = (lds_int_ptr)lds_ctl;
+  // control words through an LDS-address-space pointer in one opaque base register, immediate offsets
+  lds_int_ptr ctl = (lds_int_ptr)lds_lf;
   asm volatile("" : "+v"(ctl));
   const unsigned ctl_addr = (unsigned)(size_t)ctl;  // LDS byte address of the control block
   if (FIXED && HOIST) {  // every lane computes the same square; one stores it
@@ -275,11 +276,8 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
       FEC_UNROLL for (int w = 0; w < 8; ++w) lds_zz[w] = zz.w[w];
     }
   }
-  if (tid == 0) {
-    FEC_UNROLL for (int w = 0; w < P_WORDS; ++w) lds_ctl[w] = 0;
-    lds_ctl[C_REMAIN] = range < QS ? range : QS;   // live slots
-    if (force_fault) lds_ctl[C_ERR] = (int)FEC_DEVERR_FORCED;   // debug hook: every wavefront leaves at its first critical section
-  }
+  // every slot starts in the free ring: the wavefronts' first pops are claims of 64 elements each
+  lf_init<RING>(lds_lf, tid, QT, range < QS ? range : QS, force_fault ? (unsigned)FEC_DEVERR_FORCED : 0u);
   __syncthreads();
 
   // Claims the next element of the range for slot `e`.  multiply's early-outs (2121-2124: identity point or zero
@@ -288,12 +286,12 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   // point (Add's first early-out returns rhs as it is), so the slot starts with result = point at step 256 - t --
   // exactly the state the reference is in after that addition.  (Besides the skipped operations this keeps identity
   // results out of the queues: with them, 39 % of all batches held at least one lane on an early-out and ran Add's /
-  // double's rare leg for the whole wavefront.)  Returns the scalar bit of the element's next step (= the queue it
-  // goes to) or 2 when the range is used up (the slot dies).
+  // double's rare leg for the whole wavefront.)  Returns the scalar bit of the element's next step (= the ring it
+  // goes to) or LF_NXT_DEAD when the range is used up (the slot dies).
   auto claim = [&](int e) -> int {
     for (;;) {
-      const int rel = lds_fetch_add(ctl, P_NEXT, 1);
-      if (rel >= range) return 2;
+      const int rel = lds_fetch_add(ctl, LF_NEXT, 1);
+      if (rel >= range) return LF_NXT_DEAD;
       const size_t g = lo + rel;
       const uint4* ks = reinterpret_cast<const uint4*>(scalars + g * 8);
       const uint4 k0 = ks[0], k1 = ks[1];
@@ -353,98 +351,28 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     return (scalars[(lo + lds_gid[e]) * 8 + (b >> 5)] >> (b & 31)) & 1u;   // (lds_gid[e] < range: written by claim())
   };
 
-  int kind = -1, count = 0;
-  int e = tid;
-  int nxt = 3;
-  unsigned spins = 0;
+  int e = 0;
+  int nxt = LF_NXT_NONE;
+  unsigned watchdog = 0;
   FEC_STAT_DECL;
-  int fill = 0;  // initial fill passes done: slots [fill * QT, (fill + 1) * QT) are claimed on pass `fill`
-  nxt = tid < range ? claim(e) : 3;
   for (;;) {
-    const lmask m_d = __builtin_amdgcn_ballot_w64(nxt == 0), m_a = __builtin_amdgcn_ballot_w64(nxt == 1);
-    const int n_d = __builtin_popcountll(m_d), n_a = __builtin_popcountll(m_a);
-    const int n_fin = __builtin_popcountll(__builtin_amdgcn_ballot_w64(nxt == 2));
-    const lmask below = (1ull << lane) - 1;
-    const int rank_d = __builtin_popcountll(m_d & below), rank_a = __builtin_popcountll(m_a & below);
-    const bool filling = fill < (QS + QT - 1) / QT;
-    if (n_d + n_a + n_fin == 0 && !filling) {
-      const int q_d = ctl[C_TAIL_D] - ctl[C_HEAD_D], q_a = ctl[C_TAIL_A] - ctl[C_HEAD_A];
-      const int fl = ctl[C_INFLIGHT], rem = ctl[C_REMAIN];
-      int th0 = rem >> 3;
-      th0 = th0 < 1 ? 1 : (th0 > 64 ? 64 : th0);
-      const bool go = q_d >= th0 || q_a >= th0 || (fl == 0 && (q_d | q_a) != 0) || (rem == 0 && fl == 0) || ctl[C_ERR] != 0;
-      if (!go) {
-        FEC_STAT(6, 1);
-        __builtin_amdgcn_s_sleep(64);
-        if (++spins > (1u << 22)) {
-          if (lane == 0) ctl[C_ERR] = (int)FEC_DEVERR_SCHED_WATCHDOG;
-          break;
-        }
-        continue;
-      }
-    }
-    FEC_STAT(4, 1);   // critical sections entered
-    if (lane == 0) {
-      const int my = lds_fetch_add(ctl, C_TICKET, 1);   // (lane 0 only: a plain ds_add_rtn, not the atomic optimiser's mbcnt sequence)
-      while (ctl[C_SERVING] != my) {
-        FEC_STAT(5, 1);  // waits for the ticket
-        __builtin_amdgcn_s_sleep(FEC_TICKET_SLEEP);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const CtlWords cw = ctl_read(ctl_addr);
-    int t_d = cw.tail_d, t_a = cw.tail_a;
-    if (nxt == 0) lds_q[0][(t_d + rank_d) & (QRING - 1)] = (unsigned short)e;
-    if (nxt == 1) lds_q[1][(t_a + rank_a) & (QRING - 1)] = (unsigned short)e;
-    t_d += n_d;
-    t_a += n_a;
-    int inflight = cw.inflight - count;
-    const int remain = cw.remain - n_fin;
-    int h_d = cw.head_d, h_a = cw.head_a;
-    const int av_d = t_d - h_d, av_a = t_a - h_a;
-    const int err = cw.err;
-    int th = remain >> 3;
-    th = th < 1 ? 1 : (th > 64 ? 64 : th);
-    int pick = -1;
-    if (!filling) {
-      if (av_a >= th && av_a >= av_d) pick = 1;
-      else if (av_d >= th) pick = 0;
-      else if (av_a >= th) pick = 1;
-      else if (inflight == 0 && (av_a | av_d) != 0) pick = av_a > av_d ? 1 : 0;
-    }
-    int start = 0;
-    count = 0;
-    if (pick == 0) {
-      count = av_d < 64 ? av_d : 64;
-      start = h_d;
-      h_d += count;
-    } else if (pick == 1) {
-      count = av_a < 64 ? av_a : 64;
-      start = h_a;
-      h_a += count;
-    }
-    inflight += count;
-    const bool finished = (!filling && remain == 0 && inflight == 0) || err != 0;
-    if (lane == 0) ctl_write(ctl_addr, h_d, t_d, h_a, t_a, inflight, remain);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) ctl[C_SERVING] = ctl[C_SERVING] + 1;
-    kind = pick;
-    nxt = 3;
-    if (finished) break;
-    if (filling) {  // next part of the initial fill
-      ++fill;
-      e = fill * QT + tid;
-      if (e < QS && e < range) nxt = claim(e);
+    // hand on what the last batch left (sched_lf.hpp: no lock, no turn to wait for), take the next one
+    lf_push<RING>(ctl_addr, lane, nxt, e);
+    nxt = LF_NXT_NONE;
+    const LfPop pop = lf_pop<RING>(ctl_addr, lane, watchdog, (u32)FEC_DEVERR_SCHED_WATCHDOG);
+    if (pop.kind < 0) break;
+    if (!lf_entry<RING>(ctl_addr, pop, lane, (u32)FEC_DEVERR_SCHED_WATCHDOG, e)) break;
+    const bool active = lane < pop.count;
+    if (pop.kind == LF_Q_F) {   // free slots: each takes the next element of the range (64 claims at full width)
+      FEC_STAT(7, 1);
+      if (active) nxt = claim(e);
       continue;
     }
-    if (kind < 0) continue;
-    spins = 0;
-    const bool active = lane < count;
-    e = active ? lds_q[kind][(start + lane) & (QRING - 1)] : 0;
+    const int kind = pop.kind;
     const int step_word = active ? lds_step[e] : 0x8000;   // (a lane without an element does not veto the z == 1 form)
     int step = step_word & 0x7FFF;
     // Every global address below is formed from this index (written by claim(), always < range): a broken queue must
-    // never address memory outside the workgroup's own range -- such a lane works on element 0, stores nothing, raises C_ERR.
+    // never address memory outside the workgroup's own range -- such a lane works on element 0, stores nothing, raises the error.
     u32 gid = active ? lds_gid[e] : 0u;
     const bool oob = gid >= (u32)range;
     gid = oob ? 0u : gid;
@@ -452,12 +380,11 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     bool fin = false;
     p256::pt res = p256::identity();
     FEC_STAT(kind == 0 ? 0 : 2, 1);
-    FEC_STAT(kind == 0 ? 1 : 3, count);
+    FEC_STAT(kind == 0 ? 1 : 3, pop.count);
     // ONE task = one step of the reference's loop (2126-2134) for 64 elements that agree on the step's scalar bit:
-    //   queue 0 (bit clear): result = result.double()
-    //   queue 1 (bit set):   result = result.double(); result = result + point
-    // (Round 2 queued the doubling and the addition separately: 381 visits of the scheduler per element instead of 254,
-    // i.e. a third more of its 200-250 instructions and of its lock traffic for the same arithmetic.)
+    //   ring D (bit clear): result = result.double()
+    //   ring A (bit set):   result = result.double(); result = result + point
+    // (Round 2 queued the doubling and the addition separately: 381 visits of the scheduler per element instead of 254.)
     FEC_MARK("task_double_begin");
 #ifdef FEC_SCHED_STUB   // tools/microbench/sched_stats.hip: the scheduler alone (the task is a copy of the slot)
     res = ld_pt(lds_st + e, QS);
@@ -465,7 +392,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
     res = pdouble_in_place(lds_st + e, QS);
 #endif
     FEC_MARK("task_double_end");
-    if (kind == 1) {
+    if (kind == LF_Q_A) {
       // the addition reads its first operand from the slot (a lane's LDS accesses stay in order); inactive lanes add
       // slot 0 and element 0 of the range: harmless, never stored
       if (live) st_pt(lds_st + e, QS, res);
@@ -490,17 +417,19 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
         nxt = (int)step_bit(e, step);
       }
     }
-    if (fin) {  // the element is done: its result goes out (16-byte stores), the slot takes the next element
+    if (fin) {  // the element is done: its result goes out (16-byte stores), the slot joins the free ring
       st_out(out + (lo + gid) * 24, res);
-      nxt = claim(e);
+      nxt = LF_NXT_FREE;
     }
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(oob) != 0, 0)) {
-      if (oob) ctl[C_ERR] = (int)FEC_DEVERR_SCHED_INDEX;
+      lf_raise(ctl_addr, lane, (u32)FEC_DEVERR_SCHED_INDEX);
+      nxt = LF_NXT_NONE;
     }
   }
+  FEC_STAT(6, watchdog);
   FEC_STAT_FLUSH;
   __syncthreads();
-  if (const int ec = lds_ctl[C_ERR]) {
+  if (const int ec = lds_lf[LF_ERR]) {
     // Scheduler fault (watchdog, index guard, or the debug hook): zero-fill the workgroup's results AND set the ctx's
     // error word, which the host reads after its synchronisation -- the call returns FEC_E_LAUNCH (see kernels_ed.hip).
     for (int el = tid; el < range; el += QT) {
@@ -542,8 +471,7 @@ void p256_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const 
     const bool tab = points == env.gen[FEC_P256] && env.gen_prefix[FEC_P256] != nullptr && env.gen_prefix_bits[FEC_P256] > 0;
     const u32* pre = tab ? env.gen_prefix[FEC_P256] : (const u32*)nullptr;
     const int wbits = tab ? (int)env.gen_prefix_bits[FEC_P256] : 0;
-    // (no QS_WIDE instantiation for the fixed base: with the table pointers live as well it spills three registers)
-    hipLaunchKernelGGL((k_p256_mul_sched<true, true, QS_MAIN>), g, b, 0, s, scalars, points, out, n, per_wg, env.err,
+    hipLaunchKernelGGL((k_p256_mul_sched<true, true, QS_FIXED>), g, b, 0, s, scalars, points, out, n, per_wg, env.err,
                        env.force_fault, pre, wbits);
     return;
   }

@@ -406,7 +406,7 @@ def test_scheduler_kernels_at_slot_and_wavefront_boundaries(gpu_ctx, oracle, cur
 
 @pytest.mark.parametrize("curve", [1, 2])
 def test_scheduler_kernels_wide_slot_instantiation(gpu_ctx, oracle, curve):
-    """A launch whose workgroups own between 832 and 1 024 elements each (here 256 000 elements on 256 CUs) takes the
+    """A launch whose workgroups own between 864 and 1 024 elements each (here 256 000 elements on 256 CUs) takes the
     1 024-slot instantiation of the scheduler kernel (P-256: the scalar's bits then come from the caller's array, not
     from LDS); 2 000 per workgroup likewise.  Device-pointer call (one launch), every element against the oracle."""
     import torch

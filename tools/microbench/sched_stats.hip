@@ -23,6 +23,11 @@ int main(int argc, char** argv) {
   std::vector<unsigned long long> k(n * 4), p(n * 12);
   unsigned long long s = 12345;
   for (auto& v : k) v = sm(s);
+  // argv[2]: 1 = sparse scalars (2^255 + 1: 254 doublings, one addition), 2 = dense scalars (all ones: every step adds):
+  // with rocprofv3 --pmc SQ_INSTS_VALU these give the DYNAMIC size of a doubling task and of an addition task
+  const int pattern = argc > 2 ? atoi(argv[2]) : 0;
+  if (pattern == 1) for (size_t i = 0; i < n; ++i) { k[4 * i] = 1; k[4 * i + 1] = k[4 * i + 2] = 0; k[4 * i + 3] = 1ull << 63; }
+  if (pattern == 2) for (auto& v : k) v = ~0ull;
   for (auto& v : p) v = sm(s) >> 1;  // (any 256-bit coordinates do: multiply never validates its point)
   unsigned *dk, *dp, *dout;
   hipMalloc(&dk, n * 32);
@@ -53,9 +58,8 @@ int main(int argc, char** argv) {
            (double)st[1] / st[0], (double)st[1] / n);
     printf("addition batches %llu, lanes %llu (%.2f per batch; %.2f additions per element)\n", st[2], st[3],
            (double)st[3] / st[2], (double)st[3] / n);
-    printf("critical sections %llu (%.3f per batch), ticket waits (lane-0 sleeps) %llu (%.3f per critical section)\n", st[4],
-           (double)st[4] / (st[0] + st[2]), st[5], (double)st[5] / st[4]);
-    printf("polls of waiting wavefronts: %llu (%.3f per batch)\n", st[6], (double)st[6] / (st[0] + st[2]));
+    printf("claim tasks %llu (%.3f per 64 elements); sleeps + lost races of waiting wavefronts %llu (%.3f per batch)\n", st[7],
+           (double)st[7] * 64.0 / n, st[6], (double)st[6] / (st[0] + st[2]));
   }
   return 0;
 }
