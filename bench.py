@@ -2,9 +2,13 @@
 """
 bench.py -- headline benchmark of the batched scalar-multiplication hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N = 1)
+  python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W        (N > 1, one rank per GPU)
+
+With N > 1 and no RANK in the environment the first form starts the second one itself: N fresh rank processes through
+torch.distributed.run on 127.0.0.1 and a free port, spawned BEFORE this process has imported torch or touched a GPU
+(a process that has initialised the GPU is never replaced or re-used), and rank 0's JSON line is the output.
 
 Default workload (BASELINE.json configs[1], the headline): 2^20 secp256k1 variable-base scalar
 multiplications per GPU (--workload selects the other BASELINE configurations) on synthetic seeded inputs (forge_ec_amd/synth.py), inputs resident in HBM before the timed
@@ -70,7 +74,7 @@ TRAFFIC_NOTES = {
 PEAK_MAD32_FORMULA = 256 * 4 * 64 * 2.4e9 / 4.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -95,7 +99,7 @@ def parse():
                          "0 = off; default: the library's, 24)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (all legs together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def host_cores():
@@ -210,37 +214,95 @@ def valu_issue_cycles(pmc_json):
         return None
 
 
-def main():
-    args = parse()
+class CudaPlatform:
+    """Where the bench runs: rank `local_rank`'s MI355X, RCCL between the ranks.  (tests/bench_rehearsal.py substitutes
+    a CPU / gloo platform whose context is the oracle, to drive THIS file's N > 1 control flow with two real ranks on a
+    box without GPUs; nothing here knows about it.)"""
+    backend = "nccl"
+
+    def __init__(self, local_rank):
+        import torch
+        self.torch, self.local_rank = torch, local_rank
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+
+    def init_process_group(self, dist):
+        dist.init_process_group(backend=self.backend, device_id=self.device)
+
+    def context(self):
+        if os.environ.get("FEC_AB_LIB"):  # same-box A/B of another build of the library (tools/pmc_quick.sh, tools/quick_perf.py)
+            from forge_ec_amd import _lib
+            _lib.SO_PATH = os.path.abspath(os.environ["FEC_AB_LIB"])
+        import forge_ec_amd as F
+        return F.Context(self.local_rank)
+
+    def new_stream(self):
+        """An explicit (non-default) stream, made torch's current one; returns its raw handle."""
+        self.tstream = self.torch.cuda.Stream()
+        self.torch.cuda.set_stream(self.tstream)
+        return self.tstream.cuda_stream
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n_ranks, script, argv):
+    """`bench.py --gpus N` without a launcher: N rank processes of `script` through torch.distributed.run, as children.
+    The caller has not imported torch or touched a GPU at this point.  Returns the launcher's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL across processes needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None, platform_factory=None, script=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher around us: be the launcher (before torch is imported or a GPU is touched in this process)
+        raise SystemExit(self_launch(args.gpus, script or os.path.abspath(__file__), argv))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d but this launcher started one rank" % args.gpus)
+    if not args.no_cpu_baseline and world == 1 and platform_factory is None:
+        # build / load the CPU checker before anything touches the GPU (its first use on a box compiles it with gcc)
+        from oracle import c_oracle
+        c_oracle.native_lib()
     import torch
-    if os.environ.get("FEC_AB_LIB"):  # same-box A/B of another build of the library (tools/pmc_quick.sh, tools/quick_perf.py)
-        from forge_ec_amd import _lib
-        _lib.SO_PATH = os.path.abspath(os.environ["FEC_AB_LIB"])
+    plat = (platform_factory or CudaPlatform)(local_rank)
     import forge_ec_amd as F
     from forge_ec_amd import synth
     from forge_ec_amd.dist import shard_range
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
     dist = None
-    torch.cuda.set_device(local_rank)
     # FEC_BENCH_FORCE_DIST=1 rehearses the N>1 code path (RCCL init, overlapped gather, max-reduce)
     # with a single rank on a one-GPU box
     force_dist = os.environ.get("FEC_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
     if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        plat.init_process_group(dist)
 
     workload = args.workload
     curve, kind, alg, hbm_bytes, cfg = WORKLOADS[workload]
     cid = CURVE_ID[curve]
     limbs = F.POINT_LIMBS[cid]
-    ctx = F.Context(local_rank)
+    ctx = plat.context()
     strong = args.scaling == "strong"
     if strong:
         log2_global = args.log2_global_batch if args.log2_global_batch is not None else BASELINE_LOG2_GLOBAL.get(workload, 20)
@@ -272,16 +334,14 @@ def main():
     mean_popcount = float(np.unpackbits(np.ascontiguousarray(inputs[0]).view(np.uint8)).sum()) / n
     if workload in ALG_FROM_POPCOUNT:
         alg = ALG_FROM_POPCOUNT[workload](mean_popcount)
-    d_in = [torch.from_numpy(a.view(np.int64)).cuda() for a in inputs]
-    d_out = [torch.empty((n, limbs), dtype=torch.int64, device="cuda") for _ in range(2)]
+    d_in = [torch.from_numpy(a.view(np.int64)).to(plat.device) for a in inputs]
+    d_out = [torch.empty((n, limbs), dtype=torch.int64, device=plat.device) for _ in range(2)]
     # All launches and collectives are ordered on ONE explicit (non-default) torch stream: the library
     # launches on the stream it is handed (a null handle would mean its own ctx stream, which torch's
     # collectives know nothing about), RCCL orders its internal stream against torch's current stream
     # at enqueue, and handle.wait() makes that stream wait for the collective -- so the gather reads a
     # finished shard and the next kernel cannot overwrite a buffer the gather is still reading.
-    tstream = torch.cuda.Stream()
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
+    stream = plat.new_stream()
     assert stream != 0
 
     gather_arg = args.gather if args.gather is not None else ("both" if dist is not None else "none")
@@ -293,7 +353,7 @@ def main():
         from forge_ec_amd.dist import ResultGather
         for m in modes:
             if m != "none":
-                gathers[m] = [ResultGather(n_global, limbs, torch.device("cuda", local_rank),
+                gathers[m] = [ResultGather(n_global, limbs, plat.device,
                                            dst=0 if m == "rank0" else None) for _ in range(2)]
 
     launched = {"name": None}  # the kernel(s) the library reports for the timed launch
@@ -318,7 +378,7 @@ def main():
             else:
                 ctx.batch_double_mul_dev(cid, d_in[0].data_ptr(), d_in[1].data_ptr(), d_in[2].data_ptr(), d_out[0].data_ptr(),
                                          n, stream)
-            torch.cuda.synchronize()
+            plat.synchronize()
             return (time.perf_counter() - t0) * 1e3
         first_ms, second_ms = small_call(), small_call()
         bits = ctx.fixed_prefix_bits(cid)
@@ -351,7 +411,7 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        plat.synchronize()
 
     def timed_region(mode):
         """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
@@ -372,7 +432,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=plat.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed
@@ -390,12 +450,12 @@ def main():
         for g in gather0:
             g.finish()
     ctx.set_timing(False)
-    torch.cuda.synchronize()
+    plat.synchronize()
     if gather0 is not None and os.environ.get("FEC_BENCH_CHECK_GATHER") == "1":
         # rehearsal aid: the gathered block of this rank must equal the shard the kernel just produced
         step(0, False, gather0)
         full = gather0[0].finish()
-        torch.cuda.synchronize()
+        plat.synchronize()
         off = lo if strong else rank * n
         if full is not None and not torch.equal(full[off:off + n], d_out[0]):
             raise SystemExit("gathered shard differs from the kernel output")
@@ -428,6 +488,34 @@ def main():
             wl = "2^%d %s scalar-muls per GPU per step (BASELINE.json %s)" % (args.log2_batch, workload, cfg)
         if args.scalars_below_l and curve == "ed25519":
             wl += "; scalars below 2^252 < l"
+        bits = prefix["bits"] if prefix else 0
+        # Fixed-base and double workloads: `frac` prices the REFERENCE's operation count, but the first `bits` steps of
+        # multiply(G, .) come out of the prefix table.  frac_executed_steps scales it by the share of the steps (Ed25519:
+        # of the additions) the kernels still execute -- the number to compare with a variable-base row.
+        executed_share = None
+        if kind == "fixed" and curve == "ed25519":
+            executed_share = max(mean_popcount - bits / 2.0, 0.0) / mean_popcount if mean_popcount else None
+        elif kind == "fixed":
+            executed_share = (256 - bits) / 256.0
+        elif kind == "double":
+            executed_share = (512 - bits) / 512.0
+        table_fetch = ({0: 192, 1: 96, 2: 128}[cid] if bits else 0) if kind in ("fixed", "double") else 0
+        # The lock-step ladder (secp256k1) runs one wavefront per 64 elements, three resident per SIMD: a launch whose
+        # wavefronts are not a whole number of rounds of the chip's resident slots pays for the thin last round (a lone
+        # wavefront issues at ~4.6 cycles per instruction, three at ~3.8 each).  This is the term that bounds a small
+        # per-GPU shard (BASELINE configs[4] on 8 GPUs: 2^17 per GPU, two launches side by side).
+        rounds = None
+        if curve == "secp256k1":
+            slots = info["compute_units"] * 4 * 3
+            waves = ((n + 63) // 64) * (2 if kind == "double" else 1)
+            full, rest = divmod(waves, slots)
+            per_simd_last = rest / float(info["compute_units"] * 4)
+            rounds = {"wavefronts": waves, "resident_wavefront_slots": slots, "rounds": waves / float(slots),
+                      "last_round_wavefronts_per_simd": per_simd_last,
+                      "bound": ("whole rounds of three wavefronts per SIMD" if rest == 0 else
+                                "%d full round(s) at three wavefronts per SIMD + a last round at %.2f per SIMD: one ladder "
+                                "(256 steps) takes ~2.8 ms alone on a SIMD and ~5.4 ms for three, so the time is set by rounds "
+                                "of resident wavefronts, not by the element count" % (full, per_simd_last))}
         out = {
             "metric": "%s scalar-muls/sec (batched, %s)" % (
                 workload, "bit-exact vs CPU oracle on the parity sample" if cpu else "parity check not run in this invocation"),
@@ -442,17 +530,22 @@ def main():
                        "device": info["name"], "compute_units": info["compute_units"]},
             "roofline": {
                 "bound": "int-valu", "achieved": achieved / 1e12, "peak": PEAK_MAD32_FORMULA / 1e12,
-                "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_FORMULA, "traffic": pmc["traffic"],
+                "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_FORMULA,
+                "frac_executed_steps": (achieved / PEAK_MAD32_FORMULA * executed_share) if executed_share is not None else None,
+                "executed_share_of_reference_steps": executed_share,
+                "wavefront_rounds": rounds,
+                "traffic": pmc["traffic"],
                 "traffic_source": pmc["source"],
                 "traffic_note": TRAFFIC_NOTES.get(workload),
                 "kernel": kname, "kernel_ms": kernel_ms,
-                "algorithmic_mad32_per_unit": alg, "mean_scalar_popcount": mean_popcount, "executed_mul_insts_per_unit": EXECUTED_MULS[workload](prefix["bits"] if prefix else 0),
+                "algorithmic_mad32_per_unit": alg, "mean_scalar_popcount": mean_popcount, "executed_mul_insts_per_unit": EXECUTED_MULS[workload](bits),
                 "fixed_base_prefix_table": prefix,
                 "units_per_launch": n,
                 "peak_measured": peak_measured / 1e12, "frac_of_measured_peak": achieved / peak_measured,
                 "valu_issue_cycles_per_inst_per_simd": pmc["valu_issue_cycles"],
-                "hbm": {"achieved_GBps": n * hbm_bytes / (kernel_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
-                        "algorithmic_bytes_per_unit": hbm_bytes},
+                "hbm": {"achieved_GBps": n * (hbm_bytes + table_fetch) / (kernel_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                        "algorithmic_bytes_per_unit": hbm_bytes,
+                        "prefix_table_fetch_bytes_per_unit": table_fetch},
             },
         }
         if dist is not None:
