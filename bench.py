@@ -121,7 +121,7 @@ def cpu_baseline(workload, inputs, gpu_out, target_s):
     and compare the all-core leg's output with the GPU output (the parity sample).  The timed library is the oracle's
     source rebuilt on this box with -O3 -march=native when gcc is here (c_oracle.native_lib), else the shipped
     x86-64-v2 build; `build` says which."""
-    from oracle import c_oracle
+    c_oracle = load_checker()
     curve_name, kind = WORKLOADS[workload][0], WORKLOADS[workload][1]
     cid = CURVE_ID[curve_name]
     cores = host_cores()
@@ -154,6 +154,14 @@ def cpu_baseline(workload, inputs, gpu_out, target_s):
             "sample": "first %d of the rank-0 batch (%s), C oracle oracle/forge_ec_oracle.c (a restatement of the "
                       "reference's Rust, not rustc output), %d threads, %.1f s" % (n, workload, cores, dt),
             "parity_sample_bit_exact": ok}
+
+
+def load_checker():
+    """The CPU checker of the cpu_baseline leg -- the only place this file touches oracle/.  main() calls it once BEFORE
+    the GPU is touched when the leg will run, so that the first use on a box compiles the checker (gcc, a child process)
+    while this process holds no GPU state; cpu_baseline() then finds the library built."""
+    from oracle import c_oracle
+    return c_oracle
 
 
 def committed_pmc(workload, n):
@@ -282,8 +290,7 @@ def main(argv=None, platform_factory=None, script=None):
         raise SystemExit("--gpus %d but this launcher started one rank" % args.gpus)
     if not args.no_cpu_baseline and world == 1 and platform_factory is None:
         # build / load the CPU checker before anything touches the GPU (its first use on a box compiles it with gcc)
-        from oracle import c_oracle
-        c_oracle.native_lib()
+        load_checker().native_lib()
     import torch
     plat = (platform_factory or CudaPlatform)(local_rank)
     import forge_ec_amd as F

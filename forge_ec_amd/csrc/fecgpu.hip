@@ -13,9 +13,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <system_error>
 #include <thread>
+#include <vector>
 
 #include "../../include/fecgpu.h"
 #include "ed25519.hpp"
@@ -594,34 +596,131 @@ void queue_prefix_levels(int curve, const u32* base, const u32* ed_addends, unsi
   }
 }
 
-void ensure_gen_prefix(fec_ctx* ctx, int curve, hipStream_t s, size_t n) {
-  if (ctx->prefix_bits == 0 || ctx->gen_prefix_tried[curve]) return;
-  ctx->fixed_elems[curve] += n;
-  if (ctx->fixed_elems[curve] < ctx->prefix_after) return;
-  ctx->gen_prefix_tried[curve] = true;
-  const unsigned w = ctx->prefix_bits;
+int ensure_ed_table(fec_ctx* ctx, const u64* d_base, const u64* host_base, hipStream_t s);
+
+// ONE table per device, curve and size for the whole process: every ctx on that device (the [0, 0, 0] shard workers of a
+// multi-device ctx, the ctxs of several host threads) holds a reference to the same allocation.  A table is complete
+// before it is published (its builder waits for its stream), so a ctx that finds one needs no ordering with the builder.
+struct SharedPrefix {
+  int device, curve;
+  unsigned bits;
+  u32* table;
+  int refs;
+};
+std::mutex g_prefix_mu;                 // guards g_prefix AND serialises builds (a second ctx waits, then shares)
+std::vector<SharedPrefix> g_prefix;
+
+// the largest w <= wanted (>= 16, else 0) whose table + build scratch fit `budget_pct` of the device's free memory
+unsigned prefix_bits_within_budget(int curve, unsigned wanted, unsigned budget_pct) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  const double allowed = (double)free_b * (double)budget_pct / 100.0;
+  const unsigned floor_w = wanted < 16 ? wanted : 16;   // (a table is never shrunk below 2^16 entries: then rather none)
+  for (unsigned w = wanted; w >= floor_w && w > 0; --w)
+    if ((double)prefix_table_bytes(curve, w) + (double)prefix_half_bytes(curve, w) <= allowed) return w;
+  return 0;
+}
+
+// This ctx's reference to the shared table of `curve`, given up (the last reference frees the table; hipFree waits for
+// the device, so no launch is still reading it).
+void release_gen_prefix(fec_ctx* ctx, int curve) {
+  u32* t = ctx->d_gen_prefix[curve];
+  ctx->d_gen_prefix[curve] = nullptr;
+  ctx->gen_prefix_bits[curve] = 0;
+  if (!t) return;
+  std::lock_guard<std::mutex> lock(g_prefix_mu);
+  for (size_t i = 0; i < g_prefix.size(); ++i) {
+    if (g_prefix[i].table != t) continue;
+    if (--g_prefix[i].refs <= 0) {
+      (void)hipSetDevice(g_prefix[i].device);
+      (void)hipFree(g_prefix[i].table);
+      g_prefix.erase(g_prefix.begin() + (long)i);
+      if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    }
+    return;
+  }
+}
+
+// Attaches the ctx to the process's table of `curve` -- an existing one of the wanted size, else of the size the memory
+// budget allows -- building it (`may_build`) on stream s when there is none.  Returns 1 when the ctx now has a table, 0
+// when there is none to be had (no memory within the budget, or building is not allowed here), -1 when the build itself
+// failed (a launch or stream error: not a question of memory, the next launch may try again).
+// No table is not an error: the launches then run the whole ladder (SchedEnv carries a null table).
+int attach_gen_prefix(fec_ctx* ctx, int curve, hipStream_t s, bool may_build) {
+  if (ctx->d_gen_prefix[curve]) return 1;
+  if (ctx->prefix_bits == 0) return 0;
+  std::lock_guard<std::mutex> lock(g_prefix_mu);
+  auto find = [&](unsigned bits) -> SharedPrefix* {
+    for (auto& e : g_prefix)
+      if (e.device == ctx->device && e.curve == curve && e.bits == bits) return &e;
+    return nullptr;
+  };
+  SharedPrefix* e = find(ctx->prefix_bits);
+  unsigned w = ctx->prefix_bits;
+  if (!e) {
+    w = prefix_bits_within_budget(curve, ctx->prefix_bits, ctx->prefix_budget_pct);
+    if (w == 0) return 0;
+    e = find(w);
+  }
+  if (e) {
+    ++e->refs;
+    ctx->d_gen_prefix[curve] = e->table;
+    ctx->gen_prefix_bits[curve] = e->bits;
+    return 1;
+  }
+  if (!may_build) return 0;
   void* t = nullptr;
   void* half = nullptr;
-  auto give_up = [&] {
+  auto give_up = [&](int why) -> int {
     (void)hipGetLastError();
     if (t) (void)hipFree(t);
     if (half) (void)hipFree(half);
+    return why;
   };
-  if (hipMalloc(&t, prefix_table_bytes(curve, w)) != hipSuccess) return give_up();
-  if (prefix_half_bytes(curve, w) != 0 && hipMalloc(&half, prefix_half_bytes(curve, w)) != hipSuccess) return give_up();
+  if (hipMalloc(&t, prefix_table_bytes(curve, w)) != hipSuccess) return give_up(0);
+  if (prefix_half_bytes(curve, w) != 0 && hipMalloc(&half, prefix_half_bytes(curve, w)) != hipSuccess) return give_up(0);
+  if (curve == FEC_ED25519 && ensure_ed_table(ctx, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, s) != FEC_OK) return give_up(-1);
   order_after_previous(ctx, s);
   queue_prefix_levels(curve, reinterpret_cast<const u32*>(ctx->d_gen[curve]), ctx->d_ed_table, w, static_cast<u32*>(t),
                       static_cast<u32*>(half), s);
-  // once per ctx and curve: wait here, so that a failed build never becomes a table
+  // once per device and curve: wait here, so that a failed build never becomes a table and a finished one needs no event
   const bool launch_failed = hipGetLastError() != hipSuccess;
   const bool sync_failed = hipStreamSynchronize(s) != hipSuccess;
-  if (launch_failed || sync_failed) {
-    ctx->gen_prefix_tried[curve] = false;   // (not a question of memory: the next fixed-base launch tries again)
-    return give_up();
-  }
+  if (launch_failed || sync_failed) return give_up(-1);
   if (half) (void)hipFree(half);
+  half = nullptr;
+  try {
+    g_prefix.push_back(SharedPrefix{ctx->device, curve, w, static_cast<u32*>(t), 1});
+  } catch (...) {
+    return give_up(0);
+  }
   ctx->d_gen_prefix[curve] = static_cast<u32*>(t);
   ctx->gen_prefix_bits[curve] = w;
+  return 1;
+}
+
+// Called by every launch that multiplies `n` scalars by the generator.  Who may BUILD a table (gigabytes of device
+// memory, a host synchronisation): a host-pointer entry point -- synchronous anyway -- of a ctx that has multiplied
+// prefix_after scalars by the generator, and ANY launch of a ctx whose caller asked for tables
+// (fec_ctx_set_fixed_prefix_bits / fec_ctx_build_fixed_prefix).  A *_dev entry point of a ctx left to its defaults only
+// enqueues: it takes a table that already exists on its device (another ctx's, or an earlier host-pointer call's) and
+// never allocates or waits.  A refusal is not permanent: the ctx asks again after another kPrefixAfter multiplications.
+void ensure_gen_prefix(fec_ctx* ctx, int curve, hipStream_t s, size_t n) {
+  if (ctx->prefix_bits == 0 || ctx->d_gen_prefix[curve]) return;
+  ctx->fixed_elems[curve] += n;
+  if (ctx->gen_prefix_tried[curve]) {
+    if (ctx->fixed_elems[curve] < kPrefixAfter) return;
+    ctx->gen_prefix_tried[curve] = false;          // (the device may have memory to spare by now)
+  }
+  if (ctx->fixed_elems[curve] < ctx->prefix_after) return;
+  const bool may_build = ctx->prefix_explicit || ctx->in_host_call;
+  if (attach_gen_prefix(ctx, curve, s, may_build) == 0 && may_build) {   // refused (budget, allocation): count afresh
+    ctx->gen_prefix_tried[curve] = true;
+    ctx->fixed_elems[curve] = 0;
+  }
 }
 
 // Any OTHER fixed base: a table for this one launch, in the launch stream's scratch, sized to the batch -- 2^w entries
@@ -656,12 +755,11 @@ void per_call_prefix(fec_ctx* ctx, int curve, const u32* base, size_t n, hipStre
   env.gen_prefix[curve] = tab;
   env.gen_prefix_bits[curve] = w;
 }
-void drop_gen_prefix(fec_ctx* ctx) {  // (hipFree waits for the device: no launch is still reading a table)
+void drop_gen_prefix(fec_ctx* ctx) {
   for (int c = 0; c < 3; ++c) {
-    if (ctx->d_gen_prefix[c]) (void)hipFree(ctx->d_gen_prefix[c]);
-    ctx->d_gen_prefix[c] = nullptr;
-    ctx->gen_prefix_bits[c] = 0;
+    release_gen_prefix(ctx, c);
     ctx->gen_prefix_tried[c] = false;
+    ctx->fixed_elems[c] = 0;
   }
 }
 
@@ -796,12 +894,8 @@ int launch_double_mul(fec_ctx* ctx, int curve, const u64* d1, const u64* d2, con
   // The fixed-base product runs on the ctx's second stream beside the variable-base one (the persistent kernels, one
   // workgroup per CU, each on half of the CUs): see SideStream.
   // (Ed25519: the table kernel is short and not capped to half of the CUs; side by side pays up to 2^15 elements)
-  // FEC_SIDE_STREAM_MAX (elements; measurement knob of tools/double_mul_small_perf.py) overrides the limit
-  static const size_t side_max = [] {
-    const char* e = std::getenv("FEC_SIDE_STREAM_MAX");
-    return e && *e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)SideStream::kSideStreamMax;
-  }();
-  SideStream side(ctx, L.s, n, curve == FEC_ED25519 ? (size_t)1 << 15 : side_max);
+  // (fec_ctx_set_side_stream_max -- the measurement knob of tools/double_mul_small_perf.py -- moves the limit)
+  SideStream side(ctx, L.s, n, curve == FEC_ED25519 ? (size_t)1 << 15 : ctx->side_stream_max);
   if (curve == FEC_SECP256K1) {  // the 3-waves-per-SIMD ladder twice (fixed G, then Q) beats the fused 2-wave kernel
     secp_launch_mul(sched_env(ctx), true, a, gen, ta, n, side.s);
     side.fork_done();
@@ -1015,10 +1109,9 @@ struct HostIn {
   size_t bytes;   // only for stride == 0
 };
 template <class F>
-int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, size_t out_stride, F body,
-                  bool scheduler_kernel = false) {
+int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, size_t out_stride, F body) {
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  const size_t chunk = pipeline_chunk(ctx, scheduler_kernel);
+  const size_t chunk = pipeline_chunk(ctx);
   const size_t nchunks = (n + chunk - 1) / chunk;
   struct InPipeline {  // (SideStream: a multi-chunk pipeline keeps both streams busy by itself)
     fec_ctx* c;
@@ -1062,15 +1155,14 @@ int host_pipeline(fec_ctx* ctx, size_t n, const HostIn (&in)[3], void* hout, siz
   int rc = copy_back(nchunks - 1);
   if (rc != FEC_OK) return rc;
   return sync_and_check(ctx, ctx->stream, ctx->stream2);
-  }());
+  });
 }
 
-// Multi-device ctx: contiguous shards [g*n/N, (g+1)*n/N), one host thread per shard worker, each
-// calling the single-device entry point on its child ctx with offset pointers.  Returns the first
+// Multi-device ctx: one host thread per shard worker, each running `call(g)` for its child ctx.  Returns the first
 // failure in shard order.
 constexpr size_t kMaxShards = 16;  // fec_ctx_create_multi's limit
 template <class F>
-int multi_shard(fec_ctx* ctx, size_t n, F call) {
+int multi_each(fec_ctx* ctx, F call) {
   const size_t N = ctx->children.size();
   if (N == 0 || N > kMaxShards) return FEC_E_ARG;
   // fixed-size state: nothing here allocates, so the only thing that can throw is the creation of a thread, and
@@ -1079,12 +1171,10 @@ int multi_shard(fec_ctx* ctx, size_t n, F call) {
   std::thread workers[kMaxShards];
   for (size_t g = 0; g < N; ++g) rc[g] = FEC_OK;
   for (size_t g = 0; g < N; ++g) {
-    const size_t lo = n / N * g + (n % N) * g / N, hi = n / N * (g + 1) + (n % N) * (g + 1) / N;
-    if (hi == lo) continue;
     try {
-      workers[g] = std::thread([&rc, &call, ctx, g, lo, hi] {
+      workers[g] = std::thread([&rc, &call, g] {
         try {
-          rc[g] = call(ctx->children[g], lo, hi - lo);
+          rc[g] = call(g);
         } catch (const std::bad_alloc&) {
           rc[g] = FEC_E_OOM;
         } catch (...) {
@@ -1100,6 +1190,82 @@ int multi_shard(fec_ctx* ctx, size_t n, F call) {
   for (size_t g = 0; g < N; ++g)
     if (rc[g] != FEC_OK) return rc[g];
   return FEC_OK;
+}
+// Host-pointer calls: contiguous shards [g*n/N, (g+1)*n/N), each worker calling the single-device entry point on its
+// child ctx with offset pointers.
+template <class F>
+int multi_shard(fec_ctx* ctx, size_t n, F call) {
+  const size_t N = ctx->children.size();
+  if (N == 0 || N > kMaxShards) return FEC_E_ARG;
+  return multi_each(ctx, [&](size_t g) -> int {
+    const size_t lo = n / N * g + (n % N) * g / N, hi = n / N * (g + 1) + (n % N) * (g + 1) / N;
+    return hi == lo ? (int)FEC_OK : call(ctx->children[g], lo, hi - lo);
+  });
+}
+
+// Device-RESIDENT shards (fec_multi_batch_*_dev): shard g -- counts[g] elements -- already sits in the memory of the
+// ctx's g-th device; `launch(child, g, lo, cnt, out, stream)` enqueues the kernels for elements [lo, lo + cnt) of that
+// shard.  With `gathered` (an array on the consumer-th device of the ctx) every shard's results are also copied into
+// it at the shard's offset -- peer copies over the devices' own xGMI link to the consumer (SURVEY.md section 8e's direct
+// pattern: every device writes its block to the consumer, nothing is relayed), chunk by chunk on a stream of their own so
+// that the copy of one chunk runs under the kernels of the next.  Synchronous: returns when every shard and copy has
+// completed and every device's error word has been read.
+template <class F>
+int multi_dev_run(fec_ctx* ctx, int curve, const size_t* counts, uint64_t* const* out, uint64_t* gathered, int consumer,
+                  void* const* streams, F launch) {
+  const size_t N = ctx->children.size();
+  if (N == 0 || N > kMaxShards) return FEC_E_ARG;
+  if (gathered && (consumer < 0 || (size_t)consumer >= N)) return FEC_E_ARG;
+  const size_t pl = (size_t)plimbs(curve);
+  size_t offset[kMaxShards + 1];
+  offset[0] = 0;
+  for (size_t g = 0; g < N; ++g) offset[g + 1] = offset[g] + counts[g];
+  const int dst_dev = gathered ? ctx->children[(size_t)consumer]->device : -1;
+  return multi_each(ctx, [&](size_t g) -> int {
+    fec_ctx* c = ctx->children[g];
+    const size_t cnt = counts[g];
+    if (cnt == 0) return FEC_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return FEC_E_DEVICE;
+    hipStream_t ks = streams && streams[g] ? (hipStream_t)streams[g] : c->stream;
+    if (gathered) {
+      if (!c->stream_gather && hipStreamCreateWithFlags(&c->stream_gather, hipStreamNonBlocking) != hipSuccess) return FEC_E_COMM;
+      if (!c->ev_gather && hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming) != hipSuccess) return FEC_E_COMM;
+      if (dst_dev != c->device) {   // direct access to the consumer's memory (already enabled is fine; refused: the copy is staged by the runtime)
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, c->device, dst_dev) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(dst_dev, 0);
+        (void)hipGetLastError();
+      }
+    }
+    int rc = drained(c, [&]() -> int {
+      const size_t chunk = c->chunk < cnt ? c->chunk : cnt;
+      for (size_t lo = 0; lo < cnt; lo += chunk) {
+        const size_t m = lo + chunk <= cnt ? chunk : cnt - lo;
+        uint64_t* o = out[g] + lo * pl;
+        const int r = launch(c, g, lo, m, o, (void*)ks);
+        if (r != FEC_OK) return r;
+        if (gathered) {
+          if (hipEventRecord(c->ev_gather, ks) != hipSuccess || hipStreamWaitEvent(c->stream_gather, c->ev_gather, 0) != hipSuccess ||
+              hipMemcpyPeerAsync(gathered + (offset[g] + lo) * pl, dst_dev, o, c->device, m * pl * 8, c->stream_gather) != hipSuccess) {
+            (void)hipGetLastError();
+            return FEC_E_COMM;
+          }
+        }
+      }
+      int r = sync_and_check(c, ks);
+      if (r == FEC_OK && gathered && hipStreamSynchronize(c->stream_gather) != hipSuccess) {
+        (void)hipGetLastError();
+        r = FEC_E_COMM;
+      }
+      return r;
+    });
+    if (rc != FEC_OK) {   // nothing stays queued on the caller's arrays
+      (void)hipStreamSynchronize(ks);
+      if (c->stream_gather) (void)hipStreamSynchronize(c->stream_gather);
+      (void)hipGetLastError();
+      (void)take_device_error(c);
+    }
+    return rc;
+  });
 }
 inline bool is_multi(const fec_ctx* ctx) { return ctx && !ctx->children.empty(); }
 
@@ -1117,7 +1283,7 @@ const char* fec_strerror(int status) try {
     case FEC_E_OOM: return "out of device memory";
     case FEC_E_LAUNCH: return "kernel launch or execution failed";
     case FEC_E_UNSUPPORTED: return "operation not supported for this curve or for a multi-device ctx";
-    case FEC_E_COMM: return "multi-device ctx: a shard worker could not be started";
+    case FEC_E_COMM: return "multi-device ctx: a shard worker could not be started, or a copy between two devices failed";
     default: return "unknown fecgpu status";
   }
 } FEC_ABI_CATCH_NULL
@@ -1146,6 +1312,10 @@ int fec_ctx_create(fec_ctx** out, int device) try {
     }
     const char* after = std::getenv("FEC_FIXED_PREFIX_AFTER");
     ctx->prefix_after = after && *after ? (size_t)std::strtoull(after, nullptr, 10) : kPrefixAfter;
+    const char* side = std::getenv("FEC_SIDE_STREAM_MAX");
+    if (side && *side) ctx->side_stream_max = (size_t)std::strtoull(side, nullptr, 10);
+    // (the three variables are overrides for experiments, read once here; the interface is fec_ctx_set_fixed_prefix_bits /
+    // _after / _budget and fec_ctx_set_side_stream_max)
   }
   if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
       std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0 ||
@@ -1262,6 +1432,8 @@ void fec_ctx_destroy(fec_ctx* ctx) try {
   for (auto& e : ctx->stream_scratch)
     if (e.buf) (void)hipFree(e.buf);
   if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+  if (ctx->ev_gather) (void)hipEventDestroy(ctx->ev_gather);
+  if (ctx->stream_gather) (void)hipStreamDestroy(ctx->stream_gather);
   for (int i = 0; i < 3; ++i)
     if (ctx->d_canon_comb[i]) (void)hipFree(ctx->d_canon_comb[i]);
   for (int i = 0; i < 3; ++i)
@@ -1308,6 +1480,68 @@ int fec_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d1, 
   return launch_double_mul(ctx, curve, d1, d2, dq, dout, n, stream);
 } FEC_ABI_CATCH_STATUS
 
+// ---- device-resident shards of a multi-device ctx (include/fecgpu.h: fec_multi_batch_*_dev) ----
+namespace {
+int multi_dev_args(fec_ctx* ctx, fec_curve curve, const void* const* a, const void* const* b, uint64_t* const* out,
+                   const size_t* counts) {
+  if (!ctx || !curve_ok(curve) || !counts || !a || !out) return FEC_E_ARG;
+  if (!is_multi(ctx)) return FEC_E_UNSUPPORTED;   // a single-device ctx has fec_batch_*_dev
+  for (size_t g = 0; g < ctx->children.size(); ++g) {
+    if (counts[g] == 0) continue;
+    if (!a[g] || !out[g] || (b && !b[g])) return FEC_E_ARG;
+    if (!aligned16(a[g]) || !aligned16(out[g]) || (b && !aligned16(b[g]))) return FEC_E_ARG;
+  }
+  return FEC_OK;
+}
+}  // namespace
+
+int fec_multi_batch_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* const* scalars, const uint64_t* const* points,
+                            uint64_t* const* out, const size_t* counts, uint64_t* gathered, int consumer,
+                            void* const* streams) try {
+  int rc = multi_dev_args(ctx, curve, (const void* const*)scalars, (const void* const*)points, out, counts);
+  if (rc != FEC_OK) return rc;
+  if (gathered && !aligned16(gathered)) return FEC_E_ARG;
+  const size_t pl = (size_t)plimbs(curve);
+  return multi_dev_run(ctx, curve, counts, out, gathered, consumer, streams,
+                       [&](fec_ctx* c, size_t g, size_t lo, size_t m, uint64_t* o, void* s) {
+                         return launch_mul(c, curve, false, scalars[g] + lo * 4, points[g] + lo * pl, o, m, s);
+                       });
+} FEC_ABI_CATCH_STATUS
+
+int fec_multi_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* const* scalars, const uint64_t* const* bases,
+                                  uint64_t* const* out, const size_t* counts, uint64_t* gathered, int consumer,
+                                  void* const* streams) try {
+  int rc = multi_dev_args(ctx, curve, (const void* const*)scalars, nullptr, out, counts);
+  if (rc != FEC_OK) return rc;
+  if (gathered && !aligned16(gathered)) return FEC_E_ARG;
+  if (bases)
+    for (size_t g = 0; g < ctx->children.size(); ++g)
+      if (bases[g] && !aligned16(bases[g])) return FEC_E_ARG;
+  return multi_dev_run(ctx, curve, counts, out, gathered, consumer, streams,
+                       [&](fec_ctx* c, size_t g, size_t lo, size_t m, uint64_t* o, void* s) {
+                         // no base given: the device's own copy of the reference's generator() (and its prefix table)
+                         const uint64_t* base = bases && bases[g] ? bases[g] : c->d_gen[curve];
+                         if (curve == FEC_ED25519)
+                           return launch_ed_fixed(c, scalars[g] + lo * 4, base, base == c->d_gen[FEC_ED25519] ? c->h_gen_ed : nullptr, o, m, s);
+                         return launch_mul(c, curve, true, scalars[g] + lo * 4, base, o, m, s);
+                       });
+} FEC_ABI_CATCH_STATUS
+
+int fec_multi_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* const* u1, const uint64_t* const* u2,
+                                   const uint64_t* const* q, uint64_t* const* out, const size_t* counts, uint64_t* gathered,
+                                   int consumer, void* const* streams) try {
+  int rc = multi_dev_args(ctx, curve, (const void* const*)u1, (const void* const*)u2, out, counts);
+  if (rc != FEC_OK) return rc;
+  if (!q || (gathered && !aligned16(gathered))) return FEC_E_ARG;
+  for (size_t g = 0; g < ctx->children.size(); ++g)
+    if (counts[g] && (!q[g] || !aligned16(q[g]))) return FEC_E_ARG;
+  const size_t pl = (size_t)plimbs(curve);
+  return multi_dev_run(ctx, curve, counts, out, gathered, consumer, streams,
+                       [&](fec_ctx* c, size_t g, size_t lo, size_t m, uint64_t* o, void* s) {
+                         return launch_double_mul(c, curve, u1[g] + lo * 4, u2[g] + lo * 4, q[g] + lo * pl, o, m, s);
+                       });
+} FEC_ABI_CATCH_STATUS
+
 int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points,
                   uint64_t* out, size_t n) try {
   if (is_multi(ctx)) {
@@ -1323,7 +1557,7 @@ int fec_batch_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const 
   const HostIn in[3] = {{scalars, 32, 0}, {points, pb, 0}, {nullptr, 0, 0}};
   return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void*, void* o, size_t cnt, void* s) {
     return launch_mul(ctx, curve, false, (const u64*)a, (const u64*)b, (u64*)o, cnt, s);
-  }, curve != FEC_SECP256K1);
+  });
 } FEC_ABI_CATCH_STATUS
 
 int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* base,
@@ -1348,7 +1582,7 @@ int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, 
       r = ensure_ed_table(ctx, (const u64*)ctx->d_buf[1], base, ctx->stream);
       if (r != FEC_OK) return r;
       return hipStreamSynchronize(ctx->stream) == hipSuccess ? FEC_OK : FEC_E_LAUNCH;
-    }());
+    });
     if (rc != FEC_OK) return rc;
   }
   // the reference's generator() is recognised by value: the launches then name the ctx's own device copy, whose
@@ -1359,7 +1593,7 @@ int fec_batch_mul_fixed(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, 
     const u64* db = is_gen ? ctx->d_gen[curve] : (const u64*)b;
     if (curve == FEC_ED25519) return launch_ed_fixed(ctx, (const u64*)a, db, base, (u64*)o, cnt, s);
     return launch_mul(ctx, curve, true, (const u64*)a, db, (u64*)o, cnt, s);
-  }, curve == FEC_P256);
+  });
 } FEC_ABI_CATCH_STATUS
 
 int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, const uint64_t* u2,
@@ -1377,7 +1611,7 @@ int fec_batch_double_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* u1, cons
   const HostIn in[3] = {{u1, 32, 0}, {u2, 32, 0}, {q, pb, 0}};
   return host_pipeline(ctx, n, in, out, pb, [&](void* a, void* b, void* c, void* o, size_t cnt, void* s) {
     return launch_double_mul(ctx, curve, (const u64*)a, (const u64*)b, (const u64*)c, (u64*)o, cnt, s);
-  }, curve == FEC_ED25519);   // (P-256: its two launches divide the CUs, a chunk is several fills either way)
+  });
 } FEC_ABI_CATCH_STATUS
 
 int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars, const uint64_t* points,
@@ -1390,7 +1624,7 @@ int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars,
   int rc = ensure(ctx, 6, (n ? n : 1) * pb);   // products stay on the device
   if (rc == FEC_OK) rc = ensure(ctx, 7, pb);
   if (rc != FEC_OK) return rc;
-  const size_t msm_chunk = pipeline_chunk(ctx, curve != FEC_SECP256K1);
+  const size_t msm_chunk = pipeline_chunk(ctx);
   for (size_t lo = 0; lo < n; lo += msm_chunk) {  // the independent products, chunked
     const size_t cnt = lo + msm_chunk <= n ? msm_chunk : n - lo;
     rc = ensure(ctx, 0, cnt * 32);
@@ -1417,7 +1651,7 @@ int fec_multi_scalar_mul(fec_ctx* ctx, fec_curve curve, const uint64_t* scalars,
   }
   if (hipMemcpyAsync(out, ctx->d_buf[7], pb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
   return sync_and_check(ctx, ctx->stream);
-  }());
+  });
 } FEC_ABI_CATCH_STATUS
 
 namespace {
@@ -1461,7 +1695,7 @@ int ecdsa_verify_host(fec_ctx* ctx, int curve, const uint8_t* digests, const uin
   if (rc != FEC_OK) return rc;
   if (hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
   return sync_and_check(ctx, ctx->stream);
-  }());
+  });
 }
 }  // namespace
 
@@ -1561,7 +1795,7 @@ int fec_ecdsa_batch_verify(fec_ctx* ctx, fec_curve curve, const uint8_t* digests
   *result = res;
   if (detail) std::memcpy(detail, det, 128);
   return FEC_OK;
-  }());
+  });
 } FEC_ABI_CATCH_STATUS
 
 int fec_batch_validate_point_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf, uint8_t* d_ok,
@@ -1596,7 +1830,7 @@ int fec_batch_validate_point(fec_ctx* ctx, fec_curve curve, const uint64_t* xy, 
   if (rc != FEC_OK) return rc;
   if (hipMemcpyAsync(ok, ctx->d_buf[2], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
   return sync_and_check(ctx, ctx->stream);
-  }());
+  });
 } FEC_ABI_CATCH_STATUS
 
 int fec_batch_ecdh_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_private_keys, const uint64_t* d_pk_xy,
@@ -1643,7 +1877,7 @@ int fec_batch_ecdh(fec_ctx* ctx, fec_curve curve, const uint64_t* private_keys, 
   return host_chunked(ctx, n, in, in_stride, outs, out_stride, [&](void* const d[4], void* const o[2], size_t cnt) {
     return launch_ecdh(ctx, curve, (const u64*)d[0], (const u64*)d[1], (const unsigned char*)d[2], (unsigned char*)o[0],
                        (unsigned char*)o[1], cnt, nullptr);
-  }, curve == FEC_P256);
+  });
 } FEC_ABI_CATCH_STATUS
 
 int fec_eddsa_verify_ed25519_dev(fec_ctx* ctx, const uint64_t* d_r_xy, const uint8_t* d_r_inf, const uint64_t* d_pk_xy,
@@ -1687,7 +1921,7 @@ int fec_eddsa_verify_ed25519(fec_ctx* ctx, const uint64_t* r_xy, const uint8_t* 
   if (rc != FEC_OK) return rc;
   if (hipMemcpyAsync(status, ctx->d_buf[3], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
   return sync_and_check(ctx, ctx->stream);
-  }());
+  });
 } FEC_ABI_CATCH_STATUS
 
 int fec_schnorr_verify_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_pk_xy, const uint8_t* d_pk_inf,
@@ -1714,7 +1948,7 @@ int fec_schnorr_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_xy, con
   if (n == 0) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
   // chunked like the other element-wise calls; slots: 0 pk, 1 r, 2 s, 4 e, 5 pk_inf, 6 r_inf, 3 status
-  const size_t pc = pipeline_chunk(ctx, curve == FEC_ED25519);
+  const size_t pc = pipeline_chunk(ctx);
   const size_t chunk = pc < n ? pc : n;
   return drained(ctx, [&]() -> int {
   for (size_t lo = 0; lo < n; lo += chunk) {
@@ -1740,7 +1974,7 @@ int fec_schnorr_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_xy, con
     if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   }
   return FEC_OK;
-  }());
+  });
 } FEC_ABI_CATCH_STATUS
 
 namespace {
@@ -1838,7 +2072,7 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
   if (sides_xy) std::memcpy(sides_xy, sides, 128);
   if (sides_inf) { sides_inf[0] = flags[1]; sides_inf[1] = flags[2]; }
   return FEC_OK;
-  }());
+  });
 }
 }  // namespace
 
@@ -1913,7 +2147,7 @@ static int decode_host(fec_ctx* ctx, int op, fec_curve curve, const uint8_t* in,
     if (rc != FEC_OK) return rc;
   }
   return FEC_OK;
-  }());
+  });
 }
 
 int fec_batch_decompress(fec_ctx* ctx, fec_curve curve, const uint8_t* in, uint64_t* xy, uint8_t* inf, uint8_t* ok,
@@ -1999,7 +2233,7 @@ int fec_batch_to_affine(fec_ctx* ctx, fec_curve curve, const uint64_t* points, u
       hipMemcpyAsync(inf, ctx->d_buf[1], n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
     return FEC_E_DEVICE;
   return sync_and_check(ctx, ctx->stream);
-  }());
+  });
 } FEC_ABI_CATCH_STATUS
 
 int fec_field_op(fec_ctx* ctx, fec_curve curve, fec_field_opcode op, const uint64_t* a, const uint64_t* b,
@@ -2151,24 +2385,66 @@ int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits) try {
     return rc;
   }
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  drop_gen_prefix(ctx);   // the tables are rebuilt at the new size by the next fixed-base launches
+  drop_gen_prefix(ctx);   // the ctx's references go; tables of the new size are attached / built by the next fixed-base launches
   ctx->prefix_bits = bits;
-  ctx->prefix_after = 0;  // asked for explicitly: no waiting for the ctx to have multiplied enough
+  ctx->prefix_after = 0;        // asked for explicitly: no waiting for the ctx to have multiplied enough,
+  ctx->prefix_explicit = true;  // and any launch -- a *_dev one too -- may build
+  return FEC_OK;
+} FEC_ABI_CATCH_STATUS
+
+int fec_ctx_build_fixed_prefix(fec_ctx* ctx, fec_curve curve) try {
+  if (!ctx || !curve_ok(curve)) return FEC_E_ARG;
+  if (is_multi(ctx)) {
+    int rc = FEC_OK;
+    for (fec_ctx* c : ctx->children) {
+      const int r = fec_ctx_build_fixed_prefix(c, curve);
+      if (rc == FEC_OK) rc = r;
+    }
+    return rc;
+  }
+  if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
+  (void)attach_gen_prefix(ctx, curve, ctx->stream, true);   // (refused memory is not an error: fec_ctx_fixed_prefix_bits says what there is)
+  return sync_and_check(ctx, ctx->stream);
+} FEC_ABI_CATCH_STATUS
+
+int fec_ctx_set_fixed_prefix_after(fec_ctx* ctx, size_t elements) try {
+  if (!ctx) return FEC_E_ARG;
+  if (is_multi(ctx)) {
+    for (fec_ctx* c : ctx->children) c->prefix_after = elements;
+    return FEC_OK;
+  }
+  ctx->prefix_after = elements;
+  return FEC_OK;
+} FEC_ABI_CATCH_STATUS
+
+int fec_ctx_set_fixed_prefix_budget(fec_ctx* ctx, unsigned percent_of_free_memory) try {
+  if (!ctx || percent_of_free_memory > 100) return FEC_E_ARG;
+  if (is_multi(ctx)) {
+    for (fec_ctx* c : ctx->children) c->prefix_budget_pct = percent_of_free_memory;
+    return FEC_OK;
+  }
+  ctx->prefix_budget_pct = percent_of_free_memory;
+  return FEC_OK;
+} FEC_ABI_CATCH_STATUS
+
+int fec_ctx_set_side_stream_max(fec_ctx* ctx, size_t elements) try {
+  if (!ctx) return FEC_E_ARG;
+  if (is_multi(ctx)) {
+    for (fec_ctx* c : ctx->children) c->side_stream_max = elements;
+    return FEC_OK;
+  }
+  ctx->side_stream_max = elements;
   return FEC_OK;
 } FEC_ABI_CATCH_STATUS
 
 int fec_ctx_set_chunk(fec_ctx* ctx, size_t elements) try {
   if (is_multi(ctx)) {
     if (elements == 0) return FEC_E_ARG;
-    for (fec_ctx* c : ctx->children) {
-      c->chunk = elements;
-      c->chunk_explicit = true;
-    }
+    for (fec_ctx* c : ctx->children) c->chunk = elements;
     return FEC_OK;
   }
   if (!ctx || elements == 0) return FEC_E_ARG;
   ctx->chunk = elements;
-  ctx->chunk_explicit = true;
   return FEC_OK;
 } FEC_ABI_CATCH_STATUS
 

@@ -26,7 +26,6 @@ struct fec_ctx {
   size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t stream2 = nullptr;
   size_t chunk = (size_t)1 << 18;  // elements per pipeline chunk (see host::pipeline_chunk)
-  bool chunk_explicit = false;     // fec_ctx_set_chunk was called
   u64* d_gen[3] = {nullptr, nullptr, nullptr};  // reference generator() per curve, device copy
   u32* d_ed_table = nullptr;                    // Ed25519 fixed-base addend table (256 x 32 words)
   u64 ed_table_base[16] = {0};                  // the base point the table was built for
@@ -77,6 +76,12 @@ struct fec_ctx {
   size_t fixed_elems[3] = {0, 0, 0};         // multiplications by the generator this ctx has been asked for, per curve
   size_t prefix_after = 0;                   // a table is built once fixed_elems reaches this (see fecgpu.hip: kPrefixAfter)
   bool in_multi_chunk_pipeline = false;  // set by host_pipeline while it runs more than one chunk (fecgpu.hip: SideStream)
+  bool in_host_call = false;             // inside a host-pointer (synchronous) entry point: host::drained
+  bool prefix_explicit = false;          // the caller asked for prefix tables (fec_ctx_set_fixed_prefix_bits): any launch may build one
+  unsigned prefix_budget_pct = 25;       // a table and its build scratch may take this share of the device's FREE memory
+  size_t side_stream_max = (size_t)-1;   // u1*G runs beside u2*Q on the second stream up to this many elements (fec_ctx_set_side_stream_max)
+  hipStream_t stream_gather = nullptr;   // multi-device ctx: the peer copies of a shard's results (fec_multi_batch_*_dev)
+  hipEvent_t ev_gather = nullptr;
 };
 
 // No exception may cross the C ABI: every extern "C" definition in fecgpu.hip and canon.hip is a function-try-block
@@ -233,13 +238,24 @@ inline int sync_and_check(fec_ctx* ctx, hipStream_t a, hipStream_t b = nullptr) 
 // scheduler workgroup 1 024 elements: the launchers then take the 1 024-slot instantiation of the kernel, one fill --
 // kernels_p256.hip: wide_slots_pay.  With 832 slots only, such a chunk cost 2^20 P-256 multiplications through the
 // host-pointer entry point 34.2 ms instead of 26.0: tools/host_chunk_probe.py, profiles/host_chunk_r03.txt.)
-inline size_t pipeline_chunk(const fec_ctx* ctx, bool /*scheduler_kernel*/) { return ctx->chunk; }
+inline size_t pipeline_chunk(const fec_ctx* ctx) { return ctx->chunk; }
 
-// The way out of a host-pointer entry point whose work was queued on the ctx's own streams.  A call that fails half-way
-// (an allocation, a refused copy, a launch error) may still have copies from or into the caller's arrays queued, and the
-// caller is free to release those arrays as soon as the call is back: the streams are drained first, and a device error
-// word raised by the abandoned launches is dropped with them instead of being reported by the next, unrelated call.
-inline int drained(fec_ctx* ctx, int rc) {
+// The body of a host-pointer entry point whose work is queued on the ctx's own streams, and its way out.  A call that
+// fails half-way (an allocation, a refused copy, a launch error) may still have copies from or into the caller's arrays
+// queued, and the caller is free to release those arrays as soon as the call is back: the streams are drained first, and
+// a device error word raised by the abandoned launches is dropped with them instead of being reported by the next,
+// unrelated call.  While the body runs the ctx knows that it is inside a SYNCHRONOUS call (in_host_call): only there may
+// a launch allocate and build a fixed-base prefix table by itself (fecgpu.hip: ensure_gen_prefix) -- the *_dev entry
+// points only enqueue.
+template <class F>
+inline int drained(fec_ctx* ctx, F body) {
+  struct InHostCall {
+    fec_ctx* c;
+    bool was;
+    explicit InHostCall(fec_ctx* c_) : c(c_), was(c_->in_host_call) { c->in_host_call = true; }
+    ~InHostCall() { c->in_host_call = was; }
+  } guard(ctx);
+  const int rc = body();
   if (rc == FEC_OK) return rc;
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
@@ -254,9 +270,9 @@ inline int drained(fec_ctx* ctx, int rc) {
 // chunk however large n is.  A null input / output pointer is passed through as null.
 template <class F>
 inline int host_chunked(fec_ctx* ctx, size_t n, const void* const in[4], const size_t in_stride[4], void* const out[2],
-                        const size_t out_stride[2], F body, bool scheduler_kernel = false) {
+                        const size_t out_stride[2], F body) {
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  const size_t pc = pipeline_chunk(ctx, scheduler_kernel);
+  const size_t pc = pipeline_chunk(ctx);
   const size_t chunk = pc < n ? pc : n;
   return drained(ctx, [&]() -> int {
   for (size_t lo = 0; lo < n; lo += chunk) {
@@ -290,7 +306,7 @@ inline int host_chunked(fec_ctx* ctx, size_t n, const void* const in[4], const s
     if (rc != FEC_OK) return rc;
   }
   return FEC_OK;
-  }());
+  });
 }
 
 }  // namespace host

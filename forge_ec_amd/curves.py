@@ -72,6 +72,22 @@ class Context:
         """fec_ctx_set_fixed_prefix_bits: size of the generator's fixed-base prefix tables (0 = off, default 24)."""
         _check(self._lib.fec_ctx_set_fixed_prefix_bits(self._h, int(bits)), "fec_ctx_set_fixed_prefix_bits")
 
+    def build_fixed_prefix(self, curve):
+        """fec_ctx_build_fixed_prefix: attach or build the generator's prefix table of `curve` now (synchronous)."""
+        _check(self._lib.fec_ctx_build_fixed_prefix(self._h, int(curve)), "fec_ctx_build_fixed_prefix")
+
+    def set_fixed_prefix_after(self, elements):
+        """fec_ctx_set_fixed_prefix_after: a ctx left to its defaults builds a table after this many multiplications by G."""
+        _check(self._lib.fec_ctx_set_fixed_prefix_after(self._h, int(elements)), "fec_ctx_set_fixed_prefix_after")
+
+    def set_fixed_prefix_budget(self, percent_of_free_memory):
+        """fec_ctx_set_fixed_prefix_budget: share of the device's FREE memory a table may take (default 25 %)."""
+        _check(self._lib.fec_ctx_set_fixed_prefix_budget(self._h, int(percent_of_free_memory)), "fec_ctx_set_fixed_prefix_budget")
+
+    def set_side_stream_max(self, elements):
+        """fec_ctx_set_side_stream_max: u1*G runs beside u2*Q on the second stream up to this many elements."""
+        _check(self._lib.fec_ctx_set_side_stream_max(self._h, int(elements)), "fec_ctx_set_side_stream_max")
+
     def fixed_prefix_bits(self, curve):
         """fec_ctx_fixed_prefix_bits: bits of the prefix table `curve` has now (0 = none)."""
         r = self._lib.fec_ctx_fixed_prefix_bits(self._h, int(curve))
@@ -368,6 +384,38 @@ class Context:
     def batch_double_mul_dev(self, curve, d_u1, d_u2, d_q, d_out, n, stream=None):
         _check(self._lib.fec_batch_double_mul_dev(self._h, curve, d_u1, d_u2, d_q, d_out, n, stream),
                "fec_batch_double_mul_dev")
+
+    # ---- device-resident shards of a multi-device ctx (fec_multi_batch_*_dev): lists with one raw device pointer /
+    # count per shard worker; `gathered` a raw device pointer on the consumer-th device or None ----
+    @staticmethod
+    def _ptr_array(ptrs, n):
+        if ptrs is None:
+            return None
+        if len(ptrs) != n:
+            raise ValueError("one entry per device of the ctx")
+        return (ctypes.c_void_p * n)(*[ctypes.c_void_p(int(p) if p else 0) for p in ptrs])
+
+    def _multi_dev(self, fn, what, curve, inputs, d_out, counts, gathered, consumer, streams):
+        n = self.device_count()
+        if len(counts) != n:
+            raise ValueError("one count per device of the ctx")
+        cnt = (ctypes.c_size_t * n)(*[int(c) for c in counts])
+        args = [self._ptr_array(a, n) for a in inputs] + [self._ptr_array(d_out, n), cnt,
+                                                          ctypes.c_void_p(int(gathered)) if gathered else None, int(consumer),
+                                                          self._ptr_array(streams, n)]
+        _check(fn(self._h, int(curve), *args), what)
+
+    def multi_batch_mul_dev(self, curve, d_scalars, d_points, d_out, counts, gathered=None, consumer=0, streams=None):
+        self._multi_dev(self._lib.fec_multi_batch_mul_dev, "fec_multi_batch_mul_dev", curve, [d_scalars, d_points], d_out,
+                        counts, gathered, consumer, streams)
+
+    def multi_batch_mul_fixed_dev(self, curve, d_scalars, d_bases, d_out, counts, gathered=None, consumer=0, streams=None):
+        self._multi_dev(self._lib.fec_multi_batch_mul_fixed_dev, "fec_multi_batch_mul_fixed_dev", curve, [d_scalars, d_bases],
+                        d_out, counts, gathered, consumer, streams)
+
+    def multi_batch_double_mul_dev(self, curve, d_u1, d_u2, d_q, d_out, counts, gathered=None, consumer=0, streams=None):
+        self._multi_dev(self._lib.fec_multi_batch_double_mul_dev, "fec_multi_batch_double_mul_dev", curve, [d_u1, d_u2, d_q],
+                        d_out, counts, gathered, consumer, streams)
 
     def batch_to_affine_dev(self, curve, d_points, d_xy, d_inf, n, stream=None):
         _check(self._lib.fec_batch_to_affine_dev(self._h, curve, d_points, d_xy, d_inf, n, stream),

@@ -101,7 +101,7 @@ typedef enum {
   FEC_E_OOM = -3,         /* device or pinned-host allocation failed */
   FEC_E_LAUNCH = -4,      /* kernel launch or execution failed, or a kernel reported a fault (outputs unusable) */
   FEC_E_UNSUPPORTED = -5, /* op not defined for this curve / for a multi-device ctx */
-  FEC_E_COMM = -6         /* multi-device ctx: a shard worker could not be started */
+  FEC_E_COMM = -6         /* multi-device ctx: a shard worker could not be started, or a copy between two devices failed */
 } fec_status;
 
 typedef enum { FEC_F_ADD = 0, FEC_F_SUB = 1, FEC_F_MUL = 2, FEC_F_SQR = 3, FEC_F_NEG = 4 } fec_field_opcode;
@@ -134,9 +134,11 @@ int fec_ctx_create(fec_ctx** out, int device);
  * "gather" is the D2H copy of each shard, there is no device-to-device exchange.  Results are
  * identical to a single-device ctx.  Entry points that are not element-wise (fec_multi_scalar_mul,
  * fec_ecdsa_batch_verify, fec_schnorr_batch_verify*, fec_generator*, the measurement hooks)
- * run on devices[0]; fec_ctx_wipe, fec_ctx_check, fec_ctx_set_chunk, fec_ctx_set_fixed_prefix_bits and fec_ctx_debug_force_fault apply
+ * run on devices[0]; fec_ctx_wipe, fec_ctx_check, fec_ctx_set_chunk, the fec_ctx_set_fixed_prefix_* calls, fec_ctx_build_fixed_prefix, fec_ctx_set_side_stream_max and fec_ctx_debug_force_fault apply
  * to every shard worker;
- * the *_dev entry points take device pointers of ONE device and return FEC_E_UNSUPPORTED.
+ * the *_dev entry points take device pointers of ONE device and return FEC_E_UNSUPPORTED; shards that are already
+ * RESIDENT in the devices' memory go through fec_multi_batch_*_dev (below), which also gathers the results onto one
+ * device over xGMI.
  * devices == NULL means ordinals 0..n_devices-1. */
 int fec_ctx_create_multi(fec_ctx** out, const int* devices, int n_devices);
 /* number of shard workers of the ctx (1 for fec_ctx_create) */
@@ -326,6 +328,35 @@ int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, 
 int fec_batch_to_affine_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_points, uint64_t* d_xy,
                             uint8_t* d_inf, size_t n, void* stream);
 
+/* ---- device-RESIDENT shards of a multi-device ctx (north_star: "independent scalar-muls shard
+ * trivially across the 8 GPUs of one node with RCCL over xGMI only to gather results").  ctx is a fec_ctx_create_multi
+ * ctx with N = fec_ctx_device_count(ctx) shard workers; every array argument has N entries.  Shard g -- counts[g]
+ * elements; scalars[g], points[g] (or bases[g], or u1[g], u2[g], q[g]) and out[g] are HIP device pointers in the memory
+ * of the ctx's g-th device, 16-byte aligned -- is multiplied on its own device by the same kernels as fec_batch_*_dev,
+ * in chunks of fec_ctx_set_chunk elements; there is no exchange during the compute.  out[g] receives the shard's
+ * counts[g] * limbs results.  If `gathered` is not NULL it is an array of (sum of counts) * limbs words in the memory of
+ * the ctx's consumer-th device, and every shard's results are ALSO copied into it at the shard's offset (the sum of the
+ * counts before it): one peer copy per chunk from each device straight to the consumer over their own xGMI link --
+ * the direct pattern, nothing relayed, no ring -- on a stream of its own, so that a chunk's copy runs under the
+ * next chunk's kernels.  (The copies are hipMemcpyPeerAsync with peer access enabled where the devices allow it; the
+ * library does not link RCCL.  One process per GPU is the other way to run this: bench.py, forge_ec_amd/dist.py.)
+ * streams: NULL, or N hipStream_t handles (one per device, NULL entries allowed): the stream of device g on which the
+ * caller's producers of shard g were queued -- the kernels are queued behind them; NULL = the worker's own stream.
+ * SYNCHRONOUS: returns when every kernel and copy has completed and every device's error word has been read
+ * (FEC_E_LAUNCH as for the host-pointer calls; FEC_E_COMM when a copy between two devices failed).
+ * bases (fixed base): NULL, or NULL entries = the reference's generator() (each device's own copy, with its prefix
+ * table); a single-device ctx returns FEC_E_UNSUPPORTED (it has fec_batch_*_dev).
+ * Measured on one GPU only (devices = {0, 0}: tests/test_gpu_multi_ctx.py); unmeasured on N > 1 hardware. ---- */
+int fec_multi_batch_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* const* scalars, const uint64_t* const* points,
+                            uint64_t* const* out, const size_t* counts, uint64_t* gathered, int consumer,
+                            void* const* streams);
+int fec_multi_batch_mul_fixed_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* const* scalars,
+                                  const uint64_t* const* bases, uint64_t* const* out, const size_t* counts,
+                                  uint64_t* gathered, int consumer, void* const* streams);
+int fec_multi_batch_double_mul_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* const* u1, const uint64_t* const* u2,
+                                   const uint64_t* const* q, uint64_t* const* out, const size_t* counts,
+                                   uint64_t* gathered, int consumer, void* const* streams);
+
 /* Zeroes every device buffer the ctx owns that can hold copies of caller data (host-call staging, the
  * per-stream scratch of composed launches, the canonical-mode work areas).  Synchronises the device.
  * fec_ctx_destroy calls it; call it yourself after a batch whose inputs were sensitive. */
@@ -343,23 +374,49 @@ int fec_ctx_check(fec_ctx* ctx);
 int fec_ctx_debug_force_fault(fec_ctx* ctx, int enabled);
 
 /* Fixed-base prefix tables.  The state of Curve::multiply(generator(), k) after its first `bits` steps depends on the
- * first `bits` scalar bits alone, so a ctx computes it once -- one step of the reference's loop per entry and level, with
- * the same arithmetic -- for all 2^bits patterns and keeps the table in HBM; every multiplication by the generator
+ * first `bits` scalar bits alone, so it is computed once -- one step of the reference's loop per entry and level, with
+ * the same arithmetic -- for all 2^bits patterns and kept in HBM; every multiplication by the generator
  * (fec_batch_mul_fixed with fec_generator's point, the u1*G of the ECDSA / Schnorr entry points, fec_batch_double_mul)
- * then fetches its entry and runs the remaining steps.  Results are bit-identical with or without the table.
- * Default: 24 bits (secp256k1 3.0 GiB, P-256 1.5 GiB, Ed25519 2.0 GiB of device memory per ctx), built by the launch
- * that takes the ctx past 2^21 multiplications by that curve's generator (env FEC_FIXED_PREFIX_BITS /
- * FEC_FIXED_PREFIX_AFTER at ctx creation) -- a ctx that multiplies a few thousand scalars never allocates one.  This
- * call sets the size (at most 28 bits, 0 = off), drops the existing tables and makes the next fixed-base launch of a
- * curve build its table at once.  If the memory is refused the launches run the whole ladder.  The launch that builds
- * a table waits for the build (2-4 ms of kernels at 24 bits, plus the allocation) before it returns, *_dev entry points
- * included.  A fixed base that is NOT the generator (fec_batch_mul_fixed with a point of the caller's own) gets a table
- * for the one launch, in the launch stream's scratch, sized to the batch (2^(log2(n) - 2) entries, from 2^16 elements
- * on, never more than `bits`); 0 switches that off as well. */
+ * then fetches its entry and runs the remaining steps.  Results are bit-identical with or without a table.
+ *
+ * Policy.  A table costs device memory (24 bits: secp256k1 3.0 GiB + 1.5 GiB while it is built, P-256 1.5 + 0.75 GiB,
+ * Ed25519 2.0 GiB) and its build ends in a host synchronisation, so:
+ *  - there is ONE table per device, curve and size in the process: every ctx on that device -- the shard workers of a
+ *    {0, 0, 0} multi-device ctx, the ctxs of several host threads -- holds a reference to the same allocation; the last
+ *    reference frees it;
+ *  - a table and its build scratch never take more than the budget -- 25 % by default -- of the device memory that is
+ *    FREE at that moment (hipMemGetInfo): the size shrinks from the wanted bits down to 16, below that there is no
+ *    table; refused memory is never an error, the launches then run the whole ladder, and the ctx asks again after
+ *    another 2^21 multiplications by the generator;
+ *  - a ctx left to its defaults (24 bits wanted) builds a curve's table only from a HOST-POINTER entry point (those are
+ *    synchronous anyway), and only once it has multiplied 2^21 scalars by that curve's generator -- a ctx that
+ *    multiplies a few thousand scalars never allocates one; its *_dev entry points only ever enqueue: they use a table
+ *    that already exists on their device and never allocate or wait;
+ *  - fec_ctx_set_fixed_prefix_bits is the caller ASKING for tables: it sets the wanted size (at most 28 bits; 0 = off,
+ *    which also switches the per-launch tables below off), drops the ctx's references, and from then on the next
+ *    multiplication by a curve's generator -- from a *_dev entry point too -- attaches or builds that curve's table before
+ *    it returns (2-4 ms of kernels at 24 bits, plus the allocation).  fec_ctx_build_fixed_prefix does the same at a
+ *    point of the caller's choosing: it attaches or builds `curve`'s table now and waits for it.
+ * The environment variables FEC_FIXED_PREFIX_BITS / FEC_FIXED_PREFIX_AFTER / FEC_SIDE_STREAM_MAX are read once at ctx
+ * creation as overrides of the defaults (experiments); the calls below are the interface.
+ * A fixed base that is NOT the generator (fec_batch_mul_fixed with a point of the caller's own) gets a table for the one
+ * launch, in the launch stream's scratch, sized to the batch (2^(log2(n) - 2) entries, from 2^16 elements on, never more
+ * than the wanted bits), with no host synchronisation. */
 int fec_ctx_set_fixed_prefix_bits(fec_ctx* ctx, unsigned bits);
+/* attach or build the table of `curve` now (synchronous); FEC_OK also when no memory could be had -- ask
+ * fec_ctx_fixed_prefix_bits what there is */
+int fec_ctx_build_fixed_prefix(fec_ctx* ctx, fec_curve curve);
+/* a ctx left to its defaults builds a curve's table once it has multiplied this many scalars by its generator (default 2^21) */
+int fec_ctx_set_fixed_prefix_after(fec_ctx* ctx, size_t elements);
+/* share of the device's free memory a table and its build scratch may take, in percent (0..100, default 25; 0 = never build) */
+int fec_ctx_set_fixed_prefix_budget(fec_ctx* ctx, unsigned percent_of_free_memory);
 /* bits of the prefix table `curve` has at this moment (0 = none: not built yet, switched off, or memory refused);
  * negative fec_status on a bad argument.  Multi-device ctx: the first shard worker's. */
 int fec_ctx_fixed_prefix_bits(fec_ctx* ctx, fec_curve curve);
+/* u1*G + u2*Q (fec_batch_double_mul*, the verify pipelines): multiply(G, u1) runs on the ctx's second stream beside
+ * multiply(Q, u2) for launches of up to this many elements (default: every size; 0 = never).  Measurement knob
+ * (tools/double_mul_small_perf.py); results do not depend on it. */
+int fec_ctx_set_side_stream_max(fec_ctx* ctx, size_t elements);
 
 /* Host-pointer batches are processed as a two-lane pipeline of `elements`-sized chunks (default
  * 2^18): copies of one chunk overlap the kernel of the other, and device staging memory is bounded

@@ -36,6 +36,11 @@ class GpuContext {
     int rc = fec_ctx_create(&ctx_, device);
     if (rc != FEC_OK) throw Error(rc);
   }
+  // fec_ctx_create_multi: the element-wise calls shard over `devices` (an ordinal may repeat)
+  explicit GpuContext(const std::vector<int>& devices) {
+    int rc = fec_ctx_create_multi(&ctx_, devices.data(), (int)devices.size());
+    if (rc != FEC_OK) throw Error(rc);
+  }
   ~GpuContext() { fec_ctx_destroy(ctx_); }
   GpuContext(const GpuContext&) = delete;
   GpuContext& operator=(const GpuContext&) = delete;
@@ -56,6 +61,57 @@ class GpuContext {
     int rc = fec_ctx_fixed_prefix_bits(ctx_, curve);
     if (rc < 0) throw Error(rc);
     return (unsigned)rc;
+  }
+  // fec_ctx_build_fixed_prefix: attach or build `curve`'s table now (synchronous); the policy calls of fecgpu.h
+  void build_fixed_prefix(fec_curve curve) {
+    int rc = fec_ctx_build_fixed_prefix(ctx_, curve);
+    if (rc != FEC_OK) throw Error(rc);
+  }
+  void set_fixed_prefix_after(size_t elements) {
+    int rc = fec_ctx_set_fixed_prefix_after(ctx_, elements);
+    if (rc != FEC_OK) throw Error(rc);
+  }
+  void set_fixed_prefix_budget(unsigned percent_of_free_memory) {
+    int rc = fec_ctx_set_fixed_prefix_budget(ctx_, percent_of_free_memory);
+    if (rc != FEC_OK) throw Error(rc);
+  }
+  void set_side_stream_max(size_t elements) {
+    int rc = fec_ctx_set_side_stream_max(ctx_, elements);
+    if (rc != FEC_OK) throw Error(rc);
+  }
+  int device_count() const { return fec_ctx_device_count(ctx_); }
+  // Device-resident shards of a multi-device ctx (fec_multi_batch_*_dev): one raw device pointer / count per device of
+  // the ctx, results also gathered over xGMI into `gathered` on the consumer-th device when it is not null.  Synchronous.
+  void multi_batch_mul_dev(fec_curve curve, const std::vector<const uint64_t*>& scalars, const std::vector<const uint64_t*>& points,
+                           const std::vector<uint64_t*>& out, const std::vector<size_t>& counts, uint64_t* gathered = nullptr,
+                           int consumer = 0, const std::vector<void*>* streams = nullptr) {
+    const size_t n = (size_t)device_count();
+    if (scalars.size() != n || points.size() != n || out.size() != n || counts.size() != n || (streams && streams->size() != n))
+      throw Error(FEC_E_ARG);
+    int rc = fec_multi_batch_mul_dev(ctx_, curve, scalars.data(), points.data(), out.data(), counts.data(), gathered, consumer,
+                                     streams ? streams->data() : nullptr);
+    if (rc != FEC_OK) throw Error(rc);
+  }
+  void multi_batch_mul_fixed_dev(fec_curve curve, const std::vector<const uint64_t*>& scalars, const std::vector<const uint64_t*>* bases,
+                                 const std::vector<uint64_t*>& out, const std::vector<size_t>& counts, uint64_t* gathered = nullptr,
+                                 int consumer = 0, const std::vector<void*>* streams = nullptr) {
+    const size_t n = (size_t)device_count();
+    if (scalars.size() != n || out.size() != n || counts.size() != n || (bases && bases->size() != n) || (streams && streams->size() != n))
+      throw Error(FEC_E_ARG);
+    int rc = fec_multi_batch_mul_fixed_dev(ctx_, curve, scalars.data(), bases ? bases->data() : nullptr, out.data(), counts.data(),
+                                           gathered, consumer, streams ? streams->data() : nullptr);
+    if (rc != FEC_OK) throw Error(rc);
+  }
+  void multi_batch_double_mul_dev(fec_curve curve, const std::vector<const uint64_t*>& u1, const std::vector<const uint64_t*>& u2,
+                                  const std::vector<const uint64_t*>& q, const std::vector<uint64_t*>& out,
+                                  const std::vector<size_t>& counts, uint64_t* gathered = nullptr, int consumer = 0,
+                                  const std::vector<void*>* streams = nullptr) {
+    const size_t n = (size_t)device_count();
+    if (u1.size() != n || u2.size() != n || q.size() != n || out.size() != n || counts.size() != n || (streams && streams->size() != n))
+      throw Error(FEC_E_ARG);
+    int rc = fec_multi_batch_double_mul_dev(ctx_, curve, u1.data(), u2.data(), q.data(), out.data(), counts.data(), gathered, consumer,
+                                            streams ? streams->data() : nullptr);
+    if (rc != FEC_OK) throw Error(rc);
   }
   static GpuContext& global() {  // process-wide default context on device 0
     static GpuContext g(0);

@@ -30,6 +30,10 @@ extern "C" {
     fn fec_ctx_debug_force_fault(ctx: *mut FecCtx, enabled: c_int) -> c_int;
     fn fec_ctx_set_fixed_prefix_bits(ctx: *mut FecCtx, bits: c_uint) -> c_int;
     fn fec_ctx_fixed_prefix_bits(ctx: *mut FecCtx, curve: c_int) -> c_int;
+    fn fec_ctx_build_fixed_prefix(ctx: *mut FecCtx, curve: c_int) -> c_int;
+    fn fec_ctx_set_fixed_prefix_after(ctx: *mut FecCtx, elements: usize) -> c_int;
+    fn fec_ctx_set_fixed_prefix_budget(ctx: *mut FecCtx, percent_of_free_memory: c_uint) -> c_int;
+    fn fec_ctx_set_side_stream_max(ctx: *mut FecCtx, elements: usize) -> c_int;
     fn fec_generator(ctx: *mut FecCtx, curve: c_int, out: *mut u64) -> c_int;
     fn fec_generator_dev(ctx: *mut FecCtx, curve: c_int) -> *const u64;
     fn fec_batch_mul(ctx: *mut FecCtx, curve: c_int, scalars: *const u64, points: *const u64, out: *mut u64, n: usize) -> c_int;
@@ -57,6 +61,9 @@ extern "C" {
     fn fec_batch_mul_dev(ctx: *mut FecCtx, curve: c_int, d_scalars: *const u64, d_points: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_mul_fixed_dev(ctx: *mut FecCtx, curve: c_int, d_scalars: *const u64, d_base: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
     fn fec_batch_double_mul_dev(ctx: *mut FecCtx, curve: c_int, d_u1: *const u64, d_u2: *const u64, d_q: *const u64, d_out: *mut u64, n: usize, stream: *mut c_void) -> c_int;
+    fn fec_multi_batch_mul_dev(ctx: *mut FecCtx, curve: c_int, scalars: *const *const u64, points: *const *const u64, out: *const *mut u64, counts: *const usize, gathered: *mut u64, consumer: c_int, streams: *const *mut c_void) -> c_int;
+    fn fec_multi_batch_mul_fixed_dev(ctx: *mut FecCtx, curve: c_int, scalars: *const *const u64, bases: *const *const u64, out: *const *mut u64, counts: *const usize, gathered: *mut u64, consumer: c_int, streams: *const *mut c_void) -> c_int;
+    fn fec_multi_batch_double_mul_dev(ctx: *mut FecCtx, curve: c_int, u1: *const *const u64, u2: *const *const u64, q: *const *const u64, out: *const *mut u64, counts: *const usize, gathered: *mut u64, consumer: c_int, streams: *const *mut c_void) -> c_int;
     fn fec_eddsa_verify_ed25519_dev(ctx: *mut FecCtx, d_r_xy: *const u64, d_r_inf: *const u8, d_pk_xy: *const u64, d_pk_inf: *const u8, d_s: *const u64, d_k: *const u64, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_ecdsa_verify_p256_dev(ctx: *mut FecCtx, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
     fn fec_ecdsa_verify_secp256k1_dev(ctx: *mut FecCtx, d_digests: *const u8, d_r: *const u64, d_s: *const u64, d_pk_xy: *const u64, d_pk_inf: *const u8, d_status: *mut u8, n: usize, stream: *mut c_void) -> c_int;
@@ -152,6 +159,82 @@ impl GpuContext {
         let r = unsafe { fec_ctx_fixed_prefix_bits(self.raw, C::ID) };
         if r < 0 { check(r)?; }
         Ok(r as u32)
+    }
+
+    /// Attach or build the prefix table of curve `C`'s generator now (`fec_ctx_build_fixed_prefix`, synchronous).
+    pub fn build_fixed_prefix<C: GpuCurve>(&mut self) -> Result<()> {
+        // SAFETY: self.raw is a live ctx.
+        check(unsafe { fec_ctx_build_fixed_prefix(self.raw, C::ID) })
+    }
+
+    /// A ctx left to its defaults builds a curve's table after this many multiplications by its generator.
+    pub fn set_fixed_prefix_after(&mut self, elements: usize) -> Result<()> {
+        // SAFETY: self.raw is a live ctx.
+        check(unsafe { fec_ctx_set_fixed_prefix_after(self.raw, elements) })
+    }
+
+    /// Share of the device's free memory a prefix table may take, in percent (default 25).
+    pub fn set_fixed_prefix_budget(&mut self, percent_of_free_memory: u32) -> Result<()> {
+        // SAFETY: self.raw is a live ctx.
+        check(unsafe { fec_ctx_set_fixed_prefix_budget(self.raw, percent_of_free_memory as c_uint) })
+    }
+
+    /// `u1*G` runs beside `u2*Q` on the ctx's second stream for launches of up to this many elements (measurement knob).
+    pub fn set_side_stream_max(&mut self, elements: usize) -> Result<()> {
+        // SAFETY: self.raw is a live ctx.
+        check(unsafe { fec_ctx_set_side_stream_max(self.raw, elements) })
+    }
+
+    /// Device-resident shards of a multi-device ctx (`fec_multi_batch_mul_dev`): shard `g` -- `counts[g]` elements of
+    /// curve `C`, raw limbs as `to_raw()` lays them out -- sits in the memory of the ctx's `g`-th device; results go to
+    /// `out[g]` and, when `gathered` is given, are also copied over xGMI into that array on the `consumer`-th device.
+    /// Synchronous.
+    ///
+    /// # Safety
+    /// Every pointer must be a live HIP device allocation on the device it is listed for, 16-byte aligned and large
+    /// enough for `counts[g]` elements (`gathered`: for the sum of the counts); the slices have one entry per device.
+    pub unsafe fn multi_batch_multiply_dev<C: GpuCurve>(&mut self, scalars: &[*const u64], points: &[*const u64], out: &[*mut u64],
+                                                        counts: &[usize], gathered: Option<*mut u64>, consumer: usize,
+                                                        streams: Option<&[*mut c_void]>) -> Result<()> {
+        let n = self.device_count();
+        if scalars.len() != n || points.len() != n || out.len() != n || counts.len() != n || streams.map_or(false, |s| s.len() != n) {
+            return Err(Error::ValidationError);
+        }
+        check(fec_multi_batch_mul_dev(self.raw, C::ID, scalars.as_ptr(), points.as_ptr(), out.as_ptr(), counts.as_ptr(),
+                                      gathered.unwrap_or(std::ptr::null_mut()), consumer as c_int,
+                                      streams.map_or(std::ptr::null(), |s| s.as_ptr())))
+    }
+
+    /// `fec_multi_batch_mul_fixed_dev`: as above with one base per device (`None` = the reference's `generator()`).
+    ///
+    /// # Safety
+    /// As for [`GpuContext::multi_batch_multiply_dev`].
+    pub unsafe fn multi_batch_multiply_fixed_dev<C: GpuCurve>(&mut self, scalars: &[*const u64], bases: Option<&[*const u64]>, out: &[*mut u64],
+                                                              counts: &[usize], gathered: Option<*mut u64>, consumer: usize,
+                                                              streams: Option<&[*mut c_void]>) -> Result<()> {
+        let n = self.device_count();
+        if scalars.len() != n || out.len() != n || counts.len() != n || bases.map_or(false, |b| b.len() != n) || streams.map_or(false, |s| s.len() != n) {
+            return Err(Error::ValidationError);
+        }
+        check(fec_multi_batch_mul_fixed_dev(self.raw, C::ID, scalars.as_ptr(), bases.map_or(std::ptr::null(), |b| b.as_ptr()), out.as_ptr(),
+                                            counts.as_ptr(), gathered.unwrap_or(std::ptr::null_mut()), consumer as c_int,
+                                            streams.map_or(std::ptr::null(), |s| s.as_ptr())))
+    }
+
+    /// `fec_multi_batch_double_mul_dev`: `u1[i]*G + u2[i]*Q[i]` on device-resident shards.
+    ///
+    /// # Safety
+    /// As for [`GpuContext::multi_batch_multiply_dev`].
+    pub unsafe fn multi_batch_double_multiply_dev<C: GpuCurve>(&mut self, u1: &[*const u64], u2: &[*const u64], q: &[*const u64], out: &[*mut u64],
+                                                               counts: &[usize], gathered: Option<*mut u64>, consumer: usize,
+                                                               streams: Option<&[*mut c_void]>) -> Result<()> {
+        let n = self.device_count();
+        if u1.len() != n || u2.len() != n || q.len() != n || out.len() != n || counts.len() != n || streams.map_or(false, |s| s.len() != n) {
+            return Err(Error::ValidationError);
+        }
+        check(fec_multi_batch_double_mul_dev(self.raw, C::ID, u1.as_ptr(), u2.as_ptr(), q.as_ptr(), out.as_ptr(), counts.as_ptr(),
+                                             gathered.unwrap_or(std::ptr::null_mut()), consumer as c_int,
+                                             streams.map_or(std::ptr::null(), |s| s.as_ptr())))
     }
 
     /// Elements per pipeline chunk of the host-pointer calls (tuning knob; results do not depend on it).

@@ -282,6 +282,28 @@ static void fixed_base_prefix_tables() {
   CHECK(same && ctx.fixed_prefix_bits(FEC_P256) == 0, "tables off: same products, no table");
 }
 
+// the device-resident multi-GPU calls through the C++ mirror, as far as a program without a HIP allocator can go: a
+// single-device ctx refuses them, a {0, 0} ctx accepts empty shards; the policy setters are callable
+static void multi_device_resident_calls() {
+  GpuContext one(0);
+  bool refused = false;
+  try {
+    one.multi_batch_mul_dev(FEC_P256, {nullptr}, {nullptr}, {nullptr}, {0});
+  } catch (const Error& e) {
+    refused = e.status == FEC_E_UNSUPPORTED;
+  }
+  CHECK(refused, "fec_multi_batch_mul_dev on a single-device ctx is FEC_E_UNSUPPORTED");
+  GpuContext two(std::vector<int>{0, 0});
+  CHECK(two.device_count() == 2, "a {0, 0} ctx has two shard workers");
+  two.multi_batch_mul_dev(FEC_P256, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {0, 0});
+  two.multi_batch_mul_fixed_dev(FEC_ED25519, {nullptr, nullptr}, nullptr, {nullptr, nullptr}, {0, 0});
+  two.multi_batch_double_mul_dev(FEC_SECP256K1, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {0, 0});
+  two.set_fixed_prefix_after(1u << 21);
+  two.set_fixed_prefix_budget(25);
+  two.set_side_stream_max((size_t)-1);
+  CHECK(true, "empty shards and the policy setters");
+}
+
 static void canonical_mode() {
   GpuContext ctx(0);
   // secp256k1: 1*G, 2*G, 3*G (3*G.x is the BIP-340 vector-0 public key)
@@ -307,6 +329,7 @@ int main() {
   try {
     canonical_mode();
     fixed_base_prefix_tables();
+    multi_device_resident_calls();
     secp256k1_field_arithmetic();
     secp256k1_point_arithmetic();
     secp256k1_scalar_multiplication();

@@ -18,9 +18,9 @@ ENUMS = {"fec_curve", "fec_field_opcode", "fec_point_opcode", "fec_status"}  # C
 
 def c_to_rust(t):
     t = re.sub(r"\s+", " ", t.strip())
-    const = "const " in t or t.startswith("const")
-    stars = t.count("*")
-    base = t.replace("const", "").replace("*", "").strip()
+    parts = t.split("*")          # "const uint64_t* const*" -> ["const uint64_t", " const", ""]
+    stars = len(parts) - 1
+    base = parts[0].replace("const", "").strip()
     prim = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint8_t": "u8", "void": "c_void", "char": "c_char",
             "float": "c_float", "double": "c_double", "fec_ctx": "FecCtx"}
     if base in ENUMS:
@@ -28,10 +28,11 @@ def c_to_rust(t):
     r = prim[base]
     if stars == 0:
         return "()" if r == "c_void" else r
-    # pointer depth: innermost constness follows the C declaration, outer levels are mutable out-params
-    out = ("*const " if const else "*mut ") + r
-    for _ in range(stars - 1):
-        out = "*mut " + out
+    # every pointer level is *const when what it points to is const-qualified in the C declaration (the qualifier in
+    # front of the base type for the innermost level, the one written after the previous `*` for the outer ones)
+    out = r
+    for level in range(stars):
+        out = ("*const " if "const" in parts[level] else "*mut ") + out
     return out
 
 
