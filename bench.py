@@ -377,6 +377,7 @@ def main(argv=None, platform_factory=None, script=None):
         if want_bits is None:
             want_bits = int(os.environ.get("FEC_FIXED_PREFIX_BITS") or 24)
         ctx.set_fixed_prefix_bits(want_bits)
+        ctx.build_fixed_prefix(cid)    # attach / build now: the table exists before anything is timed
 
         def small_call():
             t0 = time.perf_counter()

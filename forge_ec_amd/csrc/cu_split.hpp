@@ -3,10 +3,10 @@
 // The P-256 scheduler kernel holds one workgroup per CU for its whole run (146 KiB of LDS), so two launches on two
 // streams -- multiply(G, u1) beside multiply(Q, u2) in the ECDSA / Schnorr pipelines and the double multiplication --
 // each own a fixed set of CUs, and whichever finishes first leaves its CUs idle.  Round 2 gave each half of the chip
-// (p256_launch_mul's cu_divisor = 2): the fixed-base launch (affine addend: twelve products per addition instead of
+// (halves): the fixed-base launch (affine addend: twelve products per addition instead of
 // sixteen, and 24 of its 256 steps a table fetch) then finished 8 ms before the variable-base one.  The CUs are
 // divided in proportion to the work instead: SchedEnv::cus is the number of CUs a launch may take, so the split is a
-// SchedEnv per launch (cu_divisor stays 1).
+// SchedEnv per launch.
 #pragma once
 #include "../../include/fecgpu.h"
 #include "kernels.hpp"

@@ -115,10 +115,18 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline int ensure(fec_ctx* ctx, int slot, size_t bytes) {
   if (ctx->d_cap[slot] >= bytes) return FEC_OK;
   if (ctx->d_buf[slot]) {
-    // a staging buffer may hold a caller's keys: it is cleared before it goes back to the allocator (hipFree waits
-    // for the device, so the memset has run by the time the memory is released)
-    (void)hipMemsetAsync(ctx->d_buf[slot], 0, ctx->d_cap[slot], ctx->stream);
+    // A staging buffer may hold a caller's keys: it is cleared before it goes back to the allocator.  Slots 4..7 belong to
+    // the pipeline's second lane (stream2), so the clear is not queued on one stream behind whatever the other still has in
+    // flight: the device is drained first (growth is rare: once per ctx and size), then the memory is cleared synchronously.
+    const bool drained_ok = hipDeviceSynchronize() == hipSuccess;
+    const bool cleared = hipMemset(ctx->d_buf[slot], 0, ctx->d_cap[slot]) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     (void)hipFree(ctx->d_buf[slot]);
+    if (!drained_ok || !cleared) {   // the old contents could not be cleared: report it rather than carry on silently
+      (void)hipGetLastError();
+      ctx->d_buf[slot] = nullptr;
+      ctx->d_cap[slot] = 0;
+      return FEC_E_DEVICE;
+    }
   }
   ctx->d_buf[slot] = nullptr;
   ctx->d_cap[slot] = 0;

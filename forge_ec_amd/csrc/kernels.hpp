@@ -8,7 +8,7 @@ namespace fecgpu {
 
 // What a launch of one of the persistent scheduler kernels needs from the ctx it runs for.
 //   err         the ctx's device-visible error word (pinned host memory mapped into the device): a scheduler whose
-//               watchdog fires ORs FEC_DEVERR_* into it besides zero-filling its outputs, and every host-pointer entry
+//               watchdog fires stores its FEC_DEVERR_* code there besides zero-filling its outputs, and every host-pointer entry
 //               point reads it after its final synchronisation (fec_ctx_check for the *_dev callers) -- a scheduler
 //               fault therefore surfaces as FEC_E_LAUNCH, never as FEC_OK with zeroed points.
 //   cus         CU count of the ctx's OWN device (one persistent workgroup per CU)
@@ -28,9 +28,9 @@ struct SchedEnv {
 enum : unsigned { FEC_DEVERR_SCHED_WATCHDOG = 1u, FEC_DEVERR_SCHED_INDEX = 2u, FEC_DEVERR_FORCED = 4u };
 
 // kernels_p256.hip: P-256 Curve::multiply, workgroup task scheduler.  out[i] = multiply(fixed ? points[0] : points[i], scalars[i])
-// `cu_divisor` > 1: the launch takes at most that fraction of the CUs (a second launch on another stream runs beside it).
-void p256_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,
-                     unsigned cu_divisor = 1);
+// One persistent workgroup per CU the launch may take: env.cus (two launches that run side by side get a SchedEnv each,
+// cu_split.hpp).
+void p256_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);
 
 // kernels_ed.hip: Ed25519 variable-base Curve::multiply, persistent workgroup task scheduler (one workgroup
 // per CU, element state in LDS, slots refilled from the workgroup's range).
@@ -44,8 +44,6 @@ void ed_build_table_launch(const u32* base, u32* table, hipStream_t s);
 size_t ed_fixed_work_bytes(size_t n);
 void ed_fixed_launch(const SchedEnv& env, const u32* scalars, const u32* base, const u32* table, u32* out, size_t n, void* work,
                      hipStream_t s);
-// scalars[i] = i for i < n (8 words each): the inputs from which a fixed-base prefix table is computed
-void index_scalars_launch(u32* scalars, size_t n, hipStream_t s);
 
 // kernels_secp.hip: secp256k1 Curve::multiply, lane-per-element ladder at three wavefronts per SIMD.
 void secp_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s);

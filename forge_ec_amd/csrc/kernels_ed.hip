@@ -670,18 +670,6 @@ void ed_fixed_launch(const SchedEnv& env, const u32* scalars, const u32* base, c
   hipLaunchKernelGGL(k_ed_fixed_sorted, dim3(grid), dim3(TPB), 0, s, scalars, base, table, (const u32*)perm, out, n, prefix, wbits);
 }
 
-// scalars[i] = i (one 32-bit word, the rest zero): the inputs of a prefix-table build (fecgpu.hip: ensure_gen_prefix)
-__global__ __launch_bounds__(TPB) void k_index_scalars(u32* __restrict__ scalars, size_t n) {
-  const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-  if (i >= n) return;
-  uint4* o = reinterpret_cast<uint4*>(scalars + i * 8);
-  o[0] = make_uint4((u32)i, 0, 0, 0);
-  o[1] = make_uint4(0, 0, 0, 0);
-}
-void index_scalars_launch(u32* scalars, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_index_scalars, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, scalars, n);
-}
-
 void ed_launch_mul(const SchedEnv& env, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,
                    unsigned cu_divisor) {
   // one workgroup per CU (or per cu_divisor-th CU) of the ctx's own device, each with a contiguous range of at least

@@ -455,14 +455,11 @@ inline bool wide_slots_pay(unsigned per_wg) {
 }
 }  // namespace
 
-void p256_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s,
-                     unsigned cu_divisor) {
-  // one workgroup per CU (or per cu_divisor-th CU) of the ctx's own device, each with a contiguous range of at least
-  // 64 elements
+void p256_launch_mul(const SchedEnv& env, bool fixed, const u32* scalars, const u32* points, u32* out, size_t n, hipStream_t s) {
+  // one workgroup per CU the launch may take (env.cus), each with a contiguous range of at least 64 elements
   const unsigned cus = env.cus ? env.cus : 256u;
   size_t grid = (n + 63) / 64;
-  const unsigned cap = cu_divisor > 1 && cus >= cu_divisor ? cus / cu_divisor : cus;
-  if (grid > cap) grid = cap;
+  if (grid > cus) grid = cus;
   const unsigned per_wg = (unsigned)((n + grid - 1) / grid);
   grid = (n + per_wg - 1) / per_wg;
   const bool wide = wide_slots_pay(per_wg);

@@ -64,6 +64,9 @@ class OracleContext:
     def set_fixed_prefix_bits(self, bits):
         self.bits = int(bits)
 
+    def build_fixed_prefix(self, curve):
+        return None
+
     def fixed_prefix_bits(self, curve):
         return self.bits
 

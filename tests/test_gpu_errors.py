@@ -173,3 +173,58 @@ def test_prefix_table_policy_and_faults(oracle):
         ctx.debug_force_fault(False)
         assert np.array_equal(ctx.batch_mul_fixed(1, k, g), want)
         assert ctx.fixed_prefix_bits(1) == 9
+
+
+def test_prefix_table_is_shared_budgeted_and_never_built_by_a_default_dev_call(oracle):
+    """The table policy of fecgpu.h: (1) a ctx left to its defaults never builds from a *_dev entry point, it does from a
+    host-pointer one; (2) a second ctx on the same device attaches to the SAME allocation (no second table's worth of
+    memory); (3) the budget caps the size by the device's free memory -- a 24-bit request shrinks -- and a budget of
+    0 % means no table at all; results are identical in every case."""
+    import torch
+    import forge_ec_amd as F
+    n = 4096
+    k = V.scalars(n, 1, 881)
+    want = oracle.batch_mul_fixed(1, k, oracle.generator(1), nthreads=16)
+    dk = torch.from_numpy(k.view(np.int64)).cuda()
+    do = torch.zeros((n, 12), dtype=torch.int64, device="cuda")
+
+    def dev_call(ctx):
+        ctx.batch_mul_fixed_dev(1, dk.data_ptr(), ctx.generator_dev(1), do.data_ptr(), n)
+        ctx.check()
+        torch.cuda.synchronize()
+        return do.cpu().numpy().view(np.uint64)
+
+    with F.Context(0) as a:
+        a.set_fixed_prefix_after(n)                  # defaults otherwise: 24 bits wanted, not asked for explicitly
+        for _ in range(3):
+            assert np.array_equal(dev_call(a), want)
+        assert a.fixed_prefix_bits(1) == 0           # (1) three *_dev launches past the threshold: still no table
+        free0 = torch.cuda.mem_get_info()[0]
+        assert np.array_equal(a.batch_mul_fixed(1, k, a.generator(1)), want)   # a host-pointer call builds it
+        assert a.fixed_prefix_bits(1) == 24
+        used = free0 - torch.cuda.mem_get_info()[0]
+        assert used >= (96 << 24)                    # the P-256 table: 1.5 GiB
+        assert np.array_equal(dev_call(a), want)     # ... and the *_dev launches use it
+        with F.Context(0) as b:                      # (2) a second ctx on the device shares it
+            free1 = torch.cuda.mem_get_info()[0]
+            b.build_fixed_prefix(1)
+            assert b.fixed_prefix_bits(1) == 24
+            assert free1 - torch.cuda.mem_get_info()[0] < (96 << 24) // 4
+            assert np.array_equal(dev_call(b), want)
+        assert np.array_equal(dev_call(a), want)     # b is gone, a's reference keeps the table
+    with F.Context(0) as c:                          # (3) the budget: a share of what is FREE at that moment
+        free = torch.cuda.mem_get_info()[0]
+        ballast = torch.empty(free - (4 << 30), dtype=torch.uint8, device="cuda")   # leave 4 GiB free
+        free = torch.cuda.mem_get_info()[0]
+        assert free < (6 << 30)
+        c.set_fixed_prefix_budget(25)                # about 1 GiB: 2^24 entries (1.5 + 0.75 GiB) do not fit, 2^22 do
+        c.set_fixed_prefix_bits(24)
+        assert np.array_equal(c.batch_mul_fixed(1, k, c.generator(1)), want)
+        assert 16 <= c.fixed_prefix_bits(1) < 24
+        c.set_fixed_prefix_budget(0)
+        c.set_fixed_prefix_bits(24)
+        assert np.array_equal(c.batch_mul_fixed(1, k, c.generator(1)), want)
+        assert c.fixed_prefix_bits(1) == 0           # refused: no table, the same products
+        assert np.array_equal(dev_call(c), want)
+        del ballast
+        torch.cuda.empty_cache()

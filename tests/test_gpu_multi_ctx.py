@@ -104,3 +104,95 @@ def test_multi_ctx_rejects_device_pointers_and_bad_lists():
     bad = (ctypes.c_int * 2)(0, 99)
     assert L.fec_ctx_create_multi(ctypes.byref(h), bad, 2) != 0 and not h.value
     assert L.fec_strerror(-6).decode().startswith("multi-device")
+
+
+# ---- device-resident shards: fec_multi_batch_*_dev ----
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+@pytest.mark.parametrize("devices,counts", [([0, 0], (1000, 1777)), ([0, 0, 0], (513, 0, 2049)), ([0], (300,))])
+def test_multi_dev_shards_gathered_bit_exact(devices, counts, oracle):
+    """Shards already resident in device memory, results gathered onto the consumer device by peer copies (a one-GPU box
+    lists its GPU several times: the whole path runs, the copies are device-to-device on one device).  Every curve;
+    variable base, fixed base (the generator and a base of the caller's own) and u1*G + u2*Q; the gathered batch and
+    the per-shard outputs against a single-device ctx's *_dev call and the oracle."""
+    import torch
+    import forge_ec_amd as F
+    n = sum(counts)
+    edges = np.concatenate([[0], np.cumsum(counts)])
+    with F.Context(devices=devices) as ctx, F.Context(0) as one:
+        ctx.set_chunk(600)   # several chunks per shard: a chunk's copy runs under the next chunk's kernels
+        for curve in (0, 1, 2):
+            L = F.POINT_LIMBS[curve]
+            k, k2, p = V.scalars(n, curve, 9100), V.scalars(n, curve, 9101), V.points(n, curve, 9102)
+            shards = [(int(edges[g]), int(edges[g + 1])) for g in range(len(devices))]
+            dk = [_dev(k[a:b]) for a, b in shards]
+            dk2 = [_dev(k2[a:b]) for a, b in shards]
+            dp = [_dev(p[a:b]) for a, b in shards]
+            ptr = lambda ts: [t.data_ptr() if t.numel() else 0 for t in ts]
+            want = oracle.batch_mul(curve, k, p, nthreads=16)
+            for consumer in sorted({0, len(devices) - 1}):
+                do = [torch.zeros((b - a, L), dtype=torch.int64, device="cuda") for a, b in shards]
+                full = torch.zeros((n, L), dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                ctx.multi_batch_mul_dev(curve, ptr(dk), ptr(dp), ptr(do), counts, full.data_ptr(), consumer)
+                assert np.array_equal(full.cpu().numpy().view(np.uint64), want), (devices, curve, consumer)
+                for (a, b), t in zip(shards, do):
+                    assert np.array_equal(t.cpu().numpy().view(np.uint64), want[a:b])
+            # no gather: the shards' own outputs only
+            do = [torch.zeros((b - a, L), dtype=torch.int64, device="cuda") for a, b in shards]
+            torch.cuda.synchronize()
+            ctx.multi_batch_mul_dev(curve, ptr(dk), ptr(dp), ptr(do), counts)
+            for (a, b), t in zip(shards, do):
+                assert np.array_equal(t.cpu().numpy().view(np.uint64), want[a:b])
+            # fixed base: the generator (bases = None), then a projective base of the caller's own on every device
+            full = torch.zeros((n, L), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            ctx.multi_batch_mul_fixed_dev(curve, ptr(dk), None, ptr(do), counts, full.data_ptr(), 0)
+            g = one.generator(curve)
+            assert np.array_equal(full.cpu().numpy().view(np.uint64), oracle.batch_mul_fixed(curve, k, g, nthreads=16))
+            base = V.points(1, curve, 9103)[0]
+            dbase = [_dev(base) for _ in devices]
+            ctx.multi_batch_mul_fixed_dev(curve, ptr(dk), ptr(dbase), ptr(do), counts, full.data_ptr(), 0)
+            assert np.array_equal(full.cpu().numpy().view(np.uint64), oracle.batch_mul_fixed(curve, k, base, nthreads=16))
+            # u1*G + u2*Q
+            ctx.multi_batch_double_mul_dev(curve, ptr(dk), ptr(dk2), ptr(dp), ptr(do), counts, full.data_ptr(), 0)
+            assert np.array_equal(full.cpu().numpy().view(np.uint64), oracle.batch_double_mul(curve, k, k2, p, nthreads=16))
+
+
+def test_multi_dev_argument_errors_and_faults(oracle):
+    import torch
+    import forge_ec_amd as F
+    from forge_ec_amd._lib import FecError
+    k, p = V.scalars(128, 1, 1), V.points(128, 1, 2)
+    dk, dp = _dev(k), _dev(p)
+    do = torch.zeros((128, 12), dtype=torch.int64, device="cuda")
+    with F.Context(0) as one:
+        with pytest.raises(FecError) as ei:   # a single-device ctx has fec_batch_mul_dev
+            one.multi_batch_mul_dev(1, [dk.data_ptr()], [dp.data_ptr()], [do.data_ptr()], [128])
+        assert ei.value.status == -5
+    with F.Context(devices=[0, 0]) as ctx:
+        ptrs = lambda t: [t.data_ptr(), t.data_ptr()]
+        with pytest.raises(FecError) as ei:   # consumer out of range
+            ctx.multi_batch_mul_dev(1, ptrs(dk), ptrs(dp), ptrs(do), [64, 64], do.data_ptr(), 2)
+        assert ei.value.status == -1
+        with pytest.raises(FecError) as ei:   # a shard with elements and no input
+            ctx.multi_batch_mul_dev(1, [dk.data_ptr(), 0], ptrs(dp), ptrs(do), [64, 64])
+        assert ei.value.status == -1
+        with pytest.raises(FecError) as ei:   # misaligned output
+            ctx.multi_batch_mul_dev(1, ptrs(dk), ptrs(dp), [do.data_ptr() + 8, do.data_ptr()], [64, 64])
+        assert ei.value.status == -1
+        # a scheduler fault in one shard is FEC_E_LAUNCH from the call, and the next call is right again
+        ctx.debug_force_fault(True)
+        do2 = torch.zeros((64, 12), dtype=torch.int64, device="cuda")
+        with pytest.raises(FecError) as ei:
+            ctx.multi_batch_mul_dev(1, [dk.data_ptr(), dk[64:].data_ptr()], [dp.data_ptr(), dp[64:].data_ptr()],
+                                    [do.data_ptr(), do2.data_ptr()], [64, 64])
+        assert ei.value.status == -4
+        ctx.debug_force_fault(False)
+        full = torch.zeros((128, 12), dtype=torch.int64, device="cuda")
+        ctx.multi_batch_mul_dev(1, [dk.data_ptr(), dk[64:].data_ptr()], [dp.data_ptr(), dp[64:].data_ptr()],
+                                [do.data_ptr(), do2.data_ptr()], [64, 64], full.data_ptr(), 1)
+        assert np.array_equal(full.cpu().numpy().view(np.uint64), oracle.batch_mul(1, k, p, nthreads=8))
