@@ -14,7 +14,7 @@ P_ADD, P_DOUBLE, P_NEGATE, P_DOUBLE_TRAIT = 0, 1, 2, 3
 # every symbol include/fecgpu.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "fec_point_limbs", "fec_ctx_create", "fec_ctx_create_multi", "fec_ctx_device_count", "fec_ctx_destroy", "fec_ctx_wipe", "fec_ctx_check", "fec_ctx_debug_force_fault", "fec_ctx_set_fixed_prefix_bits", "fec_ctx_build_fixed_prefix", "fec_ctx_set_fixed_prefix_after", "fec_ctx_set_fixed_prefix_budget", "fec_ctx_fixed_prefix_bits", "fec_ctx_set_side_stream_max", "fec_generator", "fec_generator_dev", "fec_batch_mul", "fec_batch_mul_fixed",
-    "fec_batch_double_mul", "fec_batch_to_affine", "fec_batch_to_affine_dev", "fec_ecdsa_verify_secp256k1", "fec_ecdsa_verify_secp256k1_dev", "fec_ecdsa_verify_p256", "fec_ecdsa_verify_p256_dev", "fec_eddsa_verify_ed25519", "fec_eddsa_verify_ed25519_dev", "fec_ecdsa_batch_verify", "fec_batch_ecdh", "fec_batch_ecdh_dev", "fec_batch_validate_point", "fec_batch_validate_point_dev", "fec_multi_scalar_mul", "fec_schnorr_batch_verify_secp256k1", "fec_schnorr_batch_verify", "fec_schnorr_verify", "fec_schnorr_verify_dev", "fec_batch_compress", "fec_batch_compress_dev", "fec_batch_decompress", "fec_batch_encode_uncompressed", "fec_batch_decode_uncompressed", "fec_field_op", "fec_point_op", "fec_batch_mul_dev",
+    "fec_batch_double_mul", "fec_batch_to_affine", "fec_batch_to_affine_dev", "fec_ecdsa_verify_secp256k1", "fec_ecdsa_verify_secp256k1_dev", "fec_ecdsa_verify_p256", "fec_ecdsa_verify_p256_dev", "fec_eddsa_verify_ed25519", "fec_eddsa_verify_ed25519_dev", "fec_ecdsa_batch_verify", "fec_batch_ecdh", "fec_batch_ecdh_dev", "fec_batch_validate_point", "fec_batch_validate_point_dev", "fec_multi_scalar_mul", "fec_schnorr_batch_verify_secp256k1", "fec_schnorr_batch_verify", "fec_schnorr_batch_verify_ed25519", "fec_schnorr_verify", "fec_schnorr_verify_dev", "fec_batch_compress", "fec_batch_compress_dev", "fec_batch_decompress", "fec_batch_encode_uncompressed", "fec_batch_decode_uncompressed", "fec_field_op", "fec_point_op", "fec_batch_mul_dev",
     "fec_batch_mul_fixed_dev", "fec_batch_double_mul_dev", "fec_multi_batch_mul_dev", "fec_multi_batch_mul_fixed_dev", "fec_multi_batch_double_mul_dev", "fec_ctx_set_chunk", "fec_ctx_set_timing",
     "fec_ctx_last_kernel_ms", "fec_measure_peak_mad32", "fec_ctx_device_info", "fec_strerror",
 ]
@@ -138,6 +138,8 @@ def lib():
     L.fec_schnorr_batch_verify_secp256k1.restype = ci
     L.fec_schnorr_batch_verify.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]
     L.fec_schnorr_batch_verify.restype = ci
+    L.fec_schnorr_batch_verify_ed25519.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
+    L.fec_schnorr_batch_verify_ed25519.restype = ci
     L.fec_schnorr_verify.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, sz]
     L.fec_schnorr_verify.restype = ci
     L.fec_schnorr_verify_dev.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]

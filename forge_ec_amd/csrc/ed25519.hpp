@@ -463,5 +463,102 @@ FEC_DEV pt multiply_fixed(const pt& base, const u32* tab, const u32* kw) {
   return pt_select(result, identity(), early);
 }
 
+
+// ---- Scalar arithmetic the generic schnorr::batch_verify::<Ed25519, D> needs (schnorr.rs:264: s_i * a_i) ----
+struct sc4 {
+  u64 l[4];
+};
+FEC_DEV bool sc_ge_order(const sc4& r) {   // the comparison loop of 1215-1226 / 1303-1312 / 1354-1363: r >= ORDER
+  const u64 ORDER[4] = {0x5812631A5CF5D3EDULL, 0x14DEF9DEA2F79CD6ULL, 0ULL, 0x1000000000000000ULL};
+  bool ge = true, decided = false;
+  FEC_UNROLL for (int i = 3; i >= 0; --i) {
+    if (!decided && r.l[i] < ORDER[i]) {
+      ge = false;
+      decided = true;
+    } else if (!decided && r.l[i] > ORDER[i]) {
+      decided = true;
+    }
+  }
+  return ge;
+}
+FEC_DEV sc4 sc_sub_order(const sc4& r) {   // 1229-1236 / 1365-1372: the limbs minus ORDER with a borrow chain
+  const u64 ORDER[4] = {0x5812631A5CF5D3EDULL, 0x14DEF9DEA2F79CD6ULL, 0ULL, 0x1000000000000000ULL};
+  sc4 o;
+  u64 borrow = 0;
+  FEC_UNROLL for (int i = 0; i < 4; ++i) {
+    const u64 d1 = r.l[i] - ORDER[i];
+    const u64 b1 = r.l[i] < ORDER[i];
+    const u64 d2 = d1 - borrow;
+    const u64 b2 = d1 < borrow;
+    o.l[i] = d2;
+    borrow = b1 | b2;
+  }
+  return o;
+}
+// impl Add for Scalar (1193-1239): the 256-bit sum (the carry out of the top limb is dropped), then ONE conditional
+// subtraction of the order
+FEC_DEV sc4 sc_add(const sc4& a, const sc4& b) {
+  sc4 r;
+  u64 carry = 0;
+  FEC_UNROLL for (int i = 0; i < 4; ++i) {
+    const u64 s1 = a.l[i] + b.l[i];
+    const u64 o1 = s1 < a.l[i];
+    const u64 s2 = s1 + carry;
+    const u64 o2 = s2 < s1;
+    r.l[i] = s2;
+    carry = o1 | o2;
+  }
+  return sc_ge_order(r) ? sc_sub_order(r) : r;
+}
+// impl Mul for Scalar (1256-1376) AS THE RELEASE PROFILE RUNS IT (the reference's Cargo.toml:53-58 has no
+// overflow-checks: integer overflow wraps).  The eight column sums `product[i + j] += a_i * b_j` (1268-1272) add up to
+// four 128-bit products in a u128, and `product[i] += carry` (1278) adds once more: both can pass 2^128.  A debug build
+// panics there; the release build -- the one whose throughput BASELINE times -- keeps the sum modulo 2^128 and goes on,
+// which is what this computes.  `overflowed` is set when any of those additions wrapped, i.e. when a debug build would
+// have panicked on these operands.  Then, literally: the low four limbs; if any high limb is non-zero, 256 times
+// `result += high` with the Add above (1343-1349); one conditional subtraction of the order (1352-1373).
+FEC_DEV sc4 sc_mul_release(const sc4& a, const sc4& b, bool& overflowed) {
+  u64 lo[8], hi[8];
+  FEC_UNROLL for (int k = 0; k < 8; ++k) lo[k] = hi[k] = 0;
+  bool ovf = false;
+  FEC_UNROLL for (int i = 0; i < 4; ++i) {
+    FEC_UNROLL for (int j = 0; j < 4; ++j) {
+      const u64 pl = a.l[i] * b.l[j], ph = mulhi64(a.l[i], b.l[j]);
+      const u64 nl = lo[i + j] + pl;
+      const u64 c = nl < pl;
+      const u64 nh = hi[i + j] + ph;
+      const bool o1 = nh < ph;
+      const u64 nh2 = nh + c;
+      const bool o2 = nh2 < nh;
+      ovf = ovf || o1 || o2;
+      lo[i + j] = nl;
+      hi[i + j] = nh2;
+    }
+  }
+  u64 limb[8];
+  u64 carry = 0;   // (`carry = product[i] >> 64` is below 2^64)
+  FEC_UNROLL for (int k = 0; k < 8; ++k) {
+    const u64 nl = lo[k] + carry;
+    const u64 c = nl < carry;
+    const u64 nh = hi[k] + c;
+    ovf = ovf || (nh < c);
+    limb[k] = nl;
+    carry = nh;
+  }
+  overflowed = ovf;
+  sc4 result, high;
+  FEC_UNROLL for (int i = 0; i < 4; ++i) {
+    result.l[i] = limb[i];
+    high.l[i] = limb[4 + i];
+  }
+  const bool high_nonzero = (high.l[0] | high.l[1] | high.l[2] | high.l[3]) != 0;
+  if (!(high_nonzero || sc_ge_order(result))) return result;           // 1299-1313: already below the order
+  if (high_nonzero) {
+#pragma unroll 1
+    for (int k = 0; k < 256; ++k) result = sc_add(result, high);       // 1347-1349
+  }
+  return sc_ge_order(result) ? sc_sub_order(result) : result;          // 1352-1373
+}
+
 }  // namespace ed
 }  // namespace fecgpu

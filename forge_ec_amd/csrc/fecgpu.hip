@@ -69,6 +69,8 @@ struct Secp {
   FEC_DEV static fe f_sqr(const fe& a) { return secp::sqr(a); }
   FEC_DEV static fe f_neg(const fe& a) { return secp::neg(a); }
   FEC_DEV static fe sc_mul(const fe& a, const fe& b) { return secp::sc_mul(a, b); }   // impl Mul for Scalar (2410-2456)
+  FEC_DEV static fe sc_mul_flag(const fe& a, const fe& b, bool& overflowed) { overflowed = false; return sc_mul(a, b); }
+  FEC_DEV static pt from_affine(const fe& x, const fe& y) { pt p; p.x = x; p.y = y; p.z = fe_small(1); return p; }   // 1365-1373
   // FieldElement::to_bytes (138-178): mont_reduce, i.e. Mul by raw 1; big-endian bytes
   FEC_DEV static fe bytes_value(const fe& a) { return secp::mul(a, fe_small(1)); }
   static constexpr bool BYTES_BIG_ENDIAN = true;
@@ -110,6 +112,8 @@ struct P256 {
   FEC_DEV static fe f_sqr(const fe& a) { return p256::sqr(a); }
   FEC_DEV static fe f_neg(const fe& a) { return p256::neg(a); }
   FEC_DEV static fe sc_mul(const fe& a, const fe& b) { return p256::sc_mul32(a, b); }  // impl Mul for Scalar (p256.rs:1409-1432)
+  FEC_DEV static fe sc_mul_flag(const fe& a, const fe& b, bool& overflowed) { overflowed = false; return sc_mul(a, b); }
+  FEC_DEV static pt from_affine(const fe& x, const fe& y) { pt p; p.x = x; p.y = y; p.z = fe_small(1); return p; }
   // FieldElement::to_bytes (p256.rs:288-300): the raw limbs; big-endian bytes
   FEC_DEV static fe bytes_value(const fe& a) { return a; }
   static constexpr bool BYTES_BIG_ENDIAN = true;
@@ -153,6 +157,29 @@ struct Ed {
   FEC_DEV static fe f_mul(const fe& a, const fe& b) { return ed::mul(a, b); }
   FEC_DEV static fe f_sqr(const fe& a) { return ed::mul(a, a); }
   FEC_DEV static fe f_neg(const fe& a) { return ed::neg(a); }
+  // impl Mul for Scalar (ed25519.rs:1256-1376) under the release profile: u128 sums wrap, `overflowed` says that one did
+  FEC_DEV static fe sc_mul_flag(const fe& a, const fe& b, bool& overflowed) {
+    ed::sc4 x, y;
+    FEC_UNROLL for (int i = 0; i < 4; ++i) {
+      x.l[i] = (u64)a.w[2 * i] | ((u64)a.w[2 * i + 1] << 32);
+      y.l[i] = (u64)b.w[2 * i] | ((u64)b.w[2 * i + 1] << 32);
+    }
+    const ed::sc4 r = ed::sc_mul_release(x, y, overflowed);
+    fe o;
+    FEC_UNROLL for (int i = 0; i < 4; ++i) {
+      o.w[2 * i] = (u32)r.l[i];
+      o.w[2 * i + 1] = (u32)(r.l[i] >> 32);
+    }
+    return o;
+  }
+  FEC_DEV static pt from_affine(const fe& x, const fe& y) {   // ed25519.rs:1813-1826: z = one(), t = x * y
+    pt p;
+    p.x = x;
+    p.y = y;
+    p.z = fe_small(1);
+    p.t = ed::mul(x, y);
+    return p;
+  }
   // FieldElement::to_bytes (ed25519.rs:295-310): reduce(); LITTLE-endian bytes
   FEC_DEV static fe bytes_value(const fe& a) { return ed::reduce(a); }
   static constexpr bool BYTES_BIG_ENDIAN = false;
@@ -354,16 +381,19 @@ __global__ __launch_bounds__(TPB) void k_to_affine(const u32* __restrict__ point
 template <class C>
 __global__ __launch_bounds__(TPB) void k_schnorr_pre(const u32* __restrict__ pk_xy, const u32* __restrict__ ss,
                                                      const u32* __restrict__ as, u32* __restrict__ sa,
-                                                     u32* __restrict__ p_out, size_t n) {
+                                                     u32* __restrict__ p_out, unsigned char* __restrict__ wrapped, size_t n) {
   const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
   fe s, a;
   FEC_UNROLL for (int w = 0; w < 8; ++w) { s.w[w] = ss[i * 8 + w]; a.w[w] = as[i * 8 + w]; }
-  const fe prod = C::sc_mul(s, a);                            // impl Mul for Scalar
+  bool ovf = false;
+  const fe prod = C::sc_mul_flag(s, a, ovf);                  // impl Mul for Scalar (Ed25519: release profile, see Ed)
+  if (ovf && wrapped) *wrapped = 1;                           // (every writer stores the same value)
   FEC_UNROLL for (int w = 0; w < 8; ++w) sa[i * 8 + w] = prod.w[w];
-  // from_affine (1365-1373): the caller has rejected identities
-  FEC_UNROLL for (int w = 0; w < 16; ++w) p_out[i * 24 + w] = pk_xy[i * 16 + w];
-  FEC_UNROLL for (int w = 0; w < 8; ++w) p_out[i * 24 + 16 + w] = w == 0 ? 1u : 0u;
+  // from_affine: the caller has rejected identities
+  fe x, y;
+  FEC_UNROLL for (int w = 0; w < 8; ++w) { x.w[w] = pk_xy[i * 16 + w]; y.w[w] = pk_xy[i * 16 + 8 + w]; }
+  C::store(p_out + i * C::PW, 1, C::from_affine(x, y));
 }
 // q_i = from_affine(R_i) + ep_i   (277-279)
 template <class C>
@@ -378,10 +408,7 @@ __global__ __launch_bounds__(TPB) void k_schnorr_mid(const u32* __restrict__ r_x
   __syncthreads();
   const int e = threadIdx.x;
   if (e < valid) {
-    typename C::pt r;
-    r.x = load_fe(lds_r + e, TPB);
-    r.y = load_fe(lds_r + 8 * TPB + e, TPB);
-    r.z = fe_small(1);
+    const typename C::pt r = C::from_affine(load_fe(lds_r + e, TPB), load_fe(lds_r + 8 * TPB + e, TPB));
     C::store(lds_p + e, TPB, C::padd(r, C::load(lds_p + e, TPB)));
   }
   __syncthreads();
@@ -400,10 +427,12 @@ __global__ __launch_bounds__(64) void k_schnorr_fold_compare(const u32* __restri
                                                              unsigned char* __restrict__ flags,
                                                              unsigned int* __restrict__ done, size_t n) {
   constexpr bool kSecp = __is_same(typename C::pt, secp::pt);
-  __shared__ __attribute__((aligned(16))) u32 sh[kSecp ? secp::coop::WORDS : p256::coop::WORDS];
+  constexpr bool kEd = __is_same(typename C::pt, ed::pt);
+  __shared__ __attribute__((aligned(16))) u32 sh[kSecp ? secp::coop::WORDS : (kEd ? ed::coop::WORDS : p256::coop::WORDS)];
   const u32* terms = blockIdx.x == 0 ? terms_a : terms_b;
-  typename C::pt acc;  // the whole wavefront folds: each addition on four (secp256k1) / five (P-256) lanes
+  typename C::pt acc;  // the whole wavefront folds: each addition on four (secp256k1, Ed25519) / five (P-256) lanes
   if constexpr (kSecp) acc = fold_coop_secp(terms, n, sh);
+  else if constexpr (kEd) acc = fold_coop_ed(terms, n, sh);
   else acc = fold_coop_p256(terms, n, sh);
   if (threadIdx.x != 0) return;
   C::store(sums + blockIdx.x * C::PW, 1, acc);
@@ -412,10 +441,14 @@ __global__ __launch_bounds__(64) void k_schnorr_fold_compare(const u32* __restri
   __threadfence();
   fe x[2], y[2];
   bool inf[2];
+  bool panics = false;
 #pragma unroll 1
   for (int k = 0; k < 2; ++k) {
     typename C::pt p = C::load(sums + k * C::PW, 1);
     fe xx, yy;
+    if constexpr (kEd) {   // to_affine (1793-1811) unwraps z.invert(): a zero z of a point that is not the identity panics (1805)
+      if (!lane_of(ed::is_identity(p)) && lane_of(fe_is_zero(p.z))) panics = true;
+    }
     inf[k] = lane_of(C::to_affine(p, xx, yy));
     x[k] = xx;
     y[k] = yy;
@@ -423,7 +456,7 @@ __global__ __launch_bounds__(64) void k_schnorr_fold_compare(const u32* __restri
     store_fe(out_xy + k * 16 + 8, 1, yy);
   }
   const bool same = lane_of(fe_eq(x[0], x[1]) & fe_eq(y[0], y[1]));
-  flags[0] = (same || (inf[0] && inf[1])) ? 1 : 0;
+  flags[0] = panics ? 2 : ((same || (inf[0] && inf[1])) ? 1 : 0);
   flags[1] = inf[0] ? 1 : 0;
   flags[2] = inf[1] ? 1 : 0;
 }
@@ -1981,19 +2014,19 @@ namespace {
 // schnorr::batch_verify::<C, D> (forge-ec-signature/src/schnorr.rs:194-290) for C = Secp256k1 / P256
 int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* r_xy,
                          const uint8_t* r_inf, const uint64_t* s, const uint64_t* a, const uint64_t* e, size_t n,
-                         uint8_t* result, uint64_t* sides_xy, uint8_t* sides_inf) {
+                         uint8_t* result, uint64_t* sides_xy, uint8_t* sides_inf, uint8_t* debug_build_panics = nullptr) {
   FEC_FIRST_DEVICE(ctx);
-  if (!ctx || !result || (n && (!pk_xy || !r_xy || !s || !a || !e))) return FEC_E_ARG;
-  if (curve != FEC_SECP256K1 && curve != FEC_P256) return FEC_E_UNSUPPORTED;
+  if (!ctx || !result || !curve_ok(curve) || (n && (!pk_xy || !r_xy || !s || !a || !e))) return FEC_E_ARG;
   *result = 0;
+  if (debug_build_panics) *debug_build_panics = 0;
   if (sides_xy) std::memset(sides_xy, 0, 16 * sizeof(uint64_t));
   if (sides_inf) sides_inf[0] = sides_inf[1] = 0;
   if (n == 0) return FEC_OK;                                   // 197-199
   for (size_t i = 0; i < n; ++i)                               // 204-225 (only the identity tests can reject)
     if ((pk_inf && pk_inf[i]) || (r_inf && r_inf[i])) return FEC_OK;
   if (hipSetDevice(ctx->device) != hipSuccess) return FEC_E_DEVICE;
-  const bool secp = curve == FEC_SECP256K1;
-  const size_t pb = 96;
+  const bool secp = curve == FEC_SECP256K1, edw = curve == FEC_ED25519;
+  const size_t pb = (size_t)plimbs(curve) * 8;
   unsigned char flags[8] = {0};  // (host targets of the last copies: outside the drained scope, see fec_ecdsa_batch_verify)
   uint64_t sides[16];
   return drained(ctx, [&]() -> int {
@@ -2004,7 +2037,7 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
   for (int i = 0; i < 5 && rc == FEC_OK; ++i) rc = ensure(ctx, i, bytes[i]);
   if (rc == FEC_OK) rc = ensure(ctx, 5, n * pb);
   if (rc == FEC_OK) rc = ensure(ctx, 6, n * pb);
-  if (rc == FEC_OK) rc = ensure(ctx, 7, 2 * pb + 128 + 16);
+  if (rc == FEC_OK) rc = ensure(ctx, 7, 2 * pb + 128 + 32);
   if (rc != FEC_OK) return rc;
   for (int i = 0; i < 5; ++i)
     if (hipMemcpyAsync(ctx->d_buf[i], src[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
@@ -2014,8 +2047,37 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
   u32* d_sides = (u32*)(tail + 2 * pb);
   unsigned char* d_flags = (unsigned char*)(tail + 2 * pb + 128);
   unsigned int* d_done = (unsigned int*)(tail + 2 * pb + 128 + 8);
-  if (hipMemsetAsync(tail + 2 * pb + 128, 0, 16, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
-  {
+  unsigned char* d_wrapped = (unsigned char*)(tail + 2 * pb + 128 + 16);   // Ed25519: some s_i * a_i wrapped a u128 sum
+  if (hipMemsetAsync(tail + 2 * pb + 128, 0, 32, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  if (edw) {
+    // Ed25519 (the generic batch_verify::<Ed25519, D>): the same pipeline with that curve's kernels -- multiply(G, .) by
+    // the table kernel, the two variable-base products by the scheduler kernel -- one after the other on the ctx stream
+    // work area: s*a (32 n), from_affine(P) (128 n), e*P (128 n), R + e*P (128 n)
+    char* work = static_cast<char*>(scratch_for(ctx, ctx->stream, n * (32 + 3 * pb)));
+    if (!work) return FEC_E_OOM;
+    u32* sa = reinterpret_cast<u32*>(work);
+    u32* pp = reinterpret_cast<u32*>(work + n * 32);
+    u32* ep = reinterpret_cast<u32*>(work + n * (32 + pb));
+    u32* qq = reinterpret_cast<u32*>(work + n * (32 + 2 * pb));
+    const dim3 g(grid_for(n)), b(TPB);
+    {
+      Launch L(ctx, nullptr, "k_schnorr_pre");
+      hipLaunchKernelGGL((k_schnorr_pre<Ed>), g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3], sa, pp, d_wrapped, n);
+      rc = L.done();
+      if (rc != FEC_OK) return rc;
+    }
+    rc = launch_ed_fixed(ctx, (const u64*)sa, ctx->d_gen[FEC_ED25519], ctx->h_gen_ed, (u64*)ctx->d_buf[5], n, nullptr);   // A_i (266-268)
+    if (rc != FEC_OK) return rc;
+    {
+      Launch L(ctx, nullptr, "k_schnorr_pre + k_ed_fixed_base + k_ed_mul_pers x2 + k_schnorr_mid");
+      const SchedEnv env = sched_env(ctx);
+      ed_launch_mul(env, (const u32*)ctx->d_buf[4], pp, ep, n, L.s);                                                        // e_i P_i (276)
+      hipLaunchKernelGGL((k_schnorr_mid<Ed>), g, b, 0, L.s, (const u32*)ctx->d_buf[1], (const u32*)ep, qq, n);
+      ed_launch_mul(env, (const u32*)ctx->d_buf[3], qq, (u32*)ctx->d_buf[6], n, L.s);                                       // B_i (282)
+      rc = L.done();
+      if (rc != FEC_OK) return rc;
+    }
+  } else {
     // work area: s*a (32 n), from_affine(P) (96 n), e*P (96 n), R + e*P (96 n)
     char* work = static_cast<char*>(scratch_for(ctx, ctx->stream, n * 320));
     if (!work) return FEC_E_OOM;
@@ -2032,8 +2094,8 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
       if (secp) secp_launch_mul(e, fixed, k, p, o, n, st);
       else p256_launch_mul(e, fixed, k, p, o, n, st);
     };
-    if (secp) hipLaunchKernelGGL((k_schnorr_pre<Secp>), g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3], sa, pp, n);
-    else hipLaunchKernelGGL((k_schnorr_pre<P256>), g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3], sa, pp, n);
+    if (secp) hipLaunchKernelGGL((k_schnorr_pre<Secp>), g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3], sa, pp, (unsigned char*)nullptr, n);
+    else hipLaunchKernelGGL((k_schnorr_pre<P256>), g, b, 0, L.s, (const u32*)ctx->d_buf[0], (const u32*)ctx->d_buf[2], (const u32*)ctx->d_buf[3], sa, pp, (unsigned char*)nullptr, n);
     // the A terms do not depend on the B chain: they run on the ctx's second stream beside it (at the moderate n
     // this entry point is meant for, a launch fills a fraction of the chip and is bound by one ladder's latency)
     hipEvent_t ev_pre = nullptr, ev_a = nullptr;
@@ -2062,13 +2124,17 @@ int schnorr_batch_verify(fec_ctx* ctx, int curve, const uint64_t* pk_xy, const u
     if (rc != FEC_OK) return rc;
   }
   if (secp) hipLaunchKernelGGL((k_schnorr_fold_compare<Secp>), dim3(2), dim3(64), 0, ctx->stream, (const u32*)ctx->d_buf[5], (const u32*)ctx->d_buf[6], d_sums, d_sides, d_flags, d_done, n);
+  else if (edw) hipLaunchKernelGGL((k_schnorr_fold_compare<Ed>), dim3(2), dim3(64), 0, ctx->stream, (const u32*)ctx->d_buf[5], (const u32*)ctx->d_buf[6], d_sums, d_sides, d_flags, d_done, n);
   else hipLaunchKernelGGL((k_schnorr_fold_compare<P256>), dim3(2), dim3(64), 0, ctx->stream, (const u32*)ctx->d_buf[5], (const u32*)ctx->d_buf[6], d_sums, d_sides, d_flags, d_done, n);
   if (hipGetLastError() != hipSuccess) return FEC_E_LAUNCH;
-  if (hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+  if (hipMemcpyAsync(flags + 4, d_wrapped, 1, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return FEC_E_DEVICE;
+  if (hipMemcpyAsync(flags, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipMemcpyAsync(sides, d_sides, 128, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
     return FEC_E_DEVICE;
   if (int rc_sync = sync_and_check(ctx, ctx->stream)) return rc_sync;
   *result = flags[0];
+  if (debug_build_panics) *debug_build_panics = flags[4];
+  if (flags[0] == 2) return FEC_OK;   // (the reference panics in to_affine: no sides)
   if (sides_xy) std::memcpy(sides_xy, sides, 128);
   if (sides_inf) { sides_inf[0] = flags[1]; sides_inf[1] = flags[2]; }
   return FEC_OK;
@@ -2087,6 +2153,13 @@ int fec_schnorr_batch_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_x
                              const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s, const uint64_t* a,
                              const uint64_t* e, size_t n, uint8_t* result, uint64_t* sides_xy, uint8_t* sides_inf) try {
   return schnorr_batch_verify(ctx, curve, pk_xy, pk_inf, r_xy, r_inf, s, a, e, n, result, sides_xy, sides_inf);
+} FEC_ABI_CATCH_STATUS
+
+int fec_schnorr_batch_verify_ed25519(fec_ctx* ctx, const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* r_xy,
+                                     const uint8_t* r_inf, const uint64_t* s, const uint64_t* a, const uint64_t* e, size_t n,
+                                     uint8_t* result, uint64_t* sides_xy, uint8_t* sides_inf, uint8_t* debug_build_panics) try {
+  return schnorr_batch_verify(ctx, FEC_ED25519, pk_xy, pk_inf, r_xy, r_inf, s, a, e, n, result, sides_xy, sides_inf,
+                              debug_build_panics);
 } FEC_ABI_CATCH_STATUS
 
 int fec_batch_compress_dev(fec_ctx* ctx, fec_curve curve, const uint64_t* d_xy, const uint8_t* d_inf,

@@ -315,7 +315,8 @@ class Context:
         return bool(res[0]), sides, sinf
 
     def schnorr_batch_verify(self, curve, pk_xy, r_xy, s, a, e, pk_inf=None, r_inf=None):
-        """schnorr::batch_verify::<C, D> (schnorr.rs:194-290) for curve = SECP256K1 or P256; as the secp256k1 form."""
+        """schnorr::batch_verify::<C, D> (schnorr.rs:194-290) for any curve; as the secp256k1 form.  (ED25519: the release
+        profile's behaviour; schnorr_batch_verify_ed25519 also says whether a debug build would have panicked.)"""
         pk, rr = _u64(pk_xy, 8), _u64(r_xy, 8)
         ss, aa, ee = _u64(s, 4), _u64(a, 4), _u64(e, 4)
         n = ss.shape[0]
@@ -332,6 +333,29 @@ class Context:
         _check(self._lib.fec_schnorr_batch_verify(self._h, curve, _ptr(pk), _ptr(pi), _ptr(rr), _ptr(ri), _ptr(ss), _ptr(aa),
                                                   _ptr(ee), n, _ptr(res), _ptr(sides), _ptr(sinf)), "fec_schnorr_batch_verify")
         return bool(res[0]), sides, sinf
+
+    def schnorr_batch_verify_ed25519(self, pk_xy, r_xy, s, a, e, pk_inf=None, r_inf=None):
+        """fec_schnorr_batch_verify_ed25519: schnorr::batch_verify::<Ed25519, D> with the scalar Mul as the reference's
+        RELEASE profile runs it (u128 sums wrap).  -> (result 0 / 1 / 2 = the reference panics in to_affine, sides (16,),
+        sides_inf (2,), debug_build_panics: a debug build panics on these inputs instead)."""
+        pk, rr = _u64(pk_xy, 8), _u64(r_xy, 8)
+        ss, aa, ee = _u64(s, 4), _u64(a, 4), _u64(e, 4)
+        n = ss.shape[0]
+        if not (pk.shape[0] == rr.shape[0] == aa.shape[0] == ee.shape[0] == n):
+            raise ValueError("inputs differ in length")
+        pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)).reshape(-1) if pk_inf is not None else None
+        ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)).reshape(-1) if r_inf is not None else None
+        for flags in (pi, ri):
+            if flags is not None and flags.shape[0] != n:
+                raise ValueError("infinity flags and the signatures differ in length")
+        res = np.zeros(1, dtype=np.uint8)
+        sides = np.zeros(16, dtype=np.uint64)
+        sinf = np.zeros(2, dtype=np.uint8)
+        dbg = np.zeros(1, dtype=np.uint8)
+        _check(self._lib.fec_schnorr_batch_verify_ed25519(self._h, _ptr(pk), _ptr(pi), _ptr(rr), _ptr(ri), _ptr(ss), _ptr(aa),
+                                                          _ptr(ee), n, _ptr(res), _ptr(sides), _ptr(sinf), _ptr(dbg)),
+               "fec_schnorr_batch_verify_ed25519")
+        return int(res[0]), sides, sinf, bool(dbg[0])
 
     def schnorr_verify(self, curve, pk_xy, r_xy, s, e, pk_inf=None, r_inf=None):
         """Schnorr::<C, D>::verify per signature (schnorr.rs:90-140) from the point computation on, the challenges

@@ -42,7 +42,8 @@
  *                         CompressedPoint::from_affine builds, point.rs:38-67), with each curve's
  *                         FieldElement::to_bytes (secp256k1.rs:138-178, p256.rs:288-300, ed25519.rs:295-310)
  *   fec_schnorr_verify    Schnorr::<C, D>::verify per signature after the hash (forge-ec-signature/src/schnorr.rs:90-140)
- *   fec_schnorr_batch_verify   schnorr::batch_verify::<C, D> for C = Secp256k1 / P256 (194-290)
+ *   fec_schnorr_batch_verify   schnorr::batch_verify::<C, D> for C = Secp256k1 / P256 / Ed25519 (194-290; Ed25519 with its
+ *                         Scalar Mul as the release profile runs it, ed25519.rs:1256-1376: fec_schnorr_batch_verify_ed25519)
  *   fec_schnorr_batch_verify_secp256k1   schnorr::batch_verify::<Secp256k1, D> (forge-ec-signature/src/
  *                         schnorr.rs:194-290): the 3n scalar multiplications in parallel, then the two
  *                         strictly sequential `+=` folds (268, 281) and the affine comparison (286).
@@ -265,12 +266,25 @@ int fec_schnorr_batch_verify_secp256k1(fec_ctx* ctx, const uint64_t* pk_xy, cons
                                        const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s,
                                        const uint64_t* a, const uint64_t* e, size_t n, uint8_t* result,
                                        uint64_t* sides_xy, uint8_t* sides_inf);
-/* The same for curve = FEC_SECP256K1 or FEC_P256 (schnorr::batch_verify is generic over C: Curve, schnorr.rs:194; the
- * P-256 instance uses that curve's point arithmetic and its Scalar Mul, p256.rs:1409-1432).  FEC_ED25519:
- * FEC_E_UNSUPPORTED (its scalar Mul is not restated). */
+/* The same for any curve (schnorr::batch_verify is generic over C: Curve, schnorr.rs:194; the P-256 instance uses that
+ * curve's point arithmetic and its Scalar Mul, p256.rs:1409-1432; FEC_ED25519: see fec_schnorr_batch_verify_ed25519,
+ * which this calls without the extra flag -- *result may then also be 2). */
 int fec_schnorr_batch_verify(fec_ctx* ctx, fec_curve curve, const uint64_t* pk_xy, const uint8_t* pk_inf,
                              const uint64_t* r_xy, const uint8_t* r_inf, const uint64_t* s, const uint64_t* a,
                              const uint64_t* e, size_t n, uint8_t* result, uint64_t* sides_xy, uint8_t* sides_inf);
+/* schnorr::batch_verify::<Ed25519, D>.  The `s_i * a_i` of line 264 is Ed25519's `impl Mul for Scalar`
+ * (ed25519.rs:1256-1376), which sums up to four 128-bit products -- and then a carry -- into a u128 without widening
+ * (1268-1272, 1278).  What happens when such a sum passes 2^128 depends on the build profile: with overflow checks (a
+ * debug build) it panics, under the reference's release profile (/root/reference/Cargo.toml:53-58, no `overflow-checks`:
+ * the profile whose CPU throughput BASELINE times) it wraps modulo 2^128 and the function carries on -- for full-size
+ * scalars that is the usual case, not a corner.  This entry point reproduces the RELEASE behaviour and says when the two
+ * differ: *debug_build_panics (1 byte, may be NULL) = 1 when, for at least one signature, one of those sums wrapped --
+ * a debug build would have panicked at the first such signature instead of returning *result.
+ * *result: 1 true, 0 false, 2 = the reference panics in BOTH profiles (286: to_affine unwraps the inverse of a zero z
+ * of a point that is not the identity, ed25519.rs:1805; sides stay zero).  Other arguments as above. */
+int fec_schnorr_batch_verify_ed25519(fec_ctx* ctx, const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* r_xy,
+                                     const uint8_t* r_inf, const uint64_t* s, const uint64_t* a, const uint64_t* e, size_t n,
+                                     uint8_t* result, uint64_t* sides_xy, uint8_t* sides_inf, uint8_t* debug_build_panics);
 /* Schnorr::<C, D>::verify per signature (forge-ec-signature/src/schnorr.rs:90-140), all three curves, from the point
  * computation on: the caller keeps the two message special cases (92-99) and hashes -- e = from_bytes_reduced(H(R || P
  * || m)), 107-123, raw limbs.  status[i] = 1 true, 0 false, 2 where the reference panics (Ed25519 only: to_affine

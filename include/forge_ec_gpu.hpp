@@ -317,6 +317,27 @@ inline bool batch_verify(GpuContext& ctx, const std::vector<AffinePoint<FEC_SECP
 // (CtOption::unwrap on None) on this input.
 enum class Verify : uint8_t { False = 0, True = 1, ReferencePanics = 2 };
 
+namespace schnorr {
+// schnorr::batch_verify::<Ed25519, D> (fec_schnorr_batch_verify_ed25519): the verdict under the reference's RELEASE
+// profile (its scalar Mul's u128 sums wrap), and whether a debug build -- overflow checks on -- would have panicked on
+// these inputs instead.  Raw arrays as the C ABI takes them: x, y limbs per point, Scalar::to_raw() limbs per scalar.
+struct Ed25519BatchVerdict {
+  Verify result;
+  bool debug_build_panics;
+};
+inline Ed25519BatchVerdict batch_verify_ed25519(GpuContext& ctx, const std::vector<uint64_t>& pk_xy, const std::vector<uint64_t>& r_xy,
+                                                const std::vector<uint64_t>& s, const std::vector<uint64_t>& weights,
+                                                const std::vector<uint64_t>& challenges) {
+  const size_t n = s.size() / 4;
+  if (pk_xy.size() != n * 8 || r_xy.size() != n * 8 || weights.size() != n * 4 || challenges.size() != n * 4) throw Error(FEC_E_ARG);
+  uint8_t result = 0, dbg = 0;
+  int rc = fec_schnorr_batch_verify_ed25519(ctx.raw(), pk_xy.data(), nullptr, r_xy.data(), nullptr, s.data(), weights.data(),
+                                            challenges.data(), n, &result, nullptr, nullptr, &dbg);
+  if (rc != FEC_OK) throw Error(rc);
+  return {static_cast<Verify>(result), dbg != 0};
+}
+}  // namespace schnorr
+
 namespace detail {
 template <fec_curve C>
 inline void pack_affine(const std::vector<AffinePoint<C>>& pts, std::vector<uint64_t>& xy, std::vector<uint8_t>& inf) {

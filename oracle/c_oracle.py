@@ -86,6 +86,10 @@ def lib():
         L.fo_secp256k1_schnorr_batch_verify.restype = ctypes.c_int
         L.fo_p256_schnorr_batch_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, p, p]
         L.fo_p256_schnorr_batch_verify.restype = ctypes.c_int
+        L.fo_ed25519_schnorr_batch_verify.argtypes = [p, p, p, p, p, p, p, ctypes.c_size_t, p, p, p]
+        L.fo_ed25519_schnorr_batch_verify.restype = ctypes.c_int
+        L.fo_ed25519_scalar_mul_release.argtypes = [p, p, p]
+        L.fo_ed25519_scalar_mul_release.restype = ctypes.c_int
         L.fo_batch_schnorr_verify.argtypes = [ctypes.c_int, p, p, p, p, p, p, p, ctypes.c_size_t, ctypes.c_int]
         L.fo_batch_schnorr_verify.restype = None
         L.fo_batch_compress.argtypes = [ctypes.c_int, p, p, p, ctypes.c_size_t]
@@ -391,6 +395,30 @@ def schnorr_batch_verify(curve, pk_xy, pk_inf, r_xy, r_inf, s, a, e):
                                             _ptr(ri) if ri is not None else None, _ptr(s), _ptr(a), _ptr(e), n,
                                             _ptr(sides), _ptr(sinf))
     return rc, sides, sinf
+
+
+def ed25519_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e):
+    """schnorr::batch_verify::<Ed25519, D> under the release profile (wrapping u128 sums in the scalar Mul):
+    -> (result 0 / 1 / 2 = the reference panics in to_affine, sides (16,), sides_inf (2,), debug_build_panics 0 / 1)."""
+    pk_xy, r_xy, s, a, e = _u64(pk_xy), _u64(r_xy), _u64(s), _u64(a), _u64(e)
+    n = s.size // 4
+    pi = np.ascontiguousarray(np.asarray(pk_inf, dtype=np.uint8)) if pk_inf is not None else None
+    ri = np.ascontiguousarray(np.asarray(r_inf, dtype=np.uint8)) if r_inf is not None else None
+    sides = np.zeros(16, dtype=np.uint64)
+    sinf = np.zeros(2, dtype=np.uint8)
+    dbg = np.zeros(1, dtype=np.uint8)
+    rc = lib().fo_ed25519_schnorr_batch_verify(_ptr(pk_xy), _ptr(pi) if pi is not None else None, _ptr(r_xy),
+                                               _ptr(ri) if ri is not None else None, _ptr(s), _ptr(a), _ptr(e), n,
+                                               _ptr(sides), _ptr(sinf), _ptr(dbg))
+    return rc, sides, sinf, int(dbg[0])
+
+
+def ed25519_scalar_mul_release(a, b):
+    """impl Mul for Scalar (ed25519.rs:1256-1376), release profile: -> (product (4,) uint64, overflowed 0 / 1)."""
+    a, b = _u64(a), _u64(b)
+    out = np.zeros(4, dtype=np.uint64)
+    ovf = lib().fo_ed25519_scalar_mul_release(_ptr(a), _ptr(b), _ptr(out))
+    return out, int(ovf)
 
 
 def batch_schnorr_verify(curve, pk_xy, pk_inf, r_xy, r_inf, s, e, nthreads=1):

@@ -1488,6 +1488,112 @@ void fo_batch_secp256k1_ecdsa_verify(const unsigned char* digests, const u64* r,
   for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
 }
 
+/* ---- Ed25519 Scalar arithmetic for schnorr::batch_verify::<Ed25519, D> (schnorr.rs:264: signatures[i].s * a[i]) ----
+ * impl Add for Scalar, ed25519.rs:1193-1239: the 256-bit sum (the carry out of the top limb is dropped), one
+ * conditional subtraction of ORDER. */
+static const u64 ES_ORDER[4] = {0x5812631A5CF5D3EDULL, 0x14DEF9DEA2F79CD6ULL, 0ULL, 0x1000000000000000ULL};
+static int es_ge_order(const u64 r[4]) {                     /* the loops at 1215-1226, 1303-1312, 1354-1363 */
+  for (int i = 3; i >= 0; --i) {
+    if (r[i] < ES_ORDER[i]) return 0;
+    if (r[i] > ES_ORDER[i]) return 1;
+  }
+  return 1;
+}
+static void es_sub_order(u64 r[4]) {                         /* 1229-1236, 1365-1372 */
+  u64 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    const __int128 diff = (__int128)r[i] - (__int128)ES_ORDER[i] - (__int128)borrow;
+    r[i] = (u64)diff;
+    borrow = diff < 0 ? 1 : 0;
+  }
+}
+static void es_add(const u64 a[4], const u64 b[4], u64 out[4]) {
+  u64 r[4], carry = 0;
+  for (int i = 0; i < 4; ++i) {
+    const u128 sum = (u128)a[i] + (u128)b[i] + (u128)carry;
+    r[i] = (u64)sum;
+    carry = (u64)(sum >> 64);
+  }
+  if (es_ge_order(r)) es_sub_order(r);
+  memcpy(out, r, sizeof r);
+}
+/* impl Mul for Scalar, ed25519.rs:1256-1376, AS THE RELEASE PROFILE RUNS IT: /root/reference/Cargo.toml:53-58
+ * ([profile.release]: opt-level 3, thin lto, codegen-units 1 -- no `overflow-checks` key, so u128 `+=` wraps; a debug
+ * build panics instead).  1268-1272 sum up to four 128-bit products into a u128 and 1278 adds the carry on top: both can
+ * pass 2^128.  *overflowed = 1 when one of those additions wrapped (the operands on which a debug build panics). */
+static void es_mul_release(const u64 a[4], const u64 b[4], u64 out[4], int* overflowed) {
+  u128 product[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int ovf = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const u128 term = (u128)a[i] * (u128)b[j];
+      const u128 sum = product[i + j] + term;                /* wraps modulo 2^128 */
+      if (sum < term) ovf = 1;
+      product[i + j] = sum;
+    }
+  u128 carry = 0;
+  for (int i = 0; i < 8; ++i) {
+    const u128 sum = product[i] + carry;
+    if (sum < carry) ovf = 1;
+    carry = sum >> 64;
+    product[i] = sum & (u128)0xFFFFFFFFFFFFFFFFULL;
+  }
+  if (overflowed) *overflowed = ovf;
+  u64 result[4], high[4];
+  for (int i = 0; i < 4; ++i) { result[i] = (u64)product[i]; high[i] = (u64)product[i + 4]; }
+  const int high_nonzero = (high[0] | high[1] | high[2] | high[3]) != 0;
+  if (high_nonzero || es_ge_order(result)) {                 /* 1299-1316 */
+    if (high_nonzero)
+      for (int k = 0; k < 256; ++k) es_add(result, high, result);   /* 1347-1349: result += high_bits, 256 times */
+    if (es_ge_order(result)) es_sub_order(result);           /* 1352-1373 */
+  }
+  memcpy(out, result, sizeof result);
+}
+int fo_ed25519_scalar_mul_release(const u64 a[4], const u64 b[4], u64 out[4]) {
+  int ovf = 0;
+  es_mul_release(a, b, out, &ovf);
+  return ovf;
+}
+
+/* schnorr::batch_verify::<Ed25519, D> (schnorr.rs:194-290), release profile.  Arguments as for the two functions
+ * below; 1 true, 0 false, 2 = the reference panics in to_affine (286: z.invert().unwrap() on a zero z of a point that
+ * is not the identity, ed25519.rs:1805).  *debug_build_panics (optional) = 1 when some s_i * a_i wrapped a u128. */
+int fo_ed25519_schnorr_batch_verify(const u64* pk_xy, const uint8_t* pk_inf, const u64* r_xy, const uint8_t* r_inf,
+                                    const u64* s, const u64* a, const u64* e, size_t n, u64* sides, uint8_t* sides_inf,
+                                    uint8_t* debug_build_panics) {
+  if (sides) memset(sides, 0, 16 * sizeof(u64));
+  if (sides_inf) sides_inf[0] = sides_inf[1] = 0;
+  if (debug_build_panics) *debug_build_panics = 0;
+  if (n == 0) return 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (pk_inf && pk_inf[i]) return 0;
+    if (r_inf && r_inf[i]) return 0;
+  }
+  ept g = e_generator();
+  ept s_g = e_identity(), r_e_p = e_identity();
+  for (size_t i = 0; i < n; ++i) {
+    u64 sa[4];
+    int ovf = 0;
+    es_mul_release(s + 4 * i, a + 4 * i, sa, &ovf);
+    if (ovf && debug_build_panics) *debug_build_panics = 1;
+    ept t = e_multiply(&g, sa);
+    s_g = e_padd(&s_g, &t);
+    ept P = e_from_affine(pk_xy + 8 * i, 0);
+    ept ep = e_multiply(&P, e + 4 * i);
+    ept R = e_from_affine(r_xy + 8 * i, 0);
+    ept rp = e_padd(&R, &ep);
+    ept arp = e_multiply(&rp, a + 4 * i);
+    r_e_p = e_padd(&r_e_p, &arp);
+  }
+  if (!e_is_identity(&s_g) && fe_is_zero(&s_g.z)) return 2;      /* to_affine(s_g) is evaluated first */
+  if (!e_is_identity(&r_e_p) && fe_is_zero(&r_e_p.z)) return 2;
+  fe x1, y1, x2, y2;
+  int i1 = e_to_affine(&s_g, &x1, &y1), i2 = e_to_affine(&r_e_p, &x2, &y2);
+  if (sides) { st(sides, x1); st(sides + 4, y1); st(sides + 8, x2); st(sides + 12, y2); }
+  if (sides_inf) { sides_inf[0] = (uint8_t)i1; sides_inf[1] = (uint8_t)i2; }
+  return (fe_eq(&x1, &x2) && fe_eq(&y1, &y2)) || (i1 && i2);     /* AffinePoint::ct_eq 1759-1763 */
+}
+
 /* forge-ec-signature/src/schnorr.rs:194-290  schnorr::batch_verify::<Secp256k1, D>, with the
  * per-signature challenges e_i = from_bytes_reduced(H(R || P || m)) (236-256) and the random
  * weights a_i (228-233, OsRng) supplied by the caller as raw scalar limbs.

@@ -110,6 +110,14 @@ int fo_secp256k1_schnorr_batch_verify(const uint64_t* pk_xy, const uint8_t* pk_i
 int fo_p256_schnorr_batch_verify(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* r_xy,
                                  const uint8_t* r_inf, const uint64_t* s, const uint64_t* a,
                                  const uint64_t* e, size_t n, uint64_t* sides, uint8_t* sides_inf);
+/* the same for C = Ed25519 with the RELEASE-profile scalar Mul (ed25519.rs:1256-1376: u128 sums wrap; Cargo.toml:53-58);
+ * 2 = the reference panics in to_affine; *debug_build_panics (optional) = 1 when some s_i * a_i wrapped a u128, i.e. a
+ * debug build (overflow checks on) panics on these inputs */
+int fo_ed25519_schnorr_batch_verify(const uint64_t* pk_xy, const uint8_t* pk_inf, const uint64_t* r_xy,
+                                    const uint8_t* r_inf, const uint64_t* s, const uint64_t* a, const uint64_t* e,
+                                    size_t n, uint64_t* sides, uint8_t* sides_inf, uint8_t* debug_build_panics);
+/* impl Mul for Scalar (Ed25519) under the release profile: out = a * b, returns 1 when a u128 sum wrapped */
+int fo_ed25519_scalar_mul_release(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 /* Schnorr::<C, D>::verify per signature (schnorr.rs:90-140) from the point computation on, curve 0 / 1 / 2:
  * 1 true, 0 false, 2 = the reference panics (Ed25519 only); e = from_bytes_reduced(hash) supplied */
 int fo_schnorr_verify(int curve, const uint64_t pk_xy[8], int pk_inf, const uint64_t r_xy[8], int r_inf,

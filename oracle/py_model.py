@@ -1082,6 +1082,101 @@ def p256_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e):
     return (1 if ok else 0), [x1, y1, x2, y2], [int(i1), int(i2)]
 
 
+class Ed25519Scalar:
+    """ed25519.rs Scalar: Add (1193-1239) and Mul (1256-1376) as the RELEASE profile runs them (the reference's
+    Cargo.toml:53-58 sets no overflow-checks: u128 `+=` wraps modulo 2^128 where a debug build panics)."""
+    ORDER = [0x5812631A5CF5D3ED, 0x14DEF9DEA2F79CD6, 0, 0x1000000000000000]
+
+    @staticmethod
+    def ge_order(r):  # the loops at 1215-1226 / 1303-1312 / 1354-1363
+        for i in (3, 2, 1, 0):
+            if r[i] < Ed25519Scalar.ORDER[i]:
+                return False
+            if r[i] > Ed25519Scalar.ORDER[i]:
+                return True
+        return True
+
+    @staticmethod
+    def sub_order(r):  # 1229-1236: limb-wise with a borrow, `diff as u64`
+        out, borrow = [], 0
+        for i in range(4):
+            diff = r[i] - Ed25519Scalar.ORDER[i] - borrow
+            out.append(diff & M64)
+            borrow = 1 if diff < 0 else 0
+        return out
+
+    @staticmethod
+    def add(a, b):
+        r, carry = [], 0
+        for i in range(4):
+            total = a[i] + b[i] + carry
+            r.append(total & M64)
+            carry = total >> 64
+        return Ed25519Scalar.sub_order(r) if Ed25519Scalar.ge_order(r) else r   # (the last carry is dropped)
+
+    @staticmethod
+    def mul_release(a, b):
+        """-> (product limbs, overflowed): overflowed = some u128 sum of 1268-1272 / 1278 passed 2^128."""
+        m128 = (1 << 128) - 1
+        product, ovf = [0] * 8, False
+        for i in range(4):
+            for j in range(4):
+                total = product[i + j] + a[i] * b[j]
+                ovf = ovf or total > m128
+                product[i + j] = total & m128
+        carry = 0
+        for i in range(8):
+            total = product[i] + carry
+            ovf = ovf or total > m128
+            total &= m128
+            carry = total >> 64
+            product[i] = total & M64
+        result, high = product[0:4], product[4:8]
+        if any(high) or Ed25519Scalar.ge_order(result):
+            if any(high):
+                for _ in range(256):                      # 1347-1349: result += high_bits
+                    result = Ed25519Scalar.add(result, high)
+            if Ed25519Scalar.ge_order(result):
+                result = Ed25519Scalar.sub_order(result)
+        return result, ovf
+
+
+def ed25519_schnorr_batch_verify(pk_xy, pk_inf, r_xy, r_inf, s, a, e):
+    """schnorr.rs:194-290 for C = Ed25519 under the release profile.  -> (result, sides, sides_inf, debug_build_panics):
+    result 1 true / 0 false / 2 = the reference panics in to_affine (ed25519.rs:1805); debug_build_panics = some
+    s_i * a_i wrapped a u128 sum."""
+    F = Ed
+    n = len(s)
+    zero = [0, 0, 0, 0]
+    if n == 0:
+        return 0, [zero] * 4, [0, 0], 0
+    for i in range(n):
+        if (pk_inf is not None and pk_inf[i]) or (r_inf is not None and r_inf[i]):
+            return 0, [zero] * 4, [0, 0], 0
+
+    def from_affine(xy):  # 1813-1826 (the identities were rejected above)
+        x, y = list(xy[0:4]), list(xy[4:8])
+        return (x, y, [1, 0, 0, 0], F.mul(x, y))
+
+    g = F.generator()
+    s_g, r_e_p = F.identity(), F.identity()
+    panics = 0
+    for i in range(n):
+        sa, ovf = Ed25519Scalar.mul_release(list(s[i]), list(a[i]))
+        panics |= int(ovf)
+        s_g = F.padd(s_g, F.multiply(g, sa))
+        ep = F.multiply(from_affine(pk_xy[i]), list(e[i]))
+        rp = F.padd(from_affine(r_xy[i]), ep)
+        r_e_p = F.padd(r_e_p, F.multiply(rp, list(a[i])))
+    for p in (s_g, r_e_p):
+        if not F.is_identity(p) and _is_zero(p[2]):
+            return 2, [zero] * 4, [0, 0], panics
+    x1, y1, i1 = F.to_affine(s_g)
+    x2, y2, i2 = F.to_affine(r_e_p)
+    ok = (x1 == x2 and y1 == y2) or (i1 and i2)
+    return (1 if ok else 0), [x1, y1, x2, y2], [int(i1), int(i2)], panics
+
+
 def schnorr_verify(curve, pk_xy, pk_inf, r_xy, r_inf, s, e):
     """Schnorr::<C, D>::verify (forge-ec-signature/src/schnorr.rs:90-140) from line 125 on, the challenge
     e = from_bytes_reduced(H(R || P || m)) given.  1 true, 0 false, 2 = the reference panics (Ed25519's to_affine

@@ -55,6 +55,7 @@ extern "C" {
     fn fec_batch_decode_uncompressed(ctx: *mut FecCtx, curve: c_int, r#in: *const u8, xy: *mut u64, inf: *mut u8, ok: *mut u8, n: usize) -> c_int;
     fn fec_schnorr_batch_verify_secp256k1(ctx: *mut FecCtx, pk_xy: *const u64, pk_inf: *const u8, r_xy: *const u64, r_inf: *const u8, s: *const u64, a: *const u64, e: *const u64, n: usize, result: *mut u8, sides_xy: *mut u64, sides_inf: *mut u8) -> c_int;
     fn fec_schnorr_batch_verify(ctx: *mut FecCtx, curve: c_int, pk_xy: *const u64, pk_inf: *const u8, r_xy: *const u64, r_inf: *const u8, s: *const u64, a: *const u64, e: *const u64, n: usize, result: *mut u8, sides_xy: *mut u64, sides_inf: *mut u8) -> c_int;
+    fn fec_schnorr_batch_verify_ed25519(ctx: *mut FecCtx, pk_xy: *const u64, pk_inf: *const u8, r_xy: *const u64, r_inf: *const u8, s: *const u64, a: *const u64, e: *const u64, n: usize, result: *mut u8, sides_xy: *mut u64, sides_inf: *mut u8, debug_build_panics: *mut u8) -> c_int;
     fn fec_schnorr_verify(ctx: *mut FecCtx, curve: c_int, pk_xy: *const u64, pk_inf: *const u8, r_xy: *const u64, r_inf: *const u8, s: *const u64, e: *const u64, status: *mut u8, n: usize) -> c_int;
     fn fec_field_op(ctx: *mut FecCtx, curve: c_int, op: c_int, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
     fn fec_point_op(ctx: *mut FecCtx, curve: c_int, op: c_int, p: *const u64, q: *const u64, out: *mut u64, n: usize) -> c_int;
@@ -638,7 +639,8 @@ fn marshal_affine<C: GpuCurve>(pts: &[C::PointAffine]) -> (Vec<u64>, Vec<u8>) {
 }
 
 /// `schnorr::batch_verify::<C, D>` for `C` = `Secp256k1` or `P256` (`forge-ec-signature/src/schnorr.rs:194-290`,
-/// generic over the curve): as [`schnorr_batch_verify_secp256k1`].  `Ed25519` -> `UnsupportedOperation`.
+/// generic over the curve): as [`schnorr_batch_verify_secp256k1`].  `Ed25519`: the release profile's behaviour, see
+/// [`schnorr_batch_verify_ed25519`].
 pub fn schnorr_batch_verify<C: GpuCurve>(ctx: &mut GpuContext, public_keys: &[C::PointAffine], sig_r: &[C::PointAffine], sig_s: &[C::Scalar], a: &[C::Scalar], e: &[C::Scalar]) -> Result<bool> {
     let n = public_keys.len();
     if sig_r.len() != n || sig_s.len() != n || a.len() != n || e.len() != n {
@@ -650,6 +652,23 @@ pub fn schnorr_batch_verify<C: GpuCurve>(ctx: &mut GpuContext, public_keys: &[C:
     // SAFETY: n elements behind every pointer; the two optional outputs are null.
     check(unsafe { fec_schnorr_batch_verify(ctx.raw, C::ID, pk_xy.as_ptr(), pk_inf.as_ptr(), r_xy.as_ptr(), r_inf.as_ptr(), s.as_ptr(), aa.as_ptr(), ee.as_ptr(), n, &mut result, core::ptr::null_mut(), core::ptr::null_mut()) })?;
     Ok(result == 1)
+}
+
+/// `schnorr::batch_verify::<Ed25519, D>` (`fec_schnorr_batch_verify_ed25519`): the verdict under the reference's
+/// release profile (the `u128` sums of Ed25519's scalar `Mul`, ed25519.rs:1268-1278, wrap), and whether a debug build
+/// -- overflow checks on -- would have panicked on these inputs instead.  `VerifyStatus::ReferencePanics` = `to_affine`
+/// unwraps the inverse of a zero `z` (both profiles).
+pub fn schnorr_batch_verify_ed25519(ctx: &mut GpuContext, public_keys: &[ed25519::AffinePoint], sig_r: &[ed25519::AffinePoint], sig_s: &[ed25519::Scalar], a: &[ed25519::Scalar], e: &[ed25519::Scalar]) -> Result<(VerifyStatus, bool)> {
+    let n = public_keys.len();
+    if sig_r.len() != n || sig_s.len() != n || a.len() != n || e.len() != n {
+        return Err(Error::ValidationError);
+    }
+    let ((pk_xy, pk_inf), (r_xy, r_inf)) = (marshal_affine::<ed25519::Ed25519>(public_keys), marshal_affine::<ed25519::Ed25519>(sig_r));
+    let (s, aa, ee) = (pack_scalars::<ed25519::Ed25519>(sig_s), pack_scalars::<ed25519::Ed25519>(a), pack_scalars::<ed25519::Ed25519>(e));
+    let (mut result, mut dbg) = (0u8, 0u8);
+    // SAFETY: n elements behind every pointer; the two optional point outputs are null.
+    check(unsafe { fec_schnorr_batch_verify_ed25519(ctx.raw, pk_xy.as_ptr(), pk_inf.as_ptr(), r_xy.as_ptr(), r_inf.as_ptr(), s.as_ptr(), aa.as_ptr(), ee.as_ptr(), n, &mut result, core::ptr::null_mut(), core::ptr::null_mut(), &mut dbg) })?;
+    Ok((match result { 1 => VerifyStatus::Valid, 2 => VerifyStatus::ReferencePanics, _ => VerifyStatus::Invalid }, dbg != 0))
 }
 
 /// `Schnorr::<C, D>::verify` per signature (`forge-ec-signature/src/schnorr.rs:90-140`) from the point computation

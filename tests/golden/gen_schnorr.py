@@ -3,7 +3,11 @@ Generates tests/golden/schnorr_vectors.json: fixtures for
   * Schnorr::<C, D>::verify per signature (forge-ec-signature/src/schnorr.rs:90-140) from the point computation on,
     the three curves: public key, signature point, s, the challenge e = from_bytes_reduced(hash), expected status;
   * schnorr::batch_verify::<P256, D> (194-290): keys, signatures, weights a, challenges e, expected boolean and the two
-    affine points line 286 compares,
+    affine points line 286 compares;
+  * Ed25519's `impl Mul for Scalar` (ed25519.rs:1256-1376) as the reference's RELEASE profile runs it (u128 sums wrap;
+    /root/reference/Cargo.toml:53-58 has no overflow-checks) with the flag "a debug build panics on these operands" --
+    including the products the reference's own tests assert (2250-2253: 1 * 2 = 2; 2303, 2309, 2315: a * 1, a * b = b * a,
+    (a * b) * c = a * (b * c) for 1, 2, 3) -- and schnorr::batch_verify::<Ed25519, D> on top of it,
 from the independent Python model oracle/py_model.py (restatement-derived; not reference-executed: no rustc here, and
 the reference's own tests call these functions only through its hard-coded "test message" shortcuts).
 
@@ -115,11 +119,57 @@ def main():
         res, sides, sinf = M.p256_schnorr_batch_verify(pk, None, r, None, s, a, e)
         out["batch_p256"].append({"pk": pk, "r": r, "s": s, "a": a, "e": e, "result": res,
                                   "sides": [list(v) for v in sides], "sides_inf": sinf})
+    # ---- Ed25519: the scalar Mul under the release profile, and batch_verify::<Ed25519, D> (own generator state: the
+    # sections above stay byte-identical) ----
+    rng2 = random.Random(0xED25519)
+    S = M.Ed25519Scalar
+    out["scalar_mul_ed25519"] = []
+    ones = (1 << 64) - 1
+    pairs = [([1, 0, 0, 0], [2, 0, 0, 0], "ed25519.rs:2250-2253 asserts 1 * 2 == 2"),
+             ([1, 0, 0, 0], [1, 0, 0, 0], "ed25519.rs:2303 asserts a * one == a (a = 1)"),
+             ([2, 0, 0, 0], [3, 0, 0, 0], "ed25519.rs:2315: (1 * 2) * 3 == 1 * (2 * 3): the inner product 2 * 3"),
+             ([3, 0, 0, 0], [2, 0, 0, 0], "ed25519.rs:2309: commutativity, 3 * 2"),
+             ([0, 0, 0, 0], [ones] * 4, "zero"),
+             ([ones] * 4, [ones] * 4, "all ones: every column sum wraps"),
+             ([ones, ones, 0, 0], [ones, ones, 0, 0], "two full limbs each: column 1 wraps (two products of 2^128 - 2^65 + 1)"),
+             ([ones, 0, 0, 0], [ones, ones, ones, ones], "one limb by four: no column has two products, nothing wraps"),
+             (list(S.ORDER), [1, 0, 0, 0], "the order itself times one: reduced to zero"),
+             ([S.ORDER[0] - 1] + list(S.ORDER[1:]), [1, 0, 0, 0], "order - 1 times one: unchanged")]
+    for _ in range(24):
+        pairs.append((limbs(rng2.randrange(W)), limbs(rng2.randrange(W)), "random 256-bit operands"))
+    for _ in range(8):
+        pairs.append((limbs(rng2.randrange(1 << 120)), limbs(rng2.randrange(1 << 120)), "operands below 2^120: the product fits 256 bits"))
+    for a, b, note in pairs:
+        prod, ovf = S.mul_release(list(a), list(b))
+        out["scalar_mul_ed25519"].append({"a": list(a), "b": list(b), "product": prod, "debug_build_panics": int(ovf), "note": note})
+    assert out["scalar_mul_ed25519"][0]["product"] == [2, 0, 0, 0] and out["scalar_mul_ed25519"][1]["product"] == [1, 0, 0, 0]
+    assert S.mul_release(S.mul_release([1, 0, 0, 0], [2, 0, 0, 0])[0], [3, 0, 0, 0])[0] == S.mul_release([1, 0, 0, 0], S.mul_release([2, 0, 0, 0], [3, 0, 0, 0])[0])[0]
+    out["batch_ed25519"] = []
+
+    def ed8():   # x, y with limbs an Ed25519 FieldElement may hold (top limb below 2^63)
+        return [v & ((1 << 63) - 1) if i % 4 == 3 else v for i, v in enumerate(limbs(rng2.randrange(W)) + limbs(rng2.randrange(W)))]
+
+    for n, kind in ((1, "random"), (3, "random"), (2, "zero weights"), (2, "small scalars"), (6, "random")):
+        pk = [ed8() for _ in range(n)]
+        r = [ed8() for _ in range(n)]
+        if kind == "small scalars":   # s_i * a_i fits one u128 column each: a debug build gets through
+            s_ = [limbs(rng2.randrange(1, 1 << 60)) for _ in range(n)]
+            a = [limbs(rng2.randrange(1, 1 << 60)) for _ in range(n)]
+        else:
+            s_ = [limbs(rng2.randrange(1, 1 << 250)) for _ in range(n)]
+            a = [[0, 0, 0, 0] if kind == "zero weights" else limbs(rng2.randrange(1, 1 << 250)) for _ in range(n)]
+        e = [limbs(rng2.randrange(1, 1 << 250)) for _ in range(n)]
+        res, sides, sinf, dbg = M.ed25519_schnorr_batch_verify(pk, None, r, None, s_, a, e)
+        out["batch_ed25519"].append({"kind": kind, "pk": pk, "r": r, "s": s_, "a": a, "e": e, "result": res,
+                                     "sides": [list(v) for v in sides], "sides_inf": sinf, "debug_build_panics": dbg})
+    assert any(c["debug_build_panics"] for c in out["batch_ed25519"]) and not all(c["debug_build_panics"] for c in out["batch_ed25519"])
     path = os.path.join(HERE, "schnorr_vectors.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=0)
         f.write("\n")
-    print(path, len(out["verify"]), "verify cases,", len(out["batch_p256"]), "batches;",
+    print(path, len(out["verify"]), "verify cases,", len(out["batch_p256"]), "P-256 batches,", len(out["scalar_mul_ed25519"]),
+          "Ed25519 scalar products (%d wrap)," % sum(c["debug_build_panics"] for c in out["scalar_mul_ed25519"]),
+          [(c["kind"], c["result"], c["debug_build_panics"]) for c in out["batch_ed25519"]],
           "statuses:", sorted(set(c["status"] for c in out["verify"])))
 
 

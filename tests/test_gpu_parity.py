@@ -970,10 +970,59 @@ def test_schnorr_batch_verify_p256_matches_oracle(gpu_ctx, oracle):
     pk, r, s, a, e = inputs(33, 950, 0)
     g1, g2 = gpu_ctx.schnorr_batch_verify(0, pk, r, s, a, e), gpu_ctx.schnorr_batch_verify_secp256k1(pk, r, s, a, e)
     assert g1[0] == g2[0] and np.array_equal(g1[1], g2[1]) and np.array_equal(g1[2], g2[2])
-    import forge_ec_amd as F
-    with pytest.raises(F.FecError) as ei:
-        gpu_ctx.schnorr_batch_verify(2, pk, r, s, a, e)
-    assert ei.value.status == -5   # FEC_E_UNSUPPORTED: Ed25519's scalar Mul is not restated
+
+
+def test_schnorr_batch_verify_ed25519_release_profile_matches_oracle(gpu_ctx, oracle):
+    """schnorr::batch_verify::<Ed25519, D> through fec_schnorr_batch_verify_ed25519 (and the generic entry point): the
+    scalar Mul of ed25519.rs:1256-1376 as the reference's RELEASE profile runs it (u128 sums wrap), the verdict, the two
+    affine points of line 286 and the flag "a debug build panics on these inputs" -- the committed fixture (which holds
+    the products the reference's own tests assert), random batches against the C oracle, zero weights, small scalars
+    (no sum wraps: the flag stays clear), infinity flags."""
+    import json
+    import os
+    t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schnorr_vectors.json")))
+    for b in t["batch_ed25519"]:
+        res, sides, sinf, dbg = gpu_ctx.schnorr_batch_verify_ed25519(b["pk"], b["r"], b["s"], b["a"], b["e"])
+        assert res == b["result"] and dbg == bool(b["debug_build_panics"]), b["kind"]
+        assert [int(v) for v in sides] == [v for fe in b["sides"] for v in fe] and list(sinf) == b["sides_inf"], b["kind"]
+    assert {(b["result"], b["debug_build_panics"]) for b in t["batch_ed25519"]} >= {(0, 0), (0, 1), (1, 0)}
+
+    def inputs(n, seed):
+        pk = V.field_elements(2 * n, 2, seed).reshape(n, 8)
+        r = V.field_elements(2 * n, 2, seed + 1).reshape(n, 8)
+        return pk, r, V.scalars(n, 2, seed + 2), V.scalars(n, 2, seed + 3), V.scalars(n, 2, seed + 4)
+
+    for n, seed in ((1, 1900), (5, 1910), (64, 1920), (257, 1930)):
+        pk, r, s, a, e = inputs(n, seed)
+        want, w_sides, w_inf, w_dbg = oracle.ed25519_schnorr_batch_verify(pk, None, r, None, s, a, e)
+        got, sides, sinf, dbg = gpu_ctx.schnorr_batch_verify_ed25519(pk, r, s, a, e)
+        assert got == want and dbg == bool(w_dbg) and np.array_equal(sides, w_sides) and np.array_equal(sinf, w_inf), n
+        if n >= 5:
+            assert dbg and sides.any()    # full-size scalars: some s_i * a_i wraps, a debug build would not get here
+        g2 = gpu_ctx.schnorr_batch_verify(2, pk, r, s, a, e)   # the generic entry point: the same verdict and points
+        assert g2[0] == (got == 1) and np.array_equal(g2[1], sides) and np.array_equal(g2[2], sinf)
+    pk, r, s, a, e = inputs(70, 1940)
+    a[3] = 0
+    e[5] = 0
+    s[7] = 0
+    s[11] = (1 << 64) - 1
+    a[11] = (1 << 64) - 1                      # all-ones operands: every column sum wraps
+    want, w_sides, w_inf, w_dbg = oracle.ed25519_schnorr_batch_verify(pk, None, r, None, s, a, e)
+    got, sides, sinf, dbg = gpu_ctx.schnorr_batch_verify_ed25519(pk, r, s, a, e)
+    assert got == want and dbg == bool(w_dbg) and np.array_equal(sides, w_sides) and np.array_equal(sinf, w_inf)
+    small_s, small_a = s.copy(), a.copy()
+    small_s[:, 1:] = 0
+    small_a[:, 1:] = 0                         # one limb each: one product per column, nothing can wrap
+    want, w_sides, w_inf, w_dbg = oracle.ed25519_schnorr_batch_verify(pk, None, r, None, small_s, small_a, e)
+    got, sides, sinf, dbg = gpu_ctx.schnorr_batch_verify_ed25519(pk, r, small_s, small_a, e)
+    assert not dbg and not w_dbg and got == want and np.array_equal(sides, w_sides)
+    a0 = np.zeros_like(a)
+    got, sides, sinf, dbg = gpu_ctx.schnorr_batch_verify_ed25519(pk, r, s, a0, e)
+    assert got == 1 and list(sinf) == [1, 1] and not sides.any() and not dbg
+    inf = np.zeros(70, dtype=np.uint8)
+    inf[0] = 1
+    assert gpu_ctx.schnorr_batch_verify_ed25519(pk, r, s, a0, e, pk_inf=inf)[0] == 0
+    assert gpu_ctx.schnorr_batch_verify_ed25519(pk, r, s, a0, e, r_inf=inf)[0] == 0
 
 
 @pytest.mark.parametrize("curve", CURVES)

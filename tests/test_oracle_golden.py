@@ -423,6 +423,31 @@ def test_schnorr_verify_fixture_and_two_restatements(oracle):
         res, sides, sinf = oracle.schnorr_batch_verify(1, b["pk"], None, b["r"], None, b["s"], b["a"], b["e"])
         assert res == b["result"] and [int(v) for v in sides] == [v for fe in b["sides"] for v in fe] and list(sinf) == b["sides_inf"]
     assert [b["result"] for b in t["batch_p256"]] == [0, 0, 1]
+    # Ed25519: impl Mul for Scalar (ed25519.rs:1256-1376) under the release profile, both restatements and the fixture --
+    # whose first four products are the ones the reference's own tests assert (2250-2253: 1 * 2 == 2; 2303; 2309; 2315)
+    S = M.Ed25519Scalar
+    assert t["scalar_mul_ed25519"][0]["a"] == [1, 0, 0, 0] and t["scalar_mul_ed25519"][0]["b"] == [2, 0, 0, 0]
+    assert t["scalar_mul_ed25519"][0]["product"] == [2, 0, 0, 0] and t["scalar_mul_ed25519"][0]["debug_build_panics"] == 0
+    for c in t["scalar_mul_ed25519"]:
+        got, ovf = oracle.ed25519_scalar_mul_release(np.array(c["a"], dtype=np.uint64), np.array(c["b"], dtype=np.uint64))
+        assert [int(v) for v in got] == c["product"] and ovf == c["debug_build_panics"], c["note"]
+        assert S.mul_release(list(c["a"]), list(c["b"])) == (c["product"], bool(c["debug_build_panics"]))
+    assert sum(c["debug_build_panics"] for c in t["scalar_mul_ed25519"]) >= 8   # wrapping is the usual case, not a corner
+    # where nothing wraps and the product fits 256 bits, the reference's Mul IS multiplication modulo l
+    ell = (1 << 252) + 27742317777372353535851937790883648493
+    for c in t["scalar_mul_ed25519"]:
+        va, vb = V.int_of(c["a"]), V.int_of(c["b"])
+        if not c["debug_build_panics"] and va * vb < (1 << 256) and va * vb < 2 * ell:
+            assert V.int_of(c["product"]) == va * vb % ell, c["note"]
+    rng = np.random.default_rng(77)
+    for _ in range(200):
+        a, b = rng.integers(0, 1 << 63, size=4, dtype=np.uint64) * 2 + rng.integers(0, 2, size=4, dtype=np.uint64), rng.integers(0, 1 << 63, size=4, dtype=np.uint64) * 2 + 1
+        got, ovf = oracle.ed25519_scalar_mul_release(a, b)
+        assert ([int(v) for v in got], bool(ovf)) == S.mul_release([int(v) for v in a], [int(v) for v in b])
+    for b in t["batch_ed25519"]:
+        res, sides, sinf, dbg = oracle.ed25519_schnorr_batch_verify(b["pk"], None, b["r"], None, b["s"], b["a"], b["e"])
+        assert res == b["result"] and dbg == b["debug_build_panics"], b["kind"]
+        assert [int(v) for v in sides] == [v for fe in b["sides"] for v in fe] and list(sinf) == b["sides_inf"]
     for curve in (0, 1, 2):
         n = 4
         pk = np.ascontiguousarray(np.concatenate([V.field_elements(n, curve, 730), V.field_elements(n, curve, 731)], axis=1))
