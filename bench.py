@@ -99,6 +99,7 @@ def parse(argv=None):
                          "0 = off; default: the library's, 24)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration (all legs together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the ~1 s rocm-smi clock sampling under load (N = 1)")
     return ap.parse_args(argv)
 
 
@@ -252,6 +253,59 @@ class CudaPlatform:
 
     def synchronize(self):
         self.torch.cuda.synchronize()
+
+
+class ClockSampler:
+    """sclk / mclk of the bench's GPU under load, so that a box-to-box spread of a kernel time can be pinned on clocks or
+    ruled out.  The amdgpu sysfs tables of a shared host cannot be matched to the one GPU a container is given (its PCI
+    numbering is virtual), so the readings come from `rocm-smi --showclocks --json` -- which sees exactly the visible
+    GPU(s) -- run as a child process by a thread, again and again, while the caller keeps the kernel running (about a
+    second, outside every timed region).  summary() is None where rocm-smi is not there or says nothing."""
+
+    def __init__(self, card_index):
+        self.card = "card%d" % card_index
+        self.samples = {"sclk": [], "mclk": []}
+        self.stop = False
+        self.thread = None
+
+    def _once(self):
+        import re
+        import subprocess
+        out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        card = json.loads(out[out.index("{"):]).get(self.card, {})
+        for key, val in card.items():
+            m = re.search(r"(\d+)\s*mhz", str(val).lower())
+            for clk in ("sclk", "mclk"):
+                if m and key.lower().startswith(clk + " clock speed"):
+                    self.samples[clk].append(int(m.group(1)))
+
+    def _run(self):
+        while not self.stop:
+            try:
+                self._once()
+            except Exception:
+                return
+
+    def __enter__(self):
+        import threading
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.thread:
+            self.thread.join(timeout=30.0)
+
+    def summary(self):
+        if not self.samples["sclk"] and not self.samples["mclk"]:
+            return None
+        out = {"source": "rocm-smi --showclocks, sampled while the kernel ran back to back"}
+        for key in ("sclk", "mclk"):
+            v = self.samples[key]
+            if v:
+                out[key + "_mhz"] = {"min": min(v), "max": max(v), "samples": len(v)}
+        return out
 
 
 def free_port():
@@ -468,6 +522,17 @@ def main(argv=None, platform_factory=None, script=None):
         if full is not None and not torch.equal(full[off:off + n], d_out[0]):
             raise SystemExit("gathered shard differs from the kernel output")
     kernel_ms = float(np.mean(kms))
+    clocks_under_load = None
+    if world == 1 and platform_factory is None and not args.no_clock_probe:
+        # about a second of the kernel back to back (outside every timed region) while rocm-smi is asked for the clocks
+        with ClockSampler(local_rank) as clocks:
+            t_end = time.perf_counter() + 1.2
+            i = 0
+            while time.perf_counter() < t_end:
+                step(i, False, None)
+                plat.synchronize()
+                i += 1
+        clocks_under_load = clocks.summary()
     peak_measured = ctx.measure_peak_mad32()
     info = ctx.device_info()
 
@@ -542,6 +607,7 @@ def main(argv=None, platform_factory=None, script=None):
                 "frac_executed_steps": (achieved / PEAK_MAD32_FORMULA * executed_share) if executed_share is not None else None,
                 "executed_share_of_reference_steps": executed_share,
                 "wavefront_rounds": rounds,
+                "clocks_under_load": clocks_under_load,
                 "traffic": pmc["traffic"],
                 "traffic_source": pmc["source"],
                 "traffic_note": TRAFFIC_NOTES.get(workload),

@@ -13,10 +13,10 @@
 
 namespace fecgpu {
 
-// ms per 2^20 elements on the whole chip (profiles/bench_r03, tools/fixed_prefix_ab.py): variable base with projective
+// ms per 2^20 elements on the whole chip (tools/p256_split_constants.py, round 4 kernels): variable base with projective
 // base points / with affine ones (from_affine(public key): the twelve-product addition), fixed base, fixed base from the
 // prefix table
-constexpr double kP256VarMs = 23.8, kP256VarAffineMs = 21.4, kP256FixedMs = 21.3, kP256FixedPrefixMs = 19.45;
+constexpr double kP256VarMs = 23.3, kP256VarAffineMs = 20.9, kP256FixedMs = 20.9, kP256FixedPrefixMs = 19.1;
 
 // env_fixed / env_var: `env` with the CUs of the fixed-base launch and of the variable-base launch(es) that run beside
 // it on the other stream (`var_ms`: their summed cost per 2^20 elements, from the constants above).  Below 2^19

@@ -19,4 +19,4 @@ done
 for WL in ed25519-fixed ed25519-var; do   # the Ed25519 workloads again with scalars below l
   timeout -k 10 300 python bench.py --workload $WL --steps 10 --warmup 2 --scalars-below-l > gpurun_out/bench_${TAG}_${WL}_below_l.json 2> /dev/null || { echo "bench $WL --scalars-below-l failed"; exit 1; }
 done
-bash tools/pmc_refresh.sh $TAG
+# the PMC passes are a call of their own (gpurun limits a call to 20 minutes): bash tools/pmc_refresh.sh $TAG
