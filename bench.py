@@ -255,56 +255,97 @@ class CudaPlatform:
         self.torch.cuda.synchronize()
 
 
+CLOCK_HELPER = r"""
+import json, re, subprocess, sys, threading
+card = sys.argv[1]
+samples = {"sclk": [], "mclk": []}
+state = {"on": False}
+def once():
+    out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+    c = json.loads(out[out.index("{"):]).get(card, {})
+    for key, val in c.items():
+        m = re.search(r"(\d+)\s*mhz", str(val).lower())
+        for clk in ("sclk", "mclk"):
+            if m and key.lower().startswith(clk + " clock speed"):
+                samples[clk].append(int(m.group(1)))
+def loop():
+    while state["on"]:
+        try:
+            once()
+        except Exception:
+            return
+t = None
+for line in sys.stdin:
+    cmd = line.strip()
+    if cmd == "start":
+        state["on"] = True
+        t = threading.Thread(target=loop, daemon=True)
+        t.start()
+    elif cmd == "stop":
+        state["on"] = False
+        if t:
+            t.join(timeout=30)
+        print(json.dumps(samples), flush=True)
+        break
+"""
+
+
 class ClockSampler:
     """sclk / mclk of the bench's GPU under load, so that a box-to-box spread of a kernel time can be pinned on clocks or
     ruled out.  The amdgpu sysfs tables of a shared host cannot be matched to the one GPU a container is given (its PCI
-    numbering is virtual), so the readings come from `rocm-smi --showclocks --json` -- which sees exactly the visible
-    GPU(s) -- run as a child process by a thread, again and again, while the caller keeps the kernel running (about a
-    second, outside every timed region).  summary() is None where rocm-smi is not there or says nothing."""
+    numbering is virtual), so the readings come from `rocm-smi --showclocks --json`, which sees exactly the visible
+    GPU(s).  rocm-smi is run by a HELPER process that main() starts before this process has touched the GPU (a process
+    that holds the GPU never forks a program); the helper samples, again and again, between `start` and `stop`, while the
+    caller keeps the kernel running back to back (about a second, outside every timed region)."""
 
     def __init__(self, card_index):
-        self.card = "card%d" % card_index
-        self.samples = {"sclk": [], "mclk": []}
-        self.stop = False
-        self.thread = None
-
-    def _once(self):
-        import re
         import subprocess
-        out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
-        card = json.loads(out[out.index("{"):]).get(self.card, {})
-        for key, val in card.items():
-            m = re.search(r"(\d+)\s*mhz", str(val).lower())
-            for clk in ("sclk", "mclk"):
-                if m and key.lower().startswith(clk + " clock speed"):
-                    self.samples[clk].append(int(m.group(1)))
+        self.proc = None
+        try:
+            self.proc = subprocess.Popen([sys.executable, "-c", CLOCK_HELPER, "card%d" % card_index], stdin=subprocess.PIPE,
+                                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        except Exception:
+            self.proc = None
+        self.result = None
 
-    def _run(self):
-        while not self.stop:
-            try:
-                self._once()
-            except Exception:
-                return
+    def _send(self, word):
+        try:
+            self.proc.stdin.write(word + "\n")
+            self.proc.stdin.flush()
+            return True
+        except Exception:
+            return False
 
     def __enter__(self):
-        import threading
-        self.thread = threading.Thread(target=self._run, daemon=True)
-        self.thread.start()
+        if self.proc:
+            self._send("start")
         return self
 
     def __exit__(self, *a):
-        self.stop = True
-        if self.thread:
-            self.thread.join(timeout=30.0)
+        if self.proc and self._send("stop"):
+            try:
+                self.result = json.loads(self.proc.stdout.readline() or "null")
+            except Exception:
+                self.result = None
+        self.close()
+
+    def close(self):
+        if self.proc:
+            try:
+                self.proc.stdin.close()
+                self.proc.wait(timeout=30)
+            except Exception:
+                self.proc.kill()
+            self.proc = None
 
     def summary(self):
-        if not self.samples["sclk"] and not self.samples["mclk"]:
+        v = self.result or {}
+        if not v.get("sclk") and not v.get("mclk"):
             return None
-        out = {"source": "rocm-smi --showclocks, sampled while the kernel ran back to back"}
+        out = {"source": "rocm-smi --showclocks, sampled by a helper process while the kernel ran back to back"}
         for key in ("sclk", "mclk"):
-            v = self.samples[key]
-            if v:
-                out[key + "_mhz"] = {"min": min(v), "max": max(v), "samples": len(v)}
+            if v.get(key):
+                out[key + "_mhz"] = {"min": min(v[key]), "max": max(v[key]), "samples": len(v[key])}
         return out
 
 
@@ -345,6 +386,8 @@ def main(argv=None, platform_factory=None, script=None):
     if not args.no_cpu_baseline and world == 1 and platform_factory is None:
         # build / load the CPU checker before anything touches the GPU (its first use on a box compiles it with gcc)
         load_checker().native_lib()
+    # the clock probe's helper process, likewise started while this process holds no GPU state
+    clock_sampler = ClockSampler(local_rank) if (world == 1 and platform_factory is None and not args.no_clock_probe) else None
     import torch
     plat = (platform_factory or CudaPlatform)(local_rank)
     import forge_ec_amd as F
@@ -523,9 +566,9 @@ def main(argv=None, platform_factory=None, script=None):
             raise SystemExit("gathered shard differs from the kernel output")
     kernel_ms = float(np.mean(kms))
     clocks_under_load = None
-    if world == 1 and platform_factory is None and not args.no_clock_probe:
-        # about a second of the kernel back to back (outside every timed region) while rocm-smi is asked for the clocks
-        with ClockSampler(local_rank) as clocks:
+    if clock_sampler is not None:
+        # about a second of the kernel back to back (outside every timed region) while the helper asks rocm-smi for the clocks
+        with clock_sampler as clocks:
             t_end = time.perf_counter() + 1.2
             i = 0
             while time.perf_counter() < t_end:

@@ -496,7 +496,7 @@ FEC_DEV ed::pt pdbl_mem(const u32* la, int stride) {
 
 // ---------------------------------------------------------------------------------------------------
 // One workgroup of TWELVE wavefronts per CU (three per SIMD, 168 VGPRs) owns a contiguous RANGE of elements and
-// keeps PS = 832 of them in slots -- the addend in LDS (128 B per slot, 104 KiB), the running result in the
+// keeps PS = 864 of them in slots -- the addend in LDS (128 B per slot, 108 KiB), the running result in the
 // element's slot of the OUTPUT array (read and rewritten by ~128 additions per element; L2 / Infinity Cache
 // traffic) -- refilling a slot from the range the moment its element finishes: no
 // workgroup tail until the whole range is done.  Add and double read their operands from memory where they are
@@ -510,7 +510,8 @@ constexpr int PT = 768;     // threads per workgroup: 12 wavefronts, three per S
 #ifndef FEC_ED_PS
 #define FEC_ED_PS 864
 #endif
-constexpr int PS_MAIN = FEC_ED_PS;  // element slots per workgroup (12 x 64 in flight + 64 queued).  Same-box sweeps (profiles/slot_sweep_r03.txt), ms and
+constexpr int PS_MAIN = FEC_ED_PS;  // element slots per workgroup (12 x 64 in flight + 96 queued).  With the lock-free rings (profiles/sched_r04/ab_libs_r04b.txt):
+                                    // 800 -> 18.09 ms, 832 -> 17.89, 864 -> 17.20, 880 -> 16.95 / 17.46 on two boxes, 896 -> 17.49.  Round 3's sweeps with the lock (profiles/slot_sweep_r03.txt), ms and
                                     // L2-side traffic per 2^20: 1024 -> 17.87 / 27.0 GB, 960 -> 19.05, 896 -> 18.43, 864 -> 18.10, 832 -> 17.75 / 18.4 GB, 800 -> 19.95, 768 -> 19.02
 // The second instantiation, 1 024 slots: for launches whose workgroups get a little more than a whole number of
 // 832-element fills (2^18 elements: 1 024 per workgroup, 6.6 ms against 5.0) -- see kernels_p256.hip: wide_slots_pay.

@@ -5,18 +5,16 @@
 // Every step doubles, but only the lanes whose bit is set need the (twice as expensive) addition.
 // Executing the addition for whole wavefronts under a mask wastes half of it; a step-synchronous
 // compaction (round 1) packs it but leaves SIMDs idle at three barriers per step (PMC: 40 % of wave
-// cycles parked, VALUBusy 82 %, profiles/pmc_r02_base_p256).  Here a workgroup keeps 832 elements'
+// cycles parked, VALUBusy 82 %, profiles/pmc_r02_base_p256).  Here a workgroup keeps 864 elements'
 // state in LDS slots, and its wavefronts pull BATCHES from two ready queues: 64 elements whose next step has a
 // clear scalar bit (a doubling), or 64 elements whose next step has a set bit (a doubling and then the addition).  Elements therefore
 // advance at their own pace (each one still sees exactly the reference's operation sequence, so
 // results are bit-identical), every batch is full until the workgroup's whole range is done, there is no
 // workgroup barrier inside the ladder, and a wavefront holds no point state between batches.
 //
-// Queues, counters and the step table are LDS words guarded by one LDS ticket lock taken by lane 0 of
-// a wavefront once per batch (push the finished batch, pop the next: ~100 cycles against a
-// 8 000-15 000-cycle batch).  Forward progress: a wavefront waits only while another one has a batch
-// in flight; when nothing is in flight any non-empty queue is handed out as a partial batch.  Waiting
-// wavefronts poll the counters WITHOUT the lock (plain loads, long s_sleep) and the lock is FIFO.
+// The queues are lock-free rings in LDS driven by LDS fetch-and-add (sched_lf.hpp; rounds 2-3 guarded them with a FIFO
+// ticket lock: a 1 020-cycle hand-over per batch): a third ring holds the slots whose element has finished, so that
+// claims run 64 at a time.  Forward progress and the batch policy: sched_lf.hpp.
 #include <hip/hip_runtime.h>
 
 #include "../../include/fecgpu.h"
@@ -221,15 +219,17 @@ FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u
 // wavefronts with the operands of Add / double left in memory (padd_in_place, pdouble_in_place: no spills) 26.3 ms;
 // rare legs in place, control words in LDS address space 24.9 ms -- round 3: the ladder's prefix answered by claim(),
 // z2z2 once per element 24.3 ms; one task per ladder step 23.8 ms; 832 slots with the whole scalar in LDS: the same
-// time at 1.05x the algorithmic bytes instead of 2.2x.
+// time at 1.05x the algorithmic bytes instead of 2.2x -- round 4: lock-free rings, claims of 64
+// elements at full width, 864 slots: 23.2-23.4 ms, 13-21 % less at 2^14 .. 2^17 elements.
 // ---------------------------------------------------------------------------------------------------
 namespace {
 constexpr int QT = 768;      // threads per workgroup: 12 wavefronts, three per SIMD
 #ifndef FEC_P256_QS
 #define FEC_P256_QS 864
 #endif
-constexpr int QS_MAIN = FEC_P256_QS;  // element slots per workgroup (12 x 64 in flight + 64 queued).  Same-box sweeps (profiles/slot_sweep_r03.txt):
-                                      // 1024 -> 23.79 ms / 527 MB of L2-side traffic, 960 -> 24.79, 896 -> 24.21, 832 -> 23.91 ms / 378 MB
+constexpr int QS_MAIN = FEC_P256_QS;  // element slots per workgroup (12 x 64 in flight + 96 queued).  Same-box sweep with the lock-free rings
+                                      // (profiles/sched_r04/ab_libs_r04b.txt): 800 -> 24.16 ms, 832 -> 24.06, 864 -> 23.21, 896 -> 23.25 (round 3's, with the lock:
+                                      // profiles/slot_sweep_r03.txt)
 // The second instantiation: 1 024 slots, the scalar NOT in LDS (there is no room for it beside 1 024 points and z2z2:
 // a step's bit is read from the caller's array instead).  For launches whose workgroups get a little more than a
 // whole number of 832-element fills -- the late, thinly occupied last fill costs 5-22 % there (2^18 elements: 1 024 per

@@ -20,11 +20,11 @@
 //     A ring holds more positions than there are slots and a slot sits in at most one position, so a position is
 //     never reserved again before it has been read: no entry is ever overwritten unread.
 //   * a wavefront pushes what its batch produced and pops the next one from ONE snapshot of {AV_D, AV_A, AV_F, REMAIN}
-//     (one ds_read_b128): a ring is taken when it holds a full batch of 64 -- while fewer than 512 slots are live:
-//     REMAIN / 8 entries -- free slots first (the claim of 64 elements runs at full width instead of for a whole
+//     (one ds_read_b128): a ring is taken when it holds a full batch of 64 -- while fewer than 256 slots are live:
+//     REMAIN / 4 entries (FEC_LF_TAIL_SHIFT) -- free slots first (the claim of 64 elements runs at full width instead of for a whole
 //     wavefront per finished lane), then the fuller of D / A; otherwise the wavefront sleeps.
 //     Progress: if every wavefront waits, every live slot is queued, so AV_D + AV_A + AV_F = REMAIN, and three counts
-//     below the threshold (<= REMAIN / 8 each) cannot add up to REMAIN.
+//     below the threshold (<= REMAIN / 4 each) cannot add up to REMAIN.
 //   * REMAIN = live slots (a slot dies when claim() finds the range used up); REMAIN == 0 ends the kernel; an error
 //     (watchdog, index guard, debug hook) sets LF_ERRFLAG in REMAIN so that every wavefront sees it in the same read.
 //
@@ -186,7 +186,7 @@ FEC_DEV LfPop lf_pop(unsigned ctl, int lane, unsigned& watchdog, u32 watchdog_co
     if (remain == 0u || (remain & LF_ERRFLAG) != 0u) return r;
     int th = (int)(remain >> FEC_LF_TAIL_SHIFT);
     th = th < 1 ? 1 : (th > 64 ? 64 : th);
-    // A ring is taken when it holds a full batch -- or, while fewer than 512 slots are live, REMAIN / 8 entries: free
+    // A ring is taken when it holds a full batch -- or, while fewer than 256 slots are live, REMAIN / 4 entries: free
     // slots first (their claims refill the pool), then the fuller of A / D.  Anything less WAITS: a sleeping
     // wavefront costs its SIMD no issue slots (the other two have work), a thin batch costs them a whole task's.
     int pick = -1, want = 0;

@@ -17,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
   timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$ROOT/$OUT/$name" -o "$name" -- \
-    python3 "$ROOT/bench.py" --workload "$WL" --log2-batch "$LOG2" --steps 3 --warmup 1 --no-cpu-baseline \
+    python3 "$ROOT/bench.py" --workload "$WL" --log2-batch "$LOG2" --steps 3 --warmup 1 --no-cpu-baseline --no-clock-probe \
     > "$ROOT/$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$ROOT/$OUT/$name.log"; return 1; }
   echo "pass $name ok"
 }
@@ -28,5 +28,5 @@ run fetch FETCH_SIZE &&
 run write WRITE_SIZE &&
 run grbm GRBM_GUI_ACTIVE &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats" -o stats -- \
-  python3 "$ROOT/bench.py" --workload "$WL" --log2-batch "$LOG2" --steps 10 --warmup 2 --no-cpu-baseline \
+  python3 "$ROOT/bench.py" --workload "$WL" --log2-batch "$LOG2" --steps 10 --warmup 2 --no-cpu-baseline --no-clock-probe \
   > "$ROOT/$OUT/stats.log" 2>&1 && echo "stats ok" && tail -1 "$ROOT/$OUT/stats.log"

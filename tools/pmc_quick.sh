@@ -9,7 +9,7 @@ ROOT=$(pwd); OUT="$ROOT/gpurun_out/pmcq_$TAG"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/$C" -o $C -- \
-    python3 "$ROOT/bench.py" --workload "$WL" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/$C.log" 2>&1 || { echo "pass $C failed"; tail -n 5 "$OUT/$C.log"; exit 1; }
+    python3 "$ROOT/bench.py" --workload "$WL" --steps 3 --warmup 1 --no-cpu-baseline --no-clock-probe > "$OUT/$C.log" 2>&1 || { echo "pass $C failed"; tail -n 5 "$OUT/$C.log"; exit 1; }
 done
 python3 - "$OUT" "$NEEDLE" <<'PY'
 import csv, glob, sys
