@@ -196,3 +196,45 @@ def test_multi_dev_argument_errors_and_faults(oracle):
         ctx.multi_batch_mul_dev(1, [dk.data_ptr(), dk[64:].data_ptr()], [dp.data_ptr(), dp[64:].data_ptr()],
                                 [do.data_ptr(), do2.data_ptr()], [64, 64], full.data_ptr(), 1)
         assert np.array_equal(full.cpu().numpy().view(np.uint64), oracle.batch_mul(1, k, p, nthreads=8))
+
+
+def test_multi_dev_caller_streams_and_shared_prefix_table(oracle):
+    """(1) `streams`: the kernels of shard g are queued behind the caller's producer on the stream it names (here the
+    host-to-device copies of the shard's inputs, issued on a torch stream and NOT synchronised before the call);
+    (2) the shard workers of a [0, 0, 0] ctx that is asked for prefix tables all attach to ONE table on the device
+    (they build concurrently from three host threads) and the fixed-base products do not change."""
+    import torch
+    import forge_ec_amd as F
+    n, curve = 6000, 1
+    counts = (2000, 2500, 1500)
+    edges = np.concatenate([[0], np.cumsum(counts)])
+    k, p = V.scalars(n, curve, 9300), V.points(n, curve, 9301)
+    want = oracle.batch_mul(curve, k, p, nthreads=16)
+    with F.Context(devices=[0, 0, 0]) as ctx:
+        streams = [torch.cuda.Stream() for _ in counts]
+        hk = [torch.from_numpy(k[a:b].view(np.int64)).pin_memory() for a, b in zip(edges[:-1], edges[1:])]
+        hp = [torch.from_numpy(p[a:b].view(np.int64)).pin_memory() for a, b in zip(edges[:-1], edges[1:])]
+        dk = [torch.empty_like(t, device="cuda") for t in hk]
+        dp = [torch.empty_like(t, device="cuda") for t in hp]
+        do = [torch.zeros((c, 12), dtype=torch.int64, device="cuda") for c in counts]
+        full = torch.zeros((n, 12), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        for g, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                dk[g].copy_(hk[g], non_blocking=True)
+                dp[g].copy_(hp[g], non_blocking=True)
+        ctx.multi_batch_mul_dev(curve, [t.data_ptr() for t in dk], [t.data_ptr() for t in dp], [t.data_ptr() for t in do],
+                                counts, full.data_ptr(), 1, streams=[s.cuda_stream for s in streams])
+        assert np.array_equal(full.cpu().numpy().view(np.uint64), want)
+        # (2)
+        free0 = torch.cuda.mem_get_info()[0]
+        ctx.set_fixed_prefix_bits(20)
+        g1 = oracle.generator(curve)
+        got = ctx.batch_mul_fixed(curve, k, g1)            # three workers, three host threads, one table
+        assert np.array_equal(got, oracle.batch_mul_fixed(curve, k, g1, nthreads=16))
+        assert ctx.fixed_prefix_bits(curve) == 20
+        used = free0 - torch.cuda.mem_get_info()[0]
+        assert (96 << 20) <= used < 2 * (96 << 20) + (64 << 20)     # one 96 MiB table (and staging), not three
+        ctx.set_side_stream_max(0)                         # the measurement knob: results do not depend on it
+        k2 = V.scalars(n, curve, 9302)
+        assert np.array_equal(ctx.batch_double_mul(curve, k, k2, p), oracle.batch_double_mul(curve, k, k2, p, nthreads=16))
