@@ -112,6 +112,45 @@ def main():
     print(json.dumps({"pipeline": "validate_point ed25519", "n": m, "mismatches": bad, "valid": int(want.sum()),
                       "gpu_s": round(t1 - t0, 3), "oracle_s": round(t2 - t1, 1)}), flush=True)
     total += bad
+    # round 4: device-resident shards of a multi-device ctx gathered onto one device (this box: its GPU listed twice), whole
+    # batch against the oracle results computed above for the same scalars / points of curve 1
+    import torch
+    with F.Context(devices=[0, 0]) as mctx:
+        for curve in (0, 1, 2):
+            L = F.POINT_LIMBS[curve]
+            k = V.scalars(n, curve, 8001 + curve + so)
+            p = V.points(n, curve, 8011 + curve + so)
+            cut = n // 2 + 12345 % max(n // 4, 1)
+            shards = ((0, cut), (cut, n))
+            dk = [torch.from_numpy(k[a:b].view(np.int64)).cuda() for a, b in shards]
+            dp = [torch.from_numpy(p[a:b].view(np.int64)).cuda() for a, b in shards]
+            do = [torch.zeros((b - a, L), dtype=torch.int64, device="cuda") for a, b in shards]
+            full = torch.zeros((n, L), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mctx.multi_batch_mul_dev(curve, [t.data_ptr() for t in dk], [t.data_ptr() for t in dp], [t.data_ptr() for t in do],
+                                     [b - a for a, b in shards], full.data_ptr(), 0)
+            t1 = time.perf_counter()
+            want = O.batch_mul(curve, k, p, nthreads=16); t2 = time.perf_counter()
+            total += report("multi_batch_mul_dev [0, 0] gathered, curve %d" % curve, full.cpu().numpy().view(np.uint64), want, t1 - t0, t2 - t1)
+    # round 4: schnorr::batch_verify::<Ed25519, D> (release-profile scalar Mul), batches of 512 signatures
+    bad = 0
+    t_gpu = t_cpu = 0.0
+    nb = max(1, min(16, n >> 12))
+    for b in range(nb):
+        m5 = 512
+        pk = np.ascontiguousarray(np.concatenate([V.field_elements(m5, 2, 9051 + so + 7 * b), V.field_elements(m5, 2, 9052 + so + 7 * b)], axis=1))
+        rr = np.ascontiguousarray(np.concatenate([V.field_elements(m5, 2, 9053 + so + 7 * b), V.field_elements(m5, 2, 9054 + so + 7 * b)], axis=1))
+        ss, aa, ee = V.scalars(m5, 2, 9055 + so + 7 * b), V.scalars(m5, 2, 9056 + so + 7 * b), V.scalars(m5, 2, 9057 + so + 7 * b)
+        t0 = time.perf_counter(); got = ctx.schnorr_batch_verify_ed25519(pk, rr, ss, aa, ee); t1 = time.perf_counter()
+        want = O.ed25519_schnorr_batch_verify(pk, None, rr, None, ss, aa, ee); t2 = time.perf_counter()
+        t_gpu += t1 - t0
+        t_cpu += t2 - t1
+        if not (got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]) and got[3] == bool(want[3])):
+            bad += 1
+    print(json.dumps({"pipeline": "schnorr batch_verify ed25519 (release profile), %d batches of 512" % nb, "mismatches": bad,
+                      "gpu_s": round(t_gpu, 3), "oracle_s": round(t_cpu, 1)}), flush=True)
+    total += bad
     print(json.dumps({"total_mismatches": total}))
     sys.exit(1 if total else 0)
 

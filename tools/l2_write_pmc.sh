@@ -1,3 +1,6 @@
+#!/bin/bash
+# tools/microbench/l2_write under rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (run ON the GPU box from the repo root):
+#   [L2_KIB=<KiB per workgroup>] bash tools/l2_write_pmc.sh      -> bytes per launch and store flavour
 ROOT=$(pwd); cd /tmp && export TMPDIR=/tmp
 for C in WRITE_SIZE FETCH_SIZE; do
   timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $ROOT/gpurun_out/l2_write_r04/$C -o x -- $ROOT/tools/microbench/l2_write ${L2_KIB:-8} 100 > $ROOT/gpurun_out/l2_write_r04_$C.log 2>&1 || { echo failed $C; tail -5 $ROOT/gpurun_out/l2_write_r04_$C.log; exit 1; }
