@@ -20,7 +20,7 @@ constexpr double kP256VarMs = 23.3, kP256VarAffineMs = 20.9, kP256FixedMs = 20.9
 
 // env_fixed / env_var: `env` with the CUs of the fixed-base launch and of the variable-base launch(es) that run beside
 // it on the other stream (`var_ms`: their summed cost per 2^20 elements, from the constants above).  Below 2^19
-// elements the halves stay: a workgroup then holds about one fill of its 832 slots and its time is a ladder's latency,
+// elements the halves stay: a workgroup then holds about one fill of its 864 slots and its time is a ladder's latency,
 // not its share of the elements (2^17: 6.4 ms in halves, 7.9 ms split 112 + 144).
 inline void p256_cu_split(const SchedEnv& env, size_t n, double var_ms, SchedEnv& env_fixed, SchedEnv& env_var) {
   const unsigned cus = env.cus ? env.cus : 256u;

@@ -244,7 +244,7 @@ inline int sync_and_check(fec_ctx* ctx, hipStream_t a, hipStream_t b = nullptr) 
 
 // Elements per chunk of a host-pointer call: 2^18 unless fec_ctx_set_chunk says otherwise.  (A chunk gives a persistent
 // scheduler workgroup 1 024 elements: the launchers then take the 1 024-slot instantiation of the kernel, one fill --
-// kernels_p256.hip: wide_slots_pay.  With 832 slots only, such a chunk cost 2^20 P-256 multiplications through the
+// kernels_p256.hip: wide_slots_pay.  With 832 slots only (round 3), such a chunk cost 2^20 P-256 multiplications through the
 // host-pointer entry point 34.2 ms instead of 26.0: tools/host_chunk_probe.py, profiles/host_chunk_r03.txt.)
 inline size_t pipeline_chunk(const fec_ctx* ctx) { return ctx->chunk; }
 

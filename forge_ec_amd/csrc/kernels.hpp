@@ -12,7 +12,7 @@ namespace fecgpu {
 //               point reads it after its final synchronisation (fec_ctx_check for the *_dev callers) -- a scheduler
 //               fault therefore surfaces as FEC_E_LAUNCH, never as FEC_OK with zeroed points.
 //   cus         CU count of the ctx's OWN device (one persistent workgroup per CU)
-//   force_fault debug hook (fec_ctx_debug_force_fault): the kernels raise their C_ERR word at once, so that the
+//   force_fault debug hook (fec_ctx_debug_force_fault): the kernels raise their error word at once, so that the
 //               whole error path can be exercised by a test
 //   gen, gen_prefix, gen_prefix_bits   per curve: the device address of the reference's generator() and its fixed-base
 //               prefix table (the state of multiply(G, k) after the first gen_prefix_bits steps, for every pattern of

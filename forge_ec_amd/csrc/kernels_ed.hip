@@ -514,7 +514,7 @@ constexpr int PS_MAIN = FEC_ED_PS;  // element slots per workgroup (12 x 64 in f
                                     // 800 -> 18.09 ms, 832 -> 17.89, 864 -> 17.20, 880 -> 16.95 / 17.46 on two boxes, 896 -> 17.49.  Round 3's sweeps with the lock (profiles/slot_sweep_r03.txt), ms and
                                     // L2-side traffic per 2^20: 1024 -> 17.87 / 27.0 GB, 960 -> 19.05, 896 -> 18.43, 864 -> 18.10, 832 -> 17.75 / 18.4 GB, 800 -> 19.95, 768 -> 19.02
 // The second instantiation, 1 024 slots: for launches whose workgroups get a little more than a whole number of
-// 832-element fills (2^18 elements: 1 024 per workgroup, 6.6 ms against 5.0) -- see kernels_p256.hip: wide_slots_pay.
+// PS_MAIN-element fills (2^18 elements: 1 024 per workgroup, 6.6 ms against 5.0) -- see kernels_p256.hip: wide_slots_pay.
 constexpr int PS_WIDE = 1024;
 }  // namespace
 
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
   for (;;) {
     // hand on what the last batch left (sched_lf.hpp: no lock, no turn to wait for; the release fence in front of the
     // publishing add orders this batch's result stores before the entries that hand the slots on), take the next one
-    lf_push<RING>(ctl_addr, lane, nxt, e);
+    lf_push<RING>(ctl_addr, lane, nxt, e, (u32)FEC_DEVERR_SCHED_WATCHDOG);
     nxt = LF_NXT_NONE;
     const LfPop pop = lf_pop<RING>(ctl_addr, lane, watchdog, (u32)FEC_DEVERR_SCHED_WATCHDOG);
     if (pop.kind < 0) break;

@@ -212,7 +212,7 @@ FEC_DEV p256::pt padd_in_place(const u32* lp, int stride, const u32* gq, const u
 
 // ---------------------------------------------------------------------------------------------------
 // Persistent workgroups (the shape of k_ed_mul_pers): one workgroup of TWELVE wavefronts per CU -- three per SIMD,
-// 168 VGPRs, the asm field blocks at v[122:167] -- owns a contiguous RANGE of elements and keeps QS = 832 of them
+// 168 VGPRs, the asm field blocks at v[122:167] -- owns a contiguous RANGE of elements and keeps QS = 864 of them
 // in LDS slots (point 96 B + scalar 32 B + z2z2 of the base point 32 B), refilling a slot from the range the moment its
 // element finishes: no workgroup tail until the whole range is done.  History per 2^20 batch -- round 2: 512 elements
 // per workgroup, two workgroups of four wavefronts per CU 28.55 ms; persistent, eight wavefronts 28.2-28.4 ms; twelve
@@ -232,7 +232,7 @@ constexpr int QS_MAIN = FEC_P256_QS;  // element slots per workgroup (12 x 64 in
                                       // profiles/slot_sweep_r03.txt)
 // The second instantiation: 1 024 slots, the scalar NOT in LDS (there is no room for it beside 1 024 points and z2z2:
 // a step's bit is read from the caller's array instead).  For launches whose workgroups get a little more than a
-// whole number of 832-element fills -- the late, thinly occupied last fill costs 5-22 % there (2^18 elements: 1 024 per
+// whole number of QS_MAIN-element fills -- the late, thinly occupied last fill costs 5-22 % there (2^18 elements: 1 024 per
 // workgroup, 8.25 ms against 6.8; 2^19: 13.3 against 12.7) -- p256_launch_mul picks it by the per-workgroup count.
 constexpr int QS_WIDE = 1024;
 // Fixed base: no z2z2 per slot (one for the workgroup), so the scalar fits beside the point at any slot count
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   __shared__ u32 lds_st[24 * QS];               // X, Y, Z of slot e: word w at lds_st[w * QS + e]
   // z2z2 = base.z * base.z of slot e's element (variable base): one of the sixteen products of EVERY addition of an
   // element depends on its base point alone, so claim() computes it once with the same sqr() and the ~128 additions
-  // read it back.  With 832 slots it fits beside the whole scalar (160 B per slot, 146 KiB in all).  (Round 2 parked
+  // read it back.  With 864 slots it fits beside the whole scalar (160 B per slot, 146 KiB in all).  (Round 2 parked
   // z2z2 in the element's output slot instead: 23 GB of L2-side traffic and no in-place calls -- removed; this form has
   // neither.)
   __shared__ u32 lds_zq[(FIXED ? 0 : 8 * QS) + 8];
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(QT, 1) void k_p256_mul_sched(const u32* __restrict_
   FEC_STAT_DECL;
   for (;;) {
     // hand on what the last batch left (sched_lf.hpp: no lock, no turn to wait for), take the next one
-    lf_push<RING>(ctl_addr, lane, nxt, e);
+    lf_push<RING>(ctl_addr, lane, nxt, e, (u32)FEC_DEVERR_SCHED_WATCHDOG);
     nxt = LF_NXT_NONE;
     const LfPop pop = lf_pop<RING>(ctl_addr, lane, watchdog, (u32)FEC_DEVERR_SCHED_WATCHDOG);
     if (pop.kind < 0) break;

@@ -1,28 +1,36 @@
 // sched_lf.hpp -- the lock-free ready queues of the workgroup task schedulers (kernels_p256.hip, kernels_ed.hip).
 //
 // Rounds 2-3 guarded two ready rings and their counters with a FIFO ticket lock taken once per batch: measured
-// (profiles/sched_stats_r03.txt) a hand-over cost ~1 020 cycles, a batch carried ~277 VALU instructions that were not
-// its arithmetic (ballots, the ticket poll, seven control words read and rewritten, claim() run by a whole wavefront
-// whenever ONE lane finished), and with the tasks stubbed out the kernel still took 10.5 ms of 23.8.  Here nothing is
-// locked and nobody polls for a turn:
+// (profiles/sched_stats_r03.txt) a hand-over cost ~1 020 cycles, a batch carried ~150 VALU instructions of scheduler
+// (ballots, the ticket poll, seven control words read and rewritten, claim() run by a whole wavefront whenever ONE lane
+// finished), and with the tasks stubbed out the kernel still took 10.5 ms of 23.8.  Here nothing is locked and nobody
+// polls for a turn (stubbed: 3.1 ms, 88 instructions per batch):
 //
 //   * THREE rings of slot numbers -- D (next step: the doubling alone), A (doubling and addition), F (free slots: their
 //     element has finished) -- each a multi-producer / multi-consumer queue driven by LDS fetch-and-add:
 //       producer:  pos = RES += n            (reserve n positions; D and A together in ONE ds_add_rtn_u64)
-//                  ring[pos + rank] = slot | generation(pos)
+//                  wait until ring[pos + rank] reads CONSUMED(lap - 1)         (it does, see below)
+//                  ring[pos + rank] = slot | lap(pos)
 //                  AV += n                   (publish; D and A together in one ds_add_u64)
 //       consumer:  old = AV -= want          (one ds_add_rtn_u64; the return value carries BOTH counts)
 //                  old < want: it lost a race -- AV += want, look again
 //                  pos = HEAD += want
-//                  slot = ring[pos + lane]   (an entry whose generation is not pos's has been reserved by a producer
-//                                             that has not written yet: re-read, a few cycles)
+//                  wait until ring[pos + lane] reads WRITTEN(lap)   (reserved by a producer that has not written yet:
+//                                                                    a few cycles), take the slot number,
+//                  ring[pos + lane] = CONSUMED(lap)
 //     AV counts are kept biased (LF_BIAS) so that a half of the 64-bit word never borrows from the other.
-//     A ring holds more positions than there are slots and a slot sits in at most one position, so a position is
-//     never reserved again before it has been read: no entry is ever overwritten unread.
+//     An entry is a slot number (ten bits), a consumed flag and the lap of its position modulo 32.  A ring holds more
+//     positions than there are slots and a slot sits in at most one position, so at most that many positions are
+//     unread at any time -- but the SPAN from the oldest unread position to RES is not bounded by that (the other
+//     slots go round while one consumer dawdles between its HEAD += and its read), which is why the producer looks
+//     before it writes: it never overwrites an entry that has not been consumed, however the wavefronts are
+//     scheduled.  No cycle of waits: a producer of lap g waits for consumers of lap g - 1, those for producers of
+//     lap g - 1, and so on down to lap 0, whose producers wait for nobody.  (tests/cpp/sched_lf_model.cpp runs this
+//     protocol on host threads, which ARE descheduled for long stretches.)
 //   * a wavefront pushes what its batch produced and pops the next one from ONE snapshot of {AV_D, AV_A, AV_F, REMAIN}
 //     (one ds_read_b128): a ring is taken when it holds a full batch of 64 -- while fewer than 256 slots are live:
-//     REMAIN / 4 entries (FEC_LF_TAIL_SHIFT) -- free slots first (the claim of 64 elements runs at full width instead of for a whole
-//     wavefront per finished lane), then the fuller of D / A; otherwise the wavefront sleeps.
+//     REMAIN / 4 entries (FEC_LF_TAIL_SHIFT) -- free slots first (the claim of 64 elements runs at full width instead
+//     of for a whole wavefront per finished lane), then the fuller of D / A; otherwise the wavefront sleeps.
 //     Progress: if every wavefront waits, every live slot is queued, so AV_D + AV_A + AV_F = REMAIN, and three counts
 //     below the threshold (<= REMAIN / 4 each) cannot add up to REMAIN.
 //   * REMAIN = live slots (a slot dies when claim() finds the range used up); REMAIN == 0 ends the kernel; an error
@@ -79,11 +87,13 @@ FEC_DEV u32 lf_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); 
 FEC_DEV u32 lf_rank(lmask m) {  // number of set bits of m below this lane
   return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
-// generation tag of ring position `pos` (bits 10..15 of an entry; a slot number has ten bits)
+// lap tag of ring position `pos`: (pos / RING) mod 32 in bits 11..15 of an entry; bit 10 = consumed; a slot number has
+// ten bits.  (pos - RING wraps correctly at 0: 2^32 is a multiple of 32 * RING.)
+constexpr u32 LF_CONSUMED = 0x400u;
 template <int RING>
-FEC_DEV u32 lf_gen(u32 pos) {
-  static_assert(RING == 1024 || RING == 2048, "ring sizes: the tag is (pos / RING) mod 64 in bits 10..15");
-  return RING == 1024 ? (pos & 0xFC00u) : ((pos >> 1) & 0xFC00u);
+FEC_DEV u32 lf_lap(u32 pos) {
+  static_assert(RING == 1024 || RING == 2048, "ring sizes: the tag is (pos / RING) mod 32 in bits 11..15");
+  return RING == 1024 ? ((pos << 1) & 0xF800u) : (pos & 0xF800u);
 }
 
 // The control block and the three rings are ONE LDS array of LF_INTS<RING> ints (16-byte aligned): control words, then
@@ -103,15 +113,15 @@ FEC_DEV u32 lf_read_u16(unsigned addr) {
   return r;
 }
 
-// The control block and the rings before the first push: every ring entry carries generation 63 (= "not written in
-// generation 0"), the F ring holds the `live` slots 0 .. live - 1.  Call from every thread, then __syncthreads().
+// The control block and the rings before the first push: every ring entry reads CONSUMED(lap -1), the F ring holds the
+// `live` slots 0 .. live - 1 as WRITTEN(lap 0).  Call from every thread, then __syncthreads().
 template <int RING>
 FEC_DEV void lf_init(int* ctl_words, int tid, int nthreads, int live, unsigned forced_err) {
   unsigned short* q = reinterpret_cast<unsigned short*>(ctl_words + LF_WORDS);
   for (int i = tid; i < RING; i += nthreads) {
-    q[LF_Q_D * RING + i] = 0xFFFFu;
-    q[LF_Q_A * RING + i] = 0xFFFFu;
-    q[LF_Q_F * RING + i] = i < live ? (unsigned short)i : (unsigned short)0xFFFFu;
+    q[LF_Q_D * RING + i] = 0xFC00u;                        // LF_CONSUMED | lap 31
+    q[LF_Q_A * RING + i] = 0xFC00u;
+    q[LF_Q_F * RING + i] = i < live ? (unsigned short)i : (unsigned short)0xFC00u;
   }
   if (tid == 0) {
     for (int w = 0; w < LF_WORDS; ++w) ctl_words[w] = 0;
@@ -132,9 +142,29 @@ FEC_DEV void lf_raise(unsigned ctl, int lane, u32 code) {
   }
 }
 
+// One ring entry per lane of `mine`: slot number `slot` at position `pos` of ring `kind`, written once the entry's
+// previous occupant (lap - 1) has been consumed -- which it has, unless a consumer is being very slow (see the top of
+// this file); then the producer waits for it.  Returns false -- after raising the error -- if that lasts.
+template <int RING>
+FEC_DEV bool lf_put(unsigned ctl, int lane, bool mine, int kind, u32 pos, u32 slot, u32 watchdog_code) {
+  const unsigned addr = lf_ring_addr<RING>(ctl, kind, pos);
+  const u32 expect = LF_CONSUMED | lf_lap<RING>(pos - (u32)RING);
+  for (unsigned tries = 0;; ++tries) {
+    const u32 v = mine ? lf_read_u16(addr) : expect;
+    if (__builtin_amdgcn_ballot_w64(v != expect) == 0) break;
+    if (tries > (1u << 20)) {
+      lf_raise(ctl, lane, watchdog_code);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (mine) lf_write_b16(addr, slot | lf_lap<RING>(pos));
+  return true;
+}
+
 // Hands the slots of this wavefront's lanes on: lane's slot `e` goes where `nxt` says (LF_NXT_*).
 template <int RING>
-FEC_DEV void lf_push(unsigned ctl, int lane, int nxt, int e) {
+FEC_DEV void lf_push(unsigned ctl, int lane, int nxt, int e, u32 watchdog_code) {
   const lmask m_d = __builtin_amdgcn_ballot_w64(nxt == LF_NXT_D), m_a = __builtin_amdgcn_ballot_w64(nxt == LF_NXT_A);
   if ((m_d | m_a) != 0) {
     const u32 n_d = (u32)__builtin_popcountll(m_d), n_a = (u32)__builtin_popcountll(m_a);
@@ -143,7 +173,8 @@ FEC_DEV void lf_push(unsigned ctl, int lane, int nxt, int e) {
     if (lane == 0) old = lf_add_rtn_u64(ctl + 4 * LF_RES_D, both);
     const u32 pos_d = lf_uni((u32)old), pos_a = lf_uni((u32)(old >> 32));
     const u32 pos = nxt == LF_NXT_A ? pos_a + lf_rank(m_a) : pos_d + lf_rank(m_d);
-    if (nxt == LF_NXT_D || nxt == LF_NXT_A) lf_write_b16(lf_ring_addr<RING>(ctl, nxt, pos), (u32)e | lf_gen<RING>(pos));
+    const bool mine = nxt == LF_NXT_D || nxt == LF_NXT_A;
+    if (!lf_put<RING>(ctl, lane, mine, mine ? nxt : LF_Q_D, pos, (u32)e, watchdog_code)) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) lf_add_u64(ctl + 4 * LF_AV_D, both);
   }
@@ -153,7 +184,7 @@ FEC_DEV void lf_push(unsigned ctl, int lane, int nxt, int e) {
     u32 old = 0;
     if (lane == 0) old = lf_add_rtn_u32(ctl + 4 * LF_RES_F, n_f);
     const u32 pos = lf_uni(old) + lf_rank(m_f);
-    if (nxt == LF_NXT_FREE) lf_write_b16(lf_ring_addr<RING>(ctl, LF_Q_F, pos), (u32)e | lf_gen<RING>(pos));
+    if (!lf_put<RING>(ctl, lane, nxt == LF_NXT_FREE, LF_Q_F, pos, (u32)e, watchdog_code)) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) lf_add_u32(ctl + 4 * LF_AV_F, n_f);
   }
@@ -241,19 +272,19 @@ FEC_DEV LfPop lf_pop(unsigned ctl, int lane, unsigned& watchdog, u32 watchdog_co
   }
 }
 
-// The slot number of this lane's entry of a popped batch (0 for a lane without one).  An entry that still carries
-// another generation has been reserved and not yet written: re-read.  Returns false -- after raising the error -- if
-// that lasts (a broken queue).
+// The slot number of this lane's entry of a popped batch (0 for a lane without one); the entry is marked consumed.  An
+// entry that does not yet read WRITTEN(lap of its position) has been reserved and not yet written: re-read.  Returns
+// false -- after raising the error -- if that lasts (a broken queue).
 template <int RING>
 FEC_DEV bool lf_entry(unsigned ctl, const LfPop& p, int lane, u32 watchdog_code, int& slot) {
   const u32 at = p.pos + (u32)lane;
   const bool active = lane < p.count;
-  const u32 want_gen = lf_gen<RING>(at);
+  const u32 want_tag = lf_lap<RING>(at);
   const unsigned entry = lf_ring_addr<RING>(ctl, p.kind, at);
   u32 v = 0;
   for (unsigned tries = 0;; ++tries) {
     v = active ? lf_read_u16(entry) : 0u;
-    if (__builtin_amdgcn_ballot_w64(active && (v & 0xFC00u) != want_gen) == 0) break;
+    if (__builtin_amdgcn_ballot_w64(active && (v & 0xFC00u) != want_tag) == 0) break;
     if (tries > (1u << 20)) {
       lf_raise(ctl, lane, watchdog_code);
       slot = 0;
@@ -261,6 +292,7 @@ FEC_DEV bool lf_entry(unsigned ctl, const LfPop& p, int lane, u32 watchdog_code,
     }
     __builtin_amdgcn_s_sleep(1);
   }
+  if (active) lf_write_b16(entry, LF_CONSUMED | want_tag);   // the position may be written again (a lap later)
   slot = (int)(v & 1023u);
   return true;
 }
