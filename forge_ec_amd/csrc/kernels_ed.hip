@@ -572,6 +572,13 @@ __global__ __launch_bounds__(PT, 1) void k_ed_mul_pers(const u32* __restrict__ s
   for (;;) {
     // hand on what the last batch left (sched_lf.hpp: no lock, no turn to wait for; the release fence in front of the
     // publishing add orders this batch's result stores before the entries that hand the slots on), take the next one
+#ifndef FEC_ED_NO_STORE_DRAIN
+    // this batch's result stores (global memory) have COMPLETED before the slots are handed on: the next holder of a slot
+    // is another wavefront of this CU, and although this CU's vector-memory pipeline keeps a store and a later load of
+    // the same line in order (which is what LLVM's memory model relies on when it emits no vmcnt wait for a
+    // workgroup-scope release), the hand-over does not have to lean on that -- the wait costs nothing measurable
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     lf_push<RING>(ctl_addr, lane, nxt, e, (u32)FEC_DEVERR_SCHED_WATCHDOG);
     nxt = LF_NXT_NONE;
     const LfPop pop = lf_pop<RING>(ctl_addr, lane, watchdog, (u32)FEC_DEVERR_SCHED_WATCHDOG);
