@@ -87,3 +87,30 @@ def test_two_ranks_strong_scaling_baseline_shapes(workload, log2):
         assert t["roofline"]["wavefront_rounds"]["wavefronts"] == 2 * (((1 << (log2 - 1)) + 63) // 64)   # two launches side by side
         assert t["roofline"]["executed_share_of_reference_steps"] == (512 - 24) / 512.0   # 24 of multiply(G, u1)'s steps are a table fetch
         assert abs(t["roofline"]["frac_executed_steps"] - t["roofline"]["frac"] * (512 - 24) / 512.0) < 1e-12
+
+
+def test_clock_probe_helper_parses_rocm_smi_and_survives_its_absence(tmp_path):
+    """bench.ClockSampler: the helper process (started before the GPU is touched) runs `rocm-smi --showclocks --json` between
+    `start` and `stop`; with a stand-in rocm-smi on PATH that prints what the GPU box's prints, the summary carries the
+    sclk / mclk readings; with no rocm-smi at all the summary is None and nothing raises."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("#!/bin/sh\necho 'WARNING: some banner'\n"
+                    "echo '{\"card0\": {\"fclk clock speed:\": \"(1250Mhz)\", \"mclk clock speed:\": \"(2000Mhz)\", \"mclk clock level:\": \"0\", "
+                    "\"sclk clock speed:\": \"(2391Mhz)\", \"sclk clock level:\": \"1\"}, \"card1\": {\"sclk clock speed:\": \"(95Mhz)\"}}'\n")
+    fake.chmod(0o755)
+    old_path = os.environ["PATH"]
+    try:
+        os.environ["PATH"] = str(tmp_path) + os.pathsep + old_path
+        with bench.ClockSampler(0) as c:
+            time.sleep(0.4)
+        s = c.summary()
+        assert s and s["sclk_mhz"]["min"] == s["sclk_mhz"]["max"] == 2391 and s["mclk_mhz"]["max"] == 2000 and s["sclk_mhz"]["samples"] >= 1
+        os.environ["PATH"] = str(tmp_path / "nothing-here")
+        with bench.ClockSampler(0) as c:
+            time.sleep(0.1)
+        assert c.summary() is None
+    finally:
+        os.environ["PATH"] = old_path
